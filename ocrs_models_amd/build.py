@@ -1,0 +1,68 @@
+"""Build libocrs_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m ocrs_models_amd.build          # incremental
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libocrs_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    jobs = []
+    for src in sources():
+        s, o = os.path.join(CSRC, src), os.path.join(OBJ, src + ".o")
+        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, src + ".o") for src in sources()]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,217 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave = 64 lanes, everything here hard-codes that.  No CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OCRS_OK 0
+#define OCRS_ERR_ARG 1
+#define OCRS_ERR_HIP 2
+
+#define OCRS_CHECK_ARG(cond)            \
+    do {                                \
+        if (!(cond)) return OCRS_ERR_ARG; \
+    } while (0)
+
+#define OCRS_LAUNCH_CHECK()                              \
+    do {                                                 \
+        if (hipGetLastError() != hipSuccess) return OCRS_ERR_HIP; \
+    } while (0)
+
+static constexpr int kNumCU = 256;
+
+// ----------------------------------------------------------------------------------------------
+// storage types: activations live in HBM as NHWC, either fp32 or bf16; all arithmetic is fp32.
+// ----------------------------------------------------------------------------------------------
+struct bf16 {
+    unsigned short v;
+};
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
+    return (unsigned short)(u >> 16);
+}
+
+template <class T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr bool is_bf16 = false;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <>
+struct Elem<bf16> {
+    static constexpr bool is_bf16 = true;
+    __device__ static __forceinline__ float ld(const bf16* p) { return bf2f(p->v); }
+    __device__ static __forceinline__ void st(bf16* p, float v) { p->v = f2bf(v); }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+};
+
+// 8 consecutive channels (the NHWC access quantum): 16 B for bf16, 32 B for fp32.
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+// 4 consecutive channels (MFMA accumulator quad): 8 B / 16 B
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(a, b), pack2bf(c, d));
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+__device__ __forceinline__ void load4(const bf16* p, float (&v)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+
+// ----------------------------------------------------------------------------------------------
+// wave64 helpers
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over the 16 lanes sharing (lane >> 4)
+__device__ __forceinline__ float quad16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// MFMA (matrix core) traits.  K is always consumed in chunks of KCH = 32.
+//   D[16 x 16] += A[16 x K] * B[K x 16]
+//   bf16: v_mfma_f32_16x16x32_bf16   A: lane l holds A[l&15][(l>>4)*8 + 0..7]; B: B[(l>>4)*8+0..7][l&15]
+//   fp32: v_mfma_f32_16x16x4_f32 x8  A: lane l holds A[l&15][l>>4];            B: B[l>>4][l&15]  (exact fp32)
+//   D  : lane l holds D[(l>>4)*4 + r][l&15], r = 0..3                       (both)
+// ----------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int KCH = 32;
+
+template <class T>
+struct Mma;
+
+template <>
+struct Mma<bf16> {
+    // LDS tile row: 32 bf16 + 8 pad = 80 B (16-B aligned, conflict-free ds_read_b128 over 16 rows)
+    static constexpr int LDS_PITCH = 40;
+    // packed weight fragment: 8 bf16 per lane per (chunk, tile) = one 16-B load
+    struct Frag {
+        uint4 q;
+    };
+    // fragment from an LDS tile [row][pitch] (row = M or N index, 32 consecutive k along the row);
+    // kvalid = number of valid k in this chunk (8,16,32), the rest reads as zero.
+    __device__ static __forceinline__ Frag load_p(const bf16* tile, int pitch, int row0, int lane, int kvalid) {
+        Frag f;
+        const int kg = (lane >> 4) * 8;
+        if (kg < kvalid)
+            f.q = *reinterpret_cast<const uint4*>(tile + (row0 + (lane & 15)) * pitch + kg);
+        else
+            f.q = make_uint4(0, 0, 0, 0);
+        return f;
+    }
+    // pre-packed weight fragment (see k_pack_frags): one 16-B load per lane
+    __device__ static __forceinline__ Frag load_w(const void* wpk, long frag_idx, int lane) {
+        Frag f;
+        f.q = reinterpret_cast<const uint4*>(wpk)[frag_idx * 64 + lane];
+        return f;
+    }
+    template <int KS_UNUSED>
+    __device__ static __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.q), __builtin_bit_cast(bf16x8, b.q), c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Mma<float> {
+    static constexpr int LDS_PITCH = 36;  // 32 f32 + 4 pad = 144 B (16-B aligned)
+    struct Frag {
+        float v[8];  // k-steps 0..7 of the chunk
+    };
+    __device__ static __forceinline__ Frag load_p(const float* tile, int pitch, int row0, int lane, int kvalid) {
+        Frag f;
+        const float* r = tile + (row0 + (lane & 15)) * pitch + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) f.v[ks] = (ks * 4 < kvalid) ? r[ks * 4] : 0.f;
+        return f;
+    }
+    __device__ static __forceinline__ Frag load_w(const void* wpk, long frag_idx, int lane) {
+        Frag f;
+        const float4* p = reinterpret_cast<const float4*>(wpk) + (frag_idx * 64 + lane) * 2;
+        const float4 a = p[0], b = p[1];
+        f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+        f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+        return f;
+    }
+    template <int KS>
+    __device__ static __forceinline__ f32x4 mma(const Frag& a, const Frag& b, f32x4 c) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[ks], b.v[ks], c, 0, 0, 0);
+        return c;
+    }
+};
+
+// XCD-aware persistent tile schedule: block b runs on XCD (b % 8); give each XCD a contiguous
+// range of tiles so that neighbouring tiles (which share 3x3 halo rows) hit the same L2.
+struct TileSched {
+    long first, step, end;
+    __device__ TileSched(long ntiles) {
+        const long nb = gridDim.x;
+        if ((nb & 7) == 0 && ntiles >= nb) {
+            const long per = (ntiles + 7) / 8;
+            const long xcd = blockIdx.x & 7;
+            first = xcd * per + (blockIdx.x >> 3);
+            step = nb >> 3;
+            end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+        } else {
+            first = blockIdx.x;
+            step = nb;
+            end = ntiles;
+        }
+    }
+};
+
+static inline int persistent_grid(long ntiles, int blocks_per_cu) {
+    long cap = (long)kNumCU * blocks_per_cu;
+    long g = ntiles < cap ? ntiles : cap;
+    if (g >= 8) g &= ~7L;
+    return (int)(g < 1 ? 1 : g);
+}

@@ -1,0 +1,830 @@
+// Detection U-Net backward kernels (gfx950).  Autograd of ocrs_models/models.py:7-143 restated as fused passes.
+//
+// Backward of one DepthwiseConv block  x~ -> u = dw3x3(x~) -> z = pw(u) -> y = relu(bn(z)):
+//   k_bn_bwd_reduce    sum ghat, sum ghat*zhat                 (ghat = dL/dy * [y>0], through a 2x2 max-pool if needed)
+//   k_bn_bwd_finalize  -> dz = A*ghat + B*z + C per channel, dgamma, dbeta
+//   k_pw_bwd           dz tile + recomputed u tile in LDS; MFMA dgrad (du = Wpw^T dz) and wgrad (dWpw += u^T dz)
+//   k_dw_bwd           dx~ = dw3x3^T(du), dWdw
+// plus ConvTranspose2d dgrad / wgrad, head backward, first-block (1->8) backward.
+#include "det_common.h"
+
+// ----------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][C]*/,
+                                                       const float* __restrict__ saved /*[2][C]*/, double* __restrict__ gsum /*[2][C]*/,
+                                                       int C, int H, int W, long P) {
+    extern __shared__ float s_acc[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int CG = C / 8;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mu[8], rs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = saved[c0 + i];
+        rs[i] = saved[C + c0 + i];
+    }
+    for (long p = gtid / CG; p < P; p += nthr / CG) {
+        const PixIdx px = decode_pixel(p, H, W);
+        float gh[8], zv[8];
+        load_ghat8(gs, z, C, bn, p, px, H, W, c0, gh, zv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s1[i] += gh[i];
+            s2[i] = fmaf(gh[i], (zv[i] - mu[i]) * rs[i], s2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&s_acc[c0 + i], s1[i]);
+        atomicAdd(&s_acc[C + c0 + i], s2[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+}
+
+__global__ void k_bn_bwd_finalize(const double* __restrict__ gsum, long count, int C, const float* __restrict__ gamma,
+                                  const float* __restrict__ saved, float* __restrict__ coef /*[3][C]*/, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = gsum[c], s2 = gsum[C + c];
+    const double m1 = s1 / (double)count, m2 = s2 / (double)count;
+    const double mean = saved[c], rstd = saved[C + c];
+    const double A = (double)gamma[c] * rstd;
+    coef[c] = (float)A;
+    coef[C + c] = (float)(-A * rstd * m2);
+    coef[2 * C + c] = (float)(A * (-m1 + mean * rstd * m2));
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// pointwise backward, fused dgrad + wgrad on MFMA.
+//   dgrad : D[cin][pixel] = sum_cout Wpw[cout][cin] * dz[pixel][cout]        (K = cout, weights packed K=COUT, M=CIN)
+//   wgrad : D[cin][cout]  = sum_pixel u[pixel][cin] * dz[pixel][cout]        (K = pixel; both operands from transposed LDS tiles)
+// grid.y enumerates (cin-block, cout-block) pairs of the weight gradient (blocks of <=128x128); y == 0 also does dgrad.
+// ----------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct PwBwdCfg {
+    static constexpr int CGI = (CIN < 32 ? CIN : 32) / 8;
+    static constexpr int CGO = (COUT < 32 ? COUT : 32) / 8;
+    static constexpr int CGM = CGI > CGO ? CGI : CGO;
+    static constexpr int TP = 256 / CGM;
+    static constexpr int PTW = TP / 64;
+    static constexpr int MTD = (CIN + 15) / 16;
+    static constexpr int NKD = COUT / (CGO * 8);
+    static constexpr int CIB = CIN < 128 ? CIN : 128;
+    static constexpr int COB = COUT < 128 ? COUT : 128;
+    static constexpr int WTI = (CIB + 15) / 16;
+    static constexpr int WTO = (COB + 15) / 16;
+    static constexpr int NTW = (WTI * WTO + 3) / 4;
+    static constexpr int NBI = CIN / CIB;
+    static constexpr int NBO = COUT / COB;
+    static constexpr int TPP_BF = TP + 8;  // transposed-tile pitch (elements)
+    static constexpr int TPP_F = TP + 4;
+};
+
+template <class T, int CIN, int COUT>
+__global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
+                                                GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
+                                                const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
+                                                T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/, int H, int W, long P) {
+    using Cfg = PwBwdCfg<CIN, COUT>;
+    constexpr int TP = Cfg::TP, PTW = Cfg::PTW, MTD = Cfg::MTD, CGI = Cfg::CGI, CGO = Cfg::CGO, CGM = Cfg::CGM;
+    constexpr int PITCH = Mma<T>::LDS_PITCH;
+    constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
+    constexpr int WTI = Cfg::WTI, WTO = Cfg::WTO, NTW = Cfg::NTW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tileD = reinterpret_cast<T*>(smem);               // [TP][PITCH]
+    T* dzT = tileD + TP * PITCH;                         // [WTO*16][TPP]
+    T* uT = dzT + WTO * 16 * TPP;                        // [WTI*16][TPP]
+    float* s_par = reinterpret_cast<float*>(smem + (((TP * PITCH + (WTO + WTI) * 16 * TPP) * sizeof(T) + 15) & ~15));
+    float* s_trx = s_par;                // [3][CIN]
+    float* s_wdw = s_par + 3 * CIN;      // [9][CIN]
+    float* s_bn = s_par + 12 * CIN;      // [3][COUT]
+    float* s_cf = s_bn + 3 * COUT;       // [3][COUT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * CIN; i += 256) {
+        const int r = i / CIN, c = i - r * CIN;
+        s_trx[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
+    }
+    for (int i = tid; i < 9 * CIN; i += 256) {
+        const int t = i / CIN, c = i - t * CIN;
+        s_wdw[i] = wdw[c * 9 + t];
+    }
+    for (int i = tid; i < 3 * COUT; i += 256) {
+        s_bn[i] = bn[i];
+        s_cf[i] = coef[i];
+    }
+    {
+        const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid * 8; i < (WTO + WTI) * 16 * TPP; i += 256 * 8) store8(dzT + i, zero8);  // padding rows stay zero
+    }
+    __syncthreads();
+
+    const int by = blockIdx.y;
+    const int ci_base = (by % Cfg::NBI) * Cfg::CIB, co_base = (by / Cfg::NBI) * Cfg::COB;
+    const bool do_dgrad = by == 0;
+    const int pxl = tid / CGM, cg = tid % CGM;
+
+    f32x4 accw[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long ntiles = (P + TP - 1) / TP;
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const long p = t * TP + pxl;
+        const bool pv = p < P;
+        const PixIdx px = decode_pixel(pv ? p : 0, H, W);
+        f32x4 accd[PTW][MTD];
+#pragma unroll
+        for (int a = 0; a < PTW; ++a)
+#pragma unroll
+            for (int b = 0; b < MTD; ++b) accd[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- A: dz chunks -> tileD (dgrad operand) + dzT (wgrad operand) ; dgrad MFMA
+        for (int kc = 0; kc < Cfg::NKD; ++kc) {
+            float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int c0 = (kc * CGO + cg) * 8;
+            if (cg < CGO && pv) {
+                float gh[8], zv[8];
+                load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
+            }
+            if (kc) __syncthreads();
+            if (cg < CGO) {
+                store8(tileD + pxl * PITCH + cg * 8, dz);
+                if (c0 >= co_base && c0 < co_base + Cfg::COB) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(dzT + (c0 - co_base + i) * TPP + pxl, dz[i]);
+                }
+            }
+            __syncthreads();
+            if (do_dgrad) {
+                typename Mma<T>::Frag pf[PTW];
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
+#pragma unroll
+                for (int b = 0; b < MTD; ++b) {
+                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk_d, (long)kc * MTD + b, lane);
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wf, pf[a], accd[a][b]);
+                }
+            }
+        }
+        // ---- B: store du
+        if (do_dgrad) {
+#pragma unroll
+            for (int a = 0; a < PTW; ++a) {
+                const long po = t * TP + (wave * PTW + a) * 16 + (lane & 15);
+#pragma unroll
+                for (int b = 0; b < MTD; ++b) {
+                    const int m0 = b * 16 + (lane >> 4) * 4;
+                    if (po < P && m0 < CIN) {
+                        const f32x4 v = accd[a][b];
+                        store4(du + po * CIN + m0, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        // ---- C: recompute u = dw3x3(x~) for this block's cin range -> uT
+        for (int kc = ci_base / (CGI * 8); kc < (ci_base + Cfg::CIB) / (CGI * 8); ++kc) {
+            const int c0 = (kc * CGI + cg) * 8;
+            if (cg < CGI) {
+                float u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (pv) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int hh = px.h + dy - 1;
+                        if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int ww = px.w + dx - 1;
+                            if (ww < 0 || ww >= W) continue;
+                            float v[8];
+                            load8(src_ptr(x, ((long)px.n * H + hh) * W + ww, c0), v);
+                            apply_tr8(v, s_trx, CIN, c0);
+                            const float* wt = s_wdw + (dy * 3 + dx) * CIN + c0;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) u[i] = fmaf(wt[i], v[i], u[i]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (c0 - ci_base + i) * TPP + pxl, u[i]);
+            }
+        }
+        __syncthreads();
+        // ---- D: wgrad MFMA over the pixel dimension
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int tt = wave + 4 * j;
+            if (tt < WTI * WTO) {
+                const int ti = tt % WTI, to = tt / WTI;
+#pragma unroll
+                for (int pc = 0; pc < TP / 32; ++pc) {
+                    const typename Mma<T>::Frag fa = Mma<T>::load_p(uT + pc * 32, TPP, ti * 16, lane, 32);
+                    const typename Mma<T>::Frag fb = Mma<T>::load_p(dzT + pc * 32, TPP, to * 16, lane, 32);
+                    accw[j] = Mma<T>::template mma<8>(fa, fb, accw[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- flush weight gradient (master layout [COUT][CIN])
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int tt = wave + 4 * j;
+        if (tt < WTI * WTO) {
+            const int ti = tt % WTI, to = tt / WTI;
+            const int co = co_base + to * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci_base + ti * 16 + (lane >> 4) * 4 + r;
+                if (ci < CIN && co < COUT) atomicAdd(&dwpw[(long)co * CIN + ci], accw[j][r]);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// depthwise backward: dx~[p][c] = sum_tap w[c][tap] * du[p - off(tap)][c];  dW[c][tap] = sum_p x~[p][c] * du[p - off(tap)][c]
+// 4 channels per thread (weights, transform and the 36 dW partials live in registers).
+template <class T>
+__global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [C][9]*/,
+                                                const T* __restrict__ du, T* __restrict__ gxa, T* __restrict__ gxb,
+                                                float* __restrict__ dwdw /*[C][9]*/, int H, int W, long P) {
+    extern __shared__ float s_dw[];  // [9][C]
+    const int C = x.Ca + x.Cb;
+    for (int i = threadIdx.x; i < 9 * C; i += 256) s_dw[i] = 0.f;
+    __syncthreads();
+    const int CQ = C / 4;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CQ) * 4;
+    float w[9][4], acc[9][4], sc[4], sh[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + i;
+        const float* trp = c < x.Ca ? tra + c : trb + (c - x.Ca);
+        const int trs = c < x.Ca ? x.Ca : x.Cb;
+        sc[i] = trp[0];
+        sh[i] = trp[trs];
+        lo[i] = trp[2 * trs];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            w[t][i] = wdw[c * 9 + t];
+            acc[t][i] = 0.f;
+        }
+    }
+    for (long p = gtid / CQ; p < P; p += nthr / CQ) {
+        const PixIdx px = decode_pixel(p, H, W);
+        float xv[4];
+        load4(src_ptr(x, p, c0), xv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = px.h - (dy - 1);
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ww = px.w - (dx - 1);
+                if (ww < 0 || ww >= W) continue;
+                float d[4];
+                load4(du + (((long)px.n * H + hh) * W + ww) * C + c0, d);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g[i] = fmaf(w[dy * 3 + dx][i], d[i], g[i]);
+                    acc[dy * 3 + dx][i] = fmaf(xv[i], d[i], acc[dy * 3 + dx][i]);
+                }
+            }
+        }
+        if (c0 < x.Ca) {
+            if (gxa) store4(gxa + p * x.Ca + c0, g[0], g[1], g[2], g[3]);
+        } else {
+            if (gxb) store4(gxb + p * x.Cb + (c0 - x.Ca), g[0], g[1], g[2], g[3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&s_dw[t * C + c0 + i], acc[t][i]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C; i += 256) {
+        const int t = i / C, c = i - t * C;
+        atomicAdd(&dwdw[c * 9 + t], s_dw[i]);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// first block (1 -> 8) backward.  a: dz -> du (fp32, 1 channel) + dWpw[8];  b: dWdw[9] = sum img[p] * du[p - off]
+template <class T>
+__global__ __launch_bounds__(256) void k_c1_bwd_a(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
+                                                  GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn,
+                                                  const float* __restrict__ coef, float* __restrict__ du, float* __restrict__ dwpw, int H,
+                                                  int W, long P) {
+    __shared__ float s_bn[24], s_cf[24], s_acc[8];
+    if (threadIdx.x < 24) {
+        s_bn[threadIdx.x] = bn[threadIdx.x];
+        s_cf[threadIdx.x] = coef[threadIdx.x];
+    }
+    if (threadIdx.x < 8) s_acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float wd[9], wp[8], acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const PixIdx px = decode_pixel(p, H, W);
+        float gh[8], zv[8];
+        load_ghat8(gs, z, 8, s_bn, p, px, H, W, 0, gh, zv);
+        float u = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = px.h + dy - 1;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ww = px.w + dx - 1;
+                if (ww < 0 || ww >= W) continue;
+                u = fmaf(wd[dy * 3 + dx], img[((long)px.n * H + hh) * W + ww], u);
+            }
+        }
+        u = Elem<T>::round(u);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dz = fmaf(s_cf[i], gh[i], fmaf(s_cf[8 + i], zv[i], s_cf[16 + i]));
+            d = fmaf(wp[i], dz, d);
+            acc[i] = fmaf(u, dz, acc[i]);
+        }
+        du[p] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) atomicAdd(&dwpw[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_c1_bwd_b(const float* __restrict__ img, const float* __restrict__ du, float* __restrict__ dwdw, int H,
+                                                  int W, long P) {
+    __shared__ float s_acc[9];
+    if (threadIdx.x < 9) s_acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const PixIdx px = decode_pixel(p, H, W);
+        const float xv = img[p];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = px.h - (dy - 1);
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ww = px.w - (dx - 1);
+                if (ww < 0 || ww >= W) continue;
+                acc[dy * 3 + dx] = fmaf(xv, du[((long)px.n * H + hh) * W + ww], acc[dy * 3 + dx]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float a = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) atomicAdd(&dwdw[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// ConvTranspose2d dgrad:  dx~[n,i,j,c] = sum_{ky,kx,o} g[n, 2i+ky, 2j+kx, o] * W[c,o,ky,kx]   (cropped rows/cols get no gradient)
+// GEMM: M = c (Cup), N = input pixels, K = (tap, o) = 9*Cout (zero-padded to a multiple of 32).
+template <class T, int MT>
+__global__ __launch_bounds__(256) void k_convt_dgrad(const T* __restrict__ g, const void* __restrict__ wpk, T* __restrict__ dx, int Cup, int Cout,
+                                                     int h, int w, int H, int W, int N, int MT_total) {
+    constexpr int TP = 64, PITCH = Mma<T>::LDS_PITCH;
+    __shared__ __attribute__((aligned(16))) T tile[TP * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxl = tid >> 2, cg = tid & 3;
+    const long P = (long)N * h * w;
+    const long ntiles = (P + TP - 1) / TP;
+    const int K = 9 * Cout;
+    const int nkc = (K + 31) / 32;
+    const int mt0 = blockIdx.y * MT;
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const long p = t * TP + pxl;
+        const bool pv = p < P;
+        const PixIdx px = decode_pixel(pv ? p : 0, h, w);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int k0 = kc * 32 + cg * 8;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pv && k0 < K) {
+                const int tap = k0 / Cout, o0 = k0 - tap * Cout;
+                const int Y = 2 * px.h + tap / 3, X = 2 * px.w + tap % 3;
+                if (Y < H && X < W) load8(g + (((long)px.n * H + Y) * W + X) * Cout + o0, v);
+            }
+            if (kc) __syncthreads();
+            store8(tile + pxl * PITCH + cg * 8, v);
+            __syncthreads();
+            const typename Mma<T>::Frag pf = Mma<T>::load_p(tile, PITCH, wave * 16, lane, 32);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, (long)kc * MT_total + mt0 + b, lane);
+                acc[b] = Mma<T>::template mma<8>(wf, pf, acc[b]);
+            }
+        }
+        const long po = t * TP + wave * 16 + (lane & 15);
+        if (po < P) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int m0 = (mt0 + b) * 16 + (lane >> 4) * 4;
+                if (m0 < Cup) store4(dx + po * Cup + m0, acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ConvTranspose2d wgrad: dW[c,o,ky,kx] = sum_{n,i,j} x~[n,i,j,c] * g[n,2i+ky,2j+kx,o].
+// D[c][(tap,o)] with K = input pixels.  Block = (<=128 rows of c) x (128 columns of (tap,o)); grid.y enumerates blocks.
+template <class T>
+__global__ __launch_bounds__(256) void k_convt_wgrad(const T* __restrict__ x, const float* __restrict__ tr, const T* __restrict__ g,
+                                                     float* __restrict__ dW /*[Cup][Cout][9]*/, int Cup, int Cout, int h, int w, int H, int W,
+                                                     int N) {
+    constexpr int TP = 64;
+    constexpr int TPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xT = reinterpret_cast<T*>(smem);  // [128][TPP]
+    T* gT = xT + 128 * TPP;              // [128][TPP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CB = Cup < 128 ? Cup : 128;
+    const int nbi = Cup / CB;
+    const int ci_base = (blockIdx.y % nbi) * CB;
+    const int j_base = (blockIdx.y / nbi) * 128;
+    const int J = 9 * Cout;
+    const int WTI = (CB + 15) / 16;
+    const long P = (long)N * h * w;
+    const long ntiles = (P + TP - 1) / TP;
+    {
+        const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid * 8; i < 128 * TPP; i += 256 * 8) {
+            store8(xT + i, zero8);
+            store8(gT + i, zero8);
+        }
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        // x~T[c][pos]
+        for (int it = tid; it < TP * (CB / 8); it += 256) {
+            const int pxl = it / (CB / 8), c0 = (it % (CB / 8)) * 8;
+            const long p = t * TP + pxl;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p < P) {
+                load8(x + p * Cup + ci_base + c0, v);
+                apply_tr8(v, tr, Cup, ci_base + c0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Elem<T>::st(xT + (c0 + i) * TPP + pxl, v[i]);
+        }
+        // gT[(tap,o)][pos]
+        for (int it = tid; it < TP * 16; it += 256) {
+            const int pxl = it >> 4, jj = (it & 15) * 8;
+            const long p = t * TP + pxl;
+            const int j0 = j_base + jj;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p < P && j0 < J) {
+                const PixIdx px = decode_pixel(p, h, w);
+                const int tap = j0 / Cout, o0 = j0 - tap * Cout;
+                const int Y = 2 * px.h + tap / 3, X = 2 * px.w + tap % 3;
+                if (Y < H && X < W) load8(g + (((long)px.n * H + Y) * W + X) * Cout + o0, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Elem<T>::st(gT + (jj + i) * TPP + pxl, v[i]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tt = wave + 4 * j;
+            if (tt < WTI * 8) {
+                const int ti = tt % WTI, tj = tt / WTI;
+#pragma unroll
+                for (int pc = 0; pc < TP / 32; ++pc) {
+                    const typename Mma<T>::Frag fa = Mma<T>::load_p(xT + pc * 32, TPP, ti * 16, lane, 32);
+                    const typename Mma<T>::Frag fb = Mma<T>::load_p(gT + pc * 32, TPP, tj * 16, lane, 32);
+                    acc[j] = Mma<T>::template mma<8>(fa, fb, acc[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int tt = wave + 4 * j;
+        if (tt < WTI * 8) {
+            const int ti = tt % WTI, tj = tt / WTI;
+            const int jc = j_base + tj * 16 + (lane & 15);
+            if (jc < J) {
+                const int tap = jc / Cout, o = jc - tap * Cout;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = ci_base + ti * 16 + (lane >> 4) * 4 + r;
+                    if (c < Cup) atomicAdd(&dW[((long)c * Cout + o) * 9 + tap], acc[j][r]);
+                }
+            }
+        }
+    }
+}
+
+// per-channel sum over pixels (ConvTranspose2d bias gradient)
+template <class T>
+__global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, float* __restrict__ out, int C, long P) {
+    extern __shared__ float s_acc[];
+    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int CG = C / 8;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long p = gtid / CG; p < P; p += nthr / CG) {
+        float v[8];
+        load8(g + p * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&s_acc[c0 + i], s[i]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+}
+
+// head backward: pred = sigmoid(w . x~ + b);  gl = gpred * pred * (1 - pred);  gy[p][c] = gl * w[c];  dw, db.
+template <class T>
+__global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
+                                                  const float* __restrict__ pred, const float* __restrict__ gpred, T* __restrict__ gy,
+                                                  float* __restrict__ dw, float* __restrict__ db, long P) {
+    __shared__ float s_acc[9];
+    if (threadIdx.x < 9) s_acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    float wv[8], sc[8], sh[8], lo[8], acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wv[i] = w[i];
+        sc[i] = tr[i];
+        sh[i] = tr[8 + i];
+        lo[i] = tr[16 + i];
+    }
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const float pr = pred[p];
+        const float gl = gpred[p] * (1.f - pr) * pr;
+        float v[8], o[8];
+        load8(z + p * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xv = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
+            acc[i] = fmaf(gl, xv, acc[i]);
+            o[i] = gl * wv[i];
+        }
+        acc[8] += gl;
+        store8(gy + p * 8, o);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float a = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) atomicAdd(&dw[threadIdx.x], s_acc[threadIdx.x]);
+    if (threadIdx.x == 8) atomicAdd(db, s_acc[8]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    const long cap = (long)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+// grid for kernels whose threads keep a fixed channel group: total threads must be a multiple of the group count (<= 64, divides 256)
+static inline int cg_grid(long items) { return ew_grid(items); }
+
+// wgrad-carrying persistent grids: each block flushes a weight-gradient tile with atomics, so make every block
+// chew through >= 8 pixel tiles when there are enough of them.
+static inline int wgrad_grid(long ntiles, int cap_blocks) {
+    long g = ntiles / 8;
+    if (g < 1) g = 1;
+    if (g > cap_blocks) g = cap_blocks;
+    if (g >= 8) g &= ~7L;
+    return (int)g;
+}
+
+extern "C" {
+
+// Sum of ghat and ghat*zhat over all pixels (BatchNorm2d backward reductions).  gsum [2][C] double, zeroed here.
+int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z, const float* bn, const float* saved, double* gsum, int C,
+                       int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(g1 && z && bn && saved && gsum && C % 8 == 0 && C <= 256);
+    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const long P = (long)N * H * W;
+    const int grid = cg_grid(P * (C / 8));
+    const size_t smem = 2 * C * sizeof(float);
+    if (dtype == 1) {
+        GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
+        hipLaunchKernelGGL(k_bn_bwd_reduce<bf16>, dim3(grid), dim3(256), smem, st, gs, (const bf16*)z, bn, saved, gsum, C, H, W, P);
+    } else {
+        GradSrc<float> gs{(const float*)g1, (const float*)g2, pooled};
+        hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(grid), dim3(256), smem, st, gs, (const float*)z, bn, saved, gsum, C, H, W, P);
+    }
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+int ocrs_bn_bwd_finalize(const double* gsum, long count, int C, const float* gamma, const float* saved, float* coef, float* dgamma,
+                         float* dbeta, hipStream_t st) {
+    OCRS_CHECK_ARG(gsum && gamma && saved && coef && dgamma && dbeta && C > 0 && count > 0);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, st, gsum, count, C, gamma, saved, coef, dgamma, dbeta);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C" (templates need C++ linkage)
+template <class T, int CIN, int COUT>
+static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                         int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int H, int W,
+                         long P, hipStream_t st) {
+    using Cfg = PwBwdCfg<CIN, COUT>;
+    constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
+    const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + (Cfg::WTO + Cfg::WTI) * 16 * TPP) * sizeof(T) + 15) & ~15) +
+                        (12 * CIN + 6 * COUT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return OCRS_ERR_HIP;
+        attr_set = true;
+    }
+    Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
+    GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
+    const long ntiles = (P + Cfg::TP - 1) / Cfg::TP;
+    const int gx = wgrad_grid(ntiles, 2048);
+    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
+                       wpk_d, (T*)du, dwpw, H, W, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+extern "C" {
+
+#define PW_BWD_COMBOS(X) \
+    X(8, 8) X(8, 16) X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 128) X(128, 128) X(128, 256) X(256, 256) X(256, 128) X(128, 64) \
+        X(64, 32) X(32, 16) X(16, 8)
+
+// Pointwise-conv backward of a DepthwiseConv block: du = Wpw^T dz (written, [P][Cin]); dwpw += u^T dz (accumulated, master layout
+// [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
+// wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
+int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2, int pooled,
+                const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int Cout, int N, int H, int W,
+                int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && g1 && z && bn && coef && wpk_d && du && dwpw && (Cb == 0 || trb));
+    OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
+    const int Cin = Ca + Cb;
+    const long P = (long)N * H * W;
+#define X(CI, CO)                                                                                                                         \
+    if (Cin == CI && Cout == CO)                                                                                                          \
+        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, H, W, P, st) \
+                          : launch_pw_bwd<float, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, H, W, P, st);
+    PW_BWD_COMBOS(X)
+#undef X
+    return OCRS_ERR_ARG;
+}
+
+// Depthwise-conv backward: gxa/gxb (either may be null) receive dL/dx~ split at channel Ca; dwdw accumulated in master layout [C][1][3][3].
+int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du, void* gxa, void* gxb,
+                float* dwdw, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && du && dwdw && (Ca + Cb) % 8 == 0 && Ca % 4 == 0 && (Cb == 0 || trb));
+    OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
+    const int C = Ca + Cb;
+    const long P = (long)N * H * W;
+    const int grid = cg_grid(P * (C / 4));
+    const size_t smem = 9 * C * sizeof(float);
+    if (dtype == 1) {
+        Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
+        hipLaunchKernelGGL(k_dw_bwd<bf16>, dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, (const bf16*)du, (bf16*)gxa, (bf16*)gxb, dwdw, H, W, P);
+    } else {
+        Src2<float> x{(const float*)xa, (const float*)xb, Ca, Cb};
+        hipLaunchKernelGGL(k_dw_bwd<float>, dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, (const float*)du, (float*)gxa, (float*)gxb, dwdw, H, W,
+                           P);
+    }
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// First block (1->8) backward.  du_ws: fp32 workspace [P].  dwpw [8], dwdw [9] accumulated.
+int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
+                     const float* bn, const float* coef, float* du_ws, float* dwpw, float* dwdw, int N, int H, int W, int dtype,
+                     hipStream_t st) {
+    OCRS_CHECK_ARG(img && wdw && wpw && g1 && z && bn && coef && du_ws && dwpw && dwdw);
+    const long P = (long)N * H * W;
+    const int grid = ew_grid(P);
+    if (dtype == 1) {
+        GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
+        hipLaunchKernelGGL(k_c1_bwd_a<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const bf16*)z, bn, coef, du_ws, dwpw, H, W, P);
+    } else {
+        GradSrc<float> gs{(const float*)g1, (const float*)g2, pooled};
+        hipLaunchKernelGGL(k_c1_bwd_a<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const float*)z, bn, coef, du_ws, dwpw, H, W, P);
+    }
+    hipLaunchKernelGGL(k_c1_bwd_b, dim3(grid), dim3(256), 0, st, img, du_ws, dwdw, H, W, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// ConvTranspose2d backward.  g [N][H][W][Cout] = gradient of the (cropped) output; dx [N][h][w][Cup] written;
+// dW [Cup][Cout][3][3] and dbias [Cout] accumulated.  wpk_d = ocrs_pack_frags(mode 0, K=9*Cout, M=Cup, K2=Cout, s1=1, s2=9, sm=9*Cout).
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, int Cup, int Cout, int N,
+                   int h, int w, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
+    const int MT_total = Cup / 16;
+    const long P = (long)N * h * w;
+    const long ntiles = (P + 63) / 64;
+    const int gx = persistent_grid(ntiles, 8);
+#define DG_CASE(T_, MT_)                                                                                                                     \
+    hipLaunchKernelGGL((k_convt_dgrad<T_, MT_>), dim3(gx, MT_total / MT_), dim3(256), 0, st, (const T_*)g, wpk_d, (T_*)dx, Cup, Cout, h, w, H, \
+                       W, N, MT_total);
+#define DG_DISPATCH(T_)               \
+    if (MT_total % 8 == 0) {          \
+        DG_CASE(T_, 8)                \
+    } else if (MT_total % 4 == 0) {   \
+        DG_CASE(T_, 4)                \
+    } else if (MT_total % 2 == 0) {   \
+        DG_CASE(T_, 2)                \
+    } else {                          \
+        DG_CASE(T_, 1)                \
+    }
+    if (dtype == 1) {
+        DG_DISPATCH(bf16)
+    } else {
+        DG_DISPATCH(float)
+    }
+#undef DG_DISPATCH
+#undef DG_CASE
+    OCRS_LAUNCH_CHECK();
+    const int CB = Cup < 128 ? Cup : 128;
+    const int gy = (Cup / CB) * ((9 * Cout + 127) / 128);
+    const int gxw = wgrad_grid(ntiles, 1024);
+    const long Pout = (long)N * H * W;
+    const int gs = cg_grid(Pout * (Cout / 8));
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convt_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess)
+            return OCRS_ERR_HIP;
+        attr_set = true;
+    }
+    if (dtype == 1) {
+        hipLaunchKernelGGL(k_convt_wgrad<bf16>, dim3(gxw, gy), dim3(256), 2 * 128 * 72 * 2, st, (const bf16*)x, tr, (const bf16*)g, dW, Cup, Cout,
+                           h, w, H, W, N);
+        hipLaunchKernelGGL(k_channel_sum<bf16>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const bf16*)g, dbias, Cout, Pout);
+    } else {
+        hipLaunchKernelGGL(k_convt_wgrad<float>, dim3(gxw, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)x, tr, (const float*)g, dW, Cup,
+                           Cout, h, w, H, W, N);
+        hipLaunchKernelGGL(k_channel_sum<float>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const float*)g, dbias, Cout, Pout);
+    }
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Head backward: gy [P][8] written (dtype T); dw [8], db [1] accumulated.
+int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db, long P,
+                  int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && dw && db && P > 0);
+    const int grid = ew_grid(P);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, dw, db, P);
+    else
+        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, dw, db, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,513 @@
+// Detection U-Net forward kernels (gfx950).  Reference semantics: ocrs_models/models.py:7-143.
+//
+//  k_dwpw_fwd      fused [producer BN+ReLU on load] -> depthwise 3x3 -> pointwise 1x1 (MFMA) -> z + BN batch sums
+//  k_dwpw_c1_fwd   the 1->8 first block (VALU)
+//  k_bn_finalize   batch sums -> (scale, shift, lo) + saved mean/rstd + running-stat update
+//  k_maxpool_fwd   2x2 max-pool of relu(bn(z))
+//  k_convt_fwd     ConvTranspose2d k3 s2 (+bias, +crop) as a 4-pixel-gather MFMA GEMM
+//  k_head_fwd      1x1 conv 8->1 + bias + sigmoid
+#include "det_common.h"
+
+// ----------------------------------------------------------------------------------------------
+// generic weight-fragment packer:  W[k][m]  ->  MFMA fragments [kc][mt][lane][8]
+//   mode 0: element (k, m) at src[(k / K2) * s1 + (k % K2) * s2 + m * sm]
+//   mode 1: ConvTranspose2d forward "effective" weight (src = W[Cup][Cout][3][3], K2 = Cup, M = 4*Cout):
+//           k = d*Cup + c (d = dy*2+dx), m = q*Cout + o (q = py*2+px) -> W[c][o][py+2dy][px+2dx] or 0
+// ----------------------------------------------------------------------------------------------
+template <class T>
+__global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out) {
+    const int MT = (M + 15) / 16;
+    const int nkc = (K + 31) / 32;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)nkc * MT * 64) return;
+    const int lane = (int)(idx & 63);
+    const long frag = idx >> 6;
+    const int mt = (int)(frag % MT), kc = (int)(frag / MT);
+    const int m = mt * 16 + (lane & 15);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = Elem<T>::is_bf16 ? kc * 32 + (lane >> 4) * 8 + j : kc * 32 + j * 4 + (lane >> 4);
+        float x = 0.f;
+        if (k < K && m < M) {
+            if (mode == 0) {
+                x = src[(long)(k / K2) * s1 + (long)(k % K2) * s2 + (long)m * sm];
+            } else {
+                const int Cup = K2, Cout = M / 4;
+                const int d = k / Cup, c = k % Cup, q = m / Cout, o = m % Cout;
+                const int ky = (q >> 1) + 2 * (d >> 1), kx = (q & 1) + 2 * (d & 1);
+                if (ky < 3 && kx < 3) x = src[((long)c * Cout + o) * 9 + ky * 3 + kx];
+            }
+        }
+        v[j] = x;
+    }
+    store8(out + idx * 8, v);
+}
+
+// ----------------------------------------------------------------------------------------------
+// fused depthwise+pointwise forward.
+//   CG  = channel groups (of 8) per K-chunk = min(CIN,32)/8   -> tile = TP = 256/CG pixels, one (pixel, group) per thread
+//   MT  = ceil(COUT/16) output-channel tiles, every wave computes all MT tiles for its 16*PTW pixels
+// D[cout][pixel] = sum_cin Wpw[cout][cin] * u[pixel][cin],  u = dw3x3(x~)   (channels = MFMA M, pixels = MFMA N)
+// so each lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+// ----------------------------------------------------------------------------------------------
+template <class T, int CG, int MT>
+__global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+                                                  const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
+                                                  const void* __restrict__ wpk, T* __restrict__ z, double* __restrict__ gstat /*[2][COUT]*/,
+                                                  int CIN, int COUT, int H, int W, long P) {
+    constexpr int TP = 256 / CG;
+    constexpr int PTW = TP / 64;
+    constexpr int KS = CG * 2;  // fp32 k-steps (of 4) per chunk
+    constexpr int PITCH = Mma<T>::LDS_PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                                                  // [TP][PITCH]
+    float* s_par = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));  // [12][CIN]: tr(3) | wdw(9)
+    float* s_stat = s_par + 12 * CIN;                                                       // [2][MT*16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 3 * CIN; i += 256) {
+        const int r = i / CIN, c = i - r * CIN;
+        s_par[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
+    }
+    for (int i = tid; i < 9 * CIN; i += 256) {
+        const int t = i / CIN, c = i - t * CIN;
+        s_par[3 * CIN + i] = wdw[c * 9 + t];  // tap-major in LDS
+    }
+    for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+    __syncthreads();
+
+    const int nkc = CIN / (CG * 8);
+    const int pxl = tid / CG, cg = tid % CG;
+    const long ntiles = (P + TP - 1) / TP;
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const long p = t * TP + pxl;
+        const bool pv = p < P;
+        PixIdx px = decode_pixel(pv ? p : 0, H, W);
+        f32x4 acc[PTW][MT];
+#pragma unroll
+        for (int a = 0; a < PTW; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int c0 = (kc * CG + cg) * 8;
+            float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (pv) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int hh = px.h + dy - 1;
+                    if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int ww = px.w + dx - 1;
+                        if (ww < 0 || ww >= W) continue;
+                        float v[8];
+                        load8(src_ptr(x, ((long)px.n * H + hh) * W + ww, c0), v);
+                        apply_tr8(v, s_par, CIN, c0);
+                        const float* wt = s_par + (3 + dy * 3 + dx) * CIN + c0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) u[i] = fmaf(wt[i], v[i], u[i]);
+                    }
+                }
+            }
+            if (kc) __syncthreads();  // previous chunk's fragment reads are done
+            store8(tile + pxl * PITCH + cg * 8, u);
+            __syncthreads();
+            typename Mma<T>::Frag pf[PTW];
+#pragma unroll
+            for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tile, PITCH, (wave * PTW + a) * 16, lane, CG * 8);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, (long)kc * MT + b, lane);
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<KS>(wf, pf[a], acc[a][b]);
+            }
+        }
+        // epilogue: store z (4 consecutive channels per lane) + per-channel sum / sum of squares
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m0 = b * 16 + (lane >> 4) * 4;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < PTW; ++a) {
+                const long po = t * TP + (wave * PTW + a) * 16 + (lane & 15);
+                if (po < P && m0 < COUT) {
+                    const f32x4 v = acc[a][b];
+                    store4(z + po * COUT + m0, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float q = Elem<T>::round(v[r]);  // statistics of what the consumer will read
+                        s1[r] += q;
+                        s2[r] = fmaf(q, q, s2[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
+                if ((lane & 15) == 0) {
+                    atomicAdd(&s_stat[m0 + r], a1);
+                    atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
+                }
+            }
+        }
+        __syncthreads();  // tile buffer is rewritten by the next iteration
+    }
+    __syncthreads();
+    for (int c = tid; c < COUT; c += 256) {
+        atomicAdd(&gstat[c], (double)s_stat[c]);
+        atomicAdd(&gstat[COUT + c], (double)s_stat[MT * 16 + c]);
+    }
+}
+
+// first block of the net: 1 -> 8 channels (models.py:115 in_conv.seq.0), input = the greyscale image itself.
+template <class T>
+__global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ img, const float* __restrict__ wdw /*[9]*/,
+                                                     const float* __restrict__ wpw /*[8]*/, T* __restrict__ z, double* __restrict__ gstat,
+                                                     int H, int W, long P) {
+    __shared__ float s_stat[16];
+    if (threadIdx.x < 16) s_stat[threadIdx.x] = 0.f;
+    __syncthreads();
+    float wd[9], wp[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const PixIdx px = decode_pixel(p, H, W);
+        float u = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hh = px.h + dy - 1;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ww = px.w + dx - 1;
+                if (ww < 0 || ww >= W) continue;
+                u = fmaf(wd[dy * 3 + dx], img[((long)px.n * H + hh) * W + ww], u);
+            }
+        }
+        u = Elem<T>::round(u);
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = wp[i] * u;
+            const float q = Elem<T>::round(o[i]);
+            s1[i] += q;
+            s2[i] = fmaf(q, q, s2[i]);
+        }
+        store8(z + p * 8, o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = wave_sum(s1[i]), b = wave_sum(s2[i]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&s_stat[i], a);
+            atomicAdd(&s_stat[8 + i], b);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) atomicAdd(&gstat[threadIdx.x], (double)s_stat[threadIdx.x]);
+}
+
+// BatchNorm2d training-mode statistics (biased var for normalisation, unbiased into running_var, eps 1e-5,
+// momentum 0.1)  ->  per-channel load transform + saved mean/rstd.
+__global__ void k_bn_finalize(const double* __restrict__ gstat, long count, int C, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, float eps, float momentum, float* __restrict__ tr /*[3][C]*/,
+                              float* __restrict__ saved /*[2][C] mean|rstd*/, float* __restrict__ run_mean, float* __restrict__ run_var,
+                              long long* __restrict__ nbt, float lo) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double mean = gstat[c] / (double)count;
+    double var = gstat[C + c] / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    tr[c] = sc;
+    tr[C + c] = beta[c] - (float)mean * sc;
+    tr[2 * C + c] = lo;
+    saved[c] = (float)mean;
+    saved[C + c] = rstd;
+    if (run_mean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// MaxPool2d(2) (models.py:54) over relu(bn(z)); floor output size.
+template <class T>
+__global__ __launch_bounds__(256) void k_maxpool_fwd(const T* __restrict__ z, const float* __restrict__ tr, T* __restrict__ out, int C, int H,
+                                                     int W, long Pp) {
+    const int CG = C / 8;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const long total = Pp * CG;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long pp = it / CG;
+        const int c0 = (int)(it - pp * CG) * 8;
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        const long base = ((long)q.n * H + 2 * q.h) * W + 2 * q.w;
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[8];
+            load8(z + (base + (long)(k >> 1) * W + (k & 1)) * C + c0, v);
+            apply_tr8(v, tr, C, c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = k == 0 ? v[i] : fmaxf(m[i], v[i]);
+        }
+        store8(out + pp * C + c0, m);
+    }
+}
+
+// ConvTranspose2d(Cup -> Cout, k3, s2, bias) + crop to (H, W)  (models.py:76-78, 82-87).
+// One GEMM "pixel" = an input-aligned position (i, j), i in [0, h], j in [0, w]; it produces the 2x2 output quad
+// (2i+py, 2j+px) from the four inputs x~[i-dy][j-dx]:   K = (d, c) = 4*Cup,  M = (q, o) = 4*Cout.
+// grid.y selects a block of MT*16 rows of M.
+template <class T, int MT>
+__global__ __launch_bounds__(256) void k_convt_fwd(const T* __restrict__ x, const float* __restrict__ tr, const void* __restrict__ wpk,
+                                                   const float* __restrict__ bias, T* __restrict__ out, int Cup, int Cout, int h, int w,
+                                                   int H, int W, int N, int MT_total) {
+    constexpr int TP = 64, PITCH = Mma<T>::LDS_PITCH;
+    __shared__ __attribute__((aligned(16))) T tile[TP * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pxl = tid >> 2, cg = tid & 3;
+    const int hp = h + 1, wp = w + 1;
+    const long P = (long)N * hp * wp;
+    const long ntiles = (P + TP - 1) / TP;
+    const int nkc = (4 * Cup) / 32;
+    const int mt0 = blockIdx.y * MT;
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const long p = t * TP + pxl;
+        const bool pv = p < P;
+        const PixIdx px = decode_pixel(pv ? p : 0, hp, wp);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int k0 = kc * 32 + cg * 8;
+            const int d = k0 / Cup, c0 = k0 - d * Cup;
+            const int ii = px.h - (d >> 1), jj = px.w - (d & 1);
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (pv && ii >= 0 && ii < h && jj >= 0 && jj < w) {
+                load8(x + (((long)px.n * h + ii) * w + jj) * Cup + c0, v);
+                apply_tr8(v, tr, Cup, c0);
+            }
+            if (kc) __syncthreads();
+            store8(tile + pxl * PITCH + cg * 8, v);
+            __syncthreads();
+            const typename Mma<T>::Frag pf = Mma<T>::load_p(tile, PITCH, wave * 16, lane, 32);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, (long)kc * MT_total + mt0 + b, lane);
+                acc[b] = Mma<T>::template mma<8>(wf, pf, acc[b]);
+            }
+        }
+        const long po = t * TP + wave * 16 + (lane & 15);
+        if (po < P) {
+            const PixIdx q = decode_pixel(po, hp, wp);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int m0 = (mt0 + b) * 16 + (lane >> 4) * 4;
+                const int par = m0 / Cout, o0 = m0 - par * Cout;
+                const int Y = 2 * q.h + (par >> 1), X = 2 * q.w + (par & 1);
+                if (par < 4 && Y < H && X < W) {
+                    const f32x4 a = acc[b];
+                    store4(out + (((long)q.n * H + Y) * W + X) * Cout + o0, a[0] + bias[o0], a[1] + bias[o0 + 1], a[2] + bias[o0 + 2],
+                           a[3] + bias[o0 + 3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out_conv: Conv2d(8 -> 1, 1x1, bias) + Sigmoid (models.py:125-129) on relu(bn(z)).  pred is fp32 (B,1,H,W).
+template <class T>
+__global__ __launch_bounds__(256) void k_head_fwd(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
+                                                  const float* __restrict__ b, float* __restrict__ pred, long P) {
+    float wv[8], sc[8], sh[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wv[i] = w[i];
+        sc[i] = tr[i];
+        sh[i] = tr[8 + i];
+        lo[i] = tr[16 + i];
+    }
+    const float bias = b[0];
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        float v[8];
+        load8(z + p * 8, v);
+        float s = bias;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s = fmaf(wv[i], fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]), s);
+        pred[p] = 1.f / (1.f + __expf(-s));
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    const long cap = (long)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" {
+
+int ocrs_pack_frags(const float* src, int mode, int K, int M, int K2, long s1, long s2, long sm, void* out, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(src && out && K > 0 && M > 0 && K2 > 0);
+    const long n = (long)((K + 31) / 32) * ((M + 15) / 16) * 64;
+    const int grid = (int)((n + 255) / 256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_pack_frags<bf16>, dim3(grid), dim3(256), 0, st, src, mode, K, M, K2, s1, s2, sm, (bf16*)out);
+    else
+        hipLaunchKernelGGL(k_pack_frags<float>, dim3(grid), dim3(256), 0, st, src, mode, K, M, K2, s1, s2, sm, (float*)out);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// number of bytes a packed fragment buffer needs
+long ocrs_pack_frags_bytes(int K, int M, int dtype) { return (long)((K + 31) / 32) * ((M + 15) / 16) * 64 * 8 * (dtype == 1 ? 2 : 4); }
+
+}  // extern "C" (templates need C++ linkage)
+template <class T, int CG, int MT>
+static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
+                           double* gstat, int COUT, int H, int W, long P, hipStream_t st) {
+    constexpr int TP = 256 / CG;
+    const int CIN = Ca + Cb;
+    Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
+    const long ntiles = (P + TP - 1) / TP;
+    const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + (12 * CIN + 2 * MT * 16) * sizeof(float);
+    const int grid = persistent_grid(ntiles, 8);
+    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, H, W, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+extern "C" {
+
+}  // extern "C" (templates need C++ linkage)
+template <class T>
+static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
+                             double* gstat, int COUT, int H, int W, long P, hipStream_t st) {
+    const int CIN = Ca + Cb;
+    const int cg = CIN >= 32 ? 4 : CIN / 8;
+    const int mt = (COUT + 15) / 16;
+#define DWPW_CASE(CG_, MT_) \
+    if (cg == CG_ && mt == MT_) return launch_dwpw_fwd<T, CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, H, W, P, st);
+    DWPW_CASE(1, 1) DWPW_CASE(2, 1) DWPW_CASE(2, 2) DWPW_CASE(4, 1) DWPW_CASE(4, 2) DWPW_CASE(4, 4) DWPW_CASE(4, 8) DWPW_CASE(4, 16)
+#undef DWPW_CASE
+    return OCRS_ERR_ARG;
+}
+extern "C" {
+
+// Fused DepthwiseConv block forward up to the pre-BatchNorm output (reference: ocrs_models/models.py:11-23).
+//   xa/xb : NHWC inputs (xb may be null; channel concat [xa | xb] as torch.cat at models.py:89), Ca, Cb multiples of 8
+//   tra/trb : [3][Ca] / [3][Cb] load transforms of the inputs (producer BN+ReLU, or identity)
+//   wdw   : depthwise weights in the reference layout [Cin][1][3][3]; wpk: pointwise weights packed by ocrs_pack_frags(K=Cin, M=Cout)
+//   z     : [P][Cout] pre-BN output; gstat: [2][Cout] double, sum z and sum z^2 (zeroed here)
+int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
+                  void* z, double* gstat, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    const int Cin = Ca + Cb;
+    OCRS_CHECK_ARG(xa && tra && wdw && wpk && z && gstat && (Cb == 0 || trb));
+    OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
+    OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
+    if (hipMemsetAsync(gstat, 0, 2 * Cout * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const long P = (long)N * H * W;
+    return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, H, W, P, st)
+                      : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, H, W, P, st);
+}
+
+// First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] (zeroed here).
+int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
+                     hipStream_t st) {
+    OCRS_CHECK_ARG(img && wdw && wpw && z && gstat);
+    if (hipMemsetAsync(gstat, 0, 16 * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const long P = (long)N * H * W;
+    const int grid = ew_grid(P);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_dwpw_c1_fwd<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, H, W, P);
+    else
+        hipLaunchKernelGGL(k_dwpw_c1_fwd<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, H, W, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// BatchNorm2d batch statistics -> load transform (reference: nn.BatchNorm2d at models.py:23, training mode).
+int ocrs_bn_finalize(const double* gstat, long count, int C, const float* gamma, const float* beta, float eps, float momentum, float* tr,
+                     float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st) {
+    OCRS_CHECK_ARG(gstat && gamma && beta && tr && saved && C > 0 && count > 0);
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, gstat, count, C, gamma, beta, eps, momentum, tr, saved, run_mean,
+                       run_var, nbt, lo);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// MaxPool2d(2) over relu(bn(z))  (models.py:54).  out: [N][H/2][W/2][C]
+int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && out && C % 8 == 0 && H >= 2 && W >= 2);
+    const long Pp = (long)N * (H / 2) * (W / 2);
+    const int grid = ew_grid(Pp * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_maxpool_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, (bf16*)out, C, H, W, Pp);
+    else
+        hipLaunchKernelGGL(k_maxpool_fwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, (float*)out, C, H, W, Pp);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C" (templates need C++ linkage)
+template <class T>
+static int dispatch_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h,
+                              int w, int H, int W, hipStream_t st) {
+    const int MT_total = (4 * Cout) / 16;
+    const long P = (long)N * (h + 1) * (w + 1);
+    const long ntiles = (P + 63) / 64;
+#define CONVT_CASE(MT_)                                                                                                                  \
+    {                                                                                                                                    \
+        const int gy = MT_total / MT_;                                                                                                   \
+        int gx = persistent_grid(ntiles, 8);                                                                                             \
+        hipLaunchKernelGGL((k_convt_fwd<T, MT_>), dim3(gx, gy), dim3(256), 0, st, (const T*)x, tr, wpk, bias, (T*)out, Cup, Cout, h, w, \
+                           H, W, N, MT_total);                                                                                           \
+    }
+    if (MT_total % 8 == 0)
+        CONVT_CASE(8)
+    else if (MT_total % 4 == 0)
+        CONVT_CASE(4)
+    else
+        CONVT_CASE(2)
+#undef CONVT_CASE
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+extern "C" {
+
+// ConvTranspose2d(Cup->Cout, k=3, s=2, bias) cropped to (H, W)  (models.py:76-78,82-87).
+//   x [N][h][w][Cup] with load transform tr [3][Cup]; wpk = ocrs_pack_frags(mode 1, K=4*Cup, M=4*Cout); out [N][H][W][Cout]
+int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h, int w,
+                   int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(x && tr && wpk && bias && out);
+    OCRS_CHECK_ARG(Cup % 8 == 0 && Cout % 8 == 0 && (H == 2 * h || H == 2 * h + 1) && (W == 2 * w || W == 2 * w + 1));
+    return dtype == 1 ? dispatch_convt_fwd<bf16>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st)
+                      : dispatch_convt_fwd<float>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st);
+}
+
+// out_conv 1x1 (8->1) + bias + sigmoid (models.py:125-129).  pred fp32 [N][1][H][W].
+int ocrs_head_fwd(const void* z, const float* tr, const float* w, const float* b, float* pred, long P, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && w && b && pred && P > 0);
+    const int grid = ew_grid(P);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_head_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, b, pred, P);
+    else
+        hipLaunchKernelGGL(k_head_fwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, b, pred, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

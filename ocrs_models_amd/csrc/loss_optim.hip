@@ -1,0 +1,327 @@
+// Detection loss (class-balanced hard-example BCE) and optimiser kernels (gfx950).
+//
+// Reference: balanced_cross_entropy_loss, ocrs_models/train_detection.py:225-263
+//   pos = t > 0.5, neg = t < 0.5, t = clamp(t,0,1); l = BCE(p, t) elementwise (log clamp -100);
+//   k = min(#pos, #neg); loss = mean(topk(pos*l, k) ++ topk(neg*l, k)).
+// Here everything stays on the device (the reference does two .item() syncs): exact k-th-largest threshold by a
+// 3-pass MSB radix select (11/10/10 bits of the non-negative fp32 bit pattern), then a masked sum.
+// Ties at the threshold: the reference's topk picks an implementation-defined subset; we weight every tie
+// equally with need/ties (same loss value, a valid sub-gradient).
+//
+// Optimiser: torch.optim.Adam defaults (train_detection.py:378, train_rec.py:381-382) as one multi-tensor launch,
+// clip_grad_norm_ (train_rec.py:148) as multi-tensor sum-of-squares + scale.
+#include "common.h"
+
+struct LossState {            // device-resident, one per loss call
+    unsigned long long cnt[2];   // #pos, #neg
+    unsigned long long k;        // min(cnt)
+    unsigned prefix[2];          // radix-select prefix / final threshold bits per class
+    unsigned long long need[2];  // how many still to take inside the current prefix bucket
+    unsigned long long ties[2];  // elements equal to the threshold
+    double sum_gt[2];            // sum of losses strictly above the threshold
+    float loss;
+    float frac[2];               // need / ties
+    float inv2k;                 // 1 / (2k)
+};
+
+__device__ __forceinline__ unsigned loss_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+__global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ lpx,
+                                                 unsigned char* __restrict__ cls, LossState* __restrict__ stt, long P) {
+    unsigned long long np = 0, nn = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const float p = pred[i], t0 = target[i];
+        const unsigned char c = t0 > 0.5f ? 1 : (t0 < 0.5f ? 2 : 0);
+        const float t = fminf(fmaxf(t0, 0.f), 1.f);
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
+        lpx[i] = -(t * lp + (1.f - t) * l1p);
+        cls[i] = c;
+        np += c == 1;
+        nn += c == 2;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        np += __shfl_xor(np, o, 64);
+        nn += __shfl_xor(nn, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (np) atomicAdd(&stt->cnt[0], np);
+        if (nn) atomicAdd(&stt->cnt[1], nn);
+    }
+}
+
+__global__ void k_select_init(LossState* stt) {
+    const unsigned long long k = stt->cnt[0] < stt->cnt[1] ? stt->cnt[0] : stt->cnt[1];
+    stt->k = k;
+    for (int c = 0; c < 2; ++c) {
+        stt->prefix[c] = 0;
+        stt->need[c] = k;
+        stt->ties[c] = 0;
+        stt->sum_gt[c] = 0.0;
+    }
+}
+
+// pass: 0 -> bits 30..20 (2048 bins), 1 -> bits 19..10 (1024), 2 -> bits 9..0 (1024)
+__device__ __forceinline__ void pass_bits(int pass, int& shift, int& nb) {
+    shift = pass == 0 ? 20 : (pass == 1 ? 10 : 0);
+    nb = pass == 0 ? 2048 : 1024;
+}
+
+__global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
+                                                     const LossState* __restrict__ stt, unsigned* __restrict__ hist /*[2][2048]*/, int pass,
+                                                     long P) {
+    __shared__ unsigned s_h[2 * 2048];
+    for (int i = threadIdx.x; i < 4096; i += 256) s_h[i] = 0;
+    __syncthreads();
+    int shift, nb;
+    pass_bits(pass, shift, nb);
+    const unsigned pf0 = stt->prefix[0], pf1 = stt->prefix[1];
+    const int hs = shift + (pass == 0 ? 11 : 10);  // bits above the current digit
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const unsigned char c = cls[i];
+        if (!c) continue;
+        const unsigned key = loss_key(lpx[i]);
+        const unsigned pf = c == 1 ? pf0 : pf1;
+        if (pass == 0 || (key >> hs) == pf) atomicAdd(&s_h[(c - 1) * 2048 + ((key >> shift) & (nb - 1))], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// one block of 256 threads: find the bin holding the need-th largest element, per class (blockIdx.x = class)
+__global__ __launch_bounds__(256) void k_select_scan(LossState* __restrict__ stt, unsigned* __restrict__ hist, int pass) {
+    __shared__ unsigned long long s_sum[256];
+    int shift, nb;
+    pass_bits(pass, shift, nb);
+    const int c = blockIdx.x;
+    unsigned* h = hist + c * 2048;
+    const int per = nb / 256;
+    const int tid = threadIdx.x;
+    // thread t owns bins [nb - (t+1)*per, nb - t*per) : descending order over t
+    unsigned long long loc = 0;
+    for (int j = 0; j < per; ++j) loc += h[nb - 1 - (tid * per + j)];
+    s_sum[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const unsigned long long v = s_sum[t];
+            s_sum[t] = run;  // exclusive prefix (count of strictly larger digits before this thread's bins)
+            run += v;
+        }
+    }
+    __syncthreads();
+    const unsigned long long need = stt->need[c];
+    const unsigned long long before = s_sum[tid];
+    if (need > 0 && before < need && before + loc >= need) {
+        unsigned long long run = before;
+        for (int j = 0; j < per; ++j) {
+            const int bin = nb - 1 - (tid * per + j);
+            const unsigned long long v = h[bin];
+            if (run + v >= need) {
+                stt->prefix[c] = (stt->prefix[c] << (pass == 0 ? 11 : 10)) | (unsigned)bin;
+                stt->need[c] = need - run;
+                stt->ties[c] = v;
+                break;
+            }
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2048; i += 256) h[i] = 0;  // ready for the next pass
+}
+
+__global__ __launch_bounds__(256) void k_topk_sum(const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
+                                                  LossState* __restrict__ stt, long P) {
+    const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
+    double s0 = 0.0, s1 = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const unsigned char c = cls[i];
+        if (!c) continue;
+        const float v = lpx[i];
+        const unsigned key = loss_key(v);
+        if (c == 1) {
+            if (key > t0) s0 += (double)v;
+        } else {
+            if (key > t1) s1 += (double)v;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (s0 != 0.0) atomicAdd(&stt->sum_gt[0], s0);
+        if (s1 != 0.0) atomicAdd(&stt->sum_gt[1], s1);
+    }
+}
+
+__global__ void k_loss_final(LossState* stt, float* loss_out) {
+    const unsigned long long k = stt->k;
+    double tot = 0.0;
+    for (int c = 0; c < 2; ++c) {
+        const double thr = (double)__uint_as_float(stt->prefix[c]);
+        tot += stt->sum_gt[c] + (double)stt->need[c] * thr;
+        stt->frac[c] = stt->ties[c] ? (float)((double)stt->need[c] / (double)stt->ties[c]) : 0.f;
+    }
+    const float loss = k ? (float)(tot / (2.0 * (double)k)) : __uint_as_float(0x7fc00000u);  // mean of an empty tensor = NaN
+    stt->loss = loss;
+    stt->inv2k = k ? (float)(1.0 / (2.0 * (double)k)) : 0.f;
+    *loss_out = loss;
+}
+
+// d loss / d pred: weight * (p - t) / max(p (1 - p), 1e-12)   (ATen binary_cross_entropy_backward)
+__global__ __launch_bounds__(256) void k_bce_bwd(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ lpx,
+                                                 const unsigned char* __restrict__ cls, const LossState* __restrict__ stt,
+                                                 const float* __restrict__ gout, float* __restrict__ gpred, long P) {
+    const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
+    const float f0 = stt->frac[0], f1 = stt->frac[1];
+    const float s = gout[0] * stt->inv2k;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const unsigned char c = cls[i];
+        float g = 0.f;
+        if (c) {
+            const unsigned key = loss_key(lpx[i]);
+            const unsigned thr = c == 1 ? t0 : t1;
+            const float wgt = key > thr ? 1.f : (key == thr ? (c == 1 ? f0 : f1) : 0.f);
+            if (wgt != 0.f) {
+                const float p = pred[i];
+                const float t = fminf(fmaxf(target[i], 0.f), 1.f);
+                g = s * wgt * (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+            }
+        }
+        gpred[i] = g;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// multi-tensor optimiser kernels.  table: [nt][5] int64 = {param, grad, exp_avg, exp_avg_sq, numel};
+// chunks: [nchunks][2] int32 = {tensor index, chunk index}; one block handles CHUNK = 2048 elements.
+// ----------------------------------------------------------------------------------------------
+static constexpr int OPT_CHUNK = 2048;
+
+__global__ __launch_bounds__(256) void k_multi_sumsq(const long long* __restrict__ table, const int* __restrict__ chunks,
+                                                     double* __restrict__ out) {
+    const int t = chunks[2 * blockIdx.x], ch = chunks[2 * blockIdx.x + 1];
+    const float* g = reinterpret_cast<const float*>(table[5 * t + 1]);
+    const long n = table[5 * t + 4];
+    float s = 0.f;
+    for (long i = (long)ch * OPT_CHUNK + threadIdx.x; i < n && i < (long)(ch + 1) * OPT_CHUNK; i += 256) s = fmaf(g[i], g[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (double)s);
+}
+
+// norm_out = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))
+__global__ void k_clip_coef(const double* sumsq, float max_norm, float* norm_out, float* coef_out) {
+    const float norm = (float)sqrt(*sumsq);
+    *norm_out = norm;
+    *coef_out = fminf(1.f, max_norm / (norm + 1e-6f));
+}
+
+__global__ __launch_bounds__(256) void k_multi_scale(const long long* __restrict__ table, const int* __restrict__ chunks,
+                                                     const float* __restrict__ coef) {
+    const int t = chunks[2 * blockIdx.x], ch = chunks[2 * blockIdx.x + 1];
+    float* g = reinterpret_cast<float*>(table[5 * t + 1]);
+    const long n = table[5 * t + 4];
+    const float c = *coef;
+    for (long i = (long)ch * OPT_CHUNK + threadIdx.x; i < n && i < (long)(ch + 1) * OPT_CHUNK; i += 256) g[i] *= c;
+}
+
+__global__ __launch_bounds__(256) void k_multi_adam(const long long* __restrict__ table, const int* __restrict__ chunks, float b1, float b2,
+                                                    float eps, float step_size, float bc2_sqrt, const float* __restrict__ gscale) {
+    const int t = chunks[2 * blockIdx.x], ch = chunks[2 * blockIdx.x + 1];
+    float* p = reinterpret_cast<float*>(table[5 * t + 0]);
+    const float* g = reinterpret_cast<const float*>(table[5 * t + 1]);
+    float* m = reinterpret_cast<float*>(table[5 * t + 2]);
+    float* v = reinterpret_cast<float*>(table[5 * t + 3]);
+    const long n = table[5 * t + 4];
+    const float gs = gscale ? *gscale : 1.f;
+    for (long i = (long)ch * OPT_CHUNK + threadIdx.x; i < n && i < (long)(ch + 1) * OPT_CHUNK; i += 256) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+__global__ void k_fill_f32(float* p, float v, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    const long cap = (long)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" {
+
+long ocrs_loss_state_bytes() { return (long)sizeof(LossState); }
+long ocrs_loss_hist_bytes() { return 2 * 2048 * (long)sizeof(unsigned); }
+
+// Class-balanced BCE forward (train_detection.py:225-263).  pred/target fp32 [P]; lpx fp32 [P] and cls u8 [P] are saved
+// for backward; state (ocrs_loss_state_bytes) and hist (ocrs_loss_hist_bytes) are device workspaces; loss_out fp32 [1].
+int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, unsigned char* cls, void* state, void* hist, float* loss_out,
+                          long P, hipStream_t st) {
+    OCRS_CHECK_ARG(pred && target && lpx && cls && state && hist && loss_out && P > 0);
+    LossState* stt = (LossState*)state;
+    if (hipMemsetAsync(state, 0, sizeof(LossState), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (hipMemsetAsync(hist, 0, 2 * 2048 * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    const int grid = ew_grid(P);
+    hipLaunchKernelGGL(k_bce_fwd, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
+    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, st, stt);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(k_select_hist, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
+        hipLaunchKernelGGL(k_select_scan, dim3(2), dim3(256), 0, st, stt, (unsigned*)hist, pass);
+    }
+    hipLaunchKernelGGL(k_topk_sum, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1), 0, st, stt, loss_out);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Backward of the above: gpred fp32 [P] written; gout = upstream gradient of the scalar loss (device fp32 [1]).
+int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* lpx, const unsigned char* cls, const void* state,
+                          const float* gout, float* gpred, long P, hipStream_t st) {
+    OCRS_CHECK_ARG(pred && target && lpx && cls && state && gout && gpred && P > 0);
+    hipLaunchKernelGGL(k_bce_bwd, dim3(ew_grid(P)), dim3(256), 0, st, pred, target, lpx, cls, (const LossState*)state, gout, gpred, P);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+int ocrs_opt_chunk() { return OPT_CHUNK; }
+
+// clip_grad_norm_(params, max_norm) (train_rec.py:148): norm_out/coef_out fp32 [1] device; sumsq double [1] device workspace.
+// scale_in_place != 0 multiplies the gradients by coef (reference behaviour); 0 leaves that to ocrs_adam_step(gscale = coef_out).
+int ocrs_clip_grad_norm(const long long* table, const int* chunks, int nchunks, float max_norm, double* sumsq, float* norm_out,
+                        float* coef_out, int scale_in_place, hipStream_t st) {
+    OCRS_CHECK_ARG(table && chunks && nchunks > 0 && sumsq && norm_out && coef_out);
+    if (hipMemsetAsync(sumsq, 0, sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    hipLaunchKernelGGL(k_multi_sumsq, dim3(nchunks), dim3(256), 0, st, table, chunks, sumsq);
+    hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, st, sumsq, max_norm, norm_out, coef_out);
+    if (scale_in_place) hipLaunchKernelGGL(k_multi_scale, dim3(nchunks), dim3(256), 0, st, table, chunks, coef_out);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// torch.optim.Adam single step over every tensor in the table.  step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t).
+int ocrs_adam_step(const long long* table, const int* chunks, int nchunks, float b1, float b2, float eps, float step_size, float bc2_sqrt,
+                   const float* gscale, hipStream_t st) {
+    OCRS_CHECK_ARG(table && chunks && nchunks > 0);
+    hipLaunchKernelGGL(k_multi_adam, dim3(nchunks), dim3(256), 0, st, table, chunks, b1, b2, eps, step_size, bc2_sqrt, gscale);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+int ocrs_fill_f32(float* p, float v, long n, hipStream_t st) {
+    OCRS_CHECK_ARG(p && n >= 0);
+    if (n == 0) return OCRS_OK;
+    hipLaunchKernelGGL(k_fill_f32, dim3(ew_grid(n)), dim3(256), 0, st, p, v, n);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+"""DetectionModel / RecognitionModel with the reference's constructor + forward signatures and
+state-dict keys (ocrs_models/models.py:93-143, 146-268), executed by hand-written gfx950 kernels
+through the C ABI of libocrs_hip.so.
+
+The nn.Module tree below exists to hold parameters/buffers under the reference's names (so
+checkpoints of the reference load unchanged, train_detection.py:198-215) -- the stock sub-modules are
+never called.  ``forward`` runs one custom autograd function for the whole network: activations are
+NHWC (fp32 or bf16) in HBM, every DepthwiseConv block stores only its pre-BatchNorm output and the
+BatchNorm+ReLU is applied by the consumers while loading (see csrc/det_common.h).
+
+There is no CPU path: tensors must be on an MI355X.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from ._lib import lib, ptr
+
+DEPTH_SCALE = [8, 16, 32, 32, 64, 128, 256]  # models.py:112
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names/shapes/initialisation = the reference's)
+# ------------------------------------------------------------------------------------------------
+class DepthwiseConv(nn.Module):
+    """models.py:7-28 -- dw3x3 (no bias) -> pw1x1 (no bias) -> BatchNorm2d -> ReLU."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.seq = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels, 3, padding=1, bias=False, groups=in_channels),
+            nn.Conv2d(in_channels, out_channels, 1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(),
+        )
+
+
+class DoubleConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.seq = nn.Sequential(DepthwiseConv(in_channels, out_channels), DepthwiseConv(out_channels, out_channels))
+
+
+class Down(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.seq = nn.Sequential(DoubleConv(in_channels, out_channels), nn.MaxPool2d(2))
+
+
+class Up(nn.Module):
+    def __init__(self, in_up_channels: int, in_cross_channels: int, out_channels: int):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_up_channels, out_channels, kernel_size=3, stride=2)
+        self.contract = DoubleConv(out_channels + in_cross_channels, out_channels)
+
+
+class _Act:
+    """NHWC activation + the per-channel load transform its consumers must apply."""
+
+    __slots__ = ("t", "tr", "C", "H", "W")
+
+    def __init__(self, t, tr, C, H, W):
+        self.t, self.tr, self.C, self.H, self.W = t, tr, C, H, W
+
+
+class _BlockRec:
+    __slots__ = ("prefix", "a", "b", "z", "tr", "saved", "Cin", "Cout", "H", "W")
+
+
+_identity_cache: dict = {}
+
+
+def _identity_tr(C, device):
+    key = (C, device)
+    t = _identity_cache.get(key)
+    if t is None:
+        t = torch.empty(3, C, dtype=torch.float32, device=device)
+        t[0] = 1.0
+        t[1] = 0.0
+        t[2] = -math.inf
+        _identity_cache[key] = t
+    return t
+
+
+class _DetRun:
+    """One forward (and later backward) pass of the detection network on the current stream."""
+
+    def __init__(self, mod, x, names, params, train):
+        self.L = lib()
+        self.mod = mod
+        self.P = dict(zip(names, params))
+        self.names = names
+        self.Bf = dict(mod.named_buffers())
+        self.train = train
+        self.dev = x.device
+        self.dtype = mod._act_dtype()
+        self.dt = _DT[self.dtype]
+        self.N = x.shape[0]
+        self.recs = {}
+        self.x = x
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def pack(self, src, mode, K, M, K2, s1, s2, sm):
+        nbytes = self.L.pack_frags_bytes(K, M, self.dt)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.L.pack_frags(ptr(src), mode, K, M, K2, s1, s2, sm, ptr(out), self.dt)
+        return out
+
+    def bn_tr(self, prefix, gstat, count, C):
+        P, Bf = self.P, self.Bf
+        tr = self.empty(3, C, dtype=torch.float32)
+        saved = self.empty(2, C, dtype=torch.float32)
+        if self.train:
+            self.L.bn_finalize(ptr(gstat), count, C, ptr(P[f"{prefix}.weight"]), ptr(P[f"{prefix}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved),
+                               ptr(Bf[f"{prefix}.running_mean"]), ptr(Bf[f"{prefix}.running_var"]), ptr(Bf[f"{prefix}.num_batches_tracked"]), 0.0)
+        else:
+            rstd = torch.rsqrt(Bf[f"{prefix}.running_var"] + 1e-5)
+            tr[0] = P[f"{prefix}.weight"].detach() * rstd
+            tr[1] = P[f"{prefix}.bias"].detach() - Bf[f"{prefix}.running_mean"] * tr[0]
+            tr[2] = 0.0
+        return tr, saved
+
+    # -- forward ---------------------------------------------------------------------------------
+    def block(self, prefix, a, b, Cout):
+        L, P, N = self.L, self.P, self.N
+        H, W = a.H, a.W
+        Cin = a.C + (b.C if b is not None else 0)
+        wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
+        wpk = self.pack(wpw, 0, Cin, Cout, Cin, 0, 1, Cin)
+        z = self.empty(N, H, W, Cout)
+        gstat = self.empty(2 * Cout, dtype=torch.float64)
+        L.dwpw_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, b.C if b is not None else 0, ptr(a.tr),
+                   ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), Cout, N, H, W, self.dt)
+        tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, Cout)
+        r = _BlockRec()
+        r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
+        self.recs[prefix] = r
+        return _Act(z, tr, Cout, H, W)
+
+    def block_c1(self, prefix, img, H, W):
+        L, P, N = self.L, self.P, self.N
+        z = self.empty(N, H, W, 8)
+        gstat = self.empty(16, dtype=torch.float64)
+        L.dwpw_c1_fwd(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(gstat), N, H, W, self.dt)
+        tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, 8)
+        r = _BlockRec()
+        r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, None, None, z, tr, saved, 1, 8, H, W
+        self.recs[prefix] = r
+        return _Act(z, tr, 8, H, W)
+
+    def double(self, prefix, a, b, Cout):
+        y = self.block(f"{prefix}.seq.0", a, b, Cout)
+        return self.block(f"{prefix}.seq.1", y, None, Cout)
+
+    def forward(self):
+        L, P, N, w = self.L, self.P, self.N, DEPTH_SCALE
+        x = self.x
+        H, W = x.shape[2], x.shape[3]
+        if H < 64 or W < 64:
+            raise RuntimeError(f"DetectionModel needs H, W >= 64 (six 2x2 poolings), got {H}x{W}")
+        a0 = self.block_c1("in_conv.seq.0", x, H, W)
+        cur = self.block("in_conv.seq.1", a0, None, w[0])
+        skips = [cur]
+        for i in range(6):
+            y = self.double(f"down.{i}.seq.0", cur, None, w[i + 1])
+            Hp, Wp = y.H // 2, y.W // 2
+            pooled = self.empty(N, Hp, Wp, y.C)
+            L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, self.dt)
+            cur = _Act(pooled, _identity_tr(y.C, self.dev), y.C, Hp, Wp)
+            skips.append(cur)
+        up = skips[6]
+        self.convt = {}
+        for i in reversed(range(6)):
+            skip = skips[i]
+            Cup, Cout = w[i + 1], w[i]
+            wpk = self.pack(P[f"up.{i}.up.weight"], 1, 4 * Cup, 4 * Cout, Cup, 0, 0, 0)
+            t = self.empty(N, skip.H, skip.W, Cout)
+            L.convt_fwd(ptr(up.t), ptr(up.tr), ptr(wpk), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W, self.dt)
+            ta = _Act(t, _identity_tr(Cout, self.dev), Cout, skip.H, skip.W)
+            self.convt[i] = (up, ta)
+            up = self.double(f"up.{i}.contract", ta, skip, Cout)
+        pred = self.empty(N, 1, H, W, dtype=torch.float32)
+        L.head_fwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(P["out_conv.0.bias"]), ptr(pred), N * H * W, self.dt)
+        self.head_in = up
+        self.pred = pred
+        self.skips = skips
+        self.HW = (H, W)
+        return pred
+
+    # -- backward --------------------------------------------------------------------------------
+    def block_bwd(self, prefix, g1, g2, pooled, need_gx=True):
+        """-> (gxa, gxb): dL/d(block input), split at the concat boundary."""
+        L, P, N, r = self.L, self.P, self.N, self.recs[prefix]
+        C, H, W = r.Cout, r.H, r.W
+        gsum = self.empty(2 * C, dtype=torch.float64)
+        L.bn_bwd_reduce(ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(r.saved), ptr(gsum), C, N, H, W, self.dt)
+        coef = self.empty(3, C, dtype=torch.float32)
+        L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(P[f"{prefix}.seq.2.weight"]), ptr(r.saved), ptr(coef),
+                          ptr(self.G[f"{prefix}.seq.2.weight"]), ptr(self.G[f"{prefix}.seq.2.bias"]))
+        wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
+        if r.Cin == 1:
+            du = self.empty(N * H * W, dtype=torch.float32)
+            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(du),
+                          ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), N, H, W, self.dt)
+            return None, None
+        a, b = r.a, r.b
+        Ca, Cb = a.C, (b.C if b is not None else 0)
+        wpk_d = self.pack(wpw, 0, C, r.Cin, C, 0, r.Cin, 1)
+        du = self.empty(N, H, W, r.Cin)
+        L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
+                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), C, N, H, W, self.dt)
+        gxa = self.empty(N, H, W, Ca) if need_gx else None
+        gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
+        L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),
+                 ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.0.weight"]), N, H, W, self.dt)
+        return gxa, gxb
+
+    def backward(self, gpred):
+        L, P, N, w = self.L, self.P, self.N, DEPTH_SCALE
+        H, W = self.HW
+        flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=self.dev)
+        self.G, off = {}, 0
+        for k in self.names:
+            n = P[k].numel()
+            self.G[k] = flat[off:off + n].view_as(P[k])
+            off += n
+        gpred = gpred.contiguous().float()
+        up = self.head_in
+        g = self.empty(N, H, W, 8)
+        L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(self.G["out_conv.0.weight"]),
+                   ptr(self.G["out_conv.0.bias"]), N * H * W, self.dt)
+        skip_g = [[] for _ in range(7)]
+        for i in range(6):
+            g1, _ = self.block_bwd(f"up.{i}.contract.seq.1", g, None, 0)
+            gxa, gxb = self.block_bwd(f"up.{i}.contract.seq.0", g1, None, 0)
+            skip_g[i].append(gxb)
+            up_in, ta = self.convt[i]
+            Cup, Cout = w[i + 1], w[i]
+            wpk_d = self.pack(P[f"up.{i}.up.weight"], 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
+            dx = self.empty(N, up_in.H, up_in.W, Cup)
+            L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
+                        ptr(self.G[f"up.{i}.up.bias"]), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+            g = dx
+        skip_g[6].append(g)
+        for i in reversed(range(6)):
+            gs = skip_g[i + 1]
+            g1, _ = self.block_bwd(f"down.{i}.seq.0.seq.1", gs[0], gs[1] if len(gs) > 1 else None, 1)
+            gx, _ = self.block_bwd(f"down.{i}.seq.0.seq.0", g1, None, 0)
+            skip_g[i].append(gx)
+        gs = skip_g[0]
+        g1, _ = self.block_bwd("in_conv.seq.1", gs[0], gs[1], 0)
+        self.block_bwd("in_conv.seq.0", g1, None, 0)
+        return [self.G[k] for k in self.names]
+
+
+class _DetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, names, *params):
+        run = _DetRun(mod, x, names, [p.detach() for p in params], mod.training)
+        pred = run.forward()
+        ctx.run = run
+        return pred
+
+    @staticmethod
+    def backward(ctx, gpred):
+        grads = ctx.run.backward(gpred)
+        ctx.run = None
+        return (None, None, None, *grads)
+
+
+class DetectionModel(nn.Module):
+    """Text detection U-Net (reference: ocrs_models/models.py:93-143).
+
+    ``forward(x: (B,1,H,W) float in [-0.5,0.5]) -> (B,1,H,W)`` text probabilities.
+    Activation storage dtype: fp32 (parity mode) unless ``act_dtype=torch.bfloat16`` is given or the call
+    happens under ``torch.autocast(dtype=torch.bfloat16)`` (throughput mode; fp32 accumulation/statistics).
+    """
+
+    def __init__(self, act_dtype: torch.dtype | None = None):
+        super().__init__()
+        depth_scale = DEPTH_SCALE
+        self.depth_scale = depth_scale
+        self.in_conv = DoubleConv(1, depth_scale[0])
+        self.down = nn.ModuleList(Down(depth_scale[i], depth_scale[i + 1]) for i in range(len(depth_scale) - 1))
+        self.up = nn.ModuleList(Up(depth_scale[i + 1], depth_scale[i], depth_scale[i]) for i in range(len(depth_scale) - 1))
+        self.out_conv = nn.Sequential(nn.Conv2d(depth_scale[0], 1, kernel_size=1), nn.Sigmoid())
+        self.act_dtype = act_dtype
+
+    def _act_dtype(self):
+        if self.act_dtype is not None:
+            return self.act_dtype
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("ocrs_models_amd.DetectionModel runs on MI355X only (no CPU path); move the model and input to 'cuda'")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"expected (B,1,H,W) input, got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("parameters must be contiguous fp32")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _DetFn.apply(x, self, names, *params)
+        run = _DetRun(self, x, names, [p.detach() for p in params], self.training)
+        return run.forward()

@@ -1,0 +1,100 @@
+"""Optimiser side of the train step: a multi-tensor Adam with ``torch.optim.Adam``'s constructor and
+``clip_grad_norm_`` with ``torch.nn.utils.clip_grad_norm_``'s semantics (reference call sites:
+ocrs_models/train_detection.py:95-97,378; ocrs_models/train_rec.py:116,148-151,381-382), each a single
+HIP launch over all parameter tensors."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ._lib import lib, ptr
+
+
+class _Table:
+    """Device pointer table {param, grad, exp_avg, exp_avg_sq, numel} + (tensor, chunk) work list."""
+
+    def __init__(self, params, grads, m=None, v=None):
+        L = lib()
+        chunk = L.opt_chunk()
+        dev = params[0].device
+        rows, chunks = [], []
+        for i, (p, g) in enumerate(zip(params, grads)):
+            rows.append([p.data_ptr(), g.data_ptr(), m[i].data_ptr() if m else 0, v[i].data_ptr() if v else 0, p.numel()])
+            chunks += [[i, c] for c in range((p.numel() + chunk - 1) // chunk)]
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        self.nchunks = len(chunks)
+        self.key = tuple(r[1] for r in rows)
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam (lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) as one kernel launch."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._tables = {}
+        self.grad_scale = None  # optional device fp32[1] multiplied into every gradient (fused clip)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        L = lib()
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if not p.is_cuda or p.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise RuntimeError("ocrs_models_amd.optim.Adam needs contiguous fp32 CUDA parameters and gradients")
+            key = tuple(p.grad.data_ptr() for p in ps) + tuple(p.data_ptr() for p in ps)
+            tb = self._tables.get(gi)
+            if tb is None or tb[0] != key:
+                t = _Table(ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps])
+                tb = (key, t)
+                self._tables[gi] = tb
+            t = tb[1]
+            for p in ps:
+                self.state[p]["step"] += 1
+            step = self.state[ps[0]]["step"]
+            b1, b2 = group["betas"]
+            step_size = group["lr"] / (1.0 - b1 ** step)
+            bc2_sqrt = math.sqrt(1.0 - b2 ** step)
+            L.adam_step(ptr(t.table), ptr(t.chunks), t.nchunks, b1, b2, group["eps"], step_size, bc2_sqrt, ptr(self.grad_scale))
+        self.grad_scale = None
+        return loss
+
+
+_clip_cache = {}
+
+
+@torch.no_grad()
+def clip_grad_norm_(parameters, max_norm: float, scale_in_place: bool = True):
+    """Total L2 norm of all gradients; gradients scaled by ``min(1, max_norm / (norm + 1e-6))``.
+
+    Returns the pre-clip norm as a 0-d device tensor (like torch).  With ``scale_in_place=False`` the
+    gradients are left untouched and ``(norm, coef)`` is returned so the scale can be fused into ``Adam.step``
+    (``opt.grad_scale = coef``).
+    """
+    L = lib()
+    ps = [p for p in ([parameters] if isinstance(parameters, torch.Tensor) else list(parameters)) if p.grad is not None]
+    if not ps:
+        return torch.zeros(())
+    key = tuple(p.grad.data_ptr() for p in ps)
+    t = _clip_cache.get(key)
+    if t is None:
+        _clip_cache.clear()
+        t = _Table(ps, [p.grad for p in ps])
+        _clip_cache[key] = t
+    dev = ps[0].device
+    sumsq = torch.empty(1, dtype=torch.float64, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    L.clip_grad_norm(ptr(t.table), ptr(t.chunks), t.nchunks, float(max_norm), ptr(sumsq), ptr(out[0:1]), ptr(out[1:2]), 1 if scale_in_place else 0)
+    if scale_in_place:
+        return out[0]
+    return out[0], out[1:2]
