@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Train-step throughput of the detection hot path on MI355X (BASELINE.json configs[1]):
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+step = forward + balanced BCE + zero_grad + backward (+ RCCL gradient all-reduce, overlapped) + Adam on a batch of
+synthetic greyscale tiles, B=32 x 1x1024x1024 per GPU (weak scaling), bf16 activations / fp32 accumulate+params,
+random-init weights (seed 1234 as train_detection.py:337).  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel family timed live with HIP events on the launch stream over the timed
+                  region; achieved = algorithmic bytes (DESIGN.md "Algorithmic bytes") / event time.
+  cpu_baseline -- oracle/ (the CPU restatement of the reference, stock ATen CPU ops) timed on this host, N=1 only.
+  crnn         -- line-crops/s of the CRNN recognition train step (configs[2]) once that path exists.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
+
+
+def alg_bytes(name, a, sz):
+    """Algorithmic HBM bytes of one launch of a kernel family, from its C-ABI arguments.
+
+    SURVEY.md 8(d) model: a fused pass reads its inputs once and writes its outputs once.
+    """
+    if name == "dwpw_fwd":  # (xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, dt)
+        return a[11] * a[12] * a[13] * (a[2] + a[3] + a[10]) * sz
+    if name == "pw_bwd":  # (xa,xb,Ca,Cb,tra,trb,wdw,g1,g2,pooled,z,bn,coef,wpk_d,du,dwpw,Cout,N,H,W,dt): g + z + x in, du out
+        P, cin, cout = a[17] * a[18] * a[19], a[2] + a[3], a[16]
+        g = cout / 4 if a[9] else cout * (2 if a[8] else 1)
+        return P * (g + cout + 2 * cin) * sz
+    if name == "dw_bwd":  # (xa,xb,Ca,Cb,tra,trb,wdw,du,gxa,gxb,dwdw,N,H,W,dt): du + x in, gx out
+        return a[11] * a[12] * a[13] * 3 * (a[2] + a[3]) * sz
+    if name == "bn_bwd_reduce":  # (g1,g2,pooled,z,bn,saved,gsum,C,N,H,W,dt)
+        P, c = a[8] * a[9] * a[10], a[7]
+        g = c / 4 if a[2] else c * (2 if a[1] else 1)
+        return P * (g + c) * sz
+    if name == "convt_fwd":  # (x,tr,wpk,bias,out,Cup,Cout,N,h,w,H,W,dt)
+        return a[7] * (a[8] * a[9] * a[5] + a[10] * a[11] * a[6]) * sz
+    if name == "convt_bwd":  # (x,tr,g,wpk_d,dx,dW,dbias,Cup,Cout,N,h,w,H,W,dt): x + g in, dx out
+        return a[9] * (2 * a[10] * a[11] * a[7] + a[12] * a[13] * a[8]) * sz
+    if name == "maxpool_fwd":  # (z,tr,out,C,N,H,W,dt)
+        return a[4] * a[5] * a[6] * a[3] * 1.25 * sz
+    return 0.0
+
+
+FAMILIES = ["dwpw_fwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce", "convt_fwd", "convt_bwd", "maxpool_fwd"]
+
+
+def cpu_baseline(steps=3, B=2, H=1024, W=1024):
+    """oracle/ detection train step (fp32, as the reference trains) on the host cores: images/s."""
+    import numpy as np
+
+    from oracle import detection as odet
+    from oracle import losses as olosses
+    from oracle import optim as ooptim
+    from oracle.params import detection_specs, make_state
+
+    P, Bf = make_state(detection_specs(), 1234)
+    r = np.random.RandomState(0)
+    x = torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, H, W)).astype(np.float32))
+    m = torch.from_numpy((r.uniform(0, 1, (B, 1, H, W)) > 0.9).astype(np.float32))
+    opt = ooptim.Adam(P.values())
+
+    def step():
+        pred = odet.forward(P, Bf, x, True)
+        loss = olosses.balanced_bce(pred, m)
+        grads = torch.autograd.grad(loss, list(P.values()))
+        opt.step(grads)
+        return loss.item()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(B / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of B={B} 1x{H}x{W} fp32 (oracle/: stock ATen CPU ops, {os.cpu_count()} logical cpus)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import ocrs_models_amd as oa
+    from ocrs_models_amd._lib import lib
+    from ocrs_models_amd.ddp import DistributedDataParallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    model = oa.DetectionModel(act_dtype=act).to(dev)
+    model.train()
+    net = DistributedDataParallel(model) if world > 1 else model
+    opt = oa.optim.Adam(model.parameters())
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    B, S = args.batch, args.size
+    img = torch.rand(B, 1, S, S, generator=g, device=dev) - 0.5
+    mask = (torch.rand(B, 1, S, S, generator=g, device=dev) > 0.9).float()
+
+    def step():
+        pred = net(img)
+        loss = oa.balanced_cross_entropy_loss(pred, mask)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    L = lib()
+    if not args.no_roofline:
+        L.timing = {k: [] for k in FAMILIES}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timing, L.timing = L.timing, None
+    final_loss = float(loss.item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    out = {
+        "metric": "detection train-step images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"detection U-Net train step (fwd+balanced BCE+bwd+Adam), {B}x1x{S}x{S} greyscale tiles per GPU",
+                   "global_batch": B * world, "tile": S, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
+    }
+    if rank == 0 and timing is not None:
+        sz = 2 if args.dtype == "bf16" else 4
+        fam = {}
+        for k, recs in timing.items():
+            if not recs:
+                continue
+            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+            tot_b = sum(alg_bytes(k, a, sz) for _, _, a in recs)
+            fam[k] = (tot_ms, tot_b, len(recs))
+        if fam:
+            dom = max(fam, key=lambda k: fam[k][0])
+            tot_ms, tot_b, n = fam[dom]
+            ach = tot_b / (tot_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
+                               "avg_launch_ms": round(tot_ms / n, 4), "alg_bytes_per_launch": round(tot_b / n)}
+            out["kernel_families_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+            out["kernel_families_gbs"] = {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in fam.items() if v[0] > 0}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,14 +67,28 @@ class _Lib:
             setattr(self, "_raw_" + name, fn)
             setattr(self, name[5:], self._wrap(name, fn, res, sig))
 
-    @staticmethod
-    def _wrap(name, fn, res, sig):
+    # name (without the ocrs_ prefix) -> list of (start_event, end_event, args); None = timing off.
+    # Used by bench.py to time the dominant kernel family live, with events on the launch stream.
+    timing = None
+
+    def _wrap(self, name, fn, res, sig):
         has_stream = sig.endswith("s")
+        short = name[5:]
+        owner = self
 
         def call(*args):
+            rec = None
+            if owner.timing is not None and short in owner.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rec = (e0, e1, args)
             if has_stream:
-                args = args + (torch.cuda.current_stream().cuda_stream,)
-            r = fn(*args)
+                r = fn(*args, torch.cuda.current_stream().cuda_stream)
+            else:
+                r = fn(*args)
+            if rec is not None:
+                rec[1].record()
+                owner.timing[short].append(rec)
             if res == "i" and sig and r != 0:
                 raise RuntimeError(f"{name} failed: {_ERR.get(r, r)}")
             return r

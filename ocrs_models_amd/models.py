@@ -226,16 +226,29 @@ class _DetRun:
         L, P, N, w = self.L, self.P, self.N, DEPTH_SCALE
         H, W = self.HW
         flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=self.dev)
-        self.G, off = {}, 0
-        for k in self.names:
-            n = P[k].numel()
-            self.G[k] = flat[off:off + n].view_as(P[k])
-            off += n
+        # flat gradient buffer laid out in backward-completion order (so DP buckets are contiguous ranges)
+        order = ["out_conv"] + [f"up.{i}" for i in range(6)] + [f"down.{i}" for i in reversed(range(6))] + ["in_conv"]
+        self.G, off, stage_end = {}, 0, {}
+        for stage in order:
+            for k in self.names:
+                if k.startswith(stage + "."):
+                    n = P[k].numel()
+                    self.G[k] = flat[off:off + n].view_as(P[k])
+                    off += n
+            stage_end[stage] = off
+        bucketer = getattr(self.mod, "_grad_bucketer", None)
+        done = [0]
+
+        def stage_done(stage):
+            if bucketer is not None:
+                bucketer.ready(flat, done[0], stage_end[stage])
+            done[0] = stage_end[stage]
         gpred = gpred.contiguous().float()
         up = self.head_in
         g = self.empty(N, H, W, 8)
         L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(self.G["out_conv.0.weight"]),
                    ptr(self.G["out_conv.0.bias"]), N * H * W, self.dt)
+        stage_done("out_conv")
         skip_g = [[] for _ in range(7)]
         for i in range(6):
             g1, _ = self.block_bwd(f"up.{i}.contract.seq.1", g, None, 0)
@@ -247,16 +260,21 @@ class _DetRun:
             dx = self.empty(N, up_in.H, up_in.W, Cup)
             L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
                         ptr(self.G[f"up.{i}.up.bias"]), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+            stage_done(f"up.{i}")
             g = dx
         skip_g[6].append(g)
         for i in reversed(range(6)):
             gs = skip_g[i + 1]
             g1, _ = self.block_bwd(f"down.{i}.seq.0.seq.1", gs[0], gs[1] if len(gs) > 1 else None, 1)
             gx, _ = self.block_bwd(f"down.{i}.seq.0.seq.0", g1, None, 0)
+            stage_done(f"down.{i}")
             skip_g[i].append(gx)
         gs = skip_g[0]
         g1, _ = self.block_bwd("in_conv.seq.1", gs[0], gs[1], 0)
         self.block_bwd("in_conv.seq.0", g1, None, 0)
+        stage_done("in_conv")
+        if bucketer is not None:
+            bucketer.finish(flat)
         return [self.G[k] for k in self.names]
 
 
