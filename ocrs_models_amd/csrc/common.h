@@ -28,12 +28,9 @@ struct bf16 {
 };
 
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
-    return (unsigned short)(u >> 16);
-}
+// fp32 -> bf16 (round to nearest even): plain casts, which hipcc lowers to v_cvt_pk_bf16_f32 on gfx950
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
 template <class T>
 struct Elem;
@@ -70,7 +67,10 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
 __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
@@ -104,12 +104,16 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-// sum over the 16 lanes sharing (lane >> 4)
+// sum over the 16 lanes sharing (lane >> 4) = one DPP row; every lane of the row gets the sum (4 DPP adds, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float quad16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
     return v;
 }
 
@@ -189,6 +193,18 @@ struct Mma<float> {
     }
 };
 
+// sum over all lanes of the wave with the same (lane % CG), CG in {1,2,4}; every lane gets its class' sum
+template <int CG>
+__device__ __forceinline__ float lane_class_sum(float v) {
+    if (CG <= 1) v += dpp_f<0xB1>(v);  // xor 1
+    if (CG <= 2) v += dpp_f<0x4E>(v);  // xor 2
+    v += dpp_f<0x124>(v);              // row_ror:4
+    v += dpp_f<0x128>(v);              // row_ror:8
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // XCD-aware persistent tile schedule: block b runs on XCD (b % 8); give each XCD a contiguous
 // range of tiles so that neighbouring tiles (which share 3x3 halo rows) hit the same L2.
 struct TileSched {
@@ -209,7 +225,14 @@ struct TileSched {
     }
 };
 
+#include <stdlib.h>
+static inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 static inline int persistent_grid(long ntiles, int blocks_per_cu) {
+    static const int bpc_env = env_int("OCRS_BPC", 0);
+    if (bpc_env > 0) blocks_per_cu = bpc_env;
     long cap = (long)kNumCU * blocks_per_cu;
     long g = ntiles < cap ? ntiles : cap;
     if (g >= 8) g &= ~7L;

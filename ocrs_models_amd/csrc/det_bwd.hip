@@ -21,20 +21,67 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(GradSrc<T> gs, const T* _
     const long nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float mu[8], rs[8];
+    float mu[8], rs[8], sc[8], sh[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         mu[i] = saved[c0 + i];
         rs[i] = saved[C + c0 + i];
+        sc[i] = bn[c0 + i];
+        sh[i] = bn[C + c0 + i];
     }
-    for (long p = gtid / CG; p < P; p += nthr / CG) {
-        const PixIdx px = decode_pixel(p, H, W);
-        float gh[8], zv[8];
-        load_ghat8(gs, z, C, bn, p, px, H, W, c0, gh, zv);
+    if (!gs.pooled) {
+        for (long p = gtid / CG; p < P; p += nthr / CG) {
+            float g[8], zv[8];
+            load8(z + p * C + c0, zv);
+            load8(gs.g1 + p * C + c0, g);
+            if (gs.g2) {
+                float g2[8];
+                load8(gs.g2 + p * C + c0, g2);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            s1[i] += gh[i];
-            s2[i] = fmaf(gh[i], (zv[i] - mu[i]) * rs[i], s2[i]);
+                for (int i = 0; i < 8; ++i) g[i] += g2[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gh = fmaf(zv[i], sc[i], sh[i]) > 0.f ? g[i] : 0.f;
+                s1[i] += gh;
+                s2[i] = fmaf(gh, (zv[i] - mu[i]) * rs[i], s2[i]);
+            }
+        }
+    } else {
+        // one thread per 2x2 pooling window: the pooled gradient goes to the first maximal element (post-ReLU space)
+        const int Hp = H >> 1, Wp = W >> 1;
+        const long Pp = (P / ((long)H * W)) * Hp * Wp;
+        for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
+            const PixIdx q = decode_pixel(pp, Hp, Wp);
+            const long base = ((long)q.n * H + 2 * q.h) * W + 2 * q.w;
+            float g[8];
+            load8(gs.g1 + pp * C + c0, g);
+            if (gs.g2) {
+                float g2[8];
+                load8(gs.g2 + pp * C + c0, g2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] += g2[i];
+            }
+            float best[8], bz[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float zv[8];
+                load8(z + (base + (long)(k >> 1) * W + (k & 1)) * C + c0, zv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float y = fmaxf(fmaf(zv[i], sc[i], sh[i]), 0.f);
+                    if (k == 0 || y > best[i]) {
+                        best[i] = y;
+                        bz[i] = zv[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gh = best[i] > 0.f ? g[i] : 0.f;
+                s1[i] += gh;
+                s2[i] = fmaf(gh, (bz[i] - mu[i]) * rs[i], s2[i]);
+            }
         }
     }
 #pragma unroll
@@ -86,14 +133,18 @@ struct PwBwdCfg {
     static constexpr int NBO = COUT / COB;
     static constexpr int TPP_BF = TP + 8;  // transposed-tile pitch (elements)
     static constexpr int TPP_F = TP + 4;
+    static constexpr int TH = 8, TW = TP / 8;  // 8x32 / 8x16 / 8x8 pixel tiles
+    static constexpr int HP = (TW + 2) * (TH + 2);
 };
 
 template <class T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
                                                 const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
-                                                T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/, int H, int W, long P) {
+                                                T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/, Tiling2 tg) {
     using Cfg = PwBwdCfg<CIN, COUT>;
+    constexpr int TW = Cfg::TW, TH = Cfg::TH;
+    const int H = tg.H, W = tg.W;
     constexpr int TP = Cfg::TP, PTW = Cfg::PTW, MTD = Cfg::MTD, CGI = Cfg::CGI, CGO = Cfg::CGO, CGM = Cfg::CGM;
     constexpr int PITCH = Mma<T>::LDS_PITCH;
     constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
@@ -102,7 +153,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     T* tileD = reinterpret_cast<T*>(smem);               // [TP][PITCH]
     T* dzT = tileD + TP * PITCH;                         // [WTO*16][TPP]
     T* uT = dzT + WTO * 16 * TPP;                        // [WTI*16][TPP]
-    float* s_par = reinterpret_cast<float*>(smem + (((TP * PITCH + (WTO + WTI) * 16 * TPP) * sizeof(T) + 15) & ~15));
+    float* xs = reinterpret_cast<float*>(smem + (((TP * PITCH + (WTO + WTI) * 16 * TPP) * sizeof(T) + 15) & ~15));  // [HP][CGI*8]
+    float* s_par = xs + Cfg::HP * CGI * 8;
     float* s_trx = s_par;                // [3][CIN]
     float* s_wdw = s_par + 3 * CIN;      // [9][CIN]
     float* s_bn = s_par + 12 * CIN;      // [3][COUT]
@@ -131,17 +183,21 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     const int ci_base = (by % Cfg::NBI) * Cfg::CIB, co_base = (by / Cfg::NBI) * Cfg::COB;
     const bool do_dgrad = by == 0;
     const int pxl = tid / CGM, cg = tid % CGM;
+    const int ty = pxl / TW, tx = pxl % TW;
 
     f32x4 accw[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const long ntiles = (P + TP - 1) / TP;
-    TileSched ts(ntiles);
+    TileSched ts(tg.ntiles);
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const long p = t * TP + pxl;
-        const bool pv = p < P;
-        const PixIdx px = decode_pixel(pv ? p : 0, H, W);
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        PixIdx px;
+        px.n = org.n;
+        px.h = org.h0 + ty;
+        px.w = org.w0 + tx;
+        const bool pv = px.h < H && px.w < W;
+        const long p = pix_linear(px, H, W);
         f32x4 accd[PTW][MTD];
 #pragma unroll
         for (int a = 0; a < PTW; ++a)
@@ -183,42 +239,34 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
         if (do_dgrad) {
 #pragma unroll
             for (int a = 0; a < PTW; ++a) {
-                const long po = t * TP + (wave * PTW + a) * 16 + (lane & 15);
+                const int oq = (wave * PTW + a) * 16 + (lane & 15);
+                PixIdx q;
+                q.n = org.n;
+                q.h = org.h0 + oq / TW;
+                q.w = org.w0 + oq % TW;
+                const bool ov = q.h < H && q.w < W;
+                const long po = pix_linear(q, H, W);
 #pragma unroll
                 for (int b = 0; b < MTD; ++b) {
                     const int m0 = b * 16 + (lane >> 4) * 4;
-                    if (po < P && m0 < CIN) {
+                    if (ov && m0 < CIN) {
                         const f32x4 v = accd[a][b];
                         store4(du + po * CIN + m0, v[0], v[1], v[2], v[3]);
                     }
                 }
             }
         }
-        // ---- C: recompute u = dw3x3(x~) for this block's cin range -> uT
+        // ---- C: recompute u = dw3x3(x~) for this block's cin range -> uT (input tile + halo staged once in LDS)
         for (int kc = ci_base / (CGI * 8); kc < (ci_base + Cfg::CIB) / (CGI * 8); ++kc) {
-            const int c0 = (kc * CGI + cg) * 8;
+            __syncthreads();  // xs free (previous chunk / previous tile readers done)
+            stage_halo<T, CGI, TW, TH>(x, s_trx, CIN, kc * CGI * 8, org, H, W, xs, tid);
+            __syncthreads();
             if (cg < CGI) {
-                float u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (pv) {
+                const int c0 = (kc * CGI + cg) * 8;
+                float u[8];
+                dw_from_lds<CGI, TW>(xs, s_wdw, CIN, c0, cg, ty, tx, u);
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int hh = px.h + dy - 1;
-                        if (hh < 0 || hh >= H) continue;
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int ww = px.w + dx - 1;
-                            if (ww < 0 || ww >= W) continue;
-                            float v[8];
-                            load8(src_ptr(x, ((long)px.n * H + hh) * W + ww, c0), v);
-                            apply_tr8(v, s_trx, CIN, c0);
-                            const float* wt = s_wdw + (dy * 3 + dx) * CIN + c0;
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) u[i] = fmaf(wt[i], v[i], u[i]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (c0 - ci_base + i) * TPP + pxl, u[i]);
+                for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (c0 - ci_base + i) * TPP + pxl, pv ? u[i] : 0.f);
             }
         }
         __syncthreads();
@@ -257,21 +305,28 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 // ----------------------------------------------------------------------------------------------
 // depthwise backward: dx~[p][c] = sum_tap w[c][tap] * du[p - off(tap)][c];  dW[c][tap] = sum_p x~[p][c] * du[p - off(tap)][c]
 // 4 channels per thread (weights, transform and the 36 dW partials live in registers).
-template <class T>
-__global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [C][9]*/,
-                                                const T* __restrict__ du, T* __restrict__ gxa, T* __restrict__ gxb,
-                                                float* __restrict__ dwdw /*[C][9]*/, int H, int W, long P) {
-    extern __shared__ float s_dw[];  // [9][C]
+template <class T, int CG>
+__global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+                                                const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
+                                                T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/, Tiling2 tg) {
+    constexpr int TH = 8, TW = 32 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8;  // SC = channels of this block's slab
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float* ds = s_mem;             // [HP][SC] du tile + halo (fp32, 0 outside the image)
+    float* s_w = ds + HP * SC;     // [9][SC] weights, tap-major
     const int C = x.Ca + x.Cb;
-    for (int i = threadIdx.x; i < 9 * C; i += 256) s_dw[i] = 0.f;
-    __syncthreads();
-    const int CQ = C / 4;
-    const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long nthr = (long)gridDim.x * 256;
-    const int c0 = (int)(gtid % CQ) * 4;
-    float w[9][4], acc[9][4], sc[4], sh[4], lo[4];
+    const int H = tg.H, W = tg.W;
+    const int cb = blockIdx.y * SC;  // first channel of the slab
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * SC; i += 256) {
+        const int t = i / SC, c = i - t * SC;
+        s_w[i] = wdw[(cb + c) * 9 + t];
+    }
+    const int pxl = tid / CG, cg = tid % CG;
+    const int ty = pxl / TW, tx = pxl % TW;
+    const int c0 = cb + cg * 8;
+    float acc[9][8], sc[8], sh[8], lo[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const int c = c0 + i;
         const float* trp = c < x.Ca ? tra + c : trb + (c - x.Ca);
         const int trs = c < x.Ca ? x.Ca : x.Cb;
@@ -279,49 +334,67 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
         sh[i] = trp[trs];
         lo[i] = trp[2 * trs];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            w[t][i] = wdw[c * 9 + t];
-            acc[t][i] = 0.f;
-        }
+        for (int t = 0; t < 9; ++t) acc[t][i] = 0.f;
     }
-    for (long p = gtid / CQ; p < P; p += nthr / CQ) {
-        const PixIdx px = decode_pixel(p, H, W);
-        float xv[4];
-        load4(src_ptr(x, p, c0), xv);
+    const bool in_a = c0 < x.Ca;
+    const T* xsrc = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
+    T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
+    const int xp = in_a ? x.Ca : x.Cb;
+    TileSched ts(tg.ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        __syncthreads();
+        for (int it = tid; it < HP * CG; it += 256) {
+            const int hp = it / CG, g8 = it - hp * CG;
+            const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+            const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (h >= 0 && h < H && w >= 0 && w < W) load8(du + (((long)org.n * H + h) * W + w) * C + cb + g8 * 8, v);
+            store8(ds + (hp * CG + g8) * 8, v);
+        }
+        __syncthreads();
+        const int h = org.h0 + ty, w = org.w0 + tx;
+        if (h < H && w < W) {
+            const long p = ((long)org.n * H + h) * W + w;
+            float xv[8], g[8];
+            load8(xsrc + p * xp, xv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int hh = px.h - (dy - 1);
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ww = px.w - (dx - 1);
-                if (ww < 0 || ww >= W) continue;
-                float d[4];
-                load4(du + (((long)px.n * H + hh) * W + ww) * C + c0, d);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    g[i] = fmaf(w[dy * 3 + dx][i], d[i], g[i]);
-                    acc[dy * 3 + dx][i] = fmaf(xv[i], d[i], acc[dy * 3 + dx][i]);
-                }
+            for (int i = 0; i < 8; ++i) {
+                xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
+                g[i] = 0.f;
             }
-        }
-        if (c0 < x.Ca) {
-            if (gxa) store4(gxa + p * x.Ca + c0, g[0], g[1], g[2], g[3]);
-        } else {
-            if (gxb) store4(gxb + p * x.Cb + (c0 - x.Ca), g[0], g[1], g[2], g[3]);
+            // tap k pairs x~[p] with du[p - off(k)]: halo index (ty+1 - (k/3-1), tx+1 - (k%3-1)) = (ty + 2 - k/3, tx + 2 - k%3)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                float d[8], wk[8];
+                load8(ds + (((ty + 2 - k / 3) * (TW + 2) + (tx + 2 - k % 3)) * CG + cg) * 8, d);
+                load8(s_w + k * SC + cg * 8, wk);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    g[i] = fmaf(wk[i], d[i], g[i]);
+                    acc[k][i] = fmaf(xv[i], d[i], acc[k][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one tap at a time: keeps the 72 dW accumulators + one tap live, not all nine
+            }
+            if (gdst) store8(gdst + p * xp, g);
         }
     }
+    __syncthreads();
+    // block reduction of the 72 per-thread partials: DPP within the wave (lanes of equal channel group), then 4 waves via LDS
+    float* s_part = ds;  // reuse the tile buffer: [4 waves][9*SC]
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&s_dw[t * C + c0 + i], acc[t][i]);
+        for (int i = 0; i < 8; ++i) {
+            const float v = lane_class_sum<CG>(acc[t][i]);
+            if (lane < CG) s_part[wave * 9 * SC + t * SC + cg * 8 + i] = v;
+        }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * C; i += 256) {
-        const int t = i / C, c = i - t * C;
-        atomicAdd(&dwdw[c * 9 + t], s_dw[i]);
+    for (int i = tid; i < 9 * SC; i += 256) {
+        const int t = i / SC, c = i - t * SC;
+        const float v = s_part[i] + s_part[9 * SC + i] + s_part[18 * SC + i] + s_part[27 * SC + i];
+        atomicAdd(&dwdw[(cb + c) * 9 + t], v);
     }
 }
 
@@ -633,6 +706,8 @@ static inline int cg_grid(long items) { return ew_grid(items); }
 // wgrad-carrying persistent grids: each block flushes a weight-gradient tile with atomics, so make every block
 // chew through >= 8 pixel tiles when there are enough of them.
 static inline int wgrad_grid(long ntiles, int cap_blocks) {
+    static const int cap_env = env_int("OCRS_WGRAD_CAP", 0);
+    if (cap_env > 0) cap_blocks = cap_env;
     long g = ntiles / 8;
     if (g < 1) g = 1;
     if (g > cap_blocks) g = cap_blocks;
@@ -672,12 +747,12 @@ int ocrs_bn_bwd_finalize(const double* gsum, long count, int C, const float* gam
 }  // extern "C" (templates need C++ linkage)
 template <class T, int CIN, int COUT>
 static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
-                         int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int H, int W,
-                         long P, hipStream_t st) {
+                         int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int N, int H,
+                         int W, hipStream_t st) {
     using Cfg = PwBwdCfg<CIN, COUT>;
     constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
     const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + (Cfg::WTO + Cfg::WTI) * 16 * TPP) * sizeof(T) + 15) & ~15) +
-                        (12 * CIN + 6 * COUT) * sizeof(float);
+                        (Cfg::HP * Cfg::CGI * 8 + 12 * CIN + 6 * COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -687,10 +762,10 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     }
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
-    const long ntiles = (P + Cfg::TP - 1) / Cfg::TP;
-    const int gx = wgrad_grid(ntiles, 2048);
+    const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
+    const int gx = wgrad_grid(tg.ntiles, 2048);
     hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
-                       wpk_d, (T*)du, dwpw, H, W, P);
+                       wpk_d, (T*)du, dwpw, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -709,11 +784,11 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     OCRS_CHECK_ARG(xa && tra && wdw && g1 && z && bn && coef && wpk_d && du && dwpw && (Cb == 0 || trb));
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int Cin = Ca + Cb;
-    const long P = (long)N * H * W;
+    OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \
-        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, H, W, P, st) \
-                          : launch_pw_bwd<float, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, H, W, P, st);
+        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st) \
+                          : launch_pw_bwd<float, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
     PW_BWD_COMBOS(X)
 #undef X
     return OCRS_ERR_ARG;
@@ -725,17 +800,24 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     OCRS_CHECK_ARG(xa && tra && wdw && du && dwdw && (Ca + Cb) % 8 == 0 && Ca % 4 == 0 && (Cb == 0 || trb));
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int C = Ca + Cb;
-    const long P = (long)N * H * W;
-    const int grid = cg_grid(P * (C / 4));
-    const size_t smem = 9 * C * sizeof(float);
-    if (dtype == 1) {
-        Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
-        hipLaunchKernelGGL(k_dw_bwd<bf16>, dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, (const bf16*)du, (bf16*)gxa, (bf16*)gxb, dwdw, H, W, P);
-    } else {
-        Src2<float> x{(const float*)xa, (const float*)xb, Ca, Cb};
-        hipLaunchKernelGGL(k_dw_bwd<float>, dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, (const float*)du, (float*)gxa, (float*)gxb, dwdw, H, W,
-                           P);
+    OCRS_CHECK_ARG((long)N * H * W < (1L << 31) && (C < 32 || C % 32 == 0) && Ca % 8 == 0);
+    const int cg = C >= 32 ? 4 : C / 8;
+    const int gy = C / (cg * 8);
+#define DWB(T_, CG_)                                                                                                                      \
+    {                                                                                                                                     \
+        const Tiling2 tg = make_tiling2(N, H, W, 32 / CG_, 8);                                                                            \
+        const int HP = (32 / CG_ + 2) * 10;                                                                                               \
+        const size_t smem = ((HP > 36 ? HP : 36) * CG_ * 8 + 9 * CG_ * 8) * sizeof(float);                                                                \
+        Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
+        hipLaunchKernelGGL((k_dw_bwd<T_, CG_>), dim3(persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1), gy), dim3(256), smem, st, x, tra, trb, wdw, \
+                           (const T_*)du, (T_*)gxa, (T_*)gxb, dwdw, tg);                                                                   \
     }
+    if (dtype == 1) {
+        if (cg == 1) DWB(bf16, 1) else if (cg == 2) DWB(bf16, 2) else DWB(bf16, 4)
+    } else {
+        if (cg == 1) DWB(float, 1) else if (cg == 2) DWB(float, 2) else DWB(float, 4)
+    }
+#undef DWB
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

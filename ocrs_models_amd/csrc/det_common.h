@@ -12,13 +12,80 @@ struct PixIdx {
     int n, h, w;
 };
 __device__ __forceinline__ PixIdx decode_pixel(long p, int H, int W) {
+    // all tensors here have < 2^31 pixels (checked by the C entry points): 32-bit unsigned division only
     PixIdx r;
-    const long hw = (long)H * W;
-    r.n = (int)(p / hw);
-    const int rem = (int)(p - (long)r.n * hw);
-    r.h = rem / W;
-    r.w = rem - r.h * W;
+    const unsigned q = (unsigned)p, uw = (unsigned)W, uh = (unsigned)H;
+    const unsigned row = q / uw;
+    r.w = (int)(q - row * uw);
+    r.n = (int)(row / uh);
+    r.h = (int)(row - (unsigned)r.n * uh);
     return r;
+}
+
+// 2-D pixel tiling: a tile is TH x TW pixels of one image (TW = 1 << tw_shift, TH = TP >> tw_shift), so the
+// 3x3 halo rows of a tile are mostly fetched by the same workgroup (L1) instead of three different ones.
+struct Tiling {
+    int H, W, tw_shift, tiles_x, tiles_y, ntiles;
+};
+static inline Tiling make_tiling(int N, int H, int W, int TP) {
+    Tiling t;
+    int sh = 0;
+    while ((1 << sh) < W && (1 << sh) < 32 && (1 << sh) < TP) ++sh;
+    t.H = H; t.W = W; t.tw_shift = sh;
+    const int TW = 1 << sh, TH = TP >> sh;
+    t.tiles_x = (W + TW - 1) / TW;
+    t.tiles_y = (H + TH - 1) / TH;
+    t.ntiles = N * t.tiles_x * t.tiles_y;
+    return t;
+}
+struct TileOrg {
+    int n, h0, w0;
+};
+__device__ __forceinline__ TileOrg tile_origin(const Tiling& tg, int TP, int tile) {
+    TileOrg o;
+    const int tpi = tg.tiles_x * tg.tiles_y;
+    o.n = tile / tpi;
+    const int r = tile - o.n * tpi;
+    const int ty = r / tg.tiles_x;
+    o.h0 = ty * (TP >> tg.tw_shift);
+    o.w0 = (r - ty * tg.tiles_x) << tg.tw_shift;
+    return o;
+}
+// pixel `pxl` (0..TP) of the tile -> image coordinates; returns validity
+__device__ __forceinline__ bool tile_pixel(const Tiling& tg, const TileOrg& o, int pxl, PixIdx& px) {
+    px.n = o.n;
+    px.h = o.h0 + (pxl >> tg.tw_shift);
+    px.w = o.w0 + (pxl & ((1 << tg.tw_shift) - 1));
+    return px.h < tg.H && px.w < tg.W;
+}
+__device__ __forceinline__ long pix_linear(const PixIdx& px, int H, int W) { return ((long)px.n * H + px.h) * W + px.w; }
+
+// ---- compile-time 2-D tiles for the LDS-staged stencil kernels: TH x TW pixels, halo (TH+2) x (TW+2) -----------------
+template <int TW, int TH>
+struct HaloTile {
+    static constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HW_ * HH_;
+};
+struct Tiling2 {
+    int H, W, tiles_x, tiles_y, ntiles;
+};
+static inline Tiling2 make_tiling2(int N, int H, int W, int TW, int TH) {
+    Tiling2 t;
+    t.H = H; t.W = W;
+    t.tiles_x = (W + TW - 1) / TW;
+    t.tiles_y = (H + TH - 1) / TH;
+    t.ntiles = N * t.tiles_x * t.tiles_y;
+    return t;
+}
+template <int TW, int TH>
+__device__ __forceinline__ TileOrg tile_origin2(const Tiling2& tg, int tile) {
+    TileOrg o;
+    const int tpi = tg.tiles_x * tg.tiles_y;
+    o.n = tile / tpi;
+    const int r = tile - o.n * tpi;
+    const int ty = r / tg.tiles_x;
+    o.h0 = ty * TH;
+    o.w0 = (r - ty * tg.tiles_x) * TW;
+    return o;
 }
 
 // two-source (channel-concatenated) activation: channels [0,Ca) from a, [Ca,Ca+Cb) from b.
@@ -39,6 +106,94 @@ __device__ __forceinline__ const T* src_ptr(const Src2<T>& s, long pix, int c0) 
 __device__ __forceinline__ void apply_tr8(float (&v)[8], const float* tr, int C, int c0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], tr[c0 + i], tr[C + c0 + i]), tr[2 * C + c0 + i]);
+}
+
+// u[8] = depthwise 3x3 (zero padding 1) of the transformed input x~ at pixel px, channels c0..c0+7.
+// s_tr: [3][CIN] scale|shift|lo, s_w: [9][CIN] tap-major weights (both in LDS).
+template <class T>
+__device__ __forceinline__ void dw_compute8(const Src2<T>& x, const float* s_tr, const float* s_w, int CIN, int c0, const PixIdx& px, int H,
+                                            int W, float (&u)[8]) {
+    const T* base;
+    int pitch;
+    if (c0 < x.Ca) {
+        base = x.a + c0;
+        pitch = x.Ca;
+    } else {
+        base = x.b + (c0 - x.Ca);
+        pitch = x.Cb;
+    }
+    base += pix_linear(px, H, W) * pitch;
+    float sc[8], sh[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = s_tr[c0 + i];
+        sh[i] = s_tr[CIN + c0 + i];
+        lo[i] = s_tr[2 * CIN + c0 + i];
+        u[i] = 0.f;
+    }
+    // branchless taps: an out-of-image tap reads the (always valid) centre pixel and is multiplied by 0
+    const bool hv[3] = {px.h > 0, true, px.h < H - 1};
+    const bool wv[3] = {px.w > 0, true, px.w < W - 1};
+    // all 9 tap loads are issued first (raw, 4 or 8 VGPRs each) so that they overlap; the per-tap LDS weight reads
+    // are kept behind compiler barriers so they are not all hoisted (register pressure -> occupancy).
+    float v9[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool ok = hv[t / 3] && wv[t % 3];
+        load8(base + (ok ? ((t / 3 - 1) * W + (t % 3 - 1)) * pitch : 0), v9[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool ok = hv[t / 3] && wv[t % 3];
+        float(&v)[8] = v9[t];
+        if (t % 3 == 0) asm volatile("" ::: "memory");
+        const float* wt = s_w + t * CIN + c0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xt = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
+            u[i] = fmaf(ok ? wt[i] : 0.f, xt, u[i]);
+        }
+    }
+}
+
+// Stage x~ = max(x*scale+shift, lo) for channels [ch0, ch0 + CG*8) of the tile's halo region into LDS as fp32
+// xs[halo pixel][CG*8]; pixels outside the image are written as 0 (that IS the conv's zero padding), so the
+// tap loop needs no bounds checks.  Every input element is loaded, unpacked and transformed once (x1.3-1.6 halo).
+template <class T, int CG, int TW, int TH>
+__device__ __forceinline__ void stage_halo(const Src2<T>& x, const float* s_tr, int CIN, int ch0, const TileOrg& org, int H, int W,
+                                           float* xs, int tid) {
+    using HT = HaloTile<TW, TH>;
+    for (int it = tid; it < HT::HP * CG; it += 256) {
+        const int hp = it / CG, cg = it - hp * CG;
+        const int hy = hp / HT::HW_, hx = hp - hy * HT::HW_;
+        const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
+        const int c0 = ch0 + cg * 8;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+            load8(src_ptr(x, ((long)org.n * H + h) * W + w, c0), v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], s_tr[c0 + i], s_tr[CIN + c0 + i]), s_tr[2 * CIN + c0 + i]);
+        }
+        store8(xs + (hp * CG + cg) * 8, v);
+    }
+}
+
+// u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS.
+template <int CG, int TW>
+__device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
+                                            float (&u)[8]) {
+    constexpr int HWp = TW + 2;
+    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 8;  // top-left tap of this pixel
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v[8], wv[8];
+        load8(xc + ((t / 3) * HWp + (t % 3)) * CG * 8, v);
+        load8(s_w + t * CIN + c0, wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = fmaf(wv[i], v[i], u[i]);
+    }
 }
 
 // Gradient w.r.t. a block's post-activation output y, in one of two forms:

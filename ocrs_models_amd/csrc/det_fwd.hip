@@ -51,19 +51,29 @@ __global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int
 // D[cout][pixel] = sum_cin Wpw[cout][cin] * u[pixel][cin],  u = dw3x3(x~)   (channels = MFMA M, pixels = MFMA N)
 // so each lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 // ----------------------------------------------------------------------------------------------
+template <int CG>
+struct FwdTile {  // 8-row tiles; width chosen so that TP = 256 / CG pixels: 8x32, 8x16, 8x8
+    static constexpr int TH = 8, TW = 32 / CG, TP = TH * TW;
+};
+
 template <class T, int CG, int MT>
-__global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
-                                                  const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
-                                                  const void* __restrict__ wpk, T* __restrict__ z, double* __restrict__ gstat /*[2][COUT]*/,
-                                                  int CIN, int COUT, int H, int W, long P) {
-    constexpr int TP = 256 / CG;
+__global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+                                                                    const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
+                                                                    const void* __restrict__ wpk, T* __restrict__ z,
+                                                                    double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg) {
+    using FT = FwdTile<CG>;
+    constexpr int TW = FT::TW, TH = FT::TH, TP = FT::TP;
     constexpr int PTW = TP / 64;
     constexpr int KS = CG * 2;  // fp32 k-steps (of 4) per chunk
     constexpr int PITCH = Mma<T>::LDS_PITCH;
+    constexpr int HP = HaloTile<TW, TH>::HP;
+    constexpr bool LANE_STATS = MT <= 2;  // keep BN partial sums in registers across tiles, reduce once at the end
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* tile = reinterpret_cast<T*>(smem);                                                  // [TP][PITCH]
-    float* s_par = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));  // [12][CIN]: tr(3) | wdw(9)
-    float* s_stat = s_par + 12 * CIN;                                                       // [2][MT*16]
+    T* tile = reinterpret_cast<T*>(smem);                                                   // [TP][PITCH]  dw output (MFMA operand)
+    float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // [HP][CG*8]   transformed input + halo
+    float* s_par = xs + HP * CG * 8;                                                         // [12][CIN]: tr(3) | wdw(9, tap-major)
+    float* s_stat = s_par + 12 * CIN;                                                        // [2][MT*16]
+    const int H = tg.H, W = tg.W;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 3 * CIN; i += 256) {
@@ -72,19 +82,31 @@ __global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __rest
     }
     for (int i = tid; i < 9 * CIN; i += 256) {
         const int t = i / CIN, c = i - t * CIN;
-        s_par[3 * CIN + i] = wdw[c * 9 + t];  // tap-major in LDS
+        s_par[3 * CIN + i] = wdw[c * 9 + t];
     }
     for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
     __syncthreads();
 
     const int nkc = CIN / (CG * 8);
     const int pxl = tid / CG, cg = tid % CG;
-    const long ntiles = (P + TP - 1) / TP;
-    TileSched ts(ntiles);
+    const int ty = pxl / TW, tx = pxl % TW;
+    // output pixels of this lane (MFMA N index): fixed position inside every tile
+    int oty[PTW], otx[PTW];
+#pragma unroll
+    for (int a = 0; a < PTW; ++a) {
+        const int q = (wave * PTW + a) * 16 + (lane & 15);
+        oty[a] = q / TW;
+        otx[a] = q % TW;
+    }
+    float ls1[LANE_STATS ? MT : 1][4], ls2[LANE_STATS ? MT : 1][4];
+#pragma unroll
+    for (int b = 0; b < (LANE_STATS ? MT : 1); ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ls1[b][r] = ls2[b][r] = 0.f;
+
+    TileSched ts(tg.ntiles);
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const long p = t * TP + pxl;
-        const bool pv = p < P;
-        PixIdx px = decode_pixel(pv ? p : 0, H, W);
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
         f32x4 acc[PTW][MT];
 #pragma unroll
         for (int a = 0; a < PTW; ++a)
@@ -92,27 +114,10 @@ __global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __rest
             for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int kc = 0; kc < nkc; ++kc) {
-            const int c0 = (kc * CG + cg) * 8;
-            float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (pv) {
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int hh = px.h + dy - 1;
-                    if (hh < 0 || hh >= H) continue;
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int ww = px.w + dx - 1;
-                        if (ww < 0 || ww >= W) continue;
-                        float v[8];
-                        load8(src_ptr(x, ((long)px.n * H + hh) * W + ww, c0), v);
-                        apply_tr8(v, s_par, CIN, c0);
-                        const float* wt = s_par + (3 + dy * 3 + dx) * CIN + c0;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) u[i] = fmaf(wt[i], v[i], u[i]);
-                    }
-                }
-            }
-            if (kc) __syncthreads();  // previous chunk's fragment reads are done
+            stage_halo<T, CG, TW, TH>(x, s_par, CIN, kc * CG * 8, org, H, W, xs, tid);
+            __syncthreads();  // xs ready; previous chunk's MFMA fragment reads of `tile` are also done
+            float u[8];
+            dw_from_lds<CG, TW>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);
             store8(tile + pxl * PITCH + cg * 8, u);
             __syncthreads();
             typename Mma<T>::Frag pf[PTW];
@@ -126,16 +131,17 @@ __global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __rest
             }
         }
         // epilogue: store z (4 consecutive channels per lane) + per-channel sum / sum of squares
+        const long tile_base = ((long)org.n * H + org.h0) * W + org.w0;
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
             const int m0 = b * 16 + (lane >> 4) * 4;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < PTW; ++a) {
-                const long po = t * TP + (wave * PTW + a) * 16 + (lane & 15);
-                if (po < P && m0 < COUT) {
+                const bool ov = org.h0 + oty[a] < H && org.w0 + otx[a] < W;
+                if (ov && m0 < COUT) {
                     const f32x4 v = acc[a][b];
-                    store4(z + po * COUT + m0, v[0], v[1], v[2], v[3]);
+                    store4(z + (tile_base + (long)oty[a] * W + otx[a]) * COUT + m0, v[0], v[1], v[2], v[3]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float q = Elem<T>::round(v[r]);  // statistics of what the consumer will read
@@ -144,16 +150,37 @@ __global__ __launch_bounds__(256) void k_dwpw_fwd(Src2<T> x, const float* __rest
                     }
                 }
             }
+            if constexpr (LANE_STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ls1[b][r] += s1[r];
+                    ls2[b][r] += s2[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
+                    if ((lane & 15) == 0) {
+                        atomicAdd(&s_stat[m0 + r], a1);
+                        atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (LANE_STATS) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m0 = b * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
+                const float a1 = quad16_sum(ls1[b][r]), a2 = quad16_sum(ls2[b][r]);
                 if ((lane & 15) == 0) {
                     atomicAdd(&s_stat[m0 + r], a1);
                     atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
                 }
             }
         }
-        __syncthreads();  // tile buffer is rewritten by the next iteration
     }
     __syncthreads();
     for (int c = tid; c < COUT; c += 256) {
@@ -379,14 +406,16 @@ long ocrs_pack_frags_bytes(int K, int M, int dtype) { return (long)((K + 31) / 3
 }  // extern "C" (templates need C++ linkage)
 template <class T, int CG, int MT>
 static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                           double* gstat, int COUT, int H, int W, long P, hipStream_t st) {
-    constexpr int TP = 256 / CG;
+                           double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
+    using FT = FwdTile<CG>;
+    constexpr int TP = FT::TP;
     const int CIN = Ca + Cb;
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
-    const long ntiles = (P + TP - 1) / TP;
-    const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + (12 * CIN + 2 * MT * 16) * sizeof(float);
-    const int grid = persistent_grid(ntiles, 8);
-    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, H, W, P);
+    const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
+    const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) +
+                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16) * sizeof(float);
+    const int grid = persistent_grid(tg.ntiles, 8);
+    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -395,12 +424,12 @@ extern "C" {
 }  // extern "C" (templates need C++ linkage)
 template <class T>
 static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                             double* gstat, int COUT, int H, int W, long P, hipStream_t st) {
+                             double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
     const int CIN = Ca + Cb;
     const int cg = CIN >= 32 ? 4 : CIN / 8;
     const int mt = (COUT + 15) / 16;
 #define DWPW_CASE(CG_, MT_) \
-    if (cg == CG_ && mt == MT_) return launch_dwpw_fwd<T, CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, H, W, P, st);
+    if (cg == CG_ && mt == MT_) return launch_dwpw_fwd<T, CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
     DWPW_CASE(1, 1) DWPW_CASE(2, 1) DWPW_CASE(2, 2) DWPW_CASE(4, 1) DWPW_CASE(4, 2) DWPW_CASE(4, 4) DWPW_CASE(4, 8) DWPW_CASE(4, 16)
 #undef DWPW_CASE
     return OCRS_ERR_ARG;
@@ -419,9 +448,9 @@ int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* t
     OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     if (hipMemsetAsync(gstat, 0, 2 * Cout * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
-    const long P = (long)N * H * W;
-    return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, H, W, P, st)
-                      : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, H, W, P, st);
+    OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
+    return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st)
+                      : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st);
 }
 
 // First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] (zeroed here).

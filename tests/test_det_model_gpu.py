@@ -53,7 +53,10 @@ def test_detection_fp32_matches_golden(dev, case):
         if step in (0, 2):
             sd = m.state_dict()
             for k in golden_keys(G, f"{case}/f32/state{step + 1}"):
-                tol = 0 if k.endswith("num_batches_tracked") else (4e-3 if step == 0 else 8e-3)
+                # Adam's first steps move every element by ~lr*sign(g): ONE element whose gradient is ~0 (sign decided by
+                # fp32 noise) moves a 64-element bias by 5e-3 relL2, so this is a loose sanity bound, the tight checks
+                # are the gradient comparisons above and test_adam_and_clip_match_torch
+                tol = 0 if k.endswith("num_batches_tracked") else (1e-2 if step == 0 else 2e-2)
                 e = compare_to_golden(G, f"{case}/f32/state{step + 1}/{k}", sd[k], 0, atol=1e-6)
                 assert e <= tol, (step, k, e)
 
