@@ -91,3 +91,13 @@ def compare_to_golden(npz, key, t, rtol, atol=0.0):
     e_norm = abs(np.linalg.norm(a) - ref_norm) / (ref_norm + atol + 1e-300)
     e_s = np.linalg.norm(s - s_ref) / (np.linalg.norm(s_ref) + atol + 1e-300)
     return float(max(e_norm, e_s))
+
+
+def golden_vs_golden(npz, key_a, key_b):
+    """relative error between two stored tensors/summaries (e.g. the reference's own fp32 vs fp64 result)."""
+    if f"{key_a}|full" in npz.files:
+        a, b = npz[f"{key_a}|full"].astype(np.float64), npz[f"{key_b}|full"].astype(np.float64)
+        return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+    a, b = npz[f"{key_a}|samples"].astype(np.float64), npz[f"{key_b}|samples"].astype(np.float64)
+    en = abs(float(npz[f"{key_a}|norm"]) - float(npz[f"{key_b}|norm"])) / (float(npz[f"{key_b}|norm"]) + 1e-300)
+    return float(max(en, np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)))

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import DET_CASES, compare_to_golden, det_inputs, golden_keys, load_npz
+from tests.golden_util import DET_CASES, compare_to_golden, det_inputs, golden_keys, golden_vs_golden, load_npz
 
 pytestmark = pytest.mark.gpu
 
@@ -43,12 +43,17 @@ def test_detection_fp32_matches_golden(dev, case):
             e64 = compare_to_golden(G, f"{case}/f64/pred", pred, 0)
             assert e64 < 1e-4, ("pred vs f64", e64)
             assert abs(loss.item() - float(G[f"{case}/f32/loss"])) < 1e-4 * abs(loss.item())
+            # SURVEY.md A.4 policy: err(build, fp64) <= 2 x err(reference fp32, fp64) per tensor (+ a small floor).
+            # (det1 is the minimum legal size: BN over 2..8 samples at the deep levels, the fp32 reference itself is
+            #  only good to ~1e-2 there; det2 sits at ~1e-5..1e-3.)
+            bad = {}
             for k, p in m.named_parameters():
                 e = compare_to_golden(G, f"{case}/f64/grad/{k}", p.grad, 0, atol=1e-7)
+                ref = golden_vs_golden(G, f"{case}/f32/grad/{k}", f"{case}/f64/grad/{k}")
                 worst[k] = e
-            bad = {k: v for k, v in worst.items() if v > 8e-3}
+                if e > 2 * ref + 3e-3:
+                    bad[k] = (e, ref)
             assert not bad, bad
-            assert float(np.median(list(worst.values()))) < 3e-3
         opt.step()
         if step in (0, 2):
             sd = m.state_dict()
