@@ -83,6 +83,43 @@ int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, un
 int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* lpx, const unsigned char* cls, const void* state,
                           const float* gout, float* gpred, long P, hipStream_t st);
 
+/* ------------------------------------------------------------------ recognition (CRNN) ------ */
+/* nn.Conv2d forward / dgrad, GRU input projections, nn.Linear as one implicit-GEMM kernel (ocrs_models/models.py:189-240, 245, 248). */
+int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
+                    int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st);
+/* weight gradients of Conv2d / Linear / GRU (autograd of the calls above). */
+int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA, int HB,
+                      int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
+/* Conv2d(1,32,3,p1) + ReLU + MaxPool2d(2) (models.py:180-187) fused, forward and backward. */
+int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st);
+int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
+                   hipStream_t st);
+/* BatchNorm2d + ReLU + MaxPool2d((2,2)|(2,1)) (models.py:197-199, 214-216, 231-233) forward and the pieces of its backward. */
+int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int PH, int PW, int dtype, hipStream_t st);
+int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,
+                       int dtype, hipStream_t st);
+int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* coef, void* dz, int C, int N, int H, int W, int PH, int PW, int dtype,
+                  hipStream_t st);
+/* BatchNorm2d + AvgPool2d((4,1)) + permute/reshape to (W, N, C*H) (models.py:241-242, 259-262). */
+int ocrs_avgpool_fwd(const void* z, const float* tr, float* seq, int C, int N, int H, int W, int dtype, hipStream_t st);
+int ocrs_avgpool_bn_reduce(const float* gseq, const void* z, const float* saved, double* gsum, int C, int N, int H, int W, int dtype, hipStream_t st);
+int ocrs_avgpool_dz(const float* gseq, const void* z, const float* coef, void* dz, int C, int N, int H, int W, int dtype, hipStream_t st);
+int ocrs_col_sum(const void* a, int ld, int C, float* out, long rows, int dtype, hipStream_t st);
+/* nn.GRU(128, 256, bidirectional, 2 layers) recurrence, one layer at a time (models.py:245, 264-266). */
+int ocrs_gru_layer_fwd(const float* gi, const float* whh_pk, const float* bhh, float* out, float* saved, int T, int N, hipStream_t st);
+int ocrs_gru_layer_bwd(const float* dout, const float* saved, const float* out, const float* whhT_pk, float* dgi, float* dgh, float* dhz, int T,
+                       int N, hipStream_t st);
+/* nn.LogSoftmax(dim=2) (models.py:250). */
+int ocrs_log_softmax_fwd(const void* logits, float* out, long rows, int C, int ld, int dtype, hipStream_t st);
+int ocrs_log_softmax_bwd(const float* lp, const float* g, void* dlogits, long rows, int C, int ld, int dtype, hipStream_t st);
+/* torch.nn.CTCLoss() (ocrs_models/train_rec.py:104,121): forward (alpha) and backward (beta + gradient). */
+int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, float* alpha, float* nll, float* loss,
+                 int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
+                 const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+/* preds.argmax(-1) + ctc_greedy_decode_text's collapse (train_rec.py:52; datasets/util.py:147-177). */
+int ocrs_ctc_greedy_decode(const float* lp, const long long* in_len, int* amax, int* labels, int* lens, int T, int N, int C, hipStream_t st);
+
 /* ------------------------------------------------------------------ optimiser ---------------- */
 /* table [nt][5] int64 {param, grad, exp_avg, exp_avg_sq, numel}; chunks [nchunks][2] int32 {tensor, chunk of ocrs_opt_chunk()}. */
 int ocrs_opt_chunk(void);

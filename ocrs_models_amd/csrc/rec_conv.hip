@@ -1,0 +1,752 @@
+// Dense convolution / GEMM kernels of the CRNN recogniser (gfx950).  Reference: ocrs_models/models.py:179-251.
+//
+//  k_conv_igemm    implicit-GEMM KHxKW convolution on MFMA (also plain GEMM with KH=KW=1): forward, dgrad (flipped weights),
+//                  GRU input projections, Linear.  Input tile (+halo) of 32 channels staged once in LDS; the nine taps read
+//                  MFMA B-fragments straight from that tile at shifted pixel offsets (no im2col buffer).
+//  k_wgrad_gather  weight gradient D[rowch][(tap, colch)] = sum_pos A[pos][rowch] * B[pos*stride + tap - pad][colch] (K = positions)
+//  k_conv0_*       first layer 1->32 3x3 + bias + ReLU + MaxPool2 fused (fwd, and bwd with window recompute)
+//  k_act_pool_fwd / k_rec_bn_reduce / k_dz_apply    BN+ReLU(+MaxPool (2,2)|(2,1)) forward / backward pieces
+//  k_avgpool_*     BN (no ReLU) + AvgPool2d((4,1)) on H=5, written directly as the (T, N, C) GRU input
+#include "det_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <class T, int MT, int TH, int TW>
+__global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int ldx, const void* __restrict__ wpk, T* __restrict__ out, int ldo,
+                                                    const float* __restrict__ bias, int relu, double* __restrict__ gstat, int Cin, int M,
+                                                    int MT_total, int N, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw) {
+    constexpr int PITCH = Mma<T>::LDS_PITCH;
+    constexpr int NTILES = TH * TW / 16, PTW = NTILES / 4, TPR = TW / 16;  // N-tiles per block / per wave / per tile row
+    static_assert(NTILES % 4 == 0 && TW % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);  // [(TH+KH-1)*(TW+KW-1)][PITCH]
+    const int HWp = TW + KW - 1, HHp = TH + KH - 1, HP = HWp * HHp;
+    float* s_stat = reinterpret_cast<float*>(smem + ((HP * PITCH * sizeof(T) + 15) & ~15));  // [2][MT*16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt0 = blockIdx.y * MT;
+    if (gstat) {
+        for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+    }
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+    const int ntiles = N * tiles_x * tiles_y;
+    const int ncc = Cin / 32;
+    int oty[PTW], otx[PTW];
+#pragma unroll
+    for (int a = 0; a < PTW; ++a) {
+        const int q = wave * PTW + a;
+        oty[a] = q / TPR;
+        otx[a] = (q % TPR) * 16;
+    }
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const int tpi = tiles_x * tiles_y;
+        const int n = (int)t / tpi, r = (int)t - n * tpi;
+        const int h0 = (r / tiles_x) * TH, w0 = (r % tiles_x) * TW;
+        f32x4 acc[PTW][MT];
+#pragma unroll
+        for (int a = 0; a < PTW; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < ncc; ++cc) {
+            __syncthreads();  // previous chunk's fragment reads done
+            for (int it = tid; it < HP * 4; it += 256) {
+                const int hp = it >> 2, g8 = it & 3;
+                const int hy = hp / HWp, hx = hp - hy * HWp;
+                const int h = h0 + hy - padh, w = w0 + hx - padw;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (h >= 0 && h < Hi && w >= 0 && w < Wi) load8(x + (((long)n * Hi + h) * Wi + w) * ldx + cc * 32 + g8 * 8, v);
+                store8(xs + hp * PITCH + g8 * 8, v);
+            }
+            __syncthreads();
+            for (int tap = 0; tap < KH * KW; ++tap) {
+                const int ky = tap / KW, kx = tap - ky * KW;
+                typename Mma<T>::Frag pf[PTW];
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(xs, PITCH, (oty[a] + ky) * HWp + otx[a] + kx, lane, 32);
+                const long kc = (long)tap * ncc + cc;
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, kc * MT_total + mt0 + b, lane);
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<8>(wf, pf[a], acc[a][b]);
+                }
+            }
+        }
+        // epilogue
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int m0 = (mt0 + b) * 16 + (lane >> 4) * 4;
+            float bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) bs[r4] = m0 + r4 < M ? bias[m0 + r4] : 0.f;
+            }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < PTW; ++a) {
+                const int h = h0 + oty[a], w = w0 + otx[a] + (lane & 15);
+                if (h < Ho && w < Wo && m0 < ldo) {
+                    float v[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        v[r4] = acc[a][b][r4] + bs[r4];
+                        if (relu) v[r4] = fmaxf(v[r4], 0.f);
+                    }
+                    store4(out + (((long)n * Ho + h) * Wo + w) * ldo + m0, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float q = Elem<T>::round(v[r4]);
+                        s1[r4] += q;
+                        s2[r4] = fmaf(q, q, s2[r4]);
+                    }
+                }
+            }
+            if (gstat) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float a1 = quad16_sum(s1[r4]), a2 = quad16_sum(s2[r4]);
+                    if ((lane & 15) == 0) {
+                        atomicAdd(&s_stat[b * 16 + (lane >> 4) * 4 + r4], a1);
+                        atomicAdd(&s_stat[MT * 16 + b * 16 + (lane >> 4) * 4 + r4], a2);
+                    }
+                }
+            }
+        }
+    }
+    if (gstat) {
+        __syncthreads();
+        for (int i = tid; i < MT * 16; i += 256) {
+            const int m = mt0 * 16 + i;
+            if (m < M) {
+                atomicAdd(&gstat[m], (double)s_stat[i]);
+                atomicAdd(&gstat[M + m], (double)s_stat[MT * 16 + i]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// D[ra][(tap, cb)] += sum_pos A~[pos][ra] * B[bpos(pos, tap)][cb];  A grid (N, hA, wA), B grid (N, HB, WB),
+// bpos = (i*stride + ky - padh, j*stride + kx - padw).  Block = (<=128 A channels) x (128 columns (tap, cb)); K = positions.
+// dW index = (ra * CB + cb) * ntaps + tap  (covers Conv2d [Cout][Cin][kh][kw] with A = dz, and ConvTranspose2d / Linear / GRU).
+template <class T>
+__global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, int ldA, int CA, const float* __restrict__ trA, const T* __restrict__ B,
+                                                      int ldB, int CB, float* __restrict__ dW, int N, int hA, int wA, int HB, int WB, int stride,
+                                                      int padh, int padw, int KH, int KW) {
+    constexpr int TP = 64;
+    constexpr int TPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* aT = reinterpret_cast<T*>(smem);  // [128][TPP]
+    T* bT = aT + 128 * TPP;              // [128][TPP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CA8 = (CA + 7) & ~7;
+    const int RB = CA8 < 128 ? CA8 : 128;  // rows handled by this block
+    const int nbi = (CA8 + 127) / 128;
+    const int ci_base = (blockIdx.y % nbi) * 128;
+    const int j_base = (blockIdx.y / nbi) * 128;
+    const int ntaps = KH * KW;
+    const int J = ntaps * CB;
+    const int rows_here = (CA8 - ci_base) < RB ? (CA8 - ci_base) : RB;
+    const int WTI = (rows_here + 15) / 16;
+    const long P = (long)N * hA * wA;
+    const long ntiles = (P + TP - 1) / TP;
+    {
+        const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid * 8; i < 256 * TPP; i += 256 * 8) store8(aT + i, zero8);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        for (int it = tid; it < TP * (rows_here / 8); it += 256) {
+            const int pxl = it / (rows_here / 8), c0 = (it % (rows_here / 8)) * 8;
+            const long p = t * TP + pxl;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p < P) {
+                load8(A + p * ldA + ci_base + c0, v);
+                if (trA) apply_tr8(v, trA, CA, ci_base + c0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Elem<T>::st(aT + (c0 + i) * TPP + pxl, v[i]);
+        }
+        for (int it = tid; it < TP * 16; it += 256) {
+            const int pxl = it >> 4, jj = (it & 15) * 8;
+            const long p = t * TP + pxl;
+            const int j0 = j_base + jj;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p < P && j0 < J) {
+                const PixIdx px = decode_pixel(p, hA, wA);
+                const int tap = j0 / CB, c0 = j0 - tap * CB;
+                const int Y = px.h * stride + tap / KW - padh, X = px.w * stride + tap % KW - padw;
+                if (Y >= 0 && Y < HB && X >= 0 && X < WB) load8(B + (((long)px.n * HB + Y) * WB + X) * ldB + c0, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Elem<T>::st(bT + (jj + i) * TPP + pxl, v[i]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tt = wave + 4 * j;
+            if (tt < WTI * 8) {
+                const int ti = tt % WTI, tj = tt / WTI;
+#pragma unroll
+                for (int pc = 0; pc < TP / 32; ++pc) {
+                    const typename Mma<T>::Frag fa = Mma<T>::load_p(aT + pc * 32, TPP, ti * 16, lane, 32);
+                    const typename Mma<T>::Frag fb = Mma<T>::load_p(bT + pc * 32, TPP, tj * 16, lane, 32);
+                    acc[j] = Mma<T>::template mma<8>(fa, fb, acc[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int tt = wave + 4 * j;
+        if (tt < WTI * 8) {
+            const int ti = tt % WTI, tj = tt / WTI;
+            const int jc = j_base + tj * 16 + (lane & 15);
+            if (jc < J) {
+                const int tap = jc / CB, cb = jc - tap * CB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ra = ci_base + ti * 16 + (lane >> 4) * 4 + r;
+                    if (ra < CA) atomicAdd(&dW[((long)ra * CB + cb) * ntaps + tap], acc[j][r]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// first layer: Conv2d(1,32,3,pad 1,bias) + ReLU + MaxPool2d(2) (models.py:180-187).  One thread per (pooled pixel, 8 out channels).
+template <class T>
+__global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img, const float* __restrict__ w /*[32][9]*/,
+                                                   const float* __restrict__ bias, T* __restrict__ out /*[N][H/2][W/2][32]*/, int N, int H, int W) {
+    const int Hp = H >> 1, Wp = W >> 1;
+    const long total = (long)N * Hp * Wp * 4;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long pp = it >> 2;
+        const int c0 = (int)(it & 3) * 8;
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        float patch[4][4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int h = 2 * q.h + dy - 1, ww = 2 * q.w + dx - 1;
+                patch[dy][dx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? img[((long)q.n * H + h) * W + ww] : 0.f;
+            }
+        float m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = w[(c0 + i) * 9 + k];
+            float best = 0.f;  // ReLU floor: max(relu(a), relu(b), ...) = max(0, a, b, ...)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox) {
+                    float s = bias[c0 + i];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) s = fmaf(wk[k], patch[oy + k / 3][ox + k % 3], s);
+                    best = fmaxf(best, s);
+                }
+            m[i] = best;
+        }
+        store8(out + pp * 32 + c0, m);
+    }
+}
+
+// backward of the fused first layer: dW [32][9], db [32] accumulated.  g = gradient w.r.t. the pooled output [N][H/2][W/2][32].
+template <class T>
+__global__ __launch_bounds__(256) void k_conv0_bwd(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                   const T* __restrict__ g, float* __restrict__ dW, float* __restrict__ db, int N, int H, int W) {
+    __shared__ float s_acc[32 * 10];
+    for (int i = threadIdx.x; i < 320; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int Hp = H >> 1, Wp = W >> 1;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid & 3) * 8;
+    float acc[8][10];
+    float wk[8][9], bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bs[i] = bias[c0 + i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[i][k] = w[(c0 + i) * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[i][k] = 0.f;
+    }
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid >> 2; pp < Pp; pp += nthr >> 2) {
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        float patch[4][4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int h = 2 * q.h + dy - 1, ww = 2 * q.w + dx - 1;
+                patch[dy][dx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? img[((long)q.n * H + h) * W + ww] : 0.f;
+            }
+        float gv[8];
+        load8(g + pp * 32 + c0, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float best = 0.f;
+            int bo = -1;  // -1: every candidate <= 0 -> ReLU kills the gradient
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = bs[i];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s = fmaf(wk[i][k], patch[(o >> 1) + k / 3][(o & 1) + k % 3], s);
+                if (s > best) {
+                    best = s;
+                    bo = o;
+                }
+            }
+            const float gi = bo >= 0 ? gv[i] : 0.f;
+            const int oy = bo >= 0 ? (bo >> 1) : 0, ox = bo >= 0 ? (bo & 1) : 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                // select the patch element of the winning position without dynamic register indexing
+                float pv = patch[k / 3][k % 3];
+                pv = (oy == 0 && ox == 1) ? patch[k / 3][1 + k % 3] : pv;
+                pv = (oy == 1 && ox == 0) ? patch[1 + k / 3][k % 3] : pv;
+                pv = (oy == 1 && ox == 1) ? patch[1 + k / 3][1 + k % 3] : pv;
+                acc[i][k] = fmaf(gi, pv, acc[i][k]);
+            }
+            acc[i][9] += gi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float v = lane_class_sum<4>(acc[i][k]);
+            if ((threadIdx.x & 63) < 4) atomicAdd(&s_acc[(c0 + i) * 10 + k], v);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 320; i += 256) {
+        const int c = i / 10, k = i - c * 10;
+        if (k < 9)
+            atomicAdd(&dW[c * 9 + k], s_acc[i]);
+        else
+            atomicAdd(&db[c], s_acc[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = maxpool_{PHxPW}( max(z*scale+shift, lo) )  (BN+ReLU+MaxPool, or ReLU+MaxPool with identity scale/shift)
+template <class T>
+__global__ __launch_bounds__(256) void k_act_pool_fwd(const T* __restrict__ z, const float* __restrict__ tr, T* __restrict__ out, int C, int N, int H,
+                                                      int W, int PH, int PW) {
+    const int CG = C / 8, Hp = H / PH, Wp = W / PW;
+    const long total = (long)N * Hp * Wp * CG;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long pp = it / CG;
+        const int c0 = (int)(it - pp * CG) * 8;
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        float m[8];
+        for (int k = 0; k < PH * PW; ++k) {
+            float v[8];
+            load8(z + (((long)q.n * H + q.h * PH + k / PW) * W + q.w * PW + k % PW) * C + c0, v);
+            apply_tr8(v, tr, C, c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = k == 0 ? v[i] : fmaxf(m[i], v[i]);
+        }
+        store8(out + pp * C + c0, m);
+    }
+}
+
+// BN-backward reductions through ReLU (+ max-pool PHxPW, gradient to the FIRST maximum of each window):
+// gsum[0][c] = sum ghat, gsum[1][c] = sum ghat * zhat.  g is at pooled resolution.
+template <class T>
+__global__ __launch_bounds__(256) void k_rec_bn_reduce(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
+                                                       const float* __restrict__ saved, double* __restrict__ gsum, int C, int N, int H, int W,
+                                                       int PH, int PW) {
+    extern __shared__ float s_acc[];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int CG = C / 8, Hp = H / PH, Wp = W / PW;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        float gv[8], best[8], bz[8];
+        load8(g + pp * C + c0, gv);
+        for (int k = 0; k < PH * PW; ++k) {
+            float zv[8];
+            load8(z + (((long)q.n * H + q.h * PH + k / PW) * W + q.w * PW + k % PW) * C + c0, zv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = fmaxf(fmaf(zv[i], bn[c0 + i], bn[C + c0 + i]), 0.f);
+                if (k == 0 || y > best[i]) {
+                    best[i] = y;
+                    bz[i] = zv[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gh = best[i] > 0.f ? gv[i] : 0.f;
+            s1[i] += gh;
+            s2[i] = fmaf(gh, (bz[i] - saved[c0 + i]) * saved[C + c0 + i], s2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&s_acc[c0 + i], s1[i]);
+        atomicAdd(&s_acc[C + c0 + i], s2[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+}
+
+// dz = coefA * ghat + coefB * z + coefC for every pixel (ghat routed through ReLU and the PHxPW max-pool); pixels outside
+// any window (floor mode) get coefB*z + coefC.  With bn = identity and coef = (1,0,0) this is the plain ReLU(+pool) backward.
+template <class T>
+__global__ __launch_bounds__(256) void k_dz_apply(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
+                                                  const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W, int PH, int PW) {
+    const int CG = C / 8;
+    // one thread per (window-grid cell incl. the partial last row/col, 8 channels)
+    const int Hc = (H + PH - 1) / PH, Wc = (W + PW - 1) / PW, Hp = H / PH, Wp = W / PW;
+    const long total = (long)N * Hc * Wc * CG;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long cell = it / CG;
+        const int c0 = (int)(it - cell * CG) * 8;
+        const PixIdx q = decode_pixel(cell, Hc, Wc);
+        const bool full = q.h < Hp && q.w < Wp;
+        float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (full) load8(g + (((long)q.n * Hp + q.h) * Wp + q.w) * C + c0, gv);
+        float zs[4][8], best[8];
+        int bk[8];
+        for (int k = 0; k < PH * PW; ++k) {
+            const int h = q.h * PH + k / PW, w = q.w * PW + k % PW;
+            if (h < H && w < W) {
+                load8(z + (((long)q.n * H + h) * W + w) * C + c0, zs[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float y = fmaxf(fmaf(zs[k][i], bn[c0 + i], bn[C + c0 + i]), 0.f);
+                    if (k == 0 || y > best[i]) {
+                        best[i] = y;
+                        bk[i] = k;
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < PH * PW; ++k) {
+            const int h = q.h * PH + k / PW, w = q.w * PW + k % PW;
+            if (h < H && w < W) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float gh = (full && bk[i] == k && best[i] > 0.f) ? gv[i] : 0.f;
+                    o[i] = fmaf(coef[c0 + i], gh, fmaf(coef[C + c0 + i], zs[k][i], coef[2 * C + c0 + i]));
+                }
+                store8(dz + (((long)q.n * H + h) * W + w) * C + c0, o);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d (no ReLU) + AvgPool2d((4,1)) on H=5 (models.py:234-242) written as the GRU input seq[t=w][n][c] (fp32):
+//   seq = mean_{h<4}(z[n][h][w][c]) * scale + shift
+template <class T>
+__global__ __launch_bounds__(256) void k_avgpool_fwd(const T* __restrict__ z, const float* __restrict__ tr, float* __restrict__ seq, int C, int N, int H,
+                                                     int W) {
+    const int CG = C / 8;
+    const long total = (long)N * W * CG;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long nw = it / CG;
+        const int c0 = (int)(it - nw * CG) * 8;
+        const int n = (int)(nw / W), w = (int)(nw - (long)n * W);
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int h = 0; h < 4; ++h) {
+            float v[8];
+            load8(z + (((long)n * H + h) * W + w) * C + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = fmaf(s[i] * 0.25f, tr[c0 + i], tr[C + c0 + i]);
+        store8(seq + ((long)w * N + n) * C + c0, s);
+    }
+}
+
+// reductions for its backward: ghat[n][h<4][w][c] = gseq[w][n][c] / 4, row 4: 0.  BN count = N*H*W.
+template <class T>
+__global__ __launch_bounds__(256) void k_avgpool_bn_reduce(const float* __restrict__ gseq, const T* __restrict__ z, const float* __restrict__ saved,
+                                                           double* __restrict__ gsum, int C, int N, int H, int W) {
+    extern __shared__ float s_acc[];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int CG = C / 8;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long nw = gtid / CG; nw < (long)N * W; nw += nthr / CG) {
+        const int n = (int)(nw / W), w = (int)(nw - (long)n * W);
+        float gv[8];
+        load8(gseq + ((long)w * N + n) * C + c0, gv);
+        float zs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int h = 0; h < 4; ++h) {
+            float v[8];
+            load8(z + (((long)n * H + h) * W + w) * C + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zs[i] += (v[i] - saved[c0 + i]) * saved[C + c0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s1[i] += gv[i];
+            s2[i] = fmaf(gv[i] * 0.25f, zs[i], s2[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&s_acc[c0 + i], s1[i]);
+        atomicAdd(&s_acc[C + c0 + i], s2[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_avgpool_dz(const float* __restrict__ gseq, const T* __restrict__ z, const float* __restrict__ coef,
+                                                    T* __restrict__ dz, int C, int N, int H, int W) {
+    const int CG = C / 8;
+    const long total = (long)N * H * W * CG;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+        const long p = it / CG;
+        const int c0 = (int)(it - p * CG) * 8;
+        const PixIdx q = decode_pixel(p, H, W);
+        float zv[8], gv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+        load8(z + p * C + c0, zv);
+        if (q.h < 4) load8(gseq + ((long)q.w * N + q.n) * C + c0, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf(coef[c0 + i], gv[i] * 0.25f, fmaf(coef[C + c0 + i], zv[i], coef[2 * C + c0 + i]));
+        store8(dz + p * C + c0, o);
+    }
+}
+
+// per-column sum of a [rows][ld] fp32/bf16 matrix (bias gradients)
+template <class T>
+__global__ __launch_bounds__(256) void k_col_sum(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows) {
+    extern __shared__ float s_acc[];
+    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int c = threadIdx.x % 128;
+    const int sub = threadIdx.x / 128;
+    for (int cb = 0; cb < C; cb += 128) {
+        if (cb + c < C) {
+            float s = 0.f;
+            for (long r = (long)blockIdx.x * 2 + sub; r < rows; r += (long)gridDim.x * 2) s += Elem<T>::ld(a + r * ld + cb + c);
+            atomicAdd(&s_acc[cb + c], s);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    const long cap = (long)kNumCU * 8;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <class T, int TH, int TW>
+static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M,
+                        int N, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, hipStream_t st) {
+    const int MT_total = (M + 15) / 16;
+    const int tiles = N * ((Wo + TW - 1) / TW) * ((Ho + TH - 1) / TH);
+    const int HP = (TH + KH - 1) * (TW + KW - 1);
+#define IG(MT_)                                                                                                                                  \
+    {                                                                                                                                            \
+        const size_t smem = ((HP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + 2 * MT_ * 16 * sizeof(float);                                    \
+        const int gy = (MT_total + MT_ - 1) / MT_;                                                                                               \
+        hipLaunchKernelGGL((k_conv_igemm<T, MT_, TH, TW>), dim3(persistent_grid(tiles, gy >= 4 ? 2 : 4), gy), dim3(256), smem, st, (const T*)x, ldx, \
+                           wpk, (T*)out, ldo, bias, relu, gstat, Cin, M, MT_total, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw);                         \
+    }
+    if (MT_total % 8 == 0 || MT_total > 8)
+        IG(8)
+    else if (MT_total % 4 == 0 || MT_total > 4)
+        IG(4)
+    else if (MT_total >= 2)
+        IG(2)
+    else
+        IG(1)
+#undef IG
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+extern "C" {
+
+// Implicit-GEMM convolution / GEMM:  out[n][ho][wo][m] = sum_{ky,kx,c} W[m][(ky,kx,c)] * x[n][ho+ky-padh][wo+kx-padw][c]  (+bias, ReLU)
+//   nn.Conv2d forward (models.py:189-240), its dgrad (flipped packed weights), GRU input projections and nn.Linear (KH=KW=1, Hi=Ho=1).
+//   x [N][Hi][Wi][ldx] (Cin % 32 == 0, ldx >= Cin); wpk = ocrs_pack_frags(K = KH*KW*Cin ordered (tap, c), M); out [N][Ho][Wo][ldo];
+//   gstat (nullable): [2][M] double batch sums of the (rounded) outputs, zeroed here.  Outputs rows m in [M, ldo) are written as 0(+0 bias).
+int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
+                    int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(x && wpk && out && Cin % 32 == 0 && ldx >= Cin && M > 0 && ldo >= M && ldo % 4 == 0 && KH >= 1 && KW >= 1 && KH * KW <= 9);
+    if (gstat && hipMemsetAsync(gstat, 0, 2 * M * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const bool gemm = Ho == 1 && KH == 1;
+    if (dtype == 1)
+        return gemm ? launch_igemm<bf16, 1, 128>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st)
+                    : launch_igemm<bf16, 8, 16>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st);
+    return gemm ? launch_igemm<float, 1, 128>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st)
+                : launch_igemm<float, 8, 16>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st);
+}
+
+// Weight gradient by gathering: dW[(ra*CB + cb)*KH*KW + tap] += sum_pos A~[pos][ra] * B[pos*stride + tap - pad][cb].
+//   Conv2d: A = dz [N][Ho][Wo][Cout], B = x; Linear / GRU: KH=KW=1, hA=1.  trA (nullable) = load transform of A.  dW accumulated.
+int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA, int HB,
+                      int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(A && B && dW && CB % 8 == 0 && ldA % 8 == 0 && ldB % 8 == 0 && ldA >= ((CA + 7) & ~7) && ldB >= CB);
+    const long P = (long)N * hA * wA;
+    OCRS_CHECK_ARG(P < (1L << 31));
+    const long ntiles = (P + 63) / 64;
+    const int CA8 = (CA + 7) & ~7;
+    const int gy = ((CA8 + 127) / 128) * ((KH * KW * CB + 127) / 128);
+    long gx = ntiles / 8;
+    if (gx < 1) gx = 1;
+    long cap = 2048 / gy;
+    if (cap < 8) cap = 8;
+    if (gx > cap) gx = cap;
+    if (gx >= 8) gx &= ~7L;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+            hipSuccess)
+            return OCRS_ERR_HIP;
+        attr_set = true;
+    }
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_wgrad_gather<bf16>, dim3((int)gx, gy), dim3(256), 2 * 128 * 72 * 2, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B, ldB,
+                           CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+    else
+        hipLaunchKernelGGL(k_wgrad_gather<float>, dim3((int)gx, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)A, ldA, CA, trA, (const float*)B,
+                           ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Conv2d(1,32,3,p1)+ReLU+MaxPool2d(2) fused (models.py:180-187): img fp32 (N,1,H,W) -> out [N][H/2][W/2][32].
+int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(img && w && bias && out && H % 2 == 0 && W % 2 == 0);
+    const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_conv0_fwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (bf16*)out, N, H, W);
+    else
+        hipLaunchKernelGGL(k_conv0_fwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (float*)out, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
+                   hipStream_t st) {
+    OCRS_CHECK_ARG(img && w && bias && g && dW && db);
+    const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_conv0_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (const bf16*)g, dW, db, N, H, W);
+    else
+        hipLaunchKernelGGL(k_conv0_bwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (const float*)g, dW, db, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+#define DT_DISPATCH(KERNEL, GRID, SMEM, ...)                                                     \
+    if (dtype == 1)                                                                              \
+        hipLaunchKernelGGL(KERNEL<bf16>, dim3(GRID), dim3(256), SMEM, st, __VA_ARGS__);          \
+    else                                                                                         \
+        hipLaunchKernelGGL(KERNEL<float>, dim3(GRID), dim3(256), SMEM, st, __VA_ARGS__);
+
+// BN+ReLU(+MaxPool PHxPW) forward on a pre-BN tensor z (models.py:197-199, 214-216, 231-233); tr = [3][C] load transform.
+int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int PH, int PW, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && out && C % 8 == 0 && PH * PW <= 4 && PH >= 1 && PW >= 1);
+    const int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_act_pool_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, (bf16*)out, C, N, H, W, PH, PW);
+    else
+        hipLaunchKernelGGL(k_act_pool_fwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, (float*)out, C, N, H, W, PH, PW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+// backward reductions (gsum [2][C] double zeroed here) and dz materialisation
+int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,
+                       int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(g && z && bn && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0 && PH * PW <= 4);
+    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_rec_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, (const bf16*)g, (const bf16*)z, bn, saved, gsum, C,
+                           N, H, W, PH, PW);
+    else
+        hipLaunchKernelGGL(k_rec_bn_reduce<float>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, (const float*)g, (const float*)z, bn, saved, gsum,
+                           C, N, H, W, PH, PW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* coef, void* dz, int C, int N, int H, int W, int PH, int PW, int dtype,
+                  hipStream_t st) {
+    OCRS_CHECK_ARG(g && z && bn && coef && dz && C % 8 == 0 && PH * PW <= 4);
+    const int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_dz_apply<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)g, (const bf16*)z, bn, coef, (bf16*)dz, C, N, H, W, PH, PW);
+    else
+        hipLaunchKernelGGL(k_dz_apply<float>, dim3(grid), dim3(256), 0, st, (const float*)g, (const float*)z, bn, coef, (float*)dz, C, N, H, W, PH, PW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// BatchNorm2d + AvgPool2d((4,1)) on H=5 + permute to (T=W, N, C) fp32 (models.py:241-242, 259-262), and its backward pieces.
+int ocrs_avgpool_fwd(const void* z, const float* tr, float* seq, int C, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && seq && C % 8 == 0 && H >= 4);
+    const int grid = ew_grid((long)N * W * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_avgpool_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, seq, C, N, H, W);
+    else
+        hipLaunchKernelGGL(k_avgpool_fwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, seq, C, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int ocrs_avgpool_bn_reduce(const float* gseq, const void* z, const float* saved, double* gsum, int C, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(gseq && z && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0);
+    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    const int grid = ew_grid((long)N * W * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_avgpool_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, gseq, (const bf16*)z, saved, gsum, C, N, H, W);
+    else
+        hipLaunchKernelGGL(k_avgpool_bn_reduce<float>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, gseq, (const float*)z, saved, gsum, C, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int ocrs_avgpool_dz(const float* gseq, const void* z, const float* coef, void* dz, int C, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(gseq && z && coef && dz && C % 8 == 0);
+    const int grid = ew_grid((long)N * H * W * (C / 8));
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_avgpool_dz<bf16>, dim3(grid), dim3(256), 0, st, gseq, (const bf16*)z, coef, (bf16*)dz, C, N, H, W);
+    else
+        hipLaunchKernelGGL(k_avgpool_dz<float>, dim3(grid), dim3(256), 0, st, gseq, (const float*)z, coef, (float*)dz, C, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// column sums (bias gradients): out[c] += sum_rows a[row][c]
+int ocrs_col_sum(const void* a, int ld, int C, float* out, long rows, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(a && out && C > 0 && ld >= C && rows > 0);
+    long g = (rows + 1) / 2;
+    if (g > 1024) g = 1024;
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_col_sum<bf16>, dim3((int)g), dim3(256), C * sizeof(float), st, (const bf16*)a, ld, C, out, rows);
+    else
+        hipLaunchKernelGGL(k_col_sum<float>, dim3((int)g), dim3(256), C * sizeof(float), st, (const float*)a, ld, C, out, rows);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

@@ -47,3 +47,53 @@ def balanced_cross_entropy_loss(pred: torch.Tensor, target: torch.Tensor) -> tor
     if pred.shape != target.shape:
         raise RuntimeError(f"pred {tuple(pred.shape)} and target {tuple(target.shape)} must have the same shape")
     return _BalancedBCE.apply(pred, target)
+
+
+class _CTC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_probs, targets, in_len, tg_len):
+        L = lib()
+        lp = log_probs.contiguous().float()
+        T, N, C = lp.shape
+        tg = targets.contiguous().to(torch.int32)
+        Lpad = tg.shape[1]
+        Smax = 2 * Lpad + 1
+        dev = lp.device
+        alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
+        nll = torch.empty(N, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
+        ctx.save_for_backward(lp, tg, in_len, tg_len, alpha, nll)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        lp, tg, in_len, tg_len, alpha, nll = ctx.saved_tensors
+        T, N, C = lp.shape
+        grad = torch.empty_like(lp)
+        g = gout.contiguous().float().reshape(1)
+        lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], 2 * tg.shape[1] + 1)
+        return grad, None, None, None
+
+
+class CTCLoss(torch.nn.Module):
+    """``torch.nn.CTCLoss()`` with its defaults (blank=0, reduction='mean', zero_infinity=False), the only configuration
+    the reference uses (ocrs_models/train_rec.py:104,121).
+
+    ``forward(log_probs (T,N,C), targets (N,Lpad) int, input_lengths (N,), target_lengths (N,))`` -> scalar loss.
+    Lengths may be CPU tensors / lists as in the reference; they are moved to the device (no host sync)."""
+
+    def __init__(self, blank: int = 0, reduction: str = "mean", zero_infinity: bool = False):
+        super().__init__()
+        if blank != 0 or reduction != "mean" or zero_infinity:
+            raise NotImplementedError("only torch.nn.CTCLoss() defaults are implemented (the reference's configuration)")
+
+    def forward(self, log_probs, targets, input_lengths, target_lengths):
+        if not log_probs.is_cuda:
+            raise RuntimeError("ocrs_models_amd losses run on MI355X only (no CPU path)")
+        if targets.dim() != 2:
+            raise RuntimeError("targets must be (N, Lpad) padded label rows (the layout collate_samples produces)")
+        dev = log_probs.device
+        il = torch.as_tensor(input_lengths, dtype=torch.int64).to(dev, non_blocking=True)
+        tl = torch.as_tensor(target_lengths, dtype=torch.int64).to(dev, non_blocking=True)
+        return _CTC.apply(log_probs, targets.to(dev), il, tl)

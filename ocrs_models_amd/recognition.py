@@ -1,0 +1,336 @@
+"""RecognitionModel (CRNN: conv backbone -> 2-layer BiGRU -> Linear + LogSoftmax) with the reference's constructor /
+forward signature and state-dict keys (ocrs_models/models.py:146-268), executed by the gfx950 kernels of libocrs_hip.so.
+
+Layout / dtype policy
+  * conv activations NHWC, fp32 or bf16 (bf16 when called under ``torch.autocast(dtype=torch.bfloat16)`` like
+    train_rec.py:118 does, or with ``act_dtype=torch.bfloat16``); MFMA accumulation, BatchNorm statistics fp32.
+  * the GRU always runs in fp32 (models.py:264-266), on exact-fp32 MFMA; so do the Linear and LogSoftmax here.
+  * output: log-probs (W//4 + 1, B, n_classes) fp32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from ._lib import lib, ptr
+from .models import _DT, _identity_tr
+
+_coef_cache: dict = {}
+
+
+def _unit_coef(C, device):
+    key = (C, device)
+    t = _coef_cache.get(key)
+    if t is None:
+        t = torch.zeros(3, C, dtype=torch.float32, device=device)
+        t[0] = 1.0
+        _coef_cache[key] = t
+    return t
+
+
+class _RecRun:
+    def __init__(self, mod, x, names, params, train, dtype):
+        self.L = lib()
+        self.mod = mod
+        self.P = dict(zip(names, params))
+        self.names = names
+        self.Bf = dict(mod.named_buffers())
+        self.train = train
+        self.dev = x.device
+        self.dtype = dtype
+        self.dt = _DT[self.dtype]
+        self.x = x
+        self.N, _, self.H, self.W = x.shape
+        self.ncls = self.P["output.0.weight"].shape[0]
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def pack(self, src, K, M, K2, s1, s2, sm, dt=None, offset=0):
+        dt = self.dt if dt is None else dt
+        out = torch.empty(self.L.pack_frags_bytes(K, M, dt), dtype=torch.uint8, device=self.dev)
+        self.L.pack_frags(src.data_ptr() + 4 * offset, 0, K, M, K2, s1, s2, sm, ptr(out), dt)
+        return out
+
+    def pack_conv(self, w):  # W[cout][cin][kh][kw] -> A[m=cout][k=(tap,cin)]
+        co, ci, kh, kw = w.shape
+        return self.pack(w, kh * kw * ci, co, ci, 1, kh * kw, ci * kh * kw)
+
+    def pack_conv_dgrad(self, w):  # A[m=cin][k=(tap',cout)] = W[cout][cin][ntaps-1-tap']
+        co, ci, kh, kw = w.shape
+        nt = kh * kw
+        return self.pack(w, nt * co, ci, co, -1, ci * nt, nt, offset=nt - 1)
+
+    def bn(self, prefix, gstat, count, C, lo):
+        P, Bf = self.P, self.Bf
+        tr = self.empty(3, C, dtype=torch.float32)
+        saved = self.empty(2, C, dtype=torch.float32)
+        if self.train:
+            self.L.bn_finalize(ptr(gstat), count, C, ptr(P[f"{prefix}.weight"]), ptr(P[f"{prefix}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved),
+                               ptr(Bf[f"{prefix}.running_mean"]), ptr(Bf[f"{prefix}.running_var"]), ptr(Bf[f"{prefix}.num_batches_tracked"]), lo)
+        else:
+            rstd = torch.rsqrt(Bf[f"{prefix}.running_var"] + 1e-5)
+            tr[0] = P[f"{prefix}.weight"] * rstd
+            tr[1] = P[f"{prefix}.bias"] - Bf[f"{prefix}.running_mean"] * tr[0]
+            tr[2] = lo
+        return tr, saved
+
+    def conv(self, x, w, bias, relu, stats, Hi, Wi, pad, Ho=None, Wo=None):
+        co, ci, kh, kw = w.shape
+        Ho, Wo = Ho or Hi, Wo or Wi
+        out = self.empty(self.N, Ho, Wo, co)
+        gstat = self.empty(2 * co, dtype=torch.float64) if stats else None
+        self.L.conv_igemm(ptr(x), ci, ptr(self.pack_conv(w)), ptr(out), co, ptr(bias), 1 if relu else 0, ptr(gstat), ci, co, self.N, Hi, Wi, Ho, Wo,
+                          kh, kw, pad, pad, self.dt)
+        return out, gstat
+
+    def gemm(self, x, ldx, K, wpk, bias, M, ldo, rows):
+        """fp32 GEMM: out[rows][ldo] = x[rows][K] @ W^T (+bias), W given as packed fragments (K, M)."""
+        out = self.empty(rows, ldo, dtype=torch.float32)
+        self.L.conv_igemm(ptr(x), ldx, ptr(wpk), ptr(out), ldo, ptr(bias), 0, None, K, M, 1, 1, rows, 1, rows, 1, 1, 0, 0, 0)
+        return out
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self):
+        L, P, N, H, W = self.L, self.P, self.N, self.H, self.W
+        if H != 64:
+            raise RuntimeError(f"RecognitionModel expects input height 64 (models.py:153), got {H}")
+        if W % 4 != 0:
+            raise RuntimeError(f"input width must be a multiple of 4 (two 2x2 max-pools), got {W}")
+        S = self
+        S.a0 = self.empty(N, 32, W // 2, 32)
+        L.conv0_fwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(S.a0), N, H, W, self.dt)
+        H1, W1 = 32, W // 2
+        S.z3, gs = self.conv(S.a0, P["conv.3.weight"], None, False, True, H1, W1, 1)
+        S.tr3, S.sv3 = self.bn("conv.4", gs, N * H1 * W1, 64, 0.0)
+        H2, W2 = 16, W // 4
+        S.a3 = self.empty(N, H2, W2, 64)
+        L.act_pool_fwd(ptr(S.z3), ptr(S.tr3), ptr(S.a3), 64, N, H1, W1, 2, 2, self.dt)
+        S.a7, _ = self.conv(S.a3, P["conv.7.weight"], P["conv.7.bias"], True, False, H2, W2, 1)
+        S.z9, gs = self.conv(S.a7, P["conv.9.weight"], None, False, True, H2, W2, 1)
+        S.tr9, S.sv9 = self.bn("conv.10", gs, N * H2 * W2, 128, 0.0)
+        S.a9 = self.empty(N, 8, W2, 128)
+        L.act_pool_fwd(ptr(S.z9), ptr(S.tr9), ptr(S.a9), 128, N, H2, W2, 2, 1, self.dt)
+        S.a13, _ = self.conv(S.a9, P["conv.13.weight"], P["conv.13.bias"], True, False, 8, W2, 1)
+        S.z15, gs = self.conv(S.a13, P["conv.15.weight"], None, False, True, 8, W2, 1)
+        S.tr15, S.sv15 = self.bn("conv.16", gs, N * 8 * W2, 128, 0.0)
+        S.a15 = self.empty(N, 4, W2, 128)
+        L.act_pool_fwd(ptr(S.z15), ptr(S.tr15), ptr(S.a15), 128, N, 8, W2, 2, 1, self.dt)
+        T = W2 + 1
+        S.z19, gs = self.conv(S.a15, P["conv.19.weight"], None, False, True, 4, W2, 1, Ho=5, Wo=T)
+        S.tr19, S.sv19 = self.bn("conv.20", gs, N * 5 * T, 128, -math.inf)
+        S.seq = self.empty(T, N, 128, dtype=torch.float32)
+        L.avgpool_fwd(ptr(S.z19), ptr(S.tr19), ptr(S.seq), 128, N, 5, T, self.dt)
+        S.T, S.W2 = T, W2
+        # ---- 2-layer bidirectional GRU, fp32 ----
+        rows = T * N
+        S.gru = []
+        xin, I = S.seq, 128
+        for layer in (0, 1):
+            sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+            w_ih = torch.cat([P["gru.weight_ih" + s] for s in sfx], 0)  # (1536, I)
+            b_ih = torch.cat([P["gru.bias_ih" + s] for s in sfx], 0)
+            b_hh = torch.cat([P["gru.bias_hh" + s] for s in sfx], 0)
+            w_hh = torch.stack([P["gru.weight_hh" + s] for s in sfx], 0).contiguous()  # (2, 768, 256)
+            gi = self.gemm(xin, I, I, self.pack(w_ih, I, 1536, I, 0, 1, I, dt=0), b_ih, 1536, 1536, rows)
+            nfl = 8 * 48 * 64 * 8
+            whh_pk = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
+            for d in (0, 1):
+                L.pack_frags(w_hh.data_ptr() + 4 * d * 768 * 256, 0, 256, 768, 256, 0, 1, 256, whh_pk.data_ptr() + 4 * d * nfl, 0)
+            out = self.empty(T, N, 512, dtype=torch.float32)
+            saved = self.empty(T, N, 2, 4, 256, dtype=torch.float32) if self.train else None
+            L.gru_layer_fwd(ptr(gi), ptr(whh_pk), ptr(b_hh), ptr(out), ptr(saved), T, N)
+            S.gru.append({"x": xin, "I": I, "w_ih": w_ih, "w_hh": w_hh, "out": out, "saved": saved})
+            xin, I = out, 512
+        # ---- Linear + LogSoftmax (fp32) ----
+        C = self.ncls
+        S.ldl = (C + 31) // 32 * 32
+        wout = P["output.0.weight"]
+        logits = self.gemm(xin, 512, 512, self.pack(wout, 512, C, 512, 0, 1, 512, dt=0), P["output.0.bias"], C, S.ldl, rows)
+        S.lp = self.empty(T, N, C, dtype=torch.float32)
+        L.log_softmax_fwd(ptr(logits), ptr(S.lp), rows, C, S.ldl, 0)
+        return S.lp
+
+    # ---- backward ------------------------------------------------------------------------------
+    def conv_bwd(self, name, dz, xin, Hz, Wz, Hx, Wx, pad, need_dx=True):
+        """dz: gradient w.r.t. the conv output [N][Hz][Wz][Cout]; accumulates dW, returns dx [N][Hx][Wx][Cin]."""
+        L, w = self.L, self.P[name]
+        co, ci, kh, kw = w.shape
+        L.wgrad_gather(ptr(dz), co, co, None, ptr(xin), ci, ci, ptr(self.G[name]), self.N, Hz, Wz, Hx, Wx, 1, pad, pad, kh, kw, self.dt)
+        if not need_dx:
+            return None
+        dx = self.empty(self.N, Hx, Wx, ci)
+        L.conv_igemm(ptr(dz), co, ptr(self.pack_conv_dgrad(w)), ptr(dx), ci, None, 0, None, co, ci, self.N, Hz, Wz, Hx, Wx, kh, kw, kh - 1 - pad,
+                     kw - 1 - pad, self.dt)
+        return dx
+
+    def bn_pool_bwd(self, prefix, g, z, tr, saved, C, H, W, PH, PW):
+        L = self.L
+        gsum = self.empty(2 * C, dtype=torch.float64)
+        L.rec_bn_reduce(ptr(g), ptr(z), ptr(tr), ptr(saved), ptr(gsum), C, self.N, H, W, PH, PW, self.dt)
+        coef = self.empty(3, C, dtype=torch.float32)
+        L.bn_bwd_finalize(ptr(gsum), self.N * H * W, C, ptr(self.P[f"{prefix}.weight"]), ptr(saved), ptr(coef), ptr(self.G[f"{prefix}.weight"]),
+                          ptr(self.G[f"{prefix}.bias"]))
+        dz = self.empty(self.N, H, W, C)
+        L.dz_apply(ptr(g), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, self.N, H, W, PH, PW, self.dt)
+        return dz
+
+    def relu_bwd(self, g, a, C, H, W):
+        dz = self.empty(self.N, H, W, C)
+        self.L.dz_apply(ptr(g), ptr(a), ptr(_identity_tr(C, self.dev)), ptr(_unit_coef(C, self.dev)), ptr(dz), C, self.N, H, W, 1, 1, self.dt)
+        return dz
+
+    def backward(self, g_lp):
+        L, P, N, S = self.L, self.P, self.N, self
+        T, W2, W = S.T, S.W2, self.W
+        rows = T * N
+        C = self.ncls
+        # flat gradient buffer in backward-completion order (DP buckets = contiguous ranges)
+        order = ["output.", "gru.weight_ih_l1", "gru.weight_hh_l1", "gru.bias_ih_l1", "gru.bias_hh_l1", "gru.weight_ih_l0", "gru.weight_hh_l0",
+                 "gru.bias_ih_l0", "gru.bias_hh_l0", "conv.20.", "conv.19.", "conv.16.", "conv.15.", "conv.13.", "conv.10.", "conv.9.", "conv.7.",
+                 "conv.4.", "conv.3.", "conv.0."]
+        flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=self.dev)
+        self.G, off, stage_end = {}, 0, {}
+        for stage in order:
+            for k in self.names:
+                if k.startswith(stage) and k not in self.G:
+                    n = P[k].numel()
+                    self.G[k] = flat[off:off + n].view_as(P[k])
+                    off += n
+            stage_end[stage] = off
+        assert off == flat.numel(), "parameter ordering table is incomplete"
+        bucketer = getattr(self.mod, "_grad_bucketer", None)
+        done = [0]
+
+        def stage_done(stage):
+            if bucketer is not None and stage_end[stage] > done[0]:
+                bucketer.ready(flat, done[0], stage_end[stage])
+            done[0] = max(done[0], stage_end[stage])
+
+        G = self.G
+        g_lp = g_lp.contiguous().float()
+        dlog = self.empty(rows, S.ldl, dtype=torch.float32)
+        L.log_softmax_bwd(ptr(S.lp), ptr(g_lp), ptr(dlog), rows, C, S.ldl, 0)
+        top = S.gru[1]["out"]
+        L.wgrad_gather(ptr(dlog), S.ldl, C, None, ptr(top), 512, 512, ptr(G["output.0.weight"]), 1, 1, rows, 1, rows, 1, 0, 0, 1, 1, 0)
+        L.col_sum(ptr(dlog), S.ldl, C, ptr(G["output.0.bias"]), rows, 0)
+        dout = self.gemm(dlog, S.ldl, S.ldl, self.pack(P["output.0.weight"], C, 512, C, 0, 512, 1, dt=0), None, 512, 512, rows)
+        stage_done("output.")
+        dhz = self.empty(2, 2, N, 256, dtype=torch.float32)
+        for layer in (1, 0):
+            gl = S.gru[layer]
+            I = gl["I"]
+            nfl = 24 * 16 * 64 * 8
+            whhT = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
+            for d in (0, 1):
+                L.pack_frags(gl["w_hh"].data_ptr() + 4 * d * 768 * 256, 0, 768, 256, 768, 0, 256, 1, whhT.data_ptr() + 4 * d * nfl, 0)
+            dgi = self.empty(rows, 1536, dtype=torch.float32)
+            dgh = self.empty(rows, 1536, dtype=torch.float32)
+            L.gru_layer_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(whhT), ptr(dgi), ptr(dgh), ptr(dhz), T, N)
+            sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+            # stacked views: [w_ih, w_ih_reverse] etc. are adjacent in the flat buffer (see `order`)
+            gw_ih = G["gru.weight_ih" + sfx[0]]
+            L.wgrad_gather(ptr(dgi), 1536, 1536, None, ptr(gl["x"]), I, I, ptr(gw_ih), 1, 1, rows, 1, rows, 1, 0, 0, 1, 1, 0)
+            for d in (0, 1):
+                L.wgrad_gather(dgh.data_ptr() + 4 * d * 768, 1536, 768, None, gl["out"].data_ptr() + 4 * d * 256, 512, 256,
+                               ptr(G["gru.weight_hh" + sfx[d]]), 1, T, N, T, N, 1, 1 if d == 0 else -1, 0, 1, 1, 0)
+            L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
+            L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
+            dout = self.gemm(dgi, 1536, 1536, self.pack(gl["w_ih"], 1536, I, 1536, 0, I, 1, dt=0), None, I, I, rows)
+            stage_done(f"gru.bias_hh_l{layer}")
+        dseq = dout  # [T][N][128] fp32
+        # ---- conv.20 (BN, no ReLU) + AvgPool ----
+        gsum = self.empty(256, dtype=torch.float64)
+        L.avgpool_bn_reduce(ptr(dseq), ptr(S.z19), ptr(S.sv19), ptr(gsum), 128, N, 5, T, self.dt)
+        coef = self.empty(3, 128, dtype=torch.float32)
+        L.bn_bwd_finalize(ptr(gsum), N * 5 * T, 128, ptr(P["conv.20.weight"]), ptr(S.sv19), ptr(coef), ptr(G["conv.20.weight"]), ptr(G["conv.20.bias"]))
+        dz19 = self.empty(N, 5, T, 128)
+        L.avgpool_dz(ptr(dseq), ptr(S.z19), ptr(coef), ptr(dz19), 128, N, 5, T, self.dt)
+        g15 = self.conv_bwd("conv.19.weight", dz19, S.a15, 5, T, 4, W2, 1)
+        stage_done("conv.19.")
+        dz15 = self.bn_pool_bwd("conv.16", g15, S.z15, S.tr15, S.sv15, 128, 8, W2, 2, 1)
+        g13 = self.conv_bwd("conv.15.weight", dz15, S.a13, 8, W2, 8, W2, 1)
+        stage_done("conv.15.")
+        dz13 = self.relu_bwd(g13, S.a13, 128, 8, W2)
+        L.col_sum(ptr(dz13), 128, 128, ptr(G["conv.13.bias"]), N * 8 * W2, self.dt)
+        g9 = self.conv_bwd("conv.13.weight", dz13, S.a9, 8, W2, 8, W2, 1)
+        stage_done("conv.13.")
+        dz9 = self.bn_pool_bwd("conv.10", g9, S.z9, S.tr9, S.sv9, 128, 16, W2, 2, 1)
+        g7 = self.conv_bwd("conv.9.weight", dz9, S.a7, 16, W2, 16, W2, 1)
+        stage_done("conv.9.")
+        dz7 = self.relu_bwd(g7, S.a7, 128, 16, W2)
+        L.col_sum(ptr(dz7), 128, 128, ptr(G["conv.7.bias"]), N * 16 * W2, self.dt)
+        g3 = self.conv_bwd("conv.7.weight", dz7, S.a3, 16, W2, 16, W2, 1)
+        stage_done("conv.7.")
+        dz3 = self.bn_pool_bwd("conv.4", g3, S.z3, S.tr3, S.sv3, 64, 32, W // 2, 2, 2)
+        g0 = self.conv_bwd("conv.3.weight", dz3, S.a0, 32, W // 2, 32, W // 2, 1)
+        stage_done("conv.3.")
+        L.conv0_bwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(g0), ptr(G["conv.0.weight"]), ptr(G["conv.0.bias"]), N, self.H,
+                    W, self.dt)
+        stage_done("conv.0.")
+        if bucketer is not None:
+            bucketer.finish(flat)
+        return [G[k] for k in self.names]
+
+
+class _RecFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, names, dtype, *params):
+        run = _RecRun(mod, x, names, [p.detach() for p in params], mod.training, dtype)
+        ctx.run = run
+        return run.forward()
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.run.backward(g)
+        ctx.run = None
+        return (None, None, None, None, *grads)
+
+
+class RecognitionModel(nn.Module):
+    """Text recognition CRNN (reference: ocrs_models/models.py:146-268).
+
+    ``forward(x: (B,1,64,W)) -> (W//4 + 1, B, len(alphabet)+1)`` log-probabilities (fp32)."""
+
+    def __init__(self, alphabet: str, act_dtype: torch.dtype | None = None):
+        super().__init__()
+        n_classes = len(alphabet) + 1
+        self.conv = nn.Sequential(
+            nn.Conv2d(1, 32, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(32, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(2),
+            nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(),
+            nn.Conv2d(128, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(), nn.MaxPool2d((2, 1)),
+            nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(),
+            nn.Conv2d(128, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU(), nn.MaxPool2d((2, 1)),
+            nn.Conv2d(128, 128, (2, 2), padding=1, bias=False), nn.BatchNorm2d(128), nn.AvgPool2d((4, 1)),
+        )
+        self.gru = nn.GRU(128, 256, bidirectional=True, num_layers=2)
+        self.output = nn.Sequential(nn.Linear(512, n_classes), nn.LogSoftmax(dim=2))
+        self.act_dtype = act_dtype
+
+    def _act_dtype(self):
+        if self.act_dtype is not None:
+            return self.act_dtype
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("ocrs_models_amd.RecognitionModel runs on MI355X only (no CPU path); move the model and input to 'cuda'")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise RuntimeError(f"expected (B,1,64,W) input, got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        for p in params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("parameters must be contiguous fp32")
+        dtype = self._act_dtype()
+        with torch.autocast("cuda", enabled=False):
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return _RecFn.apply(x, self, names, dtype, *params)
+            return _RecRun(self, x, names, [p.detach() for p in params], self.training, dtype).forward()

@@ -1,0 +1,127 @@
+"""Host-side sequence/text contract of the recognition train step, same behaviour as the reference's helpers:
+
+* ``DEFAULT_ALPHABET``, ``encode_text``, ``decode_text``, ``ctc_greedy_decode_text``  (datasets/hiertext.py:133-137, datasets/util.py:113-177)
+* ``round_up``, ``ctc_input_and_target_compatible``, ``collate_samples``           (train_rec.py:220-304)
+* ``RecognitionAccuracyStats``                                                     (train_rec.py:20-82) -- arg-max and the CTC collapse run
+  on the GPU (``ocrs_ctc_greedy_decode``), only the already-collapsed label rows come back for the Levenshtein distance.
+* ``transform_image``                                                              (datasets/util.py:27-35)
+"""
+from __future__ import annotations
+
+import string
+
+import torch
+
+from ._lib import lib, ptr
+
+DEFAULT_ALPHABET = (
+    " " + string.digits + "".join(chr(c) for c in range(33, 127) if not chr(c).isalnum()) + "€" + string.ascii_uppercase + string.ascii_lowercase
+)
+
+
+def transform_image(img: torch.Tensor) -> torch.Tensor:
+    """8-bit greyscale CHW -> float CHW in [-0.5, 0.5]."""
+    return img.float() / 255.0 - 0.5
+
+
+def encode_text(text: str, alphabet, unknown_char: str) -> torch.Tensor:
+    alphabet = list(alphabet)
+    unk = alphabet.index(unknown_char)
+    return torch.tensor([(alphabet.index(ch) if ch in alphabet else unk) + 1 for ch in text], dtype=torch.int32)
+
+
+def decode_text(x, alphabet) -> str:
+    if isinstance(x, torch.Tensor):
+        x = x.tolist()
+    return "".join(alphabet[c - 1] for c in x if c > 0)
+
+
+def ctc_greedy_decode_text(x, alphabet) -> str:
+    """Host version for a single label sequence (repeat test before the blank test)."""
+    if isinstance(x, torch.Tensor):
+        x = x.tolist()
+    out, last = [], None
+    for c in x:
+        if c == last:
+            continue
+        last = c
+        if c != 0:
+            out.append(alphabet[c - 1])
+    return "".join(out)
+
+
+def greedy_decode_batch(log_probs: torch.Tensor, input_lengths):
+    """(T,N,C) log-probs on the GPU -> list of N collapsed label lists (arg-max + collapse on the device, one D2H copy)."""
+    lp = log_probs.contiguous().float()
+    T, N, C = lp.shape
+    dev = lp.device
+    il = torch.as_tensor(input_lengths, dtype=torch.int64).to(dev)
+    amax = torch.empty(N, T, dtype=torch.int32, device=dev)
+    labels = torch.zeros(N, T, dtype=torch.int32, device=dev)
+    lens = torch.empty(N, dtype=torch.int32, device=dev)
+    lib().ctc_greedy_decode(ptr(lp), ptr(il), ptr(amax), ptr(labels), ptr(lens), T, N, C)
+    labels_h, lens_h = labels.cpu().tolist(), lens.cpu().tolist()
+    return [row[:n] for row, n in zip(labels_h, lens_h)], amax
+
+
+def levenshtein(a, b) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+class RecognitionAccuracyStats:
+    def __init__(self, alphabet=DEFAULT_ALPHABET):
+        self.total_chars = 0
+        self.char_errors = 0
+        self.alphabet = list(alphabet)
+
+    def update(self, targets, target_lengths, preds, pred_lengths):
+        """targets [batch, seq]; preds [seq, batch, class] log-probs; lengths per sample."""
+        assert len(target_lengths) == targets.size(0) and len(pred_lengths) == preds.size(1)
+        decoded, _ = greedy_decode_batch(preds, pred_lengths)
+        for y, labels in zip(targets.tolist(), decoded):
+            want = decode_text(y, self.alphabet)
+            got = "".join(self.alphabet[c - 1] for c in labels)
+            self.char_errors += levenshtein(want, got)
+        self.total_chars += int(sum(int(v) for v in target_lengths))
+
+    def char_error_rate(self) -> float:
+        return self.char_errors / self.total_chars
+
+    def stats_dict(self) -> dict:
+        return {"char_error_rate": self.char_error_rate()}
+
+
+def round_up(val: int, unit: int) -> int:
+    """Reference quirk kept: an exact multiple is bumped a full unit (round_up(256, 256) == 512)."""
+    return (val // unit + 1) * unit
+
+
+def ctc_input_and_target_compatible(input_len: int, target) -> bool:
+    t = target.tolist() if isinstance(target, torch.Tensor) else list(target)
+    need = max(1, len(t)) + sum(1 for i in range(1, len(t)) if t[i - 1] == t[i])
+    return input_len >= need
+
+
+def collate_samples(samples: list[dict]) -> dict:
+    """list of {'image': (1,64,w) float, 'text_seq': (L,) int32} -> padded batch dict (train_rec.py:248-304)."""
+    wmax = round_up(max(s["image"].shape[-1] for s in samples), 256)
+    lmax = round_up(max(s["text_seq"].shape[0] for s in samples), 64)
+    keep = [s for s in samples if ctc_input_and_target_compatible(s["image"].shape[-1] // 4, s["text_seq"])]
+    n = len(keep)
+    h = keep[0]["image"].shape[1] if keep else 64
+    image = torch.zeros(n, 1, h, wmax, dtype=torch.float32)
+    text = torch.zeros(n, lmax, dtype=torch.int32)
+    tl = torch.zeros(n, dtype=torch.int64)
+    iw = torch.zeros(n, dtype=torch.int64)
+    for i, s in enumerate(keep):
+        w, L = s["image"].shape[-1], s["text_seq"].shape[0]
+        image[i, :, :, :w] = s["image"]
+        text[i, :L] = s["text_seq"]
+        tl[i], iw[i] = L, w
+    return {"image": image, "text_seq": text, "text_len": tl, "image_width": iw}

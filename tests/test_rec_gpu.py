@@ -1,0 +1,264 @@
+"""Parity of the CRNN recognition path (HIP kernels through the C ABI) against PyTorch references of the same operators,
+the CPU oracle, and the golden vectors generated from the reference (tests/golden/rec.npz, ops.npz)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden_util import REC_CASE, compare_to_golden, golden_keys, golden_vs_golden, load_meta, load_npz, rec_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def nchw(x):
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def _run(dev, dtype, N, H=64, W=64):
+    from ocrs_models_amd._lib import lib
+    from ocrs_models_amd.models import _DT
+    from ocrs_models_amd.recognition import _RecRun
+
+    r = _RecRun.__new__(_RecRun)
+    r.L, r.dev, r.dtype, r.dt, r.N, r.H, r.W, r.P, r.G = lib(), dev, dtype, _DT[dtype], N, H, W, {}, {}
+    return r
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ci,co,k,pad,H,W", [(32, 64, 3, 1, 12, 20), (64, 128, 3, 1, 9, 17), (128, 128, 3, 1, 8, 33), (128, 128, 2, 1, 4, 19)])
+def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W):
+    from ocrs_models_amd._lib import ptr
+
+    g = torch.Generator().manual_seed(ci + co + k)
+    N = 3
+    Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+    x = torch.randn(N, ci, H, W, generator=g).to(dev)
+    w = (torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)).to(dev)
+    b = torch.randn(co, generator=g).to(dev)
+    r = _run(dev, dtype, N)
+    r.P = {"w": w}
+    r.G = {"w": torch.zeros_like(w)}
+    xs = nhwc(x, dtype)
+    out, gstat = r.conv(xs, w, b, True, True, H, W, pad, Ho, Wo)
+    xr = nchw(xs).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = torch.relu(F.conv2d(xr, wr, b, padding=pad))
+    tol = TOL[dtype]
+    assert rel(nchw(out), ref) < tol
+    q = ref.detach().to(dtype).float()
+    assert rel(gstat[:co], q.sum((0, 2, 3))) < 10 * tol and rel(gstat[co:], (q * q).sum((0, 2, 3))) < 10 * tol
+    dz = nhwc(torch.randn(N, co, Ho, Wo, generator=g).to(dev), dtype)
+    pre = F.conv2d(xr, wr, None, padding=pad)
+    pre.backward(nchw(dz))
+    dx = r.conv_bwd("w", dz, xs, Ho, Wo, H, W, pad)
+    torch.cuda.synchronize()
+    assert rel(nchw(dx), xr.grad) < 5 * tol, "dgrad"
+    assert rel(r.G["w"], wr.grad) < 5 * tol, "wgrad"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv0_fused(dev, dtype):
+    from ocrs_models_amd._lib import ptr
+
+    g = torch.Generator().manual_seed(2)
+    N, H, W = 2, 64, 24
+    img = (torch.rand(N, 1, H, W, generator=g) - 0.5).to(dev)
+    w = (torch.randn(32, 1, 3, 3, generator=g) / 3).to(dev)
+    b = (0.1 * torch.randn(32, generator=g)).to(dev)
+    r = _run(dev, dtype, N, H, W)
+    out = r.empty(N, H // 2, W // 2, 32)
+    r.L.conv0_fwd(ptr(img), ptr(w), ptr(b), ptr(out), N, H, W, r.dt)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.max_pool2d(torch.relu(F.conv2d(img, wr, br, padding=1)), 2)
+    tol = TOL[dtype]
+    assert rel(nchw(out), ref) < tol
+    gy = nhwc(torch.randn(N, 32, H // 2, W // 2, generator=g).to(dev), dtype)
+    ref.backward(nchw(gy))
+    dW, db = torch.zeros_like(w), torch.zeros_like(b)
+    r.L.conv0_bwd(ptr(img), ptr(w), ptr(b), ptr(gy), ptr(dW), ptr(db), N, H, W, r.dt)
+    torch.cuda.synchronize()
+    assert rel(dW, wr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+
+
+def test_log_softmax_and_ctc_match_torch(dev):
+    import ocrs_models_amd as oa
+    from ocrs_models_amd._lib import lib, ptr
+
+    g = torch.Generator().manual_seed(4)
+    T, N, C, Lpad = 37, 9, 97, 64
+    logits = 3 * torch.randn(T, N, C, generator=g)
+    tl = torch.tensor([0, 1, 5, 12, 18, 3, 7, 9, 2])
+    il = torch.tensor([37, 5, 20, 37, 37, 10, 30, 25, 4])
+    tg = torch.zeros(N, Lpad, dtype=torch.int32)
+    for i in range(N):
+        tg[i, : tl[i]] = torch.randint(1, C, (int(tl[i]),), generator=g)
+    tg[3, 1] = tg[3, 0]  # repeated labels
+    tg[4, 2:6] = tg[4, 2]
+    lg_ref = logits.clone().requires_grad_(True)
+    lp_ref = lg_ref.log_softmax(2)
+    loss_ref = torch.nn.CTCLoss()(lp_ref, tg, il, tl)
+    loss_ref.backward()
+    # ours: log-softmax kernel + CTC
+    ld = 128
+    lgd = torch.zeros(T * N, ld, device=dev)
+    lgd[:, :C] = logits.reshape(T * N, C).to(dev)
+    lp = torch.empty(T, N, C, device=dev)
+    lib().log_softmax_fwd(ptr(lgd), ptr(lp), T * N, C, ld, 0)
+    assert rel(lp, lp_ref) < 1e-6
+    lpd = lp.clone().requires_grad_(True)
+    loss = oa.CTCLoss()(lpd, tg.to(dev), il, tl)
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    loss.backward()
+    dl = torch.empty(T * N, ld, device=dev)
+    lib().log_softmax_bwd(ptr(lp), ptr(lpd.grad), ptr(dl), T * N, C, ld, 0)
+    assert rel(dl[:, :C].reshape(T, N, C), lg_ref.grad) < 1e-4
+    assert float(dl[:, C:].abs().max()) == 0.0
+    # golden CTC known answers generated from the reference's torch.nn.CTCLoss()
+    G = load_npz("ops.npz")
+    lpk = torch.from_numpy(G["ctc/log_probs"]).to(dev)
+    tgk, ilk, tlk = torch.from_numpy(G["ctc/targets"]), torch.from_numpy(G["ctc/input_lengths"]), torch.from_numpy(G["ctc/target_lengths"])
+    lpk4 = lpk[:, :4].contiguous().requires_grad_(True)
+    l4 = oa.CTCLoss()(lpk4, tgk[:4].to(dev), ilk[:4], tlk[:4])
+    assert abs(l4.item() - float(G["ctc/mean_loss_first4"])) < 1e-5
+    l4.backward()
+    assert float((lpk4.grad.cpu() - torch.from_numpy(G["ctc/grad_first4"])).abs().max()) < 1e-5
+    assert math.isinf(oa.CTCLoss()(lpk, tgk.to(dev), ilk, tlk).item())  # infeasible sample -> inf like the reference
+
+
+def test_greedy_decode_bit_exact(dev):
+    from oracle import text as otext
+    import ocrs_models_amd as oa
+
+    meta = load_meta()
+    g = torch.Generator().manual_seed(8)
+    T, N, C = 50, 7, 97
+    lp = torch.randn(T, N, C, generator=g)
+    lp[:, :, 0] += 1.5  # plenty of blanks
+    lp[10:14, 2] = lp[10, 2]  # repeats
+    lp[5, 3, 7] = lp[5, 3, 9] = lp[5, 3].max() + 1  # tie -> first index
+    il = [50, 13, 40, 50, 1, 0, 27]
+    dec, amax = oa.text.greedy_decode_batch(lp.to(dev), il)
+    want_amax = lp.argmax(-1).T
+    assert torch.equal(amax.cpu().long(), want_amax)
+    for i in range(N):
+        assert dec[i] == otext.greedy_collapse(want_amax[i, : il[i]].tolist())
+    for seq, want in meta["greedy_kats"]:
+        assert oa.text.ctc_greedy_decode_text(seq, list(oa.text.DEFAULT_ALPHABET)) == want
+
+
+def _load(model, seed):
+    from oracle.params import make_state, recognition_specs, state_dict_from
+
+    specs = recognition_specs()
+    P, Bf = make_state(specs, seed)
+    model.load_state_dict(state_dict_from(P, Bf, specs))
+    return model
+
+
+def test_recognition_fp32_matches_golden_and_oracle(dev):
+    import ocrs_models_amd as oa
+    from oracle import recognition as orec
+    from oracle.params import make_state, recognition_specs
+
+    G, meta = load_npz("rec.npz"), load_meta()
+    batch = oa.text.collate_samples(rec_samples(REC_CASE))
+    assert tuple(batch["image"].shape) == tuple(G["rec1/batch/image_shape"])
+    assert np.array_equal(batch["text_seq"].numpy(), G["rec1/batch/text_seq"])
+    assert np.array_equal(batch["text_len"].numpy(), G["rec1/batch/text_len"]) and np.array_equal(batch["image_width"].numpy(), G["rec1/batch/image_width"])
+    il = batch["image_width"].div(4, rounding_mode="floor")
+    m = _load(oa.RecognitionModel(oa.text.DEFAULT_ALPHABET), REC_CASE["seed"]).to(dev)
+    m.train()
+    opt = oa.optim.Adam(m.parameters())
+    opt.zero_grad()
+    lp = m(batch["image"].to(dev))
+    loss = oa.CTCLoss()(lp, batch["text_seq"].to(dev), il, batch["text_len"])
+    # intermediates vs the oracle
+    P, Bf = make_state(recognition_specs(), REC_CASE["seed"])
+    with torch.no_grad():
+        lp_o, mid = orec.forward(P, Bf, batch["image"], True, return_intermediates=True)
+    ref_lp = torch.from_numpy(G["rec1/f32/log_probs"])
+    assert rel(lp, ref_lp) < 1e-4, rel(lp, ref_lp)
+    assert rel(lp, lp_o) < 1e-4
+    assert abs(loss.item() - float(G["rec1/f32/loss"])) < 1e-4 * abs(loss.item())
+    # decode: bit-exact arg-max indices, strings and CER
+    stats = oa.text.RecognitionAccuracyStats()
+    stats.update(batch["text_seq"], batch["text_len"].tolist(), lp.detach(), il.tolist())
+    assert stats.char_errors == meta["rec1/f32/char_errors"] and stats.total_chars == meta["rec1/f32/total_chars"]
+    dec, amax = oa.text.greedy_decode_batch(lp.detach(), il.tolist())
+    assert np.array_equal(amax.cpu().numpy(), G["rec1/f32/argmax"])
+    alphabet = list(oa.text.DEFAULT_ALPHABET)
+    assert ["".join(alphabet[c - 1] for c in row) for row in dec] == meta["rec1/f32/decoded"]
+    loss.backward()
+    bad = {}
+    for k, p in m.named_parameters():
+        e = compare_to_golden(G, f"rec1/f64/grad/{k}", p.grad, 0, atol=1e-7)
+        ref = golden_vs_golden(G, f"rec1/f32/grad/{k}", f"rec1/f64/grad/{k}")
+        if e > 2 * ref + 2e-4:
+            bad[k] = (e, ref)
+    assert not bad, bad
+    gn = oa.optim.clip_grad_norm_(m.parameters(), 4.0)
+    assert abs(gn.item() - float(G["rec1/f32/grad_norm"])) < 1e-3 * gn.item()
+    opt.step()
+    sd = m.state_dict()
+    for k in golden_keys(G, "rec1/f32/state1"):
+        tol = 0 if k.endswith("num_batches_tracked") else 1e-2
+        assert compare_to_golden(G, f"rec1/f32/state1/{k}", sd[k], 0, atol=1e-6) <= tol, k
+
+
+def test_recognition_bf16_autocast_mode(dev):
+    """bf16 conv activations (as train_rec.py:118 trains), GRU/Linear fp32.  Tolerance stated against the noise floor of the
+    reference's own bf16 numerics: golden log-probs of the reference under CPU bf16 autocast vs its fp32 run."""
+    import ocrs_models_amd as oa
+
+    G = load_npz("rec.npz")
+    batch = oa.text.collate_samples(rec_samples(REC_CASE))
+    il = batch["image_width"].div(4, rounding_mode="floor")
+    m = _load(oa.RecognitionModel(oa.text.DEFAULT_ALPHABET), REC_CASE["seed"]).to(dev)
+    m.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lp = m(batch["image"].to(dev))
+        loss = oa.CTCLoss()(lp, batch["text_seq"].to(dev), il, batch["text_len"])
+    loss.backward()
+    f32, b16 = torch.from_numpy(G["rec1/f32/log_probs"]), torch.from_numpy(G["rec1/bf16/log_probs"])
+    floor = rel(b16, f32)
+    e = rel(lp, f32)
+    print(f"bf16 log-probs relL2 {e:.3e} (reference bf16-autocast floor {floor:.3e})")
+    assert e < 1.5 * floor + 1e-3
+    assert abs(loss.item() - float(G["rec1/f32/loss"])) < 2e-2 * abs(loss.item())
+    errs, floors = [], []
+    for k, p in m.named_parameters():
+        errs.append(compare_to_golden(G, f"rec1/f32/grad/{k}", p.grad, 0, atol=1e-7))
+        floors.append(golden_vs_golden(G, f"rec1/bf16/grad/{k}", f"rec1/f32/grad/{k}"))
+    assert float(np.median(errs)) < 1.5 * float(np.median(floors)) + 1e-2, (float(np.median(errs)), float(np.median(floors)))
+
+
+def test_recognition_eval_mode(dev):
+    import ocrs_models_amd as oa
+    from oracle import recognition as orec
+    from oracle.params import make_state, recognition_specs
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 1, 64, 100, generator=g) - 0.5
+    P, Bf = make_state(recognition_specs(), 77)
+    with torch.no_grad():
+        lp_o = orec.forward(P, Bf, x, False)
+    m = _load(oa.RecognitionModel(oa.text.DEFAULT_ALPHABET), 77).to(dev)
+    m.eval()
+    with torch.no_grad():
+        lp = m(x.to(dev))
+    assert lp.shape == (26, 3, 97)
+    assert rel(lp, lp_o) < 1e-4
