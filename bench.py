@@ -91,6 +91,79 @@ def cpu_baseline(steps=3, B=2, H=1024, W=1024):
             "sample": f"{steps} steps of B={B} 1x{H}x{W} fp32 (oracle/: stock ATen CPU ops, {os.cpu_count()} logical cpus)"}
 
 
+def synth_rec_batch(B, W, gen_seed, dev):
+    """BASELINE configs[2]: B line crops 1x64xW, targets L ~ U[5,40] resampled until CTC-feasible for W//4 steps (SURVEY 8d)."""
+    import numpy as np
+
+    r = np.random.RandomState(gen_seed)
+    img = torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, 64, W)).astype(np.float32))
+    Lpad = 64
+    text = torch.zeros(B, Lpad, dtype=torch.int32)
+    tl = torch.zeros(B, dtype=torch.int64)
+    for i in range(B):
+        while True:
+            L = int(r.randint(5, 41))
+            y = r.randint(1, 97, size=L)
+            if L + int((y[1:] == y[:-1]).sum()) <= W // 4:
+                break
+        text[i, :L] = torch.from_numpy(y.astype(np.int32))
+        tl[i] = L
+    return {"image": img.to(dev), "text_seq": text.to(dev), "text_len": tl, "image_width": torch.full((B,), W, dtype=torch.int64)}
+
+
+def bench_crnn(args, world, rank, dev, dist):
+    """CRNN recognition train step (bf16-autocast conv backbone, fp32 BiGRU, CTC, clip 4.0, Adam): line-crops/s."""
+    import ocrs_models_amd as oa
+    from ocrs_models_amd import train_rec
+    from ocrs_models_amd.ddp import DistributedDataParallel
+
+    B, W = args.rec_batch, args.rec_width
+    torch.manual_seed(1234)
+    model = oa.RecognitionModel(oa.text.DEFAULT_ALPHABET).to(dev)
+    model.train()
+    net = DistributedDataParallel(model) if world > 1 else model
+    opt = train_rec.make_optimizer(model)
+    batch = synth_rec_batch(B, W, 2000 + rank, dev)
+    loss_fn = oa.CTCLoss()
+    il = batch["image_width"].div(4, rounding_mode="floor").tolist()
+
+    def step():
+        loss, gn = train_rec.train_step(net, opt, batch, dev, None, loss_fn, check_nan=False)
+        oa.text.greedy_decode_batch(net_last_pred[0], il) if net_last_pred[0] is not None else None
+        return loss
+
+    # keep the stats work of train_rec.py:123 (arg-max + CTC collapse + D2H of the collapsed labels) inside the step
+    net_last_pred = [None]
+    orig_forward = model.forward
+
+    def fwd_hook(x):
+        out = orig_forward(x)
+        net_last_pred[0] = out.detach()
+        return out
+
+    model.forward = fwd_hook
+    for _ in range(max(2, args.warmup)):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"metric": "CRNN train-step line-crops/sec", "value": round(B * world * args.steps / dt, 1), "unit": "crops/s",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16 conv (autocast) / fp32 GRU+Linear+CTC",
+            "config": {"workload": f"CRNN train step (fwd+CTC+bwd+clip+Adam, greedy decode for stats), {B}x1x64x{W} crops per GPU, T={W // 4 + 1}",
+                       "global_batch": B * world, "final_loss": round(float(loss.item()), 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +174,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-crnn", action="store_true")
+    ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
+    ap.add_argument("--rec-width", type=int, default=400)
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -189,6 +265,11 @@ def main():
                                "avg_launch_ms": round(tot_ms / n, 4), "alg_bytes_per_launch": round(tot_b / n)}
             out["kernel_families_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
             out["kernel_families_gbs"] = {k: round(v[1] / (v[0] * 1e-3) / 1e9, 1) for k, v in fam.items() if v[0] > 0}
+    del model, net, opt, img, mask, loss
+    torch.cuda.empty_cache()
+    if not args.no_crnn:
+        crnn = bench_crnn(args, world, rank, dev, dist)
+        out["crnn"] = crnn
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -1,0 +1,55 @@
+"""Recognition training step, the body of the reference's ``train()`` loop (ocrs_models/train_rec.py:107-153):
+bf16 autocast forward + CTC loss, accuracy stats, NaN guard, backward, clip_grad_norm_(4.0), Adam step."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .losses import CTCLoss
+from .optim import Adam, clip_grad_norm_
+from .text import RecognitionAccuracyStats
+
+
+def make_optimizer(model, lr: float = 1e-3) -> Adam:
+    return Adam(model.parameters(), lr=lr)  # train_rec.py:381-382
+
+
+def train_step(model, optimizer, batch: dict, device, stats: RecognitionAccuracyStats | None = None, loss_fn=None, check_nan: bool = True,
+               max_norm: float = 4.0):
+    """One iteration of train_rec.py:107-151.  Returns (loss, grad_norm) as device scalars."""
+    loss_fn = loss_fn or CTCLoss()
+    # the model emits W/4 + 1 steps but only the first W/4 count for the loss (train_rec.py:110)
+    input_lengths = batch["image_width"].div(4, rounding_mode="floor")
+    img = batch["image"].to(device, non_blocking=True)
+    text_seq = batch["text_seq"].to(device, non_blocking=True)
+    target_lengths = batch["text_len"]
+    optimizer.zero_grad()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        pred_seq = model(img)
+        batch_loss = loss_fn(pred_seq, text_seq, input_lengths, target_lengths)
+    if stats is not None:
+        stats.update(batch["text_seq"], target_lengths.tolist(), pred_seq.detach(), input_lengths.tolist())
+    if check_nan and math.isnan(batch_loss.item()):
+        raise Exception("Training produced invalid loss. Check input and target lengths are compatible with CTC loss")
+    batch_loss.backward()
+    grad_norm = clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    optimizer.step()
+    return batch_loss.detach(), grad_norm
+
+
+def train(epoch: int, device, dataloader, model, optimizer):
+    """Epoch loop with the reference's signature and return value (train_rec.py:85-160)."""
+    model.train()
+    stats = RecognitionAccuracyStats()
+    loss_fn = CTCLoss()
+    mean_loss = torch.zeros((), device=device)
+    total_norm = torch.zeros((), device=device)
+    n = 0
+    for batch in dataloader:
+        loss, gn = train_step(model, optimizer, batch, device, stats, loss_fn)
+        mean_loss += loss
+        total_norm += gn
+        n += 1
+    print(f"Mean grad norm {float(total_norm.item()) / max(n, 1)}")
+    return float(mean_loss.item()) / max(n, 1), stats
