@@ -74,6 +74,39 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
+// raw (still packed) 8-channel vector: lets a kernel issue global loads early and convert at the point of use
+template <class T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    float4 a, b;
+};
+template <>
+struct Raw8<bf16> {
+    uint4 a;
+};
+__device__ __forceinline__ Raw8<float> load8_raw(const float* p) {
+    Raw8<float> r;
+    r.a = *reinterpret_cast<const float4*>(p);
+    r.b = *reinterpret_cast<const float4*>(p + 4);
+    return r;
+}
+__device__ __forceinline__ Raw8<bf16> load8_raw(const bf16* p) {
+    Raw8<bf16> r;
+    r.a = *reinterpret_cast<const uint4*>(p);
+    return r;
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;
+    v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void unpack8(const Raw8<bf16>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.a.z << 16); v[5] = __uint_as_float(r.a.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.a.w << 16); v[7] = __uint_as_float(r.a.w & 0xffff0000u);
+}
+
 // 4 consecutive channels (MFMA accumulator quad): 8 B / 16 B
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -196,9 +229,10 @@ struct Mma<float> {
 // sum over all lanes of the wave with the same (lane % CG), CG in {1,2,4}; every lane gets its class' sum
 template <int CG>
 __device__ __forceinline__ float lane_class_sum(float v) {
+    static_assert(CG == 1 || CG == 2 || CG == 4 || CG == 8, "lane classes");
     if (CG <= 1) v += dpp_f<0xB1>(v);  // xor 1
     if (CG <= 2) v += dpp_f<0x4E>(v);  // xor 2
-    v += dpp_f<0x124>(v);              // row_ror:4
+    if (CG <= 4) v += dpp_f<0x124>(v); // row_ror:4
     v += dpp_f<0x128>(v);              // row_ror:8
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);

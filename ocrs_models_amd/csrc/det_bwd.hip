@@ -309,24 +309,26 @@ template <class T, int CG>
 __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/, Tiling2 tg) {
-    constexpr int TH = 8, TW = 32 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8;  // SC = channels of this block's slab
+    // slab of SC = CG*8 channels per block (grid.y); 4 channels per thread -> 36 dW accumulators; tile 8 x (16/CG) pixels
+    constexpr int TH = 8, TW = 16 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
+    constexpr int NIT = (HP * CG + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    float* ds = s_mem;             // [HP][SC] du tile + halo (fp32, 0 outside the image)
-    float* s_w = ds + HP * SC;     // [9][SC] weights, tap-major
+    float* ds = s_mem;           // [HP][SC] du tile + halo (fp32, 0 outside the image)
+    float* s_w = ds + HP * SC;   // [9][SC] weights, tap-major
     const int C = x.Ca + x.Cb;
     const int H = tg.H, W = tg.W;
-    const int cb = blockIdx.y * SC;  // first channel of the slab
+    const int cb = blockIdx.y * SC;
     const int tid = threadIdx.x;
     for (int i = tid; i < 9 * SC; i += 256) {
         const int t = i / SC, c = i - t * SC;
         s_w[i] = wdw[(cb + c) * 9 + t];
     }
-    const int pxl = tid / CG, cg = tid % CG;
+    const int pxl = tid / CQ, q = tid % CQ;
     const int ty = pxl / TW, tx = pxl % TW;
-    const int c0 = cb + cg * 8;
-    float acc[9][8], sc[8], sh[8], lo[8];
+    const int c0 = cb + q * 4;
+    float acc[9][4], sc[4], sh[4], lo[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int c = c0 + i;
         const float* trp = c < x.Ca ? tra + c : trb + (c - x.Ca);
         const int trs = c < x.Ca ? x.Ca : x.Cb;
@@ -340,60 +342,78 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
     const T* xsrc = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
     T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
     const int xp = in_a ? x.Ca : x.Cb;
-    TileSched ts(tg.ntiles);
-    for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
-        __syncthreads();
-        for (int it = tid; it < HP * CG; it += 256) {
+
+    // software pipeline: raw du halo vectors of the NEXT tile are in flight while the current tile is computed
+    Raw8<T> raw[NIT];
+    unsigned okmask = 0;
+    auto issue = [&](const TileOrg& o) {
+        okmask = 0;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + j * 256;
             const int hp = it / CG, g8 = it - hp * CG;
             const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
-            const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (h >= 0 && h < H && w >= 0 && w < W) load8(du + (((long)org.n * H + h) * W + w) * C + cb + g8 * 8, v);
-            store8(ds + (hp * CG + g8) * 8, v);
+            const int h = o.h0 + hy - 1, w = o.w0 + hx - 1;
+            if (it < HP * CG && h >= 0 && h < H && w >= 0 && w < W) {
+                raw[j] = load8_raw(du + (((long)o.n * H + h) * W + w) * C + cb + g8 * 8);
+                okmask |= 1u << j;
+            }
+        }
+    };
+    TileSched ts(tg.ntiles);
+    if (ts.first < ts.end) issue(tile_origin2<TW, TH>(tg, (int)ts.first));
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        __syncthreads();  // previous tile's readers of ds are done
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + j * 256;
+            if (it < HP * CG) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (okmask & (1u << j)) unpack8(raw[j], v);
+                store8(ds + (long)it * 8, v);
+            }
         }
         __syncthreads();
+        if (t + ts.step < ts.end) issue(tile_origin2<TW, TH>(tg, (int)(t + ts.step)));
         const int h = org.h0 + ty, w = org.w0 + tx;
-        if (h < H && w < W) {
-            const long p = ((long)org.n * H + h) * W + w;
-            float xv[8], g[8];
-            load8(xsrc + p * xp, xv);
+        const bool valid = h < H && w < W;
+        const long p = valid ? ((long)org.n * H + h) * W + w : 0;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            load4(xsrc + p * xp, xv);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
-                g[i] = 0.f;
-            }
-            // tap k pairs x~[p] with du[p - off(k)]: halo index (ty+1 - (k/3-1), tx+1 - (k%3-1)) = (ty + 2 - k/3, tx + 2 - k%3)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                float d[8], wk[8];
-                load8(ds + (((ty + 2 - k / 3) * (TW + 2) + (tx + 2 - k % 3)) * CG + cg) * 8, d);
-                load8(s_w + k * SC + cg * 8, wk);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    g[i] = fmaf(wk[i], d[i], g[i]);
-                    acc[k][i] = fmaf(xv[i], d[i], acc[k][i]);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // one tap at a time: keeps the 72 dW accumulators + one tap live, not all nine
-            }
-            if (gdst) store8(gdst + p * xp, g);
+            for (int i = 0; i < 4; ++i) xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
         }
+        // tap k pairs x~[p] with du[p - off(k)]: halo index (ty + 2 - k/3, tx + 2 - k%3).  Unconditional: an out-of-image pixel of a
+        // partial tile has x~ = 0, so it adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 d4 = *reinterpret_cast<const float4*>(ds + ((ty + 2 - k / 3) * (TW + 2) + (tx + 2 - k % 3)) * SC + q * 4);
+            const float4 w4 = *reinterpret_cast<const float4*>(s_w + k * SC + q * 4);
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w}, wk[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[i] = fmaf(wk[i], d[i], g[i]);
+                acc[k][i] = fmaf(xv[i], d[i], acc[k][i]);
+            }
+        }
+        if (valid && gdst) store4(gdst + p * xp, g[0], g[1], g[2], g[3]);
     }
     __syncthreads();
-    // block reduction of the 72 per-thread partials: DPP within the wave (lanes of equal channel group), then 4 waves via LDS
-    float* s_part = ds;  // reuse the tile buffer: [4 waves][9*SC]
-    const int lane = tid & 63, wave = tid >> 6;
+    // block reduction of the 36 per-thread partials through LDS (plain stores, then a strided sum): cheap in registers,
+    // runs once per persistent block
+    float* s_red = s_w + 9 * SC;  // [36][256]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float v = lane_class_sum<CG>(acc[t][i]);
-            if (lane < CG) s_part[wave * 9 * SC + t * SC + cg * 8 + i] = v;
-        }
+        for (int i = 0; i < 4; ++i) s_red[(t * 4 + i) * 256 + tid] = acc[t][i];
     __syncthreads();
-    for (int i = tid; i < 9 * SC; i += 256) {
-        const int t = i / SC, c = i - t * SC;
-        const float v = s_part[i] + s_part[9 * SC + i] + s_part[18 * SC + i] + s_part[27 * SC + i];
+    for (int j = tid; j < 9 * SC; j += 256) {
+        const int t = j / SC, c = j - t * SC;
+        const float* src = s_red + (t * 4 + (c & 3)) * 256 + (c >> 2);
+        float v = 0.f;
+        for (int m = 0; m < 256 / CQ; ++m) v += src[m * CQ];
         atomicAdd(&dwdw[(cb + c) * 9 + t], v);
     }
 }
@@ -805,9 +825,9 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     const int gy = C / (cg * 8);
 #define DWB(T_, CG_)                                                                                                                      \
     {                                                                                                                                     \
-        const Tiling2 tg = make_tiling2(N, H, W, 32 / CG_, 8);                                                                            \
-        const int HP = (32 / CG_ + 2) * 10;                                                                                               \
-        const size_t smem = ((HP > 36 ? HP : 36) * CG_ * 8 + 9 * CG_ * 8) * sizeof(float);                                                                \
+        const Tiling2 tg = make_tiling2(N, H, W, 16 / CG_, 8);                                                                            \
+        const int HP = (16 / CG_ + 2) * 10;                                                                                               \
+        const size_t smem = (HP * CG_ * 8 + 9 * CG_ * 8 + 36 * 256) * sizeof(float);                                                                \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         hipLaunchKernelGGL((k_dw_bwd<T_, CG_>), dim3(persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1), gy), dim3(256), smem, st, x, tra, trb, wdw, \
                            (const T_*)du, (T_*)gxa, (T_*)gxb, dwdw, tg);                                                                   \

@@ -178,6 +178,50 @@ __device__ __forceinline__ void stage_halo(const Src2<T>& x, const float* s_tr, 
     }
 }
 
+// Software-pipelined form of stage_halo: halo_issue() only ISSUES the global loads of one (tile, channel-chunk) into
+// registers (NIT = ceil(HP*CG/256) raw vectors per thread); halo_commit() later applies the transform and writes LDS.
+// The caller issues the loads of the next tile before computing on the current one, so HBM latency hides under compute.
+template <class T, int CG, int TW, int TH>
+struct HaloPipe {
+    using HT = HaloTile<TW, TH>;
+    static constexpr int NIT = (HT::HP * CG + 255) / 256;
+    Raw8<T> raw[NIT];
+    unsigned okmask;
+
+    __device__ __forceinline__ void issue(const Src2<T>& x, int ch0, const TileOrg& org, int H, int W, int tid) {
+        okmask = 0;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + j * 256;
+            const int hp = it / CG, cg = it - hp * CG;
+            const int hy = hp / HT::HW_, hx = hp - hy * HT::HW_;
+            const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
+            const bool ok = it < HT::HP * CG && h >= 0 && h < H && w >= 0 && w < W;
+            if (ok) {
+                raw[j] = load8_raw(src_ptr(x, ((long)org.n * H + h) * W + w, ch0 + cg * 8));
+                okmask |= 1u << j;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(const float* s_tr, int CIN, int ch0, float* xs, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + j * 256;
+            if (it < HT::HP * CG) {
+                const int cg = it % CG;
+                const int c0 = ch0 + cg * 8;
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (okmask & (1u << j)) {
+                    unpack8(raw[j], v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], s_tr[c0 + i], s_tr[CIN + c0 + i]), s_tr[2 * CIN + c0 + i]);
+                }
+                store8(xs + (long)it * 8, v);
+            }
+        }
+    }
+};
+
 // u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS.
 template <int CG, int TW>
 __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,

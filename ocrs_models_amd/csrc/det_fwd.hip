@@ -114,8 +114,9 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
             for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int kc = 0; kc < nkc; ++kc) {
+            // (a register-prefetched variant of this staging -- HaloPipe in det_common.h -- measured slower here: +VGPRs -> spills)
             stage_halo<T, CG, TW, TH>(x, s_par, CIN, kc * CG * 8, org, H, W, xs, tid);
-            __syncthreads();  // xs ready; previous chunk's MFMA fragment reads of `tile` are also done
+            __syncthreads();  // xs ready; all readers of the previous xs / tile passed a barrier since
             float u[8];
             dw_from_lds<CG, TW>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);
             store8(tile + pxl * PITCH + cg * 8, u);
