@@ -555,99 +555,8 @@ __global__ __launch_bounds__(256) void k_convt_dgrad(const T* __restrict__ g, co
     }
 }
 
-// ConvTranspose2d wgrad: dW[c,o,ky,kx] = sum_{n,i,j} x~[n,i,j,c] * g[n,2i+ky,2j+kx,o].
-// D[c][(tap,o)] with K = input pixels.  Block = (<=128 rows of c) x (128 columns of (tap,o)); grid.y enumerates blocks.
-template <class T>
-__global__ __launch_bounds__(256) void k_convt_wgrad(const T* __restrict__ x, const float* __restrict__ tr, const T* __restrict__ g,
-                                                     float* __restrict__ dW /*[Cup][Cout][9]*/, int Cup, int Cout, int h, int w, int H, int W,
-                                                     int N) {
-    constexpr int TP = 64;
-    constexpr int TPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* xT = reinterpret_cast<T*>(smem);  // [128][TPP]
-    T* gT = xT + 128 * TPP;              // [128][TPP]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int CB = Cup < 128 ? Cup : 128;
-    const int nbi = Cup / CB;
-    const int ci_base = (blockIdx.y % nbi) * CB;
-    const int j_base = (blockIdx.y / nbi) * 128;
-    const int J = 9 * Cout;
-    const int WTI = (CB + 15) / 16;
-    const long P = (long)N * h * w;
-    const long ntiles = (P + TP - 1) / TP;
-    {
-        const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = tid * 8; i < 128 * TPP; i += 256 * 8) {
-            store8(xT + i, zero8);
-            store8(gT + i, zero8);
-        }
-    }
-    f32x4 acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    TileSched ts(ntiles);
-    for (long t = ts.first; t < ts.end; t += ts.step) {
-        // x~T[c][pos]
-        for (int it = tid; it < TP * (CB / 8); it += 256) {
-            const int pxl = it / (CB / 8), c0 = (it % (CB / 8)) * 8;
-            const long p = t * TP + pxl;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p < P) {
-                load8(x + p * Cup + ci_base + c0, v);
-                apply_tr8(v, tr, Cup, ci_base + c0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Elem<T>::st(xT + (c0 + i) * TPP + pxl, v[i]);
-        }
-        // gT[(tap,o)][pos]
-        for (int it = tid; it < TP * 16; it += 256) {
-            const int pxl = it >> 4, jj = (it & 15) * 8;
-            const long p = t * TP + pxl;
-            const int j0 = j_base + jj;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p < P && j0 < J) {
-                const PixIdx px = decode_pixel(p, h, w);
-                const int tap = j0 / Cout, o0 = j0 - tap * Cout;
-                const int Y = 2 * px.h + tap / 3, X = 2 * px.w + tap % 3;
-                if (Y < H && X < W) load8(g + (((long)px.n * H + Y) * W + X) * Cout + o0, v);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Elem<T>::st(gT + (jj + i) * TPP + pxl, v[i]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int tt = wave + 4 * j;
-            if (tt < WTI * 8) {
-                const int ti = tt % WTI, tj = tt / WTI;
-#pragma unroll
-                for (int pc = 0; pc < TP / 32; ++pc) {
-                    const typename Mma<T>::Frag fa = Mma<T>::load_p(xT + pc * 32, TPP, ti * 16, lane, 32);
-                    const typename Mma<T>::Frag fb = Mma<T>::load_p(gT + pc * 32, TPP, tj * 16, lane, 32);
-                    acc[j] = Mma<T>::template mma<8>(fa, fb, acc[j]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int tt = wave + 4 * j;
-        if (tt < WTI * 8) {
-            const int ti = tt % WTI, tj = tt / WTI;
-            const int jc = j_base + tj * 16 + (lane & 15);
-            if (jc < J) {
-                const int tap = jc / Cout, o = jc - tap * Cout;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = ci_base + ti * 16 + (lane >> 4) * 4 + r;
-                    if (c < Cup) atomicAdd(&dW[((long)c * Cout + o) * 9 + tap], acc[j][r]);
-                }
-            }
-        }
-    }
-}
+// ConvTranspose2d wgrad (dW[c,o,ky,kx] = sum_{n,i,j} x~[n,i,j,c] * g[n,2i+ky,2j+kx,o]) runs on the generic k_wgrad_gather (rec_conv.hip)
+// with A = x~ (load transform applied), B = g gathered at stride 2.
 
 // per-channel sum over pixels (ConvTranspose2d bias gradient)
 template <class T>
@@ -734,6 +643,9 @@ static inline int wgrad_grid(long ntiles, int cap_blocks) {
     if (g >= 8) g &= ~7L;
     return (int)g;
 }
+
+extern "C" int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA,
+                                 int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
 
 extern "C" {
 
@@ -891,27 +803,16 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_DISPATCH
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
-    const int CB = Cup < 128 ? Cup : 128;
-    const int gy = (Cup / CB) * ((9 * Cout + 127) / 128);
-    const int gxw = wgrad_grid(ntiles, 1024);
+    {
+        const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
+        if (rc != OCRS_OK) return rc;
+    }
     const long Pout = (long)N * H * W;
     const int gs = cg_grid(Pout * (Cout / 8));
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_convt_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess)
-            return OCRS_ERR_HIP;
-        attr_set = true;
-    }
-    if (dtype == 1) {
-        hipLaunchKernelGGL(k_convt_wgrad<bf16>, dim3(gxw, gy), dim3(256), 2 * 128 * 72 * 2, st, (const bf16*)x, tr, (const bf16*)g, dW, Cup, Cout,
-                           h, w, H, W, N);
+    if (dtype == 1)
         hipLaunchKernelGGL(k_channel_sum<bf16>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const bf16*)g, dbias, Cout, Pout);
-    } else {
-        hipLaunchKernelGGL(k_convt_wgrad<float>, dim3(gxw, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)x, tr, (const float*)g, dW, Cup,
-                           Cout, h, w, H, W, N);
+    else
         hipLaunchKernelGGL(k_channel_sum<float>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const float*)g, dbias, Cout, Pout);
-    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

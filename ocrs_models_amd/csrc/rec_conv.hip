@@ -128,24 +128,58 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
 // D[ra][(tap, cb)] += sum_pos A~[pos][ra] * B[bpos(pos, tap)][cb];  A grid (N, hA, wA), B grid (N, HB, WB),
 // bpos = (i*stride + ky - padh, j*stride + kx - padw).  Block = (<=128 A channels) x (128 columns (tap, cb)); K = positions.
 // dW index = (ra * CB + cb) * ntaps + tap  (covers Conv2d [Cout][Cin][kh][kw] with A = dz, and ConvTranspose2d / Linear / GRU).
+// LDS tiles are stored transposed ([channel][pixel], pixel = MFMA K) with the 8-pixel column blocks XOR-swizzled by
+// (row >> 3) & 7: with 16-byte-aligned rows every 8th row would otherwise start on the same bank (16-way conflicts on the
+// scalar transposed stores); lanes are mapped pixel-fastest so 16 lanes write 16 consecutive pixels of one channel.
 template <class T>
+__device__ __forceinline__ typename Mma<T>::Frag load_swz(const T* tile, int tpp, int row0, int pc, int lane);
+template <>
+__device__ __forceinline__ Mma<bf16>::Frag load_swz<bf16>(const bf16* tile, int tpp, int row0, int pc, int lane) {
+    const int row = row0 + (lane & 15);
+    const int blk = (pc * 4 + (lane >> 4)) ^ ((row >> 3) & 7);
+    Mma<bf16>::Frag f;
+    f.q = *reinterpret_cast<const uint4*>(tile + row * tpp + blk * 8);
+    return f;
+}
+template <>
+__device__ __forceinline__ Mma<float>::Frag load_swz<float>(const float* tile, int tpp, int row0, int pc, int lane) {
+    const int row = row0 + (lane & 15);
+    const int sw = (row >> 3) & 7;
+    Mma<float>::Frag f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int px = pc * 32 + ks * 4 + (lane >> 4);
+        f.v[ks] = tile[row * tpp + (((px >> 3) ^ sw) << 3) + (px & 7)];
+    }
+    return f;
+}
+
+// store the same channel of two adjacent pixels (px even) as one LDS word / pair
+__device__ __forceinline__ void st_pair(bf16* dst, float a, float b) { *reinterpret_cast<unsigned*>(dst) = pack2bf(a, b); }
+__device__ __forceinline__ void st_pair(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
+
+// TP pixels per tile (128 for bf16, 64 for fp32: LDS).  Software-pipelined: the raw global loads of tile t+1 are issued before the
+// MFMA phase of tile t (the kernel runs at one block per CU, so nothing else would hide the HBM latency).
+template <class T, int TP>
 __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, int ldA, int CA, const float* __restrict__ trA, const T* __restrict__ B,
                                                       int ldB, int CB, float* __restrict__ dW, int N, int hA, int wA, int HB, int WB, int stride,
                                                       int padh, int padw, int KH, int KW) {
-    constexpr int TP = 64;
     constexpr int TPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;
+    constexpr int NPB = TP / 64;       // 64-pixel blocks per tile (swizzle works inside a 64-pixel block)
+    constexpr int NIT = TP / 32;       // (pixel pair, group) items per thread, A side (max) and B side
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* aT = reinterpret_cast<T*>(smem);  // [128][TPP]
     T* bT = aT + 128 * TPP;              // [128][TPP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int CA8 = (CA + 7) & ~7;
-    const int RB = CA8 < 128 ? CA8 : 128;  // rows handled by this block
     const int nbi = (CA8 + 127) / 128;
     const int ci_base = (blockIdx.y % nbi) * 128;
     const int j_base = (blockIdx.y / nbi) * 128;
     const int ntaps = KH * KW;
     const int J = ntaps * CB;
-    const int rows_here = (CA8 - ci_base) < RB ? (CA8 - ci_base) : RB;
+    const int rows_here = (CA8 - ci_base) < 128 ? (CA8 - ci_base) : 128;
+    const int NGA = rows_here / 8;
+    const int NG4 = (NGA + 3) / 4;
     const int WTI = (rows_here + 15) / 16;
     const long P = (long)N * hA * wA;
     const long ntiles = (P + TP - 1) / TP;
@@ -153,49 +187,123 @@ __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, i
         const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int i = tid * 8; i < 256 * TPP; i += 256 * 8) store8(aT + i, zero8);
     }
+    // work items: (pixel PAIR, 8-channel group); lanes = 4 groups x 16 pairs per wave -> 64-byte global segments per pixel,
+    // 32-bit LDS stores (two pixels of one channel).  A: item j of this thread = (group gA[j], pair ppA[j]); B: fixed column group.
+    const int g4 = tid & 3, pp16 = (tid >> 2) & 15, blk = tid >> 6;
+    const int jjB = (blk * 4 + g4) * 8;
+    const int j0B = j_base + jjB;
+    const bool colB = j0B < J;
+    const int tapB = colB ? j0B / CB : 0, c0B = j0B - tapB * CB;
+    const int dyB = tapB / KW - padh, dxB = tapB % KW - padw;
+
+    Raw8<T> ra[NIT][2], rb[NIT][2];
+    unsigned oka = 0, okb = 0;
+    auto issue = [&](long t) {
+        const long p0 = t * TP;
+        oka = okb = 0;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + 256 * j;
+            const int grp = g4 + 4 * ((it >> 6) % NG4), pp = pp16 + 16 * ((it >> 6) / NG4);
+            if (grp < NGA && pp < TP / 2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const long p = p0 + 2 * pp + e;
+                    if (p < P) {
+                        ra[j][e] = load8_raw(A + p * ldA + ci_base + grp * 8);
+                        oka |= 1u << (2 * j + e);
+                    }
+                }
+            }
+        }
+        const PixIdx base = decode_pixel(p0 < P ? p0 : 0, hA, wA);
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int pp = pp16 + 16 * j;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int off = 2 * pp + e;
+                if (colB && p0 + off < P) {
+                    int w = base.w + off, h = base.h, n = base.n;
+                    while (w >= wA) {
+                        w -= wA;
+                        if (++h >= hA) {
+                            h = 0;
+                            ++n;
+                        }
+                    }
+                    const int Y = h * stride + dyB, X = w * stride + dxB;
+                    if (Y >= 0 && Y < HB && X >= 0 && X < WB) {
+                        rb[j][e] = load8_raw(B + (((long)n * HB + Y) * WB + X) * ldB + c0B);
+                        okb |= 1u << (2 * j + e);
+                    }
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int it = tid + 256 * j;
+            const int grp = g4 + 4 * ((it >> 6) % NG4), pp = pp16 + 16 * ((it >> 6) / NG4);
+            if (grp < NGA && pp < TP / 2) {
+                const int c0 = grp * 8;
+                float v[2][8];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[e][i] = 0.f;
+                    if (oka & (1u << (2 * j + e))) {
+                        unpack8(ra[j][e], v[e]);
+                        if (trA) apply_tr8(v[e], trA, CA, ci_base + c0);
+                    }
+                }
+                const int px = 2 * pp, pb = px >> 6, pl = px & 63;
+                T* dst = aT + c0 * TPP + pb * 64 + ((((pl >> 3) ^ ((c0 >> 3) & 7)) << 3) | (pl & 7));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) st_pair(dst + i * TPP, v[0][i], v[1][i]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int pp = pp16 + 16 * j;
+            float v[2][8];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[e][i] = 0.f;
+                if (okb & (1u << (2 * j + e))) unpack8(rb[j][e], v[e]);
+            }
+            const int px = 2 * pp, pb = px >> 6, pl = px & 63;
+            T* dst = bT + jjB * TPP + pb * 64 + ((((pl >> 3) ^ ((jjB >> 3) & 7)) << 3) | (pl & 7));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st_pair(dst + i * TPP, v[0][i], v[1][i]);
+        }
+    };
+
     f32x4 acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
     TileSched ts(ntiles);
+    if (ts.first < ts.end) issue(ts.first);
+    __syncthreads();
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        for (int it = tid; it < TP * (rows_here / 8); it += 256) {
-            const int pxl = it / (rows_here / 8), c0 = (it % (rows_here / 8)) * 8;
-            const long p = t * TP + pxl;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p < P) {
-                load8(A + p * ldA + ci_base + c0, v);
-                if (trA) apply_tr8(v, trA, CA, ci_base + c0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Elem<T>::st(aT + (c0 + i) * TPP + pxl, v[i]);
-        }
-        for (int it = tid; it < TP * 16; it += 256) {
-            const int pxl = it >> 4, jj = (it & 15) * 8;
-            const long p = t * TP + pxl;
-            const int j0 = j_base + jj;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p < P && j0 < J) {
-                const PixIdx px = decode_pixel(p, hA, wA);
-                const int tap = j0 / CB, c0 = j0 - tap * CB;
-                const int Y = px.h * stride + tap / KW - padh, X = px.w * stride + tap % KW - padw;
-                if (Y >= 0 && Y < HB && X >= 0 && X < WB) load8(B + (((long)px.n * HB + Y) * WB + X) * ldB + c0, v);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Elem<T>::st(bT + (jj + i) * TPP + pxl, v[i]);
-        }
+        commit();
         __syncthreads();
+        if (t + ts.step < ts.end) issue(t + ts.step);  // in flight during the MFMA phase
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int tt = wave + 4 * j;
             if (tt < WTI * 8) {
                 const int ti = tt % WTI, tj = tt / WTI;
 #pragma unroll
-                for (int pc = 0; pc < TP / 32; ++pc) {
-                    const typename Mma<T>::Frag fa = Mma<T>::load_p(aT + pc * 32, TPP, ti * 16, lane, 32);
-                    const typename Mma<T>::Frag fb = Mma<T>::load_p(bT + pc * 32, TPP, tj * 16, lane, 32);
-                    acc[j] = Mma<T>::template mma<8>(fa, fb, acc[j]);
-                }
+                for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const typename Mma<T>::Frag fa = load_swz<T>(aT + pb * 64, TPP, ti * 16, pc, lane);
+                        const typename Mma<T>::Frag fb = load_swz<T>(bT + pb * 64, TPP, tj * 16, pc, lane);
+                        acc[j] = Mma<T>::template mma<8>(fa, fb, acc[j]);
+                    }
             }
         }
         __syncthreads();
@@ -210,12 +318,121 @@ __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, i
                 const int tap = jc / CB, cb = jc - tap * CB;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ra = ci_base + ti * 16 + (lane >> 4) * 4 + r;
-                    if (ra < CA) atomicAdd(&dW[((long)ra * CB + cb) * ntaps + tap], acc[j][r]);
+                    const int ra_ = ci_base + ti * 16 + (lane >> 4) * 4 + r;
+                    if (ra_ < CA) atomicAdd(&dW[((long)ra_ * CB + cb) * ntaps + tap], acc[j][r]);
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conv2d 3x3 / stride 1 / pad 1 weight gradient with full operand reuse:
+//   dW[co][ci][ky][kx] += sum_{n,h,w} dz[n][h][w][co] * x[n][h+ky-1][w+kx-1][ci]
+// Block = 8x16 pixel tile x 128 output channels x one 32-channel slice of Cin (grid.y) x ALL 9 taps:
+//   dzT [128 co][128 px]                         (swizzled, staged once per tile)
+//   xT  [3 kx][32 ci][10 halo rows x 16 px]      three column-shifted copies of the transposed input halo, so the B fragment of
+//                                                 tap (ky,kx) is an ALIGNED 8-pixel read at row offset ky -- no per-tap re-staging.
+// D[co][(tap, ci32)] = 8 x 18 MFMA tiles = 36 per wave (144 accumulator registers), K = 128 pixels per tile.
+template <class T>
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad(const T* __restrict__ dz, int Cout, const T* __restrict__ x, int Cin, float* __restrict__ dW, int N,
+                                                       int H, int W) {
+    constexpr int TH = 8, TW = 16, TP = 128;
+    constexpr int DPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;  // dzT pitch
+    constexpr int XR = 10 * 16;                                // pixels of one shifted halo image
+    constexpr int XPP = Elem<T>::is_bf16 ? XR + 8 : XR + 4;   // xT pitch
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* dzT = reinterpret_cast<T*>(smem);   // [128][DPP]
+    T* xT = dzT + 128 * DPP;               // [3][32][XPP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci_base = blockIdx.y * 32;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = N * tiles_x * tiles_y;
+    const int g4 = tid & 3, pp16 = (tid >> 2) & 15, blk = tid >> 6;
+    f32x4 acc[36];
+#pragma unroll
+    for (int j = 0; j < 36; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    TileSched ts(ntiles);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const int tpi = tiles_x * tiles_y;
+        const int n = (int)t / tpi, r = (int)t - n * tpi;
+        const int h0 = (r / tiles_x) * TH, w0 = (r % tiles_x) * TW;
+        __syncthreads();  // previous tile's fragment reads are done
+        // ---- dzT: (pixel pair along w, 8-channel group) items: 64 pairs x 16 groups = 1024 -> 4 per thread
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int grp = g4 + 4 * blk, pp = pp16 + 16 * j;   // grp 0..15, pp 0..63 (pixel pair index: ty = pp / 8, tx = 2*(pp % 8))
+            const int ty = pp >> 3, tx = (pp & 7) * 2;
+            float v[2][8];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[e][i] = 0.f;
+                const int h = h0 + ty, w = w0 + tx + e;
+                if (h < H && w < W && grp * 8 < Cout) load8(dz + (((long)n * H + h) * W + w) * Cout + grp * 8, v[e]);
+            }
+            const int px = ty * 16 + tx, pb = px >> 6, pl = px & 63;
+            T* dst = dzT + grp * 8 * DPP + pb * 64 + ((((pl >> 3) ^ (grp & 7)) << 3) | (pl & 7));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st_pair(dst + i * DPP, v[0][i], v[1][i]);
+        }
+        // ---- xT: wave = 8-channel group, lanes walk the 10x18 halo pixels; each pixel goes into the (up to) three shifted copies
+        for (int hp = lane; hp < 10 * 18; hp += 64) {
+            const int hy = hp / 18, hx = hp - hy * 18;
+            const int h = h0 + hy - 1, w = w0 + hx - 1;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (h >= 0 && h < H && w >= 0 && w < W) load8(x + (((long)n * H + h) * W + w) * Cin + ci_base + wave * 8, v);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = hx - kx;  // column of this pixel in the copy shifted by kx
+                if (tx >= 0 && tx < 16) {
+                    T* dst = xT + (kx * 32 + wave * 8) * XPP + hy * 16 + tx;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(dst + i * XPP, v[i]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: 4 K-chunks of 32 pixels (= 2 tile rows); wave tiles tt = wave + 4j: ti = tt % 8, tj = tt / 8 (tap = tj/2, ci16 = tj%2)
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int kg = lane >> 4;
+            const int trow = 2 * pc + (kg >> 1), tcol = (kg & 1) * 8;  // tile row / column start of this lane's 8 pixels
+            typename Mma<T>::Frag fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[a] = load_swz<T>(dzT + (pc >> 1) * 64, DPP, (wave + 4 * a) * 16, pc & 1, lane);
+#pragma unroll
+            for (int tj = 0; tj < 18; ++tj) {
+                const int tap = tj >> 1, ky = tap / 3, kx = tap % 3;
+                const T* src = xT + (kx * 32 + (tj & 1) * 16 + (lane & 15)) * XPP + (trow + ky) * 16 + tcol;
+                typename Mma<T>::Frag fb;
+                if constexpr (Elem<T>::is_bf16) {
+                    fb.q = *reinterpret_cast<const uint4*>(src);
+                } else {
+                    // fp32 fragment: k-step ks holds pixel ks*4 + kg of the 32-pixel chunk (see Mma<float>)
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        const int pk = ks * 4 + kg;  // pixel within the chunk
+                        fb.v[ks] = xT[(kx * 32 + (tj & 1) * 16 + (lane & 15)) * XPP + (2 * pc + (pk >> 4) + ky) * 16 + (pk & 15)];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[tj * 2 + a] = Mma<T>::template mma<8>(fa[a], fb, acc[tj * 2 + a]);
+            }
+        }
+    }
+    // ---- flush: acc[tj*2 + a]: rows co = (wave + 4a)*16 + (lane>>4)*4 + r, column ci = ci_base + (tj&1)*16 + (lane&15), tap = tj>>1
+#pragma unroll
+    for (int tj = 0; tj < 18; ++tj)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ci = ci_base + (tj & 1) * 16 + (lane & 15), tap = tj >> 1;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int co = (wave + 4 * a) * 16 + (lane >> 4) * 4 + r4;
+                if (co < Cout && ci < Cin) atomicAdd(&dW[((long)co * Cin + ci) * 9 + tap], acc[tj * 2 + a][r4]);
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -610,28 +827,65 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     OCRS_CHECK_ARG(A && B && dW && CB % 8 == 0 && ldA % 8 == 0 && ldB % 8 == 0 && ldA >= ((CA + 7) & ~7) && ldB >= CB);
     const long P = (long)N * hA * wA;
     OCRS_CHECK_ARG(P < (1L << 31));
-    const long ntiles = (P + 63) / 64;
+    const int TP = dtype == 1 ? 128 : 64;
+    const long ntiles = (P + TP - 1) / TP;
     const int CA8 = (CA + 7) & ~7;
     const int gy = ((CA8 + 127) / 128) * ((KH * KW * CB + 127) / 128);
-    long gx = ntiles / 8;
+    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);  // flushing blocks (128x128 float atomics each), see ocrs_conv3x3_wgrad
+    long gx = ntiles / 4;
     if (gx < 1) gx = 1;
-    long cap = 2048 / gy;
+    long cap = target / gy;
     if (cap < 8) cap = 8;
     if (gx > cap) gx = cap;
     if (gx >= 8) gx &= ~7L;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
-            hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<bf16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
+                hipSuccess)
             return OCRS_ERR_HIP;
         attr_set = true;
     }
     if (dtype == 1)
-        hipLaunchKernelGGL(k_wgrad_gather<bf16>, dim3((int)gx, gy), dim3(256), 2 * 128 * 72 * 2, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B, ldB,
-                           CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
-    else
-        hipLaunchKernelGGL(k_wgrad_gather<float>, dim3((int)gx, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)A, ldA, CA, trA, (const float*)B,
+        hipLaunchKernelGGL((k_wgrad_gather<bf16, 128>), dim3((int)gx, gy), dim3(256), 2 * 128 * 136 * 2, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B,
                            ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+    else
+        hipLaunchKernelGGL((k_wgrad_gather<float, 64>), dim3((int)gx, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)A, ldA, CA, trA,
+                           (const float*)B, ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Conv2d 3x3 / stride 1 / pad 1 weight gradient (Cout <= 128, Cin % 32 == 0): dW [Cout][Cin][3][3] accumulated.
+int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(dz && x && dW && Cout % 8 == 0 && Cout <= 128 && Cin % 32 == 0);
+    const int ntiles = N * ((W + 15) / 16) * ((H + 7) / 8);
+    const int gy = Cin / 32;
+    // every block ends by flushing 128 x 288 accumulators with float atomics (~37k): keep the number of flushing blocks near
+    // one or two per CU (OCRS_WGRAD_BLOCKS) and let each block loop over more tiles
+    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);
+    long gx = ntiles / 4;
+    if (gx < 1) gx = 1;
+    long cap = target / gy;
+    if (cap < 8) cap = 8;
+    if (gx > cap) gx = cap;
+    if (gx >= 8) gx &= ~7L;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) !=
+                hipSuccess)
+            return OCRS_ERR_HIP;
+        attr_set = true;
+    }
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_conv3x3_wgrad<bf16>, dim3((int)gx, gy), dim3(256), (128 * 136 + 96 * 168) * 2, st, (const bf16*)dz, Cout, (const bf16*)x, Cin,
+                           dW, N, H, W);
+    else
+        hipLaunchKernelGGL(k_conv3x3_wgrad<float>, dim3((int)gx, gy), dim3(256), (128 * 132 + 96 * 164) * 4, st, (const float*)dz, Cout,
+                           (const float*)x, Cin, dW, N, H, W);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -14,6 +14,8 @@ stream wait for them before the gradients are returned to autograd / the optimis
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -25,6 +27,8 @@ class GradBucketer:
         self.bucket_bytes = bucket_bytes
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # OCRS_DDP_FORCE=1: issue the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
+        self.force = bool(int(os.environ.get("OCRS_DDP_FORCE", "0"))) and dist.is_initialized()
         self._reset()
 
     def _reset(self):
@@ -50,7 +54,7 @@ class GradBucketer:
         if hi <= lo:
             return
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         chunk = flat[lo:hi]
         if self.average:

@@ -22,8 +22,10 @@ class _Table:
         for i, (p, g) in enumerate(zip(params, grads)):
             rows.append([p.data_ptr(), g.data_ptr(), m[i].data_ptr() if m else 0, v[i].data_ptr() if v else 0, p.numel()])
             chunks += [[i, c] for c in range((p.numel() + chunk - 1) // chunk)]
-        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        self.chunks = torch.tensor(chunks, dtype=torch.int32).to(dev)
+        # gradient pointers change every step (autograd allocates fresh .grad tensors), so this table is rebuilt per step:
+        # stage it in pinned memory and copy asynchronously -- a pageable H2D copy would synchronise the host with the GPU
+        self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        self.chunks = torch.tensor(chunks, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
         self.nchunks = len(chunks)
         self.key = tuple(r[1] for r in rows)
 

@@ -159,7 +159,10 @@ class _RecRun:
         """dz: gradient w.r.t. the conv output [N][Hz][Wz][Cout]; accumulates dW, returns dx [N][Hx][Wx][Cin]."""
         L, w = self.L, self.P[name]
         co, ci, kh, kw = w.shape
-        L.wgrad_gather(ptr(dz), co, co, None, ptr(xin), ci, ci, ptr(self.G[name]), self.N, Hz, Wz, Hx, Wx, 1, pad, pad, kh, kw, self.dt)
+        if kh == 3 and kw == 3 and pad == 1 and co <= 128:
+            L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), self.N, Hz, Wz, self.dt)
+        else:
+            L.wgrad_gather(ptr(dz), co, co, None, ptr(xin), ci, ci, ptr(self.G[name]), self.N, Hz, Wz, Hx, Wx, 1, pad, pad, kh, kw, self.dt)
         if not need_dx:
             return None
         dx = self.empty(self.N, Hx, Wx, ci)
