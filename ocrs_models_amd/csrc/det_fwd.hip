@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
     constexpr int KS = CG * 2;  // fp32 k-steps (of 4) per chunk
     constexpr int PITCH = Mma<T>::LDS_PITCH;
     constexpr int HP = HaloTile<TW, TH>::HP;
-    constexpr bool LANE_STATS = MT <= 2;  // keep BN partial sums in registers across tiles, reduce once at the end
+    constexpr bool LANE_STATS = false;  // (per-lane sums across tiles cost 16 long-lived VGPRs -> spills; per-tile DPP reduce is cheap)  // keep BN partial sums in registers across tiles, reduce once at the end
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem);                                                   // [TP][PITCH]  dw output (MFMA operand)
     float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // [HP][CG*8]   transformed input + halo
