@@ -204,6 +204,74 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 #pragma unroll
             for (int b = 0; b < MTD; ++b) accd[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        if constexpr (Cfg::NKD == 1 && CIN <= 32) {
+            // ---- fast path (levels 0-1: one K chunk on both sides): ALL global loads of the tile are issued before the first barrier
+            // (g, z for dz and the input halo for the depthwise recompute), 3 barriers per tile instead of 5.
+            {
+                float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int c0 = cg * 8;
+                if (cg < CGO && pv) {
+                    float gh[8], zv[8];
+                    load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
+                }
+                stage_halo<T, CGI, TW, TH>(x, s_trx, CIN, 0, org, H, W, xs, tid);
+                if (cg < CGO) {
+                    store8(tileD + pxl * PITCH + cg * 8, dz);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(dzT + (c0 + i) * TPP + pxl, dz[i]);
+                }
+            }
+            __syncthreads();
+            {
+                typename Mma<T>::Frag pf[PTW];
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
+#pragma unroll
+                for (int b = 0; b < MTD; ++b) {
+                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk_d, (long)b, lane);
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wf, pf[a], accd[a][b]);
+                }
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) {
+                    const int oq = (wave * PTW + a) * 16 + (lane & 15);
+                    const int qh = org.h0 + oq / TW, qw = org.w0 + oq % TW;
+                    const long po = ((long)org.n * H + qh) * W + qw;
+#pragma unroll
+                    for (int b = 0; b < MTD; ++b) {
+                        const int m0 = b * 16 + (lane >> 4) * 4;
+                        if (qh < H && qw < W && m0 < CIN) {
+                            const f32x4 v = accd[a][b];
+                            store4(du + po * CIN + m0, v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                }
+                if (cg < CGI) {
+                    float u[8];
+                    dw_from_lds<CGI, TW>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (cg * 8 + i) * TPP + pxl, pv ? u[i] : 0.f);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int tt = wave + 4 * j;
+                if (tt < WTI * WTO) {
+                    const int ti = tt % WTI, to = tt / WTI;
+#pragma unroll
+                    for (int pc = 0; pc < TP / 32; ++pc) {
+                        const typename Mma<T>::Frag fa = Mma<T>::load_p(uT + pc * 32, TPP, ti * 16, lane, 32);
+                        const typename Mma<T>::Frag fb = Mma<T>::load_p(dzT + pc * 32, TPP, to * 16, lane, 32);
+                        accw[j] = Mma<T>::template mma<8>(fa, fb, accw[j]);
+                    }
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- A: dz chunks -> tileD (dgrad operand) + dzT (wgrad operand) ; dgrad MFMA
         for (int kc = 0; kc < Cfg::NKD; ++kc) {
             float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};

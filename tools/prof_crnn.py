@@ -1,0 +1,11 @@
+"""CRNN train steps only (for rocprofv3 runs)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse, torch
+import bench
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--rec-batch", type=int, default=256); ap.add_argument("--rec-width", type=int, default=400)
+a = ap.parse_args()
+torch.cuda.set_device(0)
+import torch.distributed as dist
+print(bench.bench_crnn(a, 1, 0, torch.device("cuda", 0), dist))
