@@ -57,6 +57,24 @@ def alg_bytes(name, a, sz):
     return 0.0
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/*_pmc_hbm.csv: rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE of this same bench command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from
+    inside the timed run, so this is the profile's figure, not this run's; null when the file is missing."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    if not files:
+        return {"traffic": None}
+    tot, n = 0.0, 0.0
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith("k_" + family + "<") or r["kernel"] == "k_" + family:
+            tot += (float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9
+            n += float(r["launches_per_step"])
+    return {"traffic": round(tot / n) if n else None, "traffic_source": os.path.basename(files[-1])}
+
+
 FAMILIES = ["dwpw_fwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce", "convt_fwd", "convt_bwd", "maxpool_fwd"]
 
 
@@ -277,6 +295,7 @@ def main():
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
                                "avg_launch_ms": round(tot_ms / n, 4), "alg_bytes_per_launch": round(tot_b / n)}
             out["kernel_families_ms_warmup_step"] = warm_fam_ms
+            out["roofline"].update(pmc_traffic(dom))
     del model, net, opt, img, mask, loss
     torch.cuda.empty_cache()
     if not args.no_crnn:
