@@ -223,9 +223,11 @@ struct HaloPipe {
 };
 
 // u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS.
+// wg (optional, CG == 1 only): the weights in the reference layout [8][9] in GLOBAL memory -- with 8 channels every thread uses the
+// same 72 weights, so they are read with wave-uniform addresses (scalar loads -> SGPR operands) instead of 18 LDS reads per pixel.
 template <int CG, int TW>
 __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
-                                            float (&u)[8]) {
+                                            float (&u)[8], const float* __restrict__ wg = nullptr) {
     constexpr int HWp = TW + 2;
     const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 8;  // top-left tap of this pixel
 #pragma unroll
@@ -234,7 +236,11 @@ __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*
     for (int t = 0; t < 9; ++t) {
         float v[8], wv[8];
         load8(xc + ((t / 3) * HWp + (t % 3)) * CG * 8, v);
-        load8(s_w + t * CIN + c0, wv);
+        if (CG == 1 && wg) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[i] = wg[i * 9 + t];
+        } else
+            load8(s_w + t * CIN + c0, wv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) u[i] = fmaf(wv[i], v[i], u[i]);
     }
