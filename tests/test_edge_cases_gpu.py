@@ -1,0 +1,155 @@
+"""Edge cases and size-independent properties on the GPU: ragged / odd batch shapes, the full BASELINE tile size,
+directional-derivative (finite difference) checks of the analytic gradients, run-to-run stability."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _det(seed, dev, dtype=None):
+    import ocrs_models_amd as oa
+    from oracle.params import detection_specs, make_state, state_dict_from
+
+    specs = detection_specs()
+    P, Bf = make_state(specs, seed)
+    m = oa.DetectionModel(act_dtype=dtype).to(dev)
+    m.load_state_dict(state_dict_from(P, Bf, specs))
+    return m, P, Bf
+
+
+def _rec(seed, dev):
+    import ocrs_models_amd as oa
+    from oracle.params import make_state, recognition_specs, state_dict_from
+
+    specs = recognition_specs()
+    P, Bf = make_state(specs, seed)
+    m = oa.RecognitionModel(oa.text.DEFAULT_ALPHABET).to(dev)
+    m.load_state_dict(state_dict_from(P, Bf, specs))
+    return m, P, Bf
+
+
+def test_detection_full_tile_1024_forward_and_loss(dev):
+    """BASELINE tile size (1x1x1024x1024, fp32 parity mode) against the CPU oracle: prediction and balanced-BCE loss."""
+    import ocrs_models_amd as oa
+    from oracle import detection as odet
+    from oracle import losses as olosses
+
+    torch.set_num_threads(16)
+    m, P, Bf = _det(41, dev)
+    m.train()
+    r = np.random.RandomState(41)
+    x = torch.from_numpy(r.uniform(-0.5, 0.5, (1, 1, 1024, 1024)).astype(np.float32))
+    mask = torch.from_numpy((r.uniform(0, 1, (1, 1, 1024, 1024)) > 0.9).astype(np.float32))
+    with torch.no_grad():
+        pred_o = odet.forward(P, Bf, x, True)
+        loss_o = olosses.balanced_bce(pred_o, mask)
+    with torch.no_grad():
+        pred = m(x.to(dev))
+        loss = oa.balanced_cross_entropy_loss(pred, mask.to(dev))
+    assert rel(pred, pred_o) < 1e-4
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    sd = m.state_dict()
+    for k, v in Bf.items():
+        if not k.endswith("num_batches_tracked"):
+            assert rel(sd[k], v) < 1e-4, k
+
+
+def test_detection_directional_derivative(dev):
+    """Size-independent property: (L(w + e*d) - L(w - e*d)) / 2e == <grad, d> for a random direction d (plain mean BCE on the
+    prediction so the loss is smooth; fp32 parity mode, eval-mode BN would hide the batch-stat path, so train mode is used)."""
+    m, _, _ = _det(43, dev)
+    m.train()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(2, 1, 96, 128, generator=g) - 0.5).to(dev)
+    t = (torch.rand(2, 1, 96, 128, generator=g) > 0.7).float().to(dev)
+    # direction restricted to the last block + head: perturbing all 622k parameters of a 26-layer ReLU/max-pool/BatchNorm net crosses
+    # so many kinks that the finite difference itself is off by 10-25 % (measured: -0.137 / -0.162 at eps 2e-3 / 1e-4 vs analytic
+    # -0.182); the full-network gradients are checked against the oracle's autograd in test_det_model_gpu.py instead
+    params = [p for k, p in m.named_parameters() if k.startswith("out_conv") or k.startswith("up.0.contract.seq.1")]
+
+    def loss_fn():
+        p = m(x)
+        return -(t * torch.log(p.clamp_min(1e-6)) + (1 - t) * torch.log((1 - p).clamp_min(1e-6))).mean()
+
+    loss = loss_fn()
+    loss.backward()
+    grads = [p.grad.clone() for p in params]
+    d = [torch.randn(p.shape, generator=g).to(dev) * p.detach().abs().mean() for p in params]
+    analytic = sum(float((gg.double() * dd.double()).sum()) for gg, dd in zip(grads, d))
+    eps = 1e-3
+    with torch.no_grad():
+        for p, dd in zip(params, d):
+            p.add_(eps * dd)
+        lp = loss_fn().item()
+        for p, dd in zip(params, d):
+            p.sub_(2 * eps * dd)
+        lm = loss_fn().item()
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) < 0.03 * abs(analytic) + 1e-4, (numeric, analytic)
+
+
+@pytest.mark.parametrize("B,W", [(1, 64), (5, 100), (17, 36), (3, 256)])
+def test_recognition_odd_batches_and_widths(dev, B, W):
+    """batch sizes that are not multiples of the 16-column GRU tile / 64-pixel GEMM tile, several crop widths; ragged CTC lengths,
+    an empty target and a target with repeated labels."""
+    import ocrs_models_amd as oa
+    from oracle import ctc as octc
+    from oracle import recognition as orec
+
+    m, P, Bf = _rec(50 + B, dev)
+    m.train()
+    r = np.random.RandomState(B * 1000 + W)
+    x = torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, 64, W)).astype(np.float32))
+    T = W // 4 + 1
+    il = torch.tensor([max(1, (W // 4) - (i % 3)) for i in range(B)])
+    tl = torch.tensor([min(int(il[i]) // 2, i % 7) for i in range(B)])
+    tg = torch.zeros(B, 64, dtype=torch.int32)
+    for i in range(B):
+        tg[i, : tl[i]] = torch.from_numpy(r.randint(1, 97, size=int(tl[i])).astype(np.int32))
+        if tl[i] >= 2 and 2 * int(tl[i]) <= int(il[i]):
+            tg[i, 1] = tg[i, 0]
+    lp = m(x.to(dev))
+    assert lp.shape == (T, B, 97)
+    loss = oa.CTCLoss()(lp, tg.to(dev), il, tl)
+    loss.backward()
+    lp_o = orec.forward(P, Bf, x, True)
+    loss_o = octc.ctc_loss_torch(lp_o, tg, il.tolist(), tl.tolist())
+    grads_o = torch.autograd.grad(loss_o, list(P.values()))
+    assert rel(lp, lp_o) < 1e-4
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * abs(loss_o.item()) + 1e-6
+    errs = [rel(p.grad, go) for (k, p), go in zip(m.named_parameters(), grads_o)]
+    assert max(errs) < 5e-3 and float(np.median(errs)) < 2e-4, (max(errs), float(np.median(errs)))
+    dec, amax = oa.text.greedy_decode_batch(lp.detach(), il.tolist())
+    assert torch.equal(amax.cpu().long(), lp_o.detach().argmax(-1).T)
+
+
+def test_detection_odd_batch_bf16_runs_and_is_stable(dev):
+    """bf16 throughput mode, batch 3, non-square odd size: two identical runs agree to atomics-level noise, no NaN."""
+    import ocrs_models_amd as oa
+
+    m, _, _ = _det(47, dev, torch.bfloat16)
+    m.train()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(3, 1, 200, 152, generator=g) - 0.5).to(dev)
+    t = (torch.rand(3, 1, 200, 152, generator=g) > 0.9).float().to(dev)
+    outs = []
+    for _ in range(2):
+        m.zero_grad()
+        import copy
+        sd = copy.deepcopy(m.state_dict())
+        pred = m(x)
+        loss = oa.balanced_cross_entropy_loss(pred, t)
+        loss.backward()
+        outs.append((pred.detach().clone(), loss.item(), [p.grad.clone() for p in m.parameters()]))
+        m.load_state_dict(sd)  # undo the running-stat update
+    assert torch.isfinite(outs[0][0]).all() and np.isfinite(outs[0][1])
+    # float atomics make the BN batch sums differ in the last bits between runs; bf16 storage rounding then flips a few
+    # activations, so identical runs agree only to ~1e-2 in this mode (fp32 mode: ~1e-6)
+    assert rel(outs[1][0], outs[0][0]) < 2e-2
+    assert abs(outs[1][1] - outs[0][1]) < 1e-2 * abs(outs[0][1])
