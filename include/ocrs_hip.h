@@ -91,7 +91,8 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
 int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA, int HB,
                       int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
 /* weight gradient of the 3x3 / pad 1 Conv2d layers (models.py:189-231), all nine taps per staged tile. */
-int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, int N, int H, int W, int dtype, hipStream_t st);
+long ocrs_conv3x3_wgrad_ws_floats(int Cout, int Cin, int N, int H, int W);
+int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, float* ws, int N, int H, int W, int dtype, hipStream_t st);
 /* Conv2d(1,32,3,p1) + ReLU + MaxPool2d(2) (models.py:180-187) fused, forward and backward. */
 int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,

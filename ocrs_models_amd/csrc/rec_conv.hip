@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, i
 // D[co][(tap, ci32)] = 8 x 18 MFMA tiles = 36 per wave (144 accumulator registers), K = 128 pixels per tile.
 template <class T>
 __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const T* __restrict__ dz, int Cout, const T* __restrict__ x, int Cin, float* __restrict__ dW, int N,
-                                                       int H, int W) {
+                                                       int H, int W, float* __restrict__ ws) {
     constexpr int TH = 8, TW = 16, TP = 128;
     constexpr int DPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;  // dzT pitch
     constexpr int XR = 10 * 16;                                // pixels of one shifted halo image
@@ -422,6 +422,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const T* __restrict__ dz,
         }
     }
     // ---- flush: acc[tj*2 + a]: rows co = (wave + 4a)*16 + (lane>>4)*4 + r, column ci = ci_base + (tj&1)*16 + (lane&15), tap = tj>>1
+    if (ws) {
+        // two-stage, atomic-free and deterministic: this block's partial goes to ws[blockIdx.x][tap][ci][co] with 16-byte stores
+        // (4 consecutive co per lane); k_wgrad3x3_reduce sums over blockIdx.x.  (37k float atomics per block were the bottleneck.)
+        float* wb = ws + (long)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+        for (int tj = 0; tj < 18; ++tj)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int ci = ci_base + (tj & 1) * 16 + (lane & 15), tap = tj >> 1;
+                const int co0 = (wave + 4 * a) * 16 + (lane >> 4) * 4;
+                if (co0 < Cout) {
+                    const f32x4 v = acc[tj * 2 + a];
+                    *reinterpret_cast<float4*>(wb + ((long)tap * Cin + ci) * Cout + co0) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int tj = 0; tj < 18; ++tj)
 #pragma unroll
@@ -857,13 +874,9 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     return OCRS_OK;
 }
 
-// Conv2d 3x3 / stride 1 / pad 1 weight gradient (Cout <= 128, Cin % 32 == 0): dW [Cout][Cin][3][3] accumulated.
-int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(dz && x && dW && Cout % 8 == 0 && Cout <= 128 && Cin % 32 == 0);
+static int wgrad3x3_gx(int Cin, int N, int H, int W) {
     const int ntiles = N * ((W + 15) / 16) * ((H + 7) / 8);
     const int gy = Cin / 32;
-    // every block ends by flushing 128 x 288 accumulators with float atomics (~37k): keep the number of flushing blocks near
-    // one or two per CU (OCRS_WGRAD_BLOCKS) and let each block loop over more tiles
     static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);
     long gx = ntiles / 4;
     if (gx < 1) gx = 1;
@@ -871,6 +884,28 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
     if (cap < 8) cap = 8;
     if (gx > cap) gx = cap;
     if (gx >= 8) gx &= ~7L;
+    return (int)gx;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad3x3_reduce(const float* __restrict__ ws, int gx, int Cout, int Cin, float* __restrict__ dW) {
+    const long n = 9L * Cin * Cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int b = 0; b < gx; ++b) s += ws[(long)b * n + i];
+        const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((long)Cout * Cin));
+        dW[((long)co * Cin + ci) * 9 + tap] += s;
+    }
+}
+
+// workspace (floats) for the atomic-free flush of ocrs_conv3x3_wgrad
+long ocrs_conv3x3_wgrad_ws_floats(int Cout, int Cin, int N, int H, int W) { return (long)wgrad3x3_gx(Cin, N, H, W) * 9 * Cin * Cout; }
+
+// Conv2d 3x3 / stride 1 / pad 1 weight gradient (Cout <= 128, Cin % 32 == 0): dW [Cout][Cin][3][3] += ...
+// ws: workspace of ocrs_conv3x3_wgrad_ws_floats() floats (deterministic two-stage reduction), or null (float atomics).
+int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, float* ws, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(dz && x && dW && Cout % 8 == 0 && Cout <= 128 && Cin % 32 == 0);
+    const int gy = Cin / 32;
+    const long gx = wgrad3x3_gx(Cin, N, H, W);  // few flushing blocks: each loops over many tiles
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) !=
@@ -882,10 +917,11 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
     }
     if (dtype == 1)
         hipLaunchKernelGGL(k_conv3x3_wgrad<bf16>, dim3((int)gx, gy), dim3(256), (128 * 136 + 96 * 168) * 2, st, (const bf16*)dz, Cout, (const bf16*)x, Cin,
-                           dW, N, H, W);
+                           dW, N, H, W, ws);
     else
         hipLaunchKernelGGL(k_conv3x3_wgrad<float>, dim3((int)gx, gy), dim3(256), (128 * 132 + 96 * 164) * 4, st, (const float*)dz, Cout,
-                           (const float*)x, Cin, dW, N, H, W);
+                           (const float*)x, Cin, dW, N, H, W, ws);
+    if (ws) hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((9 * Cin * Cout + 255) / 256), dim3(256), 0, st, ws, (int)gx, Cout, Cin, dW);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

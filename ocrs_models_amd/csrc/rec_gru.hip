@@ -29,6 +29,22 @@ __global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ 
     const int tp = d == 0 ? t - 1 : t + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = s == 0;
+    // epilogue operands of this thread's (hidden, batch) pair: independent of the recurrent GEMM, so their loads are issued first
+    const int jl = tid & 15, bl = tid >> 4;
+    const int b = b0 + bl, j = jt * 16 + jl;
+    const bool bv = b < N;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f, hp = 0.f;
+    if (bv) {
+        const float* gir = gi + ((long)t * N + b) * (2 * G3) + d * G3;
+        const float* bh = bhh + d * G3;
+        gi_r = gir[j];
+        gi_z = gir[GH + j];
+        gi_n = gir[2 * GH + j];
+        bh_r = bh[j];
+        bh_z = bh[GH + j];
+        bh_n = bh[2 * GH + j];
+        if (!first) hp = out[((long)tp * N + b) * 512 + d * GH + j];
+    }
     if (!first) {
         // this wave's K slab: h_prev[b0 .. b0+16][64*wave .. +64]
         for (int it = lane; it < 16 * 16; it += 64) {
@@ -58,22 +74,16 @@ __global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ 
         __syncthreads();
     }
     // epilogue: one (hidden, batch) pair per thread
-    const int jl = tid & 15, bl = tid >> 4;
-    const int b = b0 + bl, j = jt * 16 + jl;
-    if (b >= N) return;
+    if (!bv) return;
     float gh[3] = {0.f, 0.f, 0.f};
-    float hp = 0.f;
     if (!first) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) gh[g] = red[0][g][jl][bl] + red[1][g][jl][bl] + red[2][g][jl][bl] + red[3][g][jl][bl];
-        hp = out[((long)tp * N + b) * 512 + d * GH + j];
     }
-    const float* gir = gi + ((long)t * N + b) * (2 * G3) + d * G3;
-    const float* bh = bhh + d * G3;
-    const float rv = sigmoidf_(gir[j] + gh[0] + bh[j]);
-    const float zv = sigmoidf_(gir[GH + j] + gh[1] + bh[GH + j]);
-    const float hn = gh[2] + bh[2 * GH + j];
-    const float nv = tanhf(gir[2 * GH + j] + rv * hn);
+    const float rv = sigmoidf_(gi_r + gh[0] + bh_r);
+    const float zv = sigmoidf_(gi_z + gh[1] + bh_z);
+    const float hn = gh[2] + bh_n;
+    const float nv = tanhf(gi_n + rv * hn);
     const float hv = (1.f - zv) * nv + zv * hp;
     out[((long)t * N + b) * 512 + d * GH + j] = hv;
     if (saved) {
@@ -121,6 +131,22 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(const float* __restrict__ 
     const int t = d == 0 ? T - 1 - s : s;
     const int tq = d == 0 ? t + 1 : t - 1;  // time processed at the previous step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this thread's epilogue operands (independent of the GEMM): issue their loads first
+    const int jl = tid & 15, bl = tid >> 4;
+    const int b = b0 + bl, j = jt * 16 + jl;
+    const bool bv = b < N;
+    float e_dout = 0.f, e_dhz = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_hn = 0.f, e_hp = 0.f;
+    if (bv) {
+        e_dout = dout[((long)t * N + b) * 512 + d * GH + j];
+        if (s > 0) e_dhz = dhz[(((long)((s - 1) & 1) * 2 + d) * N + b) * GH + j];
+        const float* sv = saved + (((long)t * N + b) * 2 + d) * 4 * GH + j;
+        e_r = sv[0];
+        e_z = sv[GH];
+        e_n = sv[2 * GH];
+        e_hn = sv[3 * GH];
+        const int tp = d == 0 ? t - 1 : t + 1;
+        if (tp >= 0 && tp < T) e_hp = out[((long)tp * N + b) * 512 + d * GH + j];
+    }
     if (s > 0) {
         for (int it = lane; it < 16 * 48; it += 64) {
             const int row = it / 48, c4 = (it % 48) * 4;
@@ -141,12 +167,21 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(const float* __restrict__ 
         for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
         __syncthreads();
     }
-    const int jl = tid & 15, bl = tid >> 4;
-    const int b = b0 + bl, j = jt * 16 + jl;
-    if (b >= N) return;
-    float dh = dout[((long)t * N + b) * 512 + d * GH + j];
-    if (s > 0) dh += dhz[(((long)((s - 1) & 1) * 2 + d) * N + b) * GH + j] + red[0][jl][bl] + red[1][jl][bl] + red[2][jl][bl] + red[3][jl][bl];
-    dhz[(((long)(s & 1) * 2 + d) * N + b) * GH + j] = gru_gate_bwd1(saved, out, dgi, dgh, T, N, t, b, d, j, dh);
+    if (!bv) return;
+    float dh = e_dout;
+    if (s > 0) dh += e_dhz + red[0][jl][bl] + red[1][jl][bl] + red[2][jl][bl] + red[3][jl][bl];
+    const float dn_pre = dh * (1.f - e_z) * (1.f - e_n * e_n);
+    const float dz = dh * (e_hp - e_n) * e_z * (1.f - e_z);
+    const float dr = dn_pre * e_hn * e_r * (1.f - e_r);
+    float* gi_ = dgi + ((long)t * N + b) * (2 * G3) + d * G3 + j;
+    float* gh_ = dgh + ((long)t * N + b) * (2 * G3) + d * G3 + j;
+    gi_[0] = dr;
+    gi_[GH] = dz;
+    gi_[2 * GH] = dn_pre;
+    gh_[0] = dr;
+    gh_[GH] = dz;
+    gh_[2 * GH] = dn_pre * e_r;
+    dhz[(((long)(s & 1) * 2 + d) * N + b) * GH + j] = dh * e_z;
 }
 
 extern "C" {

@@ -160,7 +160,8 @@ class _RecRun:
         L, w = self.L, self.P[name]
         co, ci, kh, kw = w.shape
         if kh == 3 and kw == 3 and pad == 1 and co <= 128:
-            L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), self.N, Hz, Wz, self.dt)
+            ws = self.empty(L.conv3x3_wgrad_ws_floats(co, ci, self.N, Hz, Wz), dtype=torch.float32)
+            L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), ptr(ws), self.N, Hz, Wz, self.dt)
         else:
             L.wgrad_gather(ptr(dz), co, co, None, ptr(xin), ci, ci, ptr(self.G[name]), self.N, Hz, Wz, Hx, Wx, 1, pad, pad, kh, kw, self.dt)
         if not need_dx:
