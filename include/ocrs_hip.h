@@ -88,8 +88,9 @@ int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* l
 int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st);
 /* weight gradients of Conv2d / Linear / GRU (autograd of the calls above). */
-int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA, int HB,
-                      int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
+long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
+int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,
+                      int wA, int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
 /* weight gradient of the 3x3 / pad 1 Conv2d layers (models.py:189-231), all nine taps per staged tile. */
 long ocrs_conv3x3_wgrad_ws_floats(int Cout, int Cin, int N, int H, int W);
 int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* dW, float* ws, int N, int H, int W, int dtype, hipStream_t st);

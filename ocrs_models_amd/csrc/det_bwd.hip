@@ -712,8 +712,8 @@ static inline int wgrad_grid(long ntiles, int cap_blocks) {
     return (int)g;
 }
 
-extern "C" int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA,
-                                 int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
+extern "C" int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,
+                                 int wA, int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);
 
 extern "C" {
 
@@ -872,7 +872,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
     {
-        const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
+        const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, nullptr, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;
     }
     const long Pout = (long)N * H * W;

@@ -163,7 +163,7 @@ __device__ __forceinline__ void st_pair(float* dst, float a, float b) { *reinter
 template <class T, int TP>
 __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, int ldA, int CA, const float* __restrict__ trA, const T* __restrict__ B,
                                                       int ldB, int CB, float* __restrict__ dW, int N, int hA, int wA, int HB, int WB, int stride,
-                                                      int padh, int padw, int KH, int KW) {
+                                                      int padh, int padw, int KH, int KW, float* __restrict__ ws) {
     constexpr int TPP = Elem<T>::is_bf16 ? TP + 8 : TP + 4;
     constexpr int NPB = TP / 64;       // 64-pixel blocks per tile (swizzle works inside a 64-pixel block)
     constexpr int NIT = TP / 32;       // (pixel pair, group) items per thread, A side (max) and B side
@@ -315,14 +315,34 @@ __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, i
             const int ti = tt % WTI, tj = tt / WTI;
             const int jc = j_base + tj * 16 + (lane & 15);
             if (jc < J) {
-                const int tap = jc / CB, cb = jc - tap * CB;
+                const int ra0 = ci_base + ti * 16 + (lane >> 4) * 4;
+                if (ws) {
+                    // two-stage atomic-free flush: ws[blockIdx.x][jc][ra] (4 consecutive rows per lane = one 16-byte store)
+                    if (ra0 < CA8)
+                        *reinterpret_cast<float4*>(ws + ((long)blockIdx.x * J + jc) * CA8 + ra0) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+                } else {
+                    const int tap = jc / CB, cb = jc - tap * CB;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ra_ = ci_base + ti * 16 + (lane >> 4) * 4 + r;
-                    if (ra_ < CA) atomicAdd(&dW[((long)ra_ * CB + cb) * ntaps + tap], acc[j][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (ra0 + r < CA) atomicAdd(&dW[((long)(ra0 + r) * CB + cb) * ntaps + tap], acc[j][r]);
                 }
             }
         }
+    }
+}
+
+// dW[(ra*CB + cb)*ntaps + tap] += sum_bx ws[bx][jc = tap*CB + cb][ra]
+__global__ __launch_bounds__(256) void k_wgrad_gather_reduce(const float* __restrict__ ws, int gx, int CA, int CA8, int CB, int ntaps,
+                                                             float* __restrict__ dW) {
+    const long n = (long)ntaps * CB * CA8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int ra = (int)(i % CA8);
+        if (ra >= CA) continue;
+        float s = 0.f;
+        for (int b = 0; b < gx; ++b) s += ws[(long)b * n + i];
+        const long jc = i / CA8;
+        const int tap = (int)(jc / CB), cb = (int)(jc - (long)tap * CB);
+        dW[((long)ra * CB + cb) * ntaps + tap] += s;
     }
 }
 
@@ -837,24 +857,39 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
                 : launch_igemm<float, 8, 16>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st);
 }
 
-// Weight gradient by gathering: dW[(ra*CB + cb)*KH*KW + tap] += sum_pos A~[pos][ra] * B[pos*stride + tap - pad][cb].
-//   Conv2d: A = dz [N][Ho][Wo][Cout], B = x; Linear / GRU: KH=KW=1, hA=1.  trA (nullable) = load transform of A.  dW accumulated.
-int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, int N, int hA, int wA, int HB,
-                      int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(A && B && dW && CB % 8 == 0 && ldA % 8 == 0 && ldB % 8 == 0 && ldA >= ((CA + 7) & ~7) && ldB >= CB);
-    const long P = (long)N * hA * wA;
-    OCRS_CHECK_ARG(P < (1L << 31));
+static void wgrad_gather_grid(int CA, int CB, int ntaps, long P, int dtype, long& gx, int& gy) {
     const int TP = dtype == 1 ? 128 : 64;
     const long ntiles = (P + TP - 1) / TP;
     const int CA8 = (CA + 7) & ~7;
-    const int gy = ((CA8 + 127) / 128) * ((KH * KW * CB + 127) / 128);
-    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);  // flushing blocks (128x128 float atomics each), see ocrs_conv3x3_wgrad
-    long gx = ntiles / 4;
+    gy = ((CA8 + 127) / 128) * ((ntaps * CB + 127) / 128);
+    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);  // few flushing blocks, each loops over many tiles
+    gx = ntiles / 4;
     if (gx < 1) gx = 1;
     long cap = target / gy;
     if (cap < 8) cap = 8;
     if (gx > cap) gx = cap;
     if (gx >= 8) gx &= ~7L;
+}
+
+// workspace (floats) for the atomic-free flush of ocrs_wgrad_gather
+long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype) {
+    long gx;
+    int gy;
+    wgrad_gather_grid(CA, CB, ntaps, P, dtype, gx, gy);
+    return gx * ntaps * CB * ((CA + 7) & ~7);
+}
+
+// Weight gradient by gathering: dW[(ra*CB + cb)*KH*KW + tap] += sum_pos A~[pos][ra] * B[pos*stride + tap - pad][cb].
+//   Conv2d: A = dz [N][Ho][Wo][Cout], B = x; Linear / GRU: KH=KW=1, hA=1.  trA (nullable) = load transform of A.
+//   ws: workspace of ocrs_wgrad_gather_ws_floats() floats (deterministic two-stage reduction) or null (float atomics into dW).
+int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,
+                      int wA, int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(A && B && dW && CB % 8 == 0 && ldA % 8 == 0 && ldB % 8 == 0 && ldA >= ((CA + 7) & ~7) && ldB >= CB);
+    const long P = (long)N * hA * wA;
+    OCRS_CHECK_ARG(P < (1L << 31));
+    long gx;
+    int gy;
+    wgrad_gather_grid(CA, CB, KH * KW, P, dtype, gx, gy);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
@@ -866,10 +901,16 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     }
     if (dtype == 1)
         hipLaunchKernelGGL((k_wgrad_gather<bf16, 128>), dim3((int)gx, gy), dim3(256), 2 * 128 * 136 * 2, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B,
-                           ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+                           ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW, ws);
     else
         hipLaunchKernelGGL((k_wgrad_gather<float, 64>), dim3((int)gx, gy), dim3(256), 2 * 128 * 68 * 4, st, (const float*)A, ldA, CA, trA,
-                           (const float*)B, ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW);
+                           (const float*)B, ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW, ws);
+    if (ws) {
+        const int CA8 = (CA + 7) & ~7;
+        const long n = (long)KH * KW * CB * CA8;
+        hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, ws, (int)gx, CA, CA8, CB,
+                           KH * KW, dW);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -163,13 +163,21 @@ class _RecRun:
             ws = self.empty(L.conv3x3_wgrad_ws_floats(co, ci, self.N, Hz, Wz), dtype=torch.float32)
             L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), ptr(ws), self.N, Hz, Wz, self.dt)
         else:
-            L.wgrad_gather(ptr(dz), co, co, None, ptr(xin), ci, ci, ptr(self.G[name]), self.N, Hz, Wz, Hx, Wx, 1, pad, pad, kh, kw, self.dt)
+            self.wgrad(dz, co, co, xin, ci, ci, self.G[name], self.N, Hz, Wz, Hx, Wx, pad, pad, kh, kw, self.dt)
         if not need_dx:
             return None
         dx = self.empty(self.N, Hx, Wx, ci)
         L.conv_igemm(ptr(dz), co, ptr(self.pack_conv_dgrad(w)), ptr(dx), ci, None, 0, None, co, ci, self.N, Hz, Wz, Hx, Wx, kh, kw, kh - 1 - pad,
                      kw - 1 - pad, self.dt)
         return dx
+
+    def wgrad(self, A, ldA, CA, B, ldB, CB, dW, N, hA, wA, HB, WB, padh, padw, KH, KW, dt):
+        """dW += A^T (gathered) B with the deterministic two-stage flush (workspace from the caching allocator)."""
+        L = self.L
+        ws = self.empty(L.wgrad_gather_ws_floats(CA, CB, KH * KW, N * hA * wA, dt), dtype=torch.float32)
+        a_ptr = A if isinstance(A, int) else ptr(A)
+        b_ptr = B if isinstance(B, int) else ptr(B)
+        L.wgrad_gather(a_ptr, ldA, CA, None, b_ptr, ldB, CB, ptr(dW), ptr(ws), N, hA, wA, HB, WB, 1, padh, padw, KH, KW, dt)
 
     def bn_pool_bwd(self, prefix, g, z, tr, saved, C, H, W, PH, PW):
         L = self.L
@@ -219,7 +227,7 @@ class _RecRun:
         dlog = self.empty(rows, S.ldl, dtype=torch.float32)
         L.log_softmax_bwd(ptr(S.lp), ptr(g_lp), ptr(dlog), rows, C, S.ldl, 0)
         top = S.gru[1]["out"]
-        L.wgrad_gather(ptr(dlog), S.ldl, C, None, ptr(top), 512, 512, ptr(G["output.0.weight"]), 1, 1, rows, 1, rows, 1, 0, 0, 1, 1, 0)
+        self.wgrad(dlog, S.ldl, C, top, 512, 512, G["output.0.weight"], 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
         L.col_sum(ptr(dlog), S.ldl, C, ptr(G["output.0.bias"]), rows, 0)
         dout = self.gemm(dlog, S.ldl, S.ldl, self.pack(P["output.0.weight"], C, 512, C, 0, 512, 1, dt=0), None, 512, 512, rows)
         stage_done("output.")
@@ -237,10 +245,10 @@ class _RecRun:
             sfx = [f"_l{layer}", f"_l{layer}_reverse"]
             # stacked views: [w_ih, w_ih_reverse] etc. are adjacent in the flat buffer (see `order`)
             gw_ih = G["gru.weight_ih" + sfx[0]]
-            L.wgrad_gather(ptr(dgi), 1536, 1536, None, ptr(gl["x"]), I, I, ptr(gw_ih), 1, 1, rows, 1, rows, 1, 0, 0, 1, 1, 0)
+            self.wgrad(dgi, 1536, 1536, gl["x"], I, I, gw_ih, 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
             for d in (0, 1):
-                L.wgrad_gather(dgh.data_ptr() + 4 * d * 768, 1536, 768, None, gl["out"].data_ptr() + 4 * d * 256, 512, 256,
-                               ptr(G["gru.weight_hh" + sfx[d]]), 1, T, N, T, N, 1, 1 if d == 0 else -1, 0, 1, 1, 0)
+                self.wgrad(dgh.data_ptr() + 4 * d * 768, 1536, 768, gl["out"].data_ptr() + 4 * d * 256, 512, 256, G["gru.weight_hh" + sfx[d]], 1,
+                           T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
             L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
             L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
             dout = self.gemm(dgi, 1536, 1536, self.pack(gl["w_ih"], 1536, I, 1536, 0, I, 1, dt=0), None, I, I, rows)
