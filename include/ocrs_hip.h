@@ -68,8 +68,9 @@ int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const
                      const float* bn, const float* coef, float* du_ws, float* dwpw, float* dwdw, int N, int H, int W, int dtype,
                      hipStream_t st);
 /* autograd of ConvTranspose2d + crop. */
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, int Cup, int Cout,
-                   int N, int h, int w, int H, int W, int dtype, hipStream_t st);
+long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype);
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup,
+                   int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
 /* autograd of out_conv + sigmoid. */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
                   long P, int dtype, hipStream_t st);

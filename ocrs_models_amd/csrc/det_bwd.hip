@@ -842,9 +842,12 @@ int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const
 }
 
 // ConvTranspose2d backward.  g [N][H][W][Cout] = gradient of the (cropped) output; dx [N][h][w][Cup] written;
-// dW [Cup][Cout][3][3] and dbias [Cout] accumulated.  wpk_d = ocrs_pack_frags(mode 0, K=9*Cout, M=Cup, K2=Cout, s1=1, s2=9, sm=9*Cout).
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, int Cup, int Cout, int N,
-                   int h, int w, int H, int W, int dtype, hipStream_t st) {
+// dW [Cup][Cout][3][3] and dbias [Cout] accumulated; ws = workspace of ocrs_convt_bwd_ws_floats() floats (or null: float atomics).  wpk_d = ocrs_pack_frags(mode 0, K=9*Cout, M=Cup, K2=Cout, s1=1, s2=9, sm=9*Cout).
+extern "C" long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
+long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) { return ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype); }
+
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup, int Cout,
+                   int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
     const int MT_total = Cup / 16;
     const long P = (long)N * h * w;
@@ -872,7 +875,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
     {
-        const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, nullptr, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
+        const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;
     }
     const long Pout = (long)N * H * W;

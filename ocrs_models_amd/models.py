@@ -258,8 +258,9 @@ class _DetRun:
             Cup, Cout = w[i + 1], w[i]
             wpk_d = self.pack(P[f"up.{i}.up.weight"], 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
             dx = self.empty(N, up_in.H, up_in.W, Cup)
+            ws = self.empty(L.convt_bwd_ws_floats(Cup, Cout, N, up_in.H, up_in.W, self.dt), dtype=torch.float32)
             L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
-                        ptr(self.G[f"up.{i}.up.bias"]), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+                        ptr(self.G[f"up.{i}.up.bias"]), ptr(ws), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
             stage_done(f"up.{i}")
             g = dx
         skip_g[6].append(g)

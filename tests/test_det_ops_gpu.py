@@ -239,7 +239,8 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
     wpk_d = run.pack(Wt, 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
     dx = run.empty(N, h, w, Cup)
     dW, db = torch.zeros_like(Wt), torch.zeros_like(bias)
-    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), Cup, Cout, N, h, w, H, W, run.dt)
+    ws = torch.empty(run.L.convt_bwd_ws_floats(Cup, Cout, N, h, w, run.dt), device=dev)
+    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), ptr(ws), Cup, Cout, N, h, w, H, W, run.dt)
     torch.cuda.synchronize()
     assert rel(nchw(dx), xt.grad) < 10 * tol, "dgrad"
     assert rel(dW, Wr.grad) < 10 * tol, "wgrad"
