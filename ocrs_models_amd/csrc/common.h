@@ -239,6 +239,22 @@ __device__ __forceinline__ float lane_class_sum(float v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).  __syncthreads() also drains vmcnt(0), which
+// would wait for register-prefetched global loads of the NEXT tile; use this one inside software-pipelined tile loops.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <bool LDS_ONLY>
+__device__ __forceinline__ void tile_barrier() {
+    if constexpr (LDS_ONLY)
+        lds_barrier();
+    else
+        __syncthreads();
+}
+
+
 // XCD-aware persistent tile schedule: block b runs on XCD (b % 8); give each XCD a contiguous
 // range of tiles so that neighbouring tiles (which share 3x3 halo rows) hit the same L2.
 struct TileSched {

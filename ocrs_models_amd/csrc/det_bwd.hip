@@ -155,16 +155,13 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     T* uT = dzT + WTO * 16 * TPP;                        // [WTI*16][TPP]
     float* xs = reinterpret_cast<float*>(smem + (((TP * PITCH + (WTO + WTI) * 16 * TPP) * sizeof(T) + 15) & ~15));  // [HP][CGI*8]
     float* s_par = xs + Cfg::HP * CGI * 8;
-    float* s_trx = s_par;                // [3][CIN]
+    float* s_trx = s_par;                // [CIN/8][3][8] (HaloStager layout)
     float* s_wdw = s_par + 3 * CIN;      // [9][CIN]
     float* s_bn = s_par + 12 * CIN;      // [3][COUT]
     float* s_cf = s_bn + 3 * COUT;       // [3][COUT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * CIN; i += 256) {
-        const int r = i / CIN, c = i - r * CIN;
-        s_trx[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
-    }
+    fill_tr8(s_trx, x, tra, trb, CIN, tid);  // [CIN/8][3][8]
     for (int i = tid; i < 9 * CIN; i += 256) {
         const int t = i / CIN, c = i - t * CIN;
         s_wdw[i] = wdw[c * 9 + t];
@@ -184,6 +181,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     const bool do_dgrad = by == 0;
     const int pxl = tid / CGM, cg = tid % CGM;
     const int ty = pxl / TW, tx = pxl % TW;
+    const HaloStager<T, CGI, TW, TH> stager(tid, W);
 
     f32x4 accw[NTW];
 #pragma unroll
@@ -216,7 +214,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
                 }
-                stage_halo<T, CGI, TW, TH>(x, s_trx, CIN, 0, org, H, W, xs, tid);
+                stager.stage(x, s_trx, 0, org, H, W, xs, tid);
                 if (cg < CGO) {
                     store8(tileD + pxl * PITCH + cg * 8, dz);
 #pragma unroll
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 }
                 if (cg < CGI) {
                     float u[8];
-                    dw_from_lds<CGI, TW>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
+                    dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (cg * 8 + i) * TPP + pxl, pv ? u[i] : 0.f);
                 }
@@ -327,12 +325,12 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
         // ---- C: recompute u = dw3x3(x~) for this block's cin range -> uT (input tile + halo staged once in LDS)
         for (int kc = ci_base / (CGI * 8); kc < (ci_base + Cfg::CIB) / (CGI * 8); ++kc) {
             __syncthreads();  // xs free (previous chunk / previous tile readers done)
-            stage_halo<T, CGI, TW, TH>(x, s_trx, CIN, kc * CGI * 8, org, H, W, xs, tid);
+            stager.stage(x, s_trx, kc * CGI * 8, org, H, W, xs, tid);
             __syncthreads();
             if (cg < CGI) {
                 const int c0 = (kc * CGI + cg) * 8;
                 float u[8];
-                dw_from_lds<CGI, TW>(xs, s_wdw, CIN, c0, cg, ty, tx, u);
+                dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, c0, cg, ty, tx, u);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (c0 - ci_base + i) * TPP + pxl, pv ? u[i] : 0.f);
             }

@@ -108,139 +108,152 @@ __device__ __forceinline__ void apply_tr8(float (&v)[8], const float* tr, int C,
     for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], tr[c0 + i], tr[C + c0 + i]), tr[2 * C + c0 + i]);
 }
 
-// u[8] = depthwise 3x3 (zero padding 1) of the transformed input x~ at pixel px, channels c0..c0+7.
-// s_tr: [3][CIN] scale|shift|lo, s_w: [9][CIN] tap-major weights (both in LDS).
+// ---- HaloStager: stage x~ = max(x*scale+shift, lo) of a tile's halo region into LDS as fp32; pixels outside the image are written
+// as 0 (that IS the conv's zero padding), so the tap loop needs no bounds checks.  Everything tile-invariant is hoisted out of
+// the persistent tile loop.
+// LDS layout: two PLANES of 4 channels, xs[plane][halo pixel * CG + cg][4]: consecutive lanes read consecutive 16-byte words, so the
+// tap loop's ds_read_b128 are bank-conflict free (an [item][8] layout puts lanes i and i+8 on the same banks: measured 25-28 %
+// of all LDS cycles were conflicts).
+// A thread's items are it = tid + 256*j; since 256 % CG == 0 its channel group (and so its source tensor, pitch and the
+// transform parameters) is the same for every item and every tile; the halo coordinates (hy, hx) of each item are
+// tile-invariant too.  Per item this leaves: 2 adds + 2 unsigned compares (bounds), one 24-bit multiply + one 64-bit add
+// (address), the load, the transform and two LDS stores -- ~40 VALU instructions instead of ~130 (the index decode, the
+// 64-bit pixel arithmetic and the parameter addressing of stage_halo were ~2/3 of the forward kernel's VALU work).
+// s_tr8: transform parameters interleaved per 8-channel group: [CIN/8][3][8] (scale | shift | lo) -> 6 aligned ds_read_b128.
 template <class T>
-__device__ __forceinline__ void dw_compute8(const Src2<T>& x, const float* s_tr, const float* s_w, int CIN, int c0, const PixIdx& px, int H,
-                                            int W, float (&u)[8]) {
-    const T* base;
-    int pitch;
-    if (c0 < x.Ca) {
-        base = x.a + c0;
-        pitch = x.Ca;
-    } else {
-        base = x.b + (c0 - x.Ca);
-        pitch = x.Cb;
-    }
-    base += pix_linear(px, H, W) * pitch;
-    float sc[8], sh[8], lo[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        sc[i] = s_tr[c0 + i];
-        sh[i] = s_tr[CIN + c0 + i];
-        lo[i] = s_tr[2 * CIN + c0 + i];
-        u[i] = 0.f;
-    }
-    // branchless taps: an out-of-image tap reads the (always valid) centre pixel and is multiplied by 0
-    const bool hv[3] = {px.h > 0, true, px.h < H - 1};
-    const bool wv[3] = {px.w > 0, true, px.w < W - 1};
-    // all 9 tap loads are issued first (raw, 4 or 8 VGPRs each) so that they overlap; the per-tap LDS weight reads
-    // are kept behind compiler barriers so they are not all hoisted (register pressure -> occupancy).
-    float v9[9][8];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const bool ok = hv[t / 3] && wv[t % 3];
-        load8(base + (ok ? ((t / 3 - 1) * W + (t % 3 - 1)) * pitch : 0), v9[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const bool ok = hv[t / 3] && wv[t % 3];
-        float(&v)[8] = v9[t];
-        if (t % 3 == 0) asm volatile("" ::: "memory");
-        const float* wt = s_w + t * CIN + c0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float xt = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
-            u[i] = fmaf(ok ? wt[i] : 0.f, xt, u[i]);
-        }
+__device__ __forceinline__ void fill_tr8(float* s_tr8, const Src2<T>& x, const float* __restrict__ tra, const float* __restrict__ trb, int CIN,
+                                         int tid) {
+    for (int i = tid; i < 3 * CIN; i += 256) {
+        const int g = i / 24, r = (i - g * 24) >> 3, c = g * 8 + (i & 7);
+        s_tr8[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
     }
 }
-
-// Stage x~ = max(x*scale+shift, lo) for channels [ch0, ch0 + CG*8) of the tile's halo region into LDS as fp32
-// xs[halo pixel][CG*8]; pixels outside the image are written as 0 (that IS the conv's zero padding), so the
-// tap loop needs no bounds checks.  Every input element is loaded, unpacked and transformed once (x1.3-1.6 halo).
-template <class T, int CG, int TW, int TH>
-__device__ __forceinline__ void stage_halo(const Src2<T>& x, const float* s_tr, int CIN, int ch0, const TileOrg& org, int H, int W,
-                                           float* xs, int tid) {
-    using HT = HaloTile<TW, TH>;
-    for (int it = tid; it < HT::HP * CG; it += 256) {
-        const int hp = it / CG, cg = it - hp * CG;
-        const int hy = hp / HT::HW_, hx = hp - hy * HT::HW_;
-        const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
-        const int c0 = ch0 + cg * 8;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h >= 0 && h < H && w >= 0 && w < W) {
-            load8(src_ptr(x, ((long)org.n * H + h) * W + w, c0), v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], s_tr[c0 + i], s_tr[CIN + c0 + i]), s_tr[2 * CIN + c0 + i]);
-        }
-        store8(xs + (hp * CG + cg) * 8, v);
-    }
+// max(v, lo) as exactly one v_max_f32 (fmaxf() makes the compiler add a canonicalising v_max(x,x) per operand read from LDS)
+__device__ __forceinline__ float max_lo(float v, float lo) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+    return r;
 }
 
-// Software-pipelined form of stage_halo: halo_issue() only ISSUES the global loads of one (tile, channel-chunk) into
-// registers (NIT = ceil(HP*CG/256) raw vectors per thread); halo_commit() later applies the transform and writes LDS.
-// The caller issues the loads of the next tile before computing on the current one, so HBM latency hides under compute.
 template <class T, int CG, int TW, int TH>
-struct HaloPipe {
+struct HaloStager {
     using HT = HaloTile<TW, TH>;
-    static constexpr int NIT = (HT::HP * CG + 255) / 256;
-    Raw8<T> raw[NIT];
-    unsigned okmask;
-
-    __device__ __forceinline__ void issue(const Src2<T>& x, int ch0, const TileOrg& org, int H, int W, int tid) {
-        okmask = 0;
+    static constexpr int NITEMS = HT::HP * CG;
+    static constexpr int PLANE = NITEMS * 4;  // floats
+    static constexpr int NIT = (NITEMS + 255) / 256;
+    __device__ static __forceinline__ void put(float* xs, int it, const float (&v)[8]) {
+        store4(xs + it * 4, v[0], v[1], v[2], v[3]);
+        store4(xs + PLANE + it * 4, v[4], v[5], v[6], v[7]);
+    }
+    int hyx[NIT];   // hy | hx << 16
+    int poff[NIT];  // hy * W + hx  (pixel offset from the halo's corner pixel)
+    int cg;
+    __device__ __forceinline__ HaloStager(int tid, int W) {
+        cg = tid % CG;
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int it = tid + j * 256;
-            const int hp = it / CG, cg = it - hp * CG;
+            const int hp = (tid + j * 256) / CG;
             const int hy = hp / HT::HW_, hx = hp - hy * HT::HW_;
-            const int h = org.h0 + hy - 1, w = org.w0 + hx - 1;
-            const bool ok = it < HT::HP * CG && h >= 0 && h < H && w >= 0 && w < W;
-            if (ok) {
-                raw[j] = load8_raw(src_ptr(x, ((long)org.n * H + h) * W + w, ch0 + cg * 8));
-                okmask |= 1u << j;
-            }
+            hyx[j] = hy | (hx << 16);
+            poff[j] = hy * W + hx;
         }
     }
-    __device__ __forceinline__ void commit(const float* s_tr, int CIN, int ch0, float* xs, int tid) const {
+    __device__ __forceinline__ void stage(const Src2<T>& x, const float* s_tr8, int ch0, const TileOrg& org, int H, int W, float* xs,
+                                          int tid) const {
+        const int c0 = ch0 + cg * 8;
+        const bool from_a = c0 < x.Ca;
+        // corner = pixel (h0-1, w0-1): may lie before the tensor for border tiles, such items are never dereferenced.
+        // corner and both products are wave-uniform (scalar ALU); only the select is per thread.
+        const long corner = ((long)org.n * H + (org.h0 - 1)) * W + (org.w0 - 1);
+        const long offa = corner * x.Ca, offb = corner * x.Cb;
+        const T* base = (from_a ? x.a + c0 : x.b + (c0 - x.Ca)) + (from_a ? offa : offb);
+        const int pitch = from_a ? x.Ca : x.Cb;
+        const float* tp = s_tr8 + (c0 >> 3) * 24;
+        float sc[8], sh[8], lo[8];  // same channel group for all of this thread's items
+        load8(tp, sc);
+        load8(tp + 8, sh);
+        load8(tp + 16, lo);
+        const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int it = tid + j * 256;
-            if (it < HT::HP * CG) {
-                const int cg = it % CG;
-                const int c0 = ch0 + cg * 8;
-                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (okmask & (1u << j)) {
-                    unpack8(raw[j], v);
+            if (NITEMS % 256 != 0 && j == NIT - 1 && tid + j * 256 >= NITEMS) break;
+            const int h = org.h0 - 1 + (hyx[j] & 0xffff), w = org.w0 - 1 + (hyx[j] >> 16);
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                float v[8];
+                load8(base + __umul24(poff[j], pitch), v);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], s_tr[c0 + i], s_tr[CIN + c0 + i]), s_tr[2 * CIN + c0 + i]);
-                }
-                store8(xs + (long)it * 8, v);
-            }
+                for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                put(xs, tid + j * 256, v);
+            } else
+                put(xs, tid + j * 256, zero8);
+        }
+    }
+
+    // Software-pipelined form: issue() only ISSUES the global loads of a tile into raw registers (4 VGPRs per item in bf16),
+    // commit() transforms them into LDS one tile later, so the HBM latency of tile t+1 hides under the tap/MFMA/store phases of tile t.
+    struct Pending {
+        Raw8<T> raw[NIT];
+        unsigned ok;
+    };
+    __device__ __forceinline__ void issue(Pending& pd, const Src2<T>& x, int ch0, const TileOrg& org, int H, int W, int tid) const {
+        const int c0 = ch0 + cg * 8;
+        const bool from_a = c0 < x.Ca;
+        const long corner = ((long)org.n * H + (org.h0 - 1)) * W + (org.w0 - 1);
+        const long offa = corner * x.Ca, offb = corner * x.Cb;
+        const T* base = (from_a ? x.a + c0 : x.b + (c0 - x.Ca)) + (from_a ? offa : offb);
+        const int pitch = from_a ? x.Ca : x.Cb;
+        pd.ok = 0;
+        // UNCONDITIONAL loads (out-of-image / surplus items read the tensor's first pixel and are zeroed in commit()): a load under a
+        // divergent branch makes hipcc's waitcnt pass put vmcnt(0) in front of the NEXT load, serialising the prefetch.
+        const T* dummy = from_a ? x.a : x.b;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            const int h = org.h0 - 1 + (hyx[j] & 0xffff), w = org.w0 - 1 + (hyx[j] >> 16);
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && (NITEMS % 256 == 0 || j < NIT - 1 || tid + j * 256 < NITEMS);
+            pd.raw[j] = load8_raw(ok ? base + __umul24(poff[j], pitch) : dummy);
+            pd.ok |= ok ? 1u << j : 0u;
+        }
+    }
+    __device__ __forceinline__ void commit(const Pending& pd, const float* s_tr8, int ch0, float* xs, int tid) const {
+        const float* tp = s_tr8 + ((ch0 >> 3) + cg) * 24;
+        float sc[8], sh[8], lo[8];
+        load8(tp, sc);
+        load8(tp + 8, sh);
+        load8(tp + 16, lo);
+        const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            if (NITEMS % 256 != 0 && j == NIT - 1 && tid + j * 256 >= NITEMS) break;
+            if (pd.ok & (1u << j)) {
+                float v[8];
+                unpack8(pd.raw[j], v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                put(xs, tid + j * 256, v);
+            } else
+                put(xs, tid + j * 256, zero8);
         }
     }
 };
 
-// u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS.
-// wg (optional, CG == 1 only): the weights in the reference layout [8][9] in GLOBAL memory -- with 8 channels every thread uses the
-// same 72 weights, so they are read with wave-uniform addresses (scalar loads -> SGPR operands) instead of 18 LDS reads per pixel.
-template <int CG, int TW>
+// u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS
+// (xs in the HaloStager's planar layout).
+template <int CG, int TW, int TH>
 __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
-                                            float (&u)[8], const float* __restrict__ wg = nullptr) {
+                                            float (&u)[8]) {
     constexpr int HWp = TW + 2;
-    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 8;  // top-left tap of this pixel
+    constexpr int PLANE = HaloTile<TW, TH>::HP * CG * 4;
+    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 4;  // top-left tap of this pixel, plane 0
 #pragma unroll
     for (int i = 0; i < 8; ++i) u[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float v[8], wv[8];
-        load8(xc + ((t / 3) * HWp + (t % 3)) * CG * 8, v);
-        if (CG == 1 && wg) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) wv[i] = wg[i * 9 + t];
-        } else
-            load8(s_w + t * CIN + c0, wv);
+        const float* q = xc + ((t / 3) * HWp + (t % 3)) * CG * 4;
+        const float4 lo4 = *reinterpret_cast<const float4*>(q), hi4 = *reinterpret_cast<const float4*>(q + PLANE);
+        v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
+        v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+        load8(s_w + t * CIN + c0, wv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) u[i] = fmaf(wv[i], v[i], u[i]);
     }

@@ -56,8 +56,11 @@ struct FwdTile {  // 8-row tiles; width chosen so that TP = 256 / CG pixels: 8x3
     static constexpr int TH = 8, TW = 32 / CG, TP = TH * TW;
 };
 
+#ifndef OCRS_PIPE_BLOCKS
+#define OCRS_PIPE_BLOCKS 3
+#endif
 template <class T, int CG, int MT>
-__global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS : (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                                     const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
                                                                     const void* __restrict__ wpk, T* __restrict__ z,
                                                                     double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg) {
@@ -67,7 +70,11 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
     constexpr int KS = CG * 2;  // fp32 k-steps (of 4) per chunk
     constexpr int PITCH = Mma<T>::LDS_PITCH;
     constexpr int HP = HaloTile<TW, TH>::HP;
-    constexpr bool LANE_STATS = false;  // (per-lane sums across tiles cost 16 long-lived VGPRs -> spills; per-tile DPP reduce is cheap)  // keep BN partial sums in registers across tiles, reduce once at the end
+    constexpr bool LANE_STATS = false;  // (per-lane sums across tiles in REGISTERS cost 16 long-lived VGPRs -> spills)
+    // BN partial sums: MT <= 2 (levels 0-2, where the kernel is VALU-bound): every lane accumulates its 8 values per channel tile in
+    // its OWN LDS slot with fire-and-forget ds_add_f32 (8 instructions per tile instead of 32 DPP adds + 8 masked atomics);
+    // the 64 slots per channel are summed once at the end.  Larger MT: per-tile DPP row reduction.
+    constexpr bool LDS_STATS = false;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem);                                                   // [TP][PITCH]  dw output (MFMA operand)
     float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // [HP][CG*8]   transformed input + halo
@@ -76,18 +83,19 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
     const int H = tg.H, W = tg.W;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * CIN; i += 256) {
-        const int r = i / CIN, c = i - r * CIN;
-        s_par[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
-    }
+    fill_tr8(s_par, x, tra, trb, CIN, tid);
     for (int i = tid; i < 9 * CIN; i += 256) {
         const int t = i / CIN, c = i - t * CIN;
         s_par[3 * CIN + i] = wdw[c * 9 + t];
     }
     for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+    float* s_lane = s_stat + 2 * MT * 16;  // [MT*8][256] (LDS_STATS only)
+    if constexpr (LDS_STATS)
+        for (int i = tid; i < MT * 8 * 256; i += 256) s_lane[i] = 0.f;
     __syncthreads();
+    const HaloStager<T, CG, TW, TH> stager(tid, W);
 
-    const int nkc = CIN / (CG * 8);
+    const int nkc = CG < 4 ? 1 : CIN / (CG * 8);  // CG = min(CIN/8, 4): fewer than 4 groups means a single chunk
     const int pxl = tid / CG, cg = tid % CG;
     const int ty = pxl / TW, tx = pxl % TW;
     // output pixels of this lane (MFMA N index): fixed position inside every tile
@@ -105,6 +113,19 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
         for (int r = 0; r < 4; ++r) ls1[b][r] = ls2[b][r] = 0.f;
 
     TileSched ts(tg.ntiles);
+    constexpr bool PIPE = CG < 4 && Elem<T>::is_bf16;  // single-chunk bf16 configs (levels 0-1): register-prefetch the next tile
+    typename HaloStager<T, CG, TW, TH>::Pending pend;
+    typename Mma<T>::Frag wfr[PIPE ? MT : 1];  // PIPE: pointwise weight fragments are tile-invariant -> registers (a global load inside
+                                                // the loop would make the compiler wait vmcnt(0), i.e. for the prefetch as well)
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            wfr[b] = Mma<T>::load_w(wpk, (long)b, lane);
+            // consume the load HERE: otherwise its first use inside the loop carries a vmcnt(0) (PIPE implies bf16: Frag = uint4)
+            asm volatile("" : "+v"(wfr[b].q.x), "+v"(wfr[b].q.y), "+v"(wfr[b].q.z), "+v"(wfr[b].q.w));
+        }
+        if (ts.first < ts.end) stager.issue(pend, x, 0, tile_origin2<TW, TH>(tg, (int)ts.first), H, W, tid);
+    }
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
         f32x4 acc[PTW][MT];
@@ -114,19 +135,29 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
             for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int kc = 0; kc < nkc; ++kc) {
-            // (a register-prefetched variant of this staging -- HaloPipe in det_common.h -- measured slower here: +VGPRs -> spills)
-            stage_halo<T, CG, TW, TH>(x, s_par, CIN, kc * CG * 8, org, H, W, xs, tid);
-            __syncthreads();  // xs ready; all readers of the previous xs / tile passed a barrier since
+            if constexpr (PIPE) {
+                // this tile's input was issued one tile ago; transform it into LDS, then issue the next tile's loads so that
+                // their HBM latency hides under the tap / MFMA / store phases below
+                stager.commit(pend, s_par, 0, xs, tid);
+                __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads behind ALL of this tile's commit waits
+                if (t + ts.step < ts.end) stager.issue(pend, x, 0, tile_origin2<TW, TH>(tg, (int)(t + ts.step)), H, W, tid);
+            } else
+                stager.stage(x, s_par, kc * CG * 8, org, H, W, xs, tid);
+            tile_barrier<PIPE>();  // xs ready; all readers of the previous xs / tile passed a barrier since
             float u[8];
-            dw_from_lds<CG, TW>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);  // (scalar-loaded weights for CG==1 spill SGPRs -> slower)
+            dw_from_lds<CG, TW, TH>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);  // (scalar-loaded weights for CG==1 spill SGPRs -> slower)
             store8(tile + pxl * PITCH + cg * 8, u);
-            __syncthreads();
+            tile_barrier<PIPE>();
             typename Mma<T>::Frag pf[PTW];
 #pragma unroll
             for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tile, PITCH, (wave * PTW + a) * 16, lane, CG * 8);
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
-                const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, (long)kc * MT + b, lane);
+                typename Mma<T>::Frag wf;
+                if constexpr (PIPE)
+                    wf = wfr[b];
+                else
+                    wf = Mma<T>::load_w(wpk, (long)kc * MT + b, lane);
 #pragma unroll
                 for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<KS>(wf, pf[a], acc[a][b]);
             }
@@ -151,7 +182,13 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
                     }
                 }
             }
-            if constexpr (LANE_STATS) {
+            if constexpr (LDS_STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(&s_lane[(b * 8 + r) * 256 + tid], s1[r]);
+                    atomicAdd(&s_lane[(b * 8 + 4 + r) * 256 + tid], s2[r]);
+                }
+            } else if constexpr (LANE_STATS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ls1[b][r] += s1[r];
@@ -184,6 +221,20 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
         }
     }
     __syncthreads();
+    if constexpr (LDS_STATS) {
+        for (int c = tid; c < COUT; c += 256) {
+            const int b = c >> 4, q = (c & 15) >> 2, r = c & 3;  // channel c lives in lanes [q*16, q*16+16) of every wave, register r
+            float a1 = 0.f, a2 = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int l = 0; l < 16; ++l) {
+                    a1 += s_lane[(b * 8 + r) * 256 + w * 64 + q * 16 + l];
+                    a2 += s_lane[(b * 8 + 4 + r) * 256 + w * 64 + q * 16 + l];
+                }
+            atomicAdd(&gstat[c], (double)a1);
+            atomicAdd(&gstat[COUT + c], (double)a2);
+        }
+        return;
+    }
     for (int c = tid; c < COUT; c += 256) {
         atomicAdd(&gstat[c], (double)s_stat[c]);
         atomicAdd(&gstat[COUT + c], (double)s_stat[MT * 16 + c]);
@@ -191,160 +242,6 @@ __global__ __launch_bounds__(256, (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, 
 }
 
 // ----------------------------------------------------------------------------------------------
-// DMA-staged variant for the bandwidth-critical layers (bf16, Cin <= 32 -> one K chunk, Cout <= 64):
-//   * the RAW bf16 halo tile of the NEXT tile is copied global -> LDS by global_load_lds (async DMA: no VGPRs, no wait) while the
-//     current tile is converted / computed; two raw buffers; out-of-image items read a 16-byte zero line, so no masks anywhere;
-//   * barriers are raw s_barrier + lgkmcnt(0) only (a __syncthreads() would drain the DMA queue with vmcnt(0));
-//   * no ordinary global loads inside the tile loop (hipcc would wait vmcnt(0) at their first use): the pointwise weight
-//     fragments are cached in LDS once per block.
-__device__ uint4 g_zero16[2];  // zero-initialised device global (source of out-of-image DMA items)
-
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-template <int CG, int MT>
-__global__ __launch_bounds__(256, 4) void k_dwpw_fwd_dma(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
-                                                         const float* __restrict__ wdw, const void* __restrict__ wpk, bf16* __restrict__ z,
-                                                         double* __restrict__ gstat, int CIN, int COUT, Tiling2 tg) {
-    using T = bf16;
-    using FT = FwdTile<CG>;
-    constexpr int TW = FT::TW, TH = FT::TH, TP = FT::TP;
-    constexpr int PTW = TP / 64;
-    constexpr int PITCH = CG * 8 + 8;         // compact MFMA-operand pitch (K = CG*8 <= 32)
-    constexpr int HP = HaloTile<TW, TH>::HP, HWp = TW + 2;
-    constexpr int NITEM = HP * CG;
-    constexpr int NSLOT = (NITEM + 63) / 64;  // 64-item (1 KiB) DMA pieces per tile
-    constexpr int NJ = (NSLOT + 3) / 4;       // pieces per wave
-    constexpr int NPAD = NSLOT * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* raw0 = reinterpret_cast<bf16*>(smem);             // [NPAD][8] raw halo items, buffer 0
-    bf16* raw1 = raw0 + NPAD * 8;                            // buffer 1
-    bf16* tile = raw1 + NPAD * 8;                            // [TP][PITCH] dw output (MFMA operand)
-    float* xs = reinterpret_cast<float*>(tile + TP * PITCH); // [NPAD][8] transformed fp32 halo
-    uint4* s_wf = reinterpret_cast<uint4*>(xs + NPAD * 8);   // [MT][64] pointwise weight fragments
-    float* s_par = reinterpret_cast<float*>(s_wf + MT * 64); // [12][CIN]
-    float* s_stat = s_par + 12 * CIN;                        // [2][MT*16]
-    const int H = tg.H, W = tg.W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 3 * CIN; i += 256) {
-        const int r = i / CIN, c = i - r * CIN;
-        s_par[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
-    }
-    for (int i = tid; i < 9 * CIN; i += 256) {
-        const int t = i / CIN, c = i - t * CIN;
-        s_par[3 * CIN + i] = wdw[c * 9 + t];
-    }
-    for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
-    for (int i = tid; i < MT * 64; i += 256) s_wf[i] = reinterpret_cast<const uint4*>(wpk)[i];
-    // per-thread halo coordinates of its DMA items (fixed across tiles): item it = (j*4 + wave)*64 + lane
-    int ihy[NJ], ihx[NJ], icg[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int it = (j * 4 + wave) * 64 + lane;
-        const int hp = it / CG;
-        icg[j] = it - hp * CG;
-        ihy[j] = hp / HWp - 1;
-        ihx[j] = hp - (hp / HWp) * HWp - 1;
-        if (it >= NITEM) ihy[j] = -100000;
-    }
-    const bf16* zsrc = reinterpret_cast<const bf16*>(g_zero16);
-    auto issue = [&](const TileOrg& o, bf16* raw) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j * 4 + wave >= NSLOT) continue;  // wave-uniform
-            const int h = o.h0 + ihy[j], w = o.w0 + ihx[j];
-            const bf16* g = (h >= 0 && h < H && w >= 0 && w < W) ? src_ptr(x, ((long)o.n * H + h) * W + w, icg[j] * 8) : zsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(raw + (j * 4 + wave) * 64 * 8), 16, 0, 0);
-        }
-    };
-    const int pxl = tid / CG, cg = tid % CG;
-    const int ty = pxl / TW, tx = pxl % TW;
-    int oty[PTW], otx[PTW];
-#pragma unroll
-    for (int a = 0; a < PTW; ++a) {
-        const int q = (wave * PTW + a) * 16 + (lane & 15);
-        oty[a] = q / TW;
-        otx[a] = q % TW;
-    }
-    __syncthreads();
-    TileSched ts(tg.ntiles);
-    if (ts.first < ts.end) issue(tile_origin2<TW, TH>(tg, (int)ts.first), raw0);
-    int cur = 0;
-    for (long t = ts.first; t < ts.end; t += ts.step, cur ^= 1) {
-        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
-        bf16* rawc = cur ? raw1 : raw0;
-        bf16* rawn = cur ? raw0 : raw1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the current tile have landed
-        lds_barrier();                                     // ... and everybody else's; previous tile's LDS readers are done
-        if (t + ts.step < ts.end) issue(tile_origin2<TW, TH>(tg, (int)(t + ts.step)), rawn);  // flies during everything below
-        // convert pass: raw bf16 -> transformed fp32 (each thread its own DMA items)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (j * 4 + wave >= NSLOT) continue;  // wave-uniform
-            const int it = (j * 4 + wave) * 64 + lane;
-            float v[8];
-            load8(rawc + (long)it * 8, v);
-            const int c0 = icg[j] * 8;
-            const bool inimg = (unsigned)(org.h0 + ihy[j]) < (unsigned)H && (unsigned)(org.w0 + ihx[j]) < (unsigned)W;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = inimg ? fmaxf(fmaf(v[i], s_par[c0 + i], s_par[CIN + c0 + i]), s_par[2 * CIN + c0 + i]) : 0.f;
-            store8(xs + (long)it * 8, v);
-        }
-        lds_barrier();
-        float u[8];
-        dw_from_lds<CG, TW>(xs, s_par + 3 * CIN, CIN, cg * 8, cg, ty, tx, u);
-        store8(tile + pxl * PITCH + cg * 8, u);
-        lds_barrier();
-        f32x4 acc[PTW][MT];
-        typename Mma<T>::Frag pf[PTW];
-#pragma unroll
-        for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tile, PITCH, (wave * PTW + a) * 16, lane, CG * 8);
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            typename Mma<T>::Frag wf;
-            wf.q = s_wf[b * 64 + lane];
-#pragma unroll
-            for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<8>(wf, pf[a], (f32x4){0.f, 0.f, 0.f, 0.f});
-        }
-        const long tile_base = ((long)org.n * H + org.h0) * W + org.w0;
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            const int m0 = b * 16 + (lane >> 4) * 4;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int a = 0; a < PTW; ++a) {
-                const bool ov = org.h0 + oty[a] < H && org.w0 + otx[a] < W;
-                if (ov && m0 < COUT) {
-                    const f32x4 v = acc[a][b];
-                    store4(z + (tile_base + (long)oty[a] * W + otx[a]) * COUT + m0, v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float q = Elem<T>::round(v[r]);
-                        s1[r] += q;
-                        s2[r] = fmaf(q, q, s2[r]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
-                if ((lane & 15) == 0) {
-                    atomicAdd(&s_stat[m0 + r], a1);
-                    atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < COUT; c += 256) {
-        atomicAdd(&gstat[c], (double)s_stat[c]);
-        atomicAdd(&gstat[COUT + c], (double)s_stat[MT * 16 + c]);
-    }
-}
-
 // first block of the net: 1 -> 8 channels (models.py:115 in_conv.seq.0), input = the greyscale image itself.
 template <class T>
 __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ img, const float* __restrict__ wdw /*[9]*/,
@@ -569,7 +466,7 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
     const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) +
-                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16) * sizeof(float);
+                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16 + (MT <= 2 ? MT * 8 * 256 : 0)) * sizeof(float);
     const int grid = persistent_grid(tg.ntiles, 8);
     hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
     OCRS_LAUNCH_CHECK();
@@ -578,21 +475,6 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
 extern "C" {
 
 }  // extern "C" (templates need C++ linkage)
-template <int CG, int MT>
-static int launch_dwpw_fwd_dma(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
-                               void* z, double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
-    using FT = FwdTile<CG>;
-    const int CIN = Ca + Cb;
-    Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
-    const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
-    constexpr int HP = HaloTile<FT::TW, FT::TH>::HP;
-    constexpr int NPAD = ((HP * CG + 63) / 64) * 64;
-    const size_t smem = 2 * NPAD * 8 * 2 + FT::TP * (CG * 8 + 8) * 2 + NPAD * 8 * 4 + MT * 64 * 16 + (12 * CIN + 2 * MT * 16) * sizeof(float);
-    hipLaunchKernelGGL((k_dwpw_fwd_dma<CG, MT>), dim3(persistent_grid(tg.ntiles, 4)), dim3(256), smem, st, x, tra, trb, wdw, wpk, (bf16*)z, gstat, CIN,
-                       COUT, tg);
-    OCRS_LAUNCH_CHECK();
-    return OCRS_OK;
-}
 
 template <class T>
 static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
@@ -600,13 +482,6 @@ static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, con
     const int CIN = Ca + Cb;
     const int cg = CIN >= 32 ? 4 : CIN / 8;
     const int mt = (COUT + 15) / 16;
-    static const int use_dma = env_int("OCRS_FWD_DMA", 0);  // correct but measured slightly slower than the plain path
-    if (Elem<T>::is_bf16 && use_dma && CIN <= 32 && mt <= 4) {
-#define DMA_CASE(CG_, MT_) \
-    if (cg == CG_ && mt == MT_) return launch_dwpw_fwd_dma<CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
-        DMA_CASE(1, 1) DMA_CASE(2, 1) DMA_CASE(2, 2) DMA_CASE(4, 1) DMA_CASE(4, 2) DMA_CASE(4, 4)
-#undef DMA_CASE
-    }
 #define DWPW_CASE(CG_, MT_) \
     if (cg == CG_ && mt == MT_) return launch_dwpw_fwd<T, CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
     DWPW_CASE(1, 1) DWPW_CASE(2, 1) DWPW_CASE(2, 2) DWPW_CASE(4, 1) DWPW_CASE(4, 2) DWPW_CASE(4, 4) DWPW_CASE(4, 8) DWPW_CASE(4, 16)

@@ -207,7 +207,10 @@ def test_first_block_c1(dev, dtype):
     run.block_bwd(pfx, gy, None, 0)
     torch.cuda.synchronize()
     for k in P:
-        assert rel(run.G[k], Pr[k].grad) < 20 * tol, k
+        # With ONE input channel z_i = w_i * u, so dL/dw_i = sum(u * dz_i) = sum(z_i * dz_i) / w_i, which BatchNorm's backward makes
+        # (almost) exactly zero: the value is the rounding residue of a cancelling sum (|grad| ~ 1e-3 of its terms) and moves by a few
+        # 1e-4 relative with the order of the float atomics -> 100 * tol for that tensor only.
+        assert rel(run.G[k], Pr[k].grad) < (100 if k.endswith("seq.1.weight") else 20) * tol, k
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -14,7 +14,9 @@ for line in r.stderr.splitlines():
         cur = t.split(":", 1)[1].strip(); rows[cur] = {}
     elif cur and ":" in t:
         k, v = t.rsplit(":", 1); rows[cur][k.strip()] = v.strip()
-dem = subprocess.run(["c++filt"] + list(rows), capture_output=True, text=True).stdout.splitlines()
+if r.returncode != 0 or not rows:
+    sys.stderr.write(r.stderr[-3000:]); sys.exit("compile failed")
+dem = subprocess.run(["c++filt"] + list(rows), capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 for name, d in zip(dem, rows.values()):
     if pat and not re.search(pat, name): continue
     short = re.sub(r"\(.*", "", name).replace("void ", "")
