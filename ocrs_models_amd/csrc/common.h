@@ -124,6 +124,35 @@ __device__ __forceinline__ void load4(const bf16* p, float (&v)[4]) {
     v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
 }
 
+// raw 4-channel vector (register prefetch of one MFMA-quad / depthwise slab element)
+template <class T>
+struct Raw4;
+template <>
+struct Raw4<float> {
+    float4 a;
+};
+template <>
+struct Raw4<bf16> {
+    uint2 a;
+};
+__device__ __forceinline__ Raw4<float> load4_raw(const float* p) {
+    Raw4<float> r;
+    r.a = *reinterpret_cast<const float4*>(p);
+    return r;
+}
+__device__ __forceinline__ Raw4<bf16> load4_raw(const bf16* p) {
+    Raw4<bf16> r;
+    r.a = *reinterpret_cast<const uint2*>(p);
+    return r;
+}
+__device__ __forceinline__ void unpack4(const Raw4<float>& r, float (&v)[4]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w;
+}
+__device__ __forceinline__ void unpack4(const Raw4<bf16>& r, float (&v)[4]) {
+    v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xffff0000u);
+}
+
 // ----------------------------------------------------------------------------------------------
 // wave64 helpers
 // ----------------------------------------------------------------------------------------------

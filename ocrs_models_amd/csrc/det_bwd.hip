@@ -409,48 +409,65 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
     T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
     const int xp = in_a ? x.Ca : x.Cb;
 
-    // software pipeline: raw du halo vectors of the NEXT tile are in flight while the current tile is computed
-    Raw8<T> raw[NIT];
-    unsigned okmask = 0;
-    auto issue = [&](const TileOrg& o) {
-        okmask = 0;
+    // Software pipeline: the raw du halo vectors AND this thread's x quad of the NEXT tile are in flight while the current tile is
+    // computed.  Loads are unconditional (invalid items read element 0 and are zeroed at use: a load under a divergent branch makes
+    // hipcc put vmcnt(0) in front of the next load) and the barriers order LDS only (__syncthreads() would drain the prefetch).
+    // Tile-invariant per-thread halo coordinates / offsets are hoisted.
+    int hyx[NIT], poff[NIT];
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+        const int hp = (tid + j * 256) / CG, g8 = (tid + j * 256) - hp * CG;
+        const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+        hyx[j] = hy | (hx << 16);
+        poff[j] = (hy * W + hx) * C + cb + g8 * 8;  // element offset from the halo's corner pixel (fits 32 bits: <= 10 rows)
+    }
+    const int xoff = (ty * W + tx) * xp;  // this thread's pixel, relative to the tile origin
+    struct Pre {
+        Raw8<T> du[NIT];
+        Raw4<T> x;
+        unsigned ok;  // bit j: du item j inside the image; bit 31: this thread's pixel inside the image
+    };
+    auto issue = [&](Pre& pr, const TileOrg& o) {
+        const long corner = ((long)o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);
+        const T* dub = du + corner * C;
+        pr.ok = 0;
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int it = tid + j * 256;
-            const int hp = it / CG, g8 = it - hp * CG;
-            const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
-            const int h = o.h0 + hy - 1, w = o.w0 + hx - 1;
-            if (it < HP * CG && h >= 0 && h < H && w >= 0 && w < W) {
-                raw[j] = load8_raw(du + (((long)o.n * H + h) * W + w) * C + cb + g8 * 8);
-                okmask |= 1u << j;
-            }
+            const int h = o.h0 - 1 + (hyx[j] & 0xffff), w = o.w0 - 1 + (hyx[j] >> 16);
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && (HP * CG % 256 == 0 || j < NIT - 1 || tid + j * 256 < HP * CG);
+            pr.du[j] = load8_raw(ok ? dub + poff[j] : du);
+            pr.ok |= ok ? 1u << j : 0u;
         }
+        const bool valid = o.h0 + ty < H && o.w0 + tx < W;
+        const long org_pix = ((long)o.n * H + o.h0) * W + o.w0;
+        pr.x = load4_raw(valid ? xsrc + org_pix * xp + xoff : xsrc);
+        pr.ok |= valid ? 0x80000000u : 0u;
     };
+    Pre cur;  // consumed at the top of an iteration (commit + x transform), then immediately refilled for the next tile
     TileSched ts(tg.ntiles);
-    if (ts.first < ts.end) issue(tile_origin2<TW, TH>(tg, (int)ts.first));
+    if (ts.first < ts.end) issue(cur, tile_origin2<TW, TH>(tg, (int)ts.first));
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
-        __syncthreads();  // previous tile's readers of ds are done
+        lds_barrier();  // previous tile's readers of ds are done
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int it = tid + j * 256;
-            if (it < HP * CG) {
+            if (HP * CG % 256 == 0 || j < NIT - 1 || it < HP * CG) {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (okmask & (1u << j)) unpack8(raw[j], v);
-                store8(ds + (long)it * 8, v);
+                if (cur.ok & (1u << j)) unpack8(cur.du[j], v);
+                store8(ds + it * 8, v);
             }
         }
-        __syncthreads();
-        if (t + ts.step < ts.end) issue(tile_origin2<TW, TH>(tg, (int)(t + ts.step)));
-        const int h = org.h0 + ty, w = org.w0 + tx;
-        const bool valid = h < H && w < W;
-        const long p = valid ? ((long)org.n * H + h) * W + w : 0;
-        float xv[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            load4(xsrc + p * xp, xv);
+        const bool valid = cur.ok >> 31;
+        float xv[4];
+        unpack4(cur.x, xv);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] = fmaxf(fmaf(xv[i], sc[i], sh[i]), lo[i]);
-        }
+        for (int i = 0; i < 4; ++i) xv[i] = valid ? max_lo(fmaf(xv[i], sc[i], sh[i]), lo[i]) : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = t + ts.step < ts.end;
+        if (more) issue(cur, tile_origin2<TW, TH>(tg, (int)(t + ts.step)));
+        lds_barrier();
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
         // tap k pairs x~[p] with du[p - off(k)]: halo index (ty + 2 - k/3, tx + 2 - k%3).  Unconditional: an out-of-image pixel of a
         // partial tile has x~ = 0, so it adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
 #pragma unroll
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
                 acc[k][i] = fmaf(xv[i], d[i], acc[k][i]);
             }
         }
-        if (valid && gdst) store4(gdst + p * xp, g[0], g[1], g[2], g[3]);
+        if (valid && gdst) store4(gdst + (((long)org.n * H + org.h0) * W + org.w0) * xp + xoff, g[0], g[1], g[2], g[3]);
     }
     __syncthreads();
     // block reduction of the 36 per-thread partials through LDS (plain stores, then a strided sum): cheap in registers,
