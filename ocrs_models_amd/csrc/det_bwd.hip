@@ -188,6 +188,38 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     for (int j = 0; j < NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     TileSched ts(tg.ntiles);
+    // PIPE (levels 0-1 in bf16: one K chunk on both sides): software pipeline over tiles.  The raw x halo items and this thread's
+    // (z, g1, g2) vectors of the NEXT tile are in flight while the current tile is computed; loads are unconditional, barriers order
+    // LDS only, the dgrad weight fragments live in registers (a global load inside the loop would force vmcnt(0)).
+    // The max-pool-routed gradient (gs.pooled) needs 3 more z vectors per thread: those stay synchronous at the top of the tile.
+    constexpr bool PIPE = Cfg::NKD == 1 && CIN <= 32 && Elem<T>::is_bf16;
+    typename HaloStager<T, CGI, TW, TH>::Pending pend;
+    Raw8<T> zr, g1r, g2r;
+    bool pv_pre = false;
+    typename Mma<T>::Frag wfd[PIPE ? MTD : 1];
+    const int opix = ty * W + tx;
+    const bool has_g2 = gs.g2 != nullptr;
+    auto issue_tile = [&](long tn) {
+        const TileOrg o = tile_origin2<TW, TH>(tg, (int)tn);
+        stager.issue(pend, x, 0, o, H, W, tid);
+        pv_pre = o.h0 + ty < H && o.w0 + tx < W;
+        if (!gs.pooled) {
+            const long tb = ((long)o.n * H + o.h0) * W + o.w0;
+            const bool ld = pv_pre && cg < CGO;
+            const int off = ld ? opix * COUT + cg * 8 : 0;
+            zr = load8_raw((ld ? z + tb * COUT : z) + off);
+            g1r = load8_raw((ld ? gs.g1 + tb * COUT : gs.g1) + off);
+            g2r = load8_raw((ld && has_g2 ? gs.g2 + tb * COUT : gs.g1) + off);
+        }
+    };
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int b = 0; b < MTD; ++b) {
+            wfd[b] = Mma<T>::load_w(wpk_d, (long)b, lane);
+            asm volatile("" : "+v"(wfd[b].q.x), "+v"(wfd[b].q.y), "+v"(wfd[b].q.z), "+v"(wfd[b].q.w));
+        }
+        if (ts.first < ts.end) issue_tile(ts.first);
+    }
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
         PixIdx px;
@@ -202,7 +234,84 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 #pragma unroll
             for (int b = 0; b < MTD; ++b) accd[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        if constexpr (Cfg::NKD == 1 && CIN <= 32) {
+        if constexpr (PIPE) {
+            {
+                float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int c0 = cg * 8;
+                if (cg < CGO && pv) {
+                    float gh[8], zv[8];
+                    if (gs.pooled)
+                        load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
+                    else {
+                        float ga[8], gb[8];
+                        unpack8(zr, zv);
+                        unpack8(g1r, ga);
+                        unpack8(g2r, gb);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float gsum = has_g2 ? ga[i] + gb[i] : ga[i];
+                            gh[i] = fmaf(zv[i], s_bn[c0 + i], s_bn[COUT + c0 + i]) > 0.f ? gsum : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
+                }
+                stager.commit(pend, s_trx, 0, xs, tid);
+                if (cg < CGO) {
+                    store8(tileD + pxl * PITCH + cg * 8, dz);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(dzT + (c0 + i) * TPP + pxl, dz[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + ts.step < ts.end) issue_tile(t + ts.step);
+            lds_barrier();
+            {
+                typename Mma<T>::Frag pf[PTW];
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
+#pragma unroll
+                for (int b = 0; b < MTD; ++b)
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wfd[b], pf[a], accd[a][b]);
+#pragma unroll
+                for (int a = 0; a < PTW; ++a) {
+                    const int oq = (wave * PTW + a) * 16 + (lane & 15);
+                    const int qh = org.h0 + oq / TW, qw = org.w0 + oq % TW;
+                    const long po = ((long)org.n * H + qh) * W + qw;
+#pragma unroll
+                    for (int b = 0; b < MTD; ++b) {
+                        const int m0 = b * 16 + (lane >> 4) * 4;
+                        if (qh < H && qw < W && m0 < CIN) {
+                            const f32x4 v = accd[a][b];
+                            store4(du + po * CIN + m0, v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                }
+                if (cg < CGI) {
+                    float u[8];
+                    dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (cg * 8 + i) * TPP + pxl, pv ? u[i] : 0.f);
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int tt = wave + 4 * j;
+                if (tt < WTI * WTO) {
+                    const int ti = tt % WTI, to = tt / WTI;
+#pragma unroll
+                    for (int pc = 0; pc < TP / 32; ++pc) {
+                        const typename Mma<T>::Frag fa = Mma<T>::load_p(uT + pc * 32, TPP, ti * 16, lane, 32);
+                        const typename Mma<T>::Frag fb = Mma<T>::load_p(dzT + pc * 32, TPP, to * 16, lane, 32);
+                        accw[j] = Mma<T>::template mma<8>(fa, fb, accw[j]);
+                    }
+                }
+            }
+            lds_barrier();
+            continue;
+        } else if constexpr (Cfg::NKD == 1 && CIN <= 32) {
             // ---- fast path (levels 0-1: one K chunk on both sides): ALL global loads of the tile are issued before the first barrier
             // (g, z for dz and the input halo for the depthwise recompute), 3 barriers per tile instead of 5.
             {
