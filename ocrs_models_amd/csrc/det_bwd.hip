@@ -137,7 +137,7 @@ struct PwBwdCfg {
     static constexpr int HP = (TW + 2) * (TH + 2);
 };
 
-template <class T, int CIN, int COUT>
+template <class T, int CIN, int COUT, bool PPOOL /* pipelined max-pool-routed gradient source (PIPE configs only) */>
 __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
                                                 const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
@@ -194,18 +194,32 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     // The max-pool-routed gradient (gs.pooled) needs 3 more z vectors per thread: those stay synchronous at the top of the tile.
     constexpr bool PIPE = Cfg::NKD == 1 && CIN <= 32 && Elem<T>::is_bf16;
     typename HaloStager<T, CGI, TW, TH>::Pending pend;
-    Raw8<T> zr, g1r, g2r;
-    bool pv_pre = false;
+    Raw8<T> zr, g1r, g2r, zo[PPOOL ? 3 : 1];
     typename Mma<T>::Frag wfd[PIPE ? MTD : 1];
     const int opix = ty * W + tx;
     const bool has_g2 = gs.g2 != nullptr;
+    const int own = ((ty & 1) << 1) | (tx & 1);  // position inside the 2x2 pool window (tile origins are even)
+    bool gv_pre = false;                         // PPOOL: this thread's pixel lies inside a pool window (floor mode)
     auto issue_tile = [&](long tn) {
         const TileOrg o = tile_origin2<TW, TH>(tg, (int)tn);
         stager.issue(pend, x, 0, o, H, W, tid);
-        pv_pre = o.h0 + ty < H && o.w0 + tx < W;
-        if (!gs.pooled) {
-            const long tb = ((long)o.n * H + o.h0) * W + o.w0;
-            const bool ld = pv_pre && cg < CGO;
+        const long tb = ((long)o.n * H + o.h0) * W + o.w0;
+        if constexpr (PPOOL) {
+            const int Hp = H >> 1, Wp = W >> 1, h = o.h0 + ty, w = o.w0 + tx;
+            const bool ld = cg < CGO && h < 2 * Hp && w < 2 * Wp;
+            gv_pre = ld;
+            const T* zp = ld ? z + (tb + opix) * COUT + cg * 8 : z;
+            zr = load8_raw(zp);
+            // the other three window elements: horizontal / vertical / diagonal neighbour (static register indices)
+            const int dxo = (tx & 1) ? -COUT : COUT, dyo = (ty & 1) ? -W * COUT : W * COUT;
+            zo[0] = load8_raw(ld ? zp + dxo : z);
+            zo[1] = load8_raw(ld ? zp + dyo : z);
+            zo[2] = load8_raw(ld ? zp + dxo + dyo : z);
+            const long pp = ((long)o.n * Hp + (h >> 1)) * Wp + (w >> 1);
+            g1r = load8_raw(ld ? gs.g1 + pp * COUT + cg * 8 : gs.g1);
+            g2r = load8_raw(ld && has_g2 ? gs.g2 + pp * COUT + cg * 8 : gs.g1);
+        } else if (!gs.pooled) {
+            const bool ld = o.h0 + ty < H && o.w0 + tx < W && cg < CGO;
             const int off = ld ? opix * COUT + cg * 8 : 0;
             zr = load8_raw((ld ? z + tb * COUT : z) + off);
             g1r = load8_raw((ld ? gs.g1 + tb * COUT : gs.g1) + off);
@@ -236,11 +250,39 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 
         if constexpr (PIPE) {
             {
+                const bool gv_cur = gv_pre;
                 float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 const int c0 = cg * 8;
                 if (cg < CGO && pv) {
                     float gh[8], zv[8];
-                    if (gs.pooled)
+                    if constexpr (PPOOL) {
+                        // gradient routed through MaxPool2d(2): to the FIRST maximal element of the window, and through the ReLU
+                        float ga[8], gb[8];
+                        unpack8(zr, zv);
+                        unpack8(g1r, ga);
+                        unpack8(g2r, gb);
+                        bool win[8];
+                        float ym[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float y = fmaf(zv[i], s_bn[c0 + i], s_bn[COUT + c0 + i]);
+                            win[i] = gv_cur && y > 0.f;
+                            ym[i] = fmaxf(y, 0.f);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const bool earlier = (own ^ (j + 1)) < own;  // window index of neighbour j is own ^ (j+1)
+                            float zn[8];
+                            unpack8(zo[j], zn);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const float yo = fmaxf(fmaf(zn[i], s_bn[c0 + i], s_bn[COUT + c0 + i]), 0.f);
+                                win[i] = win[i] && (earlier ? ym[i] > yo : ym[i] >= yo);
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) gh[i] = win[i] ? (has_g2 ? ga[i] + gb[i] : ga[i]) : 0.f;
+                    } else if (gs.pooled)
                         load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
                     else {
                         float ga[8], gb[8];
@@ -869,7 +911,7 @@ int ocrs_bn_bwd_finalize(const double* gsum, long count, int C, const float* gam
 }
 
 }  // extern "C" (templates need C++ linkage)
-template <class T, int CIN, int COUT>
+template <class T, int CIN, int COUT, bool PPOOL>
 static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                          int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int N, int H,
                          int W, hipStream_t st) {
@@ -879,7 +921,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                         (Cfg::HP * Cfg::CGI * 8 + 12 * CIN + 6 * COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT, PPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess)
             return OCRS_ERR_HIP;
         attr_set = true;
@@ -888,7 +930,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
     const int gx = wgrad_grid(tg.ntiles, 2048);
-    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
+    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT, PPOOL>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
                        wpk_d, (T*)du, dwpw, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -909,10 +951,16 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
+    // pipelined pool-routed variant: bf16, one K chunk (Cin = Cout <= 32: the second conv of a Down block, models.py:52-54)
+#define XP(CI)                                                                                                                            \
+    if (pooled && dtype == 1 && Cin == CI && Cout == CI)                                                                                  \
+        return launch_pw_bwd<bf16, CI, CI, true>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
+    XP(8) XP(16) XP(32)
+#undef XP
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \
-        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st) \
-                          : launch_pw_bwd<float, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
+        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st) \
+                          : launch_pw_bwd<float, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
     PW_BWD_COMBOS(X)
 #undef X
     return OCRS_ERR_ARG;
