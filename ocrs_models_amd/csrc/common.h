@@ -255,6 +255,21 @@ struct Mma<float> {
     }
 };
 
+// gfx950 LDS transpose read (ds_read_b64_tr_b16).  Within every group of 16 lanes, lane i supplies the 8-byte-aligned LDS address of 4
+// consecutive 16-bit elements = row (i >> 2), columns (i & 3)*4.. of a 4 x 16 block (the row stride is free: it is whatever the lanes'
+// addresses say); lane c of the group RECEIVES column c of that block (rows 0..3).  With an LDS tile in the natural NHWC order
+// [position][channel] this yields, without any transposing store, the MFMA operand "row = channel, 4 consecutive K = positions" that the
+// weight-gradient GEMMs (K = pixels) need.  Semantics verified on hardware by tools/probes/tr_probe.hip.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr4(const bf16* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+// one 16x16x32 bf16 operand (8 K per lane) from two transpose reads: K = (first 4 rows | second 4 rows)
+__device__ __forceinline__ bf16x8 lds_tr8(const bf16* p0, const bf16* p1) {
+    const s16x4 a = lds_tr4(p0), b = lds_tr4(p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 // sum over all lanes of the wave with the same (lane % CG), CG in {1,2,4}; every lane gets its class' sum
 template <int CG>
 __device__ __forceinline__ float lane_class_sum(float v) {

@@ -737,6 +737,181 @@ __global__ __launch_bounds__(256) void k_c1_bwd_b(const float* __restrict__ img,
 }
 
 // ----------------------------------------------------------------------------------------------
+// ConvTranspose2d weight gradient for the top U-Net levels (bf16, Cup <= 32, Cout <= 32):
+//   dW[c][o][ky][kx] = sum_{n,i,j} x~[n,i,j,c] * g[n, 2i+ky, 2j+kx, o]           GEMM: M = c, N = (tap, o), K = input positions.
+// Both operands are staged in LDS in their NATURAL NHWC order (x~ tile [pos][Cup], the (2TH+1) x (2TW+1) output region [pix][Cout]) and
+// read as MFMA operands with the LDS transpose read (lds_tr8): no transposing stores, every g pixel is fetched once per tile
+// (the generic gather kernel re-fetches it per tap and spent its time in ds_write_b16 scatters: 1.47 ms at level 0).
+// Waves split K (32 positions each) and, for Cout = 32, the N tiles; block partial -> workspace; k_convt_wgrad_reduce sums partials.
+template <int CUP, int COUT>
+struct CtwCfg {
+    static constexpr int TW = 16, TH = COUT >= 32 ? 4 : 8, TPOS = TW * TH;
+    static constexpr int GH = 2 * TH + 1, GW = 2 * TW + 1;
+    static constexpr int MT = CUP / 16, NCOL = 9 * COUT, NT = (NCOL + 15) / 16;
+    static constexpr int KW = TPOS / 32, NW = 4 / KW, NTW = NT / NW;  // waves along K / along N, N tiles per wave
+    static_assert(NT % NW == 0, "N tiles split evenly");
+    static constexpr int XI = TPOS * CUP / 8, GI = GH * GW * COUT / 8;  // 16-byte staging items
+    static constexpr int NXI = (XI + 255) / 256, NGI = (GI + 255) / 256;
+    static constexpr int XS_EL = TPOS * CUP, GS_EL = GH * GW * COUT;
+    static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8) * 2 + 3 * CUP * 4;
+    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4;
+    static constexpr int SMEM = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+    static constexpr int PART = CUP * NT * 16;  // floats per block partial: [CUP][NT*16]
+};
+
+template <int CUP, int COUT>
+__global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__ x, const float* __restrict__ tr /*[3][CUP]*/, const bf16* __restrict__ g,
+                                                        float* __restrict__ ws, int h, int w, int H, int W, Tiling2 tg) {
+    using C = CtwCfg<CUP, COUT>;
+    constexpr int TW = C::TW, TH = C::TH, GW = C::GW, MT = C::MT, NTW = C::NTW, KW = C::KW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* xs = reinterpret_cast<bf16*>(smem);   // [TPOS][CUP]
+    bf16* gsm = xs + C::XS_EL;                  // [GH*GW][COUT]
+    bf16* zero8 = gsm + C::GS_EL;               // 8 zero elements (padding columns of the last N tile)
+    float* s_tr = reinterpret_cast<float*>(zero8 + 8);  // [CUP/8][3][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        Src2<bf16> xsrc{x, nullptr, CUP, 0};
+        fill_tr8(s_tr, xsrc, tr, nullptr, CUP, tid);
+        if (tid < 4) reinterpret_cast<unsigned*>(zero8)[tid] = 0u;
+    }
+    // ---- tile-invariant staging descriptors
+    int xoff[C::NXI], goff[C::NGI], gyx[C::NGI];
+#pragma unroll
+    for (int j = 0; j < C::NXI; ++j) {
+        const int it = tid + j * 256, pos = it / (CUP / 8), cgx = it % (CUP / 8);
+        xoff[j] = ((pos / TW) * w + (pos % TW)) * CUP + cgx * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < C::NGI; ++j) {
+        const int it = tid + j * 256, gp = it / (COUT / 8), cgg = it % (COUT / 8);
+        const int gy = gp / GW, gx = gp % GW;
+        goff[j] = (gy * W + gx) * COUT + cgg * 8;
+        gyx[j] = gy | (gx << 16);
+    }
+    // ---- tile-invariant operand addresses (LDS, elements)
+    const int i16 = lane & 15, kg = lane >> 4, ks = wave % KW, nh = wave / KW;
+    const int pr = ks * 32 + 4 * kg + (i16 >> 2);  // position supplied by this lane in the first transpose read (second: +16 = next row)
+    const bf16* a_ptr = xs + pr * CUP + (i16 & 3) * 4;
+    const int pii = pr / TW, pjj = pr % TW;
+    const bf16* b_ptr[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+        const int n0 = (nh * NTW + q) * 16 + (i16 & 3) * 4;
+        const int tap = n0 / COUT, co = n0 % COUT;
+        b_ptr[q] = n0 < C::NCOL ? gsm + ((2 * pii + tap / 3) * GW + 2 * pjj + tap % 3) * COUT + co : nullptr;
+    }
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) acc[a][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Raw8<bf16> xr[C::NXI], gr[C::NGI];
+    unsigned okx = 0, okg = 0;
+    auto issue = [&](long tn) {
+        const TileOrg o = tile_origin2<TW, TH>(tg, (int)tn);  // origin in INPUT coordinates (i0, j0)
+        const bf16* xb = x + (((long)o.n * h + o.h0) * w + o.w0) * CUP;
+        const bf16* gb = g + (((long)o.n * H + 2 * o.h0) * W + 2 * o.w0) * COUT;
+        okx = okg = 0;
+#pragma unroll
+        for (int j = 0; j < C::NXI; ++j) {
+            const int it = tid + j * 256, pos = it / (CUP / 8);
+            const bool ok = (C::XI % 256 == 0 || it < C::XI) && o.h0 + pos / TW < h && o.w0 + pos % TW < w;
+            xr[j] = load8_raw(ok ? xb + xoff[j] : x);
+            okx |= ok ? 1u << j : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NGI; ++j) {
+            const bool ok = (C::GI % 256 == 0 || tid + j * 256 < C::GI) && 2 * o.h0 + (gyx[j] & 0xffff) < H && 2 * o.w0 + (gyx[j] >> 16) < W;
+            gr[j] = load8_raw(ok ? gb + goff[j] : g);
+            okg |= ok ? 1u << j : 0u;
+        }
+    };
+    TileSched ts(tg.ntiles);
+    if (ts.first < ts.end) issue(ts.first);
+    __syncthreads();  // s_tr, zero8
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        // commit the prefetched tile: x~ = max(x*scale+shift, lo) rounded to bf16 (what the forward MFMA consumed), g as is
+#pragma unroll
+        for (int j = 0; j < C::NXI; ++j) {
+            const int it = tid + j * 256;
+            if (C::XI % 256 == 0 || it < C::XI) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (okx & (1u << j)) {
+                    const float* tp = s_tr + (it % (CUP / 8)) * 24;
+                    float sc[8], sh[8], lo[8];
+                    unpack8(xr[j], v);
+                    load8(tp, sc);
+                    load8(tp + 8, sh);
+                    load8(tp + 16, lo);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                }
+                store8(xs + it * 8, v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C::NGI; ++j) {
+            const int it = tid + j * 256;
+            if (C::GI % 256 == 0 || it < C::GI) *reinterpret_cast<uint4*>(gsm + it * 8) = (okg & (1u << j)) ? gr[j].a : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + ts.step < ts.end) issue(t + ts.step);
+        lds_barrier();
+        bf16x8 af[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) af[a] = lds_tr8(a_ptr + a * 16, a_ptr + a * 16 + 16 * CUP);
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const bf16* bp = b_ptr[q] ? b_ptr[q] : zero8;
+            const bf16x8 bfr = lds_tr8(bp, b_ptr[q] ? bp + 2 * GW * COUT : zero8);
+#pragma unroll
+            for (int a = 0; a < MT; ++a) acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][q], 0, 0, 0);
+        }
+        lds_barrier();  // all operand reads done before the next commit overwrites the tiles
+    }
+    // ---- block reduction over the KW k-waves (same N half), then the block partial -> ws[block][CUP][NT*16]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [(KW-1)][NW][MT*NTW][256]
+    if (ks > 0) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((ks - 1) * C::NW + nh) * MT * NTW + a * NTW + q) * 256 + r * 64 + lane] = acc[a][q][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+        float* part = ws + (long)blockIdx.x * C::PART;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[a][q][r];
+                    for (int k2 = 1; k2 < KW; ++k2) v += red[(((k2 - 1) * C::NW + nh) * MT * NTW + a * NTW + q) * 256 + r * 64 + lane];
+                    const int m = a * 16 + kg * 4 + r, n = (nh * NTW + q) * 16 + i16;
+                    part[m * (C::NT * 16) + n] = v;
+                }
+    }
+}
+// dW[(c*COUT + o)*9 + tap] += sum over block partials of ws[b][c][tap*COUT + o];  grid (ceil(CUP*NCOL/256), partial chunks)
+__global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restrict__ ws, int nblocks, int CUP, int COUT, int NT16, float* __restrict__ dW) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= CUP * 9 * COUT) return;
+    const int c = e / (9 * COUT), n = e - c * 9 * COUT;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += ws[((long)b * CUP + c) * NT16 + n];
+    const int tap = n / COUT, o = n - tap * COUT;
+    atomicAdd(&dW[((long)c * COUT + o) * 9 + tap], s);
+}
+
+// ----------------------------------------------------------------------------------------------
 // ConvTranspose2d dgrad:  dx~[n,i,j,c] = sum_{ky,kx,o} g[n, 2i+ky, 2j+kx, o] * W[c,o,ky,kx]   (cropped rows/cols get no gradient)
 // GEMM: M = c (Cup), N = input pixels, K = (tap, o) = 9*Cout (zero-padded to a multiple of 32).
 template <class T, int MT>
@@ -871,7 +1046,8 @@ static inline int cg_grid(long items) { return ew_grid(items); }
 static inline int wgrad_grid(long ntiles, int cap_blocks) {
     static const int cap_env = env_int("OCRS_WGRAD_CAP", 0);
     if (cap_env > 0) cap_blocks = cap_env;
-    long g = ntiles / 8;
+    static const int tpb = env_int("OCRS_WGRAD_TPB", 8);  // minimum tiles per block (each block flushes one full weight-gradient partial)
+    long g = ntiles / tpb;
     if (g < 1) g = 1;
     if (g > cap_blocks) g = cap_blocks;
     if (g >= 8) g &= ~7L;
@@ -1016,7 +1192,18 @@ int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const
 // ConvTranspose2d backward.  g [N][H][W][Cout] = gradient of the (cropped) output; dx [N][h][w][Cup] written;
 // dW [Cup][Cout][3][3] and dbias [Cout] accumulated; ws = workspace of ocrs_convt_bwd_ws_floats() floats (or null: float atomics).  wpk_d = ocrs_pack_frags(mode 0, K=9*Cout, M=Cup, K2=Cout, s1=1, s2=9, sm=9*Cout).
 extern "C" long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
-long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) { return ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype); }
+static bool convt_wgrad_tr_ok(int Cup, int Cout, int dtype) {
+    return dtype == 1 && ((Cup == 16 && Cout == 8) || (Cup == 32 && Cout == 16) || (Cup == 32 && Cout == 32));
+}
+static int convt_wgrad_tr_grid(int Cout, int N, int h, int w) {
+    const int TH = Cout >= 32 ? 4 : 8;
+    return persistent_grid((long)N * ((w + 15) / 16) * ((h + TH - 1) / TH), 4);
+}
+long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
+    const long a = ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype);
+    const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * Cup * ((9 * Cout + 15) / 16 * 16) : 0;
+    return a > b ? a : b;
+}
 
 int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup, int Cout,
                    int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
@@ -1046,7 +1233,19 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_DISPATCH
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
-    {
+    if (ws && convt_wgrad_tr_ok(Cup, Cout, dtype)) {
+#define CTW_CASE(CU_, CO_)                                                                                                                   \
+    if (Cup == CU_ && Cout == CO_) {                                                                                                         \
+        using CC = CtwCfg<CU_, CO_>;                                                                                                         \
+        const Tiling2 tg = make_tiling2(N, h, w, CC::TW, CC::TH);                                                                            \
+        const int nb = convt_wgrad_tr_grid(Cout, N, h, w);                                                                                   \
+        hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, ws, h, w, H, W, tg); \
+        const int ne = CU_ * 9 * CO_;                                                                                                        \
+        hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 255) / 256, nb >= 64 ? 16 : 1), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW); \
+    }
+        CTW_CASE(16, 8) CTW_CASE(32, 16) CTW_CASE(32, 32)
+#undef CTW_CASE
+    } else {
         const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;
     }
