@@ -74,6 +74,16 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 __device__ __forceinline__ void store8(bf16* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
+// store8 with the bf16 packing hidden from the optimiser (inline v_cvt_pk_bf16_f32).  With the plain (__bf16) casts hipcc SLP-vectorises
+// the whole producing loop (e.g. the 9-tap depthwise sum) around the packed converts and live ranges explode: k_pw_bwd<16,16> went from
+// 129 to 181 VGPRs (occupancy 3 -> 2) with store8() at the end of the tap loop.
+__device__ __forceinline__ void store8_opaque(float* p, const float (&v)[8]) { store8(p, v); }
+__device__ __forceinline__ void store8_opaque(bf16* p, const float (&v)[8]) {
+    unsigned pk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[i]) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    *reinterpret_cast<uint4*>(p) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
 // raw (still packed) 8-channel vector: lets a kernel issue global loads early and convert at the point of use
 template <class T>
 struct Raw8;

@@ -135,6 +135,8 @@ struct PwBwdCfg {
     static constexpr int TPP_F = TP + 4;
     static constexpr int TH = 8, TW = TP / 8;  // 8x32 / 8x16 / 8x8 pixel tiles
     static constexpr int HP = (TW + 2) * (TH + 2);
+    // elements of the LDS region behind tileD: transposed dz / u tiles, or (pipelined bf16 path) the natural-layout u tile [TP][40]
+    __host__ __device__ static constexpr int mid_el(int tpp) { return (WTO + WTI) * 16 * tpp > TP * 40 ? (WTO + WTI) * 16 * tpp : TP * 40; }
 };
 
 template <class T, int CIN, int COUT, bool PPOOL /* pipelined max-pool-routed gradient source (PIPE configs only) */>
@@ -153,7 +155,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     T* tileD = reinterpret_cast<T*>(smem);               // [TP][PITCH]
     T* dzT = tileD + TP * PITCH;                         // [WTO*16][TPP]
     T* uT = dzT + WTO * 16 * TPP;                        // [WTI*16][TPP]
-    float* xs = reinterpret_cast<float*>(smem + (((TP * PITCH + (WTO + WTI) * 16 * TPP) * sizeof(T) + 15) & ~15));  // [HP][CGI*8]
+    T* tileU = dzT;                                      // pipelined bf16 path instead: natural-layout u tile [TP][PITCH]
+    float* xs = reinterpret_cast<float*>(smem + (((TP * PITCH + Cfg::mid_el(TPP)) * sizeof(T) + 15) & ~15));  // [HP][CGI*8]
     float* s_par = xs + Cfg::HP * CGI * 8;
     float* s_trx = s_par;                // [CIN/8][3][8] (HaloStager layout)
     float* s_wdw = s_par + 3 * CIN;      // [9][CIN]
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     }
     {
         const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = tid * 8; i < (WTO + WTI) * 16 * TPP; i += 256 * 8) store8(dzT + i, zero8);  // padding rows stay zero
+        for (int i = tid * 8; i < TP * PITCH + Cfg::mid_el(TPP); i += 256 * 8) store8(tileD + i, zero8);  // padding rows / columns stay zero
     }
     __syncthreads();
 
@@ -299,11 +302,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                     for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
                 }
                 stager.commit(pend, s_trx, 0, xs, tid);
-                if (cg < CGO) {
-                    store8(tileD + pxl * PITCH + cg * 8, dz);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) Elem<T>::st(dzT + (c0 + i) * TPP + pxl, dz[i]);
-                }
+                if (cg < CGO) store8_opaque(tileD + pxl * PITCH + cg * 8, dz);  // natural layout: dgrad operand AND (transpose-read) wgrad operand
             }
             __builtin_amdgcn_sched_barrier(0);
             if (t + ts.step < ts.end) issue_tile(t + ts.step);
@@ -333,22 +332,27 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 if (cg < CGI) {
                     float u[8];
                     dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
+                    float uz[8];  // (a select, not an `if (!pv)` block writing u: the branch form costs 60 VGPRs)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) Elem<T>::st(uT + (cg * 8 + i) * TPP + pxl, pv ? u[i] : 0.f);
+                    for (int i = 0; i < 8; ++i) uz[i] = pv ? u[i] : 0.f;
+                    store8_opaque(tileU + pxl * PITCH + cg * 8, uz);
                 }
             }
             lds_barrier();
+            if constexpr (Elem<T>::is_bf16) {
+                // wgrad: K = pixels; both operands come straight from the natural-layout tiles through the LDS transpose read.
+                // The WTI*WTO (1, 2 or 4) output tiles x TP/32 k-steps are spread over all four waves (tile = wave % NT).
+                constexpr int NTL = WTI * WTO, KSTRIDE = 4 / NTL;
+                const int ti = (wave % NTL) % WTI, to = (wave % NTL) / WTI;
+                const int prow = 4 * (lane >> 4) + ((lane & 15) >> 2), pcol = (lane & 3) * 4;
+                static_assert((TP / 32) % KSTRIDE == 0, "k-steps divide evenly over the waves");
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int tt = wave + 4 * j;
-                if (tt < WTI * WTO) {
-                    const int ti = tt % WTI, to = tt / WTI;
-#pragma unroll
-                    for (int pc = 0; pc < TP / 32; ++pc) {
-                        const typename Mma<T>::Frag fa = Mma<T>::load_p(uT + pc * 32, TPP, ti * 16, lane, 32);
-                        const typename Mma<T>::Frag fb = Mma<T>::load_p(dzT + pc * 32, TPP, to * 16, lane, 32);
-                        accw[j] = Mma<T>::template mma<8>(fa, fb, accw[j]);
-                    }
+                for (int m = 0; m < (TP / 32) / KSTRIDE; ++m) {
+                    const int pc = wave / NTL + m * KSTRIDE;
+                    const T* ua = tileU + (pc * 32 + prow) * PITCH + ti * 16 + pcol;
+                    const T* da = tileD + (pc * 32 + prow) * PITCH + to * 16 + pcol;
+                    const bf16x8 fa = lds_tr8(ua, ua + 16 * PITCH), fb = lds_tr8(da, da + 16 * PITCH);
+                    accw[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, accw[0], 0, 0, 0);
                 }
             }
             lds_barrier();
@@ -504,6 +508,28 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
         __syncthreads();
     }
     // ---- flush weight gradient (master layout [COUT][CIN])
+    if constexpr (PIPE) {
+        // the 4/NTL waves that split K for the same output tile are summed through LDS first: same-address float atomics are the
+        // expensive part of the flush (2048 blocks x 4 waves onto 256 addresses cost +0.5 ms per launch)
+        constexpr int NTL = WTI * WTO;
+        float* red = reinterpret_cast<float*>(smem);  // [4][256]
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = accw[0][r];
+        __syncthreads();
+        if (wave < NTL) {
+            const int ti = wave % WTI, to = wave / WTI;
+            const int co = to * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = accw[0][r];
+                for (int w2 = wave + NTL; w2 < 4; w2 += NTL) v += red[w2 * 256 + r * 64 + lane];
+                const int ci = ti * 16 + (lane >> 4) * 4 + r;
+                if (ci < CIN && co < COUT) atomicAdd(&dwpw[(long)co * CIN + ci], v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int tt = wave + 4 * j;
@@ -1093,7 +1119,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                          int W, hipStream_t st) {
     using Cfg = PwBwdCfg<CIN, COUT>;
     constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
-    const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + (Cfg::WTO + Cfg::WTI) * 16 * TPP) * sizeof(T) + 15) & ~15) +
+    const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + Cfg::mid_el(TPP)) * sizeof(T) + 15) & ~15) +
                         (Cfg::HP * Cfg::CGI * 8 + 12 * CIN + 6 * COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1105,7 +1131,9 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
-    const int gx = wgrad_grid(tg.ntiles, 2048);
+    // every block flushes one weight-gradient partial with float atomics onto the same few addresses: no more blocks than are resident
+    // (3 per CU at the fast path's register budget) for the one-chunk configs, 2048 otherwise
+    const int gx = wgrad_grid(tg.ntiles, (Cfg::NKD == 1 && CIN <= 32) ? 3 * kNumCU : 2048);
     hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT, PPOOL>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
                        wpk_d, (T*)du, dwpw, tg);
     OCRS_LAUNCH_CHECK();
@@ -1113,9 +1141,13 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
 }
 extern "C" {
 
+#ifdef OCRS_PW_ONLY_16  // (compile-time experiments: tools/kres.py with KRES_FLAGS=-DOCRS_PW_ONLY_16)
+#define PW_BWD_COMBOS(X) X(16, 16)
+#else
 #define PW_BWD_COMBOS(X) \
     X(8, 8) X(8, 16) X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 128) X(128, 128) X(128, 256) X(256, 256) X(256, 128) X(128, 64) \
         X(64, 32) X(32, 16) X(16, 8)
+#endif
 
 // Pointwise-conv backward of a DepthwiseConv block: du = Wpw^T dz (written, [P][Cin]); dwpw += u^T dz (accumulated, master layout
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
@@ -1131,7 +1163,11 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 #define XP(CI)                                                                                                                            \
     if (pooled && dtype == 1 && Cin == CI && Cout == CI)                                                                                  \
         return launch_pw_bwd<bf16, CI, CI, true>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
+#ifdef OCRS_PW_ONLY_16
+    XP(16)
+#else
     XP(8) XP(16) XP(32)
+#endif
 #undef XP
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
             tile_barrier<PIPE>();  // xs ready; all readers of the previous xs / tile passed a barrier since
             float u[8];
             dw_from_lds<CG, TW, TH>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);  // (scalar-loaded weights for CG==1 spill SGPRs -> slower)
-            store8(tile + pxl * PITCH + cg * 8, u);
+            store8_opaque(tile + pxl * PITCH + cg * 8, u);
             tile_barrier<PIPE>();
             typename Mma<T>::Frag pf[PTW];
 #pragma unroll

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Print VGPR / scratch / occupancy / LDS per kernel of a .hip file (hipcc -Rpass-analysis=kernel-resource-usage)."""
-import re, subprocess, sys
+import os, re, subprocess, sys
 src = sys.argv[1]; pat = sys.argv[2] if len(sys.argv) > 2 else ""
-r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-c", src, "-o", "/tmp/kres.o",
+r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-c", src, "-o", "/tmp/kres.o", *os.environ.get("KRES_FLAGS", "").split(),
                     "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
 cur = None
 rows = {}
