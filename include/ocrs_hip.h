@@ -58,9 +58,11 @@ int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z
 int ocrs_bn_bwd_finalize(const double* gsum, long count, int C, const float* gamma, const float* saved, float* coef, float* dgamma,
                          float* dbeta, hipStream_t st);
 /* autograd of the 1x1 conv (dgrad written to du, wgrad accumulated into dwpw [Cout][Cin]). */
+/*   ws: ocrs_pw_bwd_ws_floats() floats of workspace (per-block partials, deterministic two-stage reduction) or NULL (float atomics). */
+long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W);
 int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1,
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw,
-                int Cout, int N, int H, int W, int dtype, hipStream_t st);
+                float* ws, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of the depthwise 3x3 conv (dL/dx~ split at channel Ca into gxa|gxb; dwdw [C][1][3][3] accumulated). */
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du,
                 void* gxa, void* gxb, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);

@@ -115,6 +115,34 @@ __global__ void k_bn_bwd_finalize(const double* __restrict__ gsum, long count, i
 //   wgrad : D[cin][cout]  = sum_pixel u[pixel][cin] * dz[pixel][cout]        (K = pixel; both operands from transposed LDS tiles)
 // grid.y enumerates (cin-block, cout-block) pairs of the weight gradient (blocks of <=128x128); y == 0 also does dgrad.
 // ----------------------------------------------------------------------------------------------
+// Weight-gradient flush of a persistent block: a plain store of its partial into the workspace slot of this block (summed by
+// k_wgrad_partials_reduce: deterministic, no contention) or, without a workspace, a float atomic (same-address atomics from thousands of
+// blocks were 2.5 ms of the detection step).
+__device__ __forceinline__ void flush_w(float* __restrict__ dw, float* __restrict__ ws, long idx, int nelem, float v) {
+    if (ws)
+        ws[(long)blockIdx.x * nelem + idx] = v;
+    else
+        atomicAdd(&dw[idx], v);
+}
+// dw[e] += sum_b ws[b][e];  grid (ceil(nelem/256), chunks of partials)
+__global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __restrict__ ws, int nb, int nelem, float* __restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nelem) return;
+    const int per = (nb + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
+    float s0 = 0.f, s1 = 0.f;
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
+        s0 += ws[(long)b * nelem + e];
+        s1 += ws[(long)(b + 1) * nelem + e];
+    }
+    if (b < b1) s0 += ws[(long)b * nelem + e];
+    if (gridDim.y == 1)
+        dw[e] += s0 + s1;
+    else
+        atomicAdd(&dw[e], s0 + s1);
+}
+
 template <int CIN, int COUT>
 struct PwBwdCfg {
     static constexpr int CGI = (CIN < 32 ? CIN : 32) / 8;
@@ -143,7 +171,8 @@ template <class T, int CIN, int COUT, bool PPOOL /* pipelined max-pool-routed gr
 __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
                                                 const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
-                                                T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/, Tiling2 tg) {
+                                                T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/,
+                                                float* __restrict__ ws /*[gridDim.x][COUT][CIN] block partials, or null: float atomics*/, Tiling2 tg) {
     using Cfg = PwBwdCfg<CIN, COUT>;
     constexpr int TW = Cfg::TW, TH = Cfg::TH;
     const int H = tg.H, W = tg.W;
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 float v = accw[0][r];
                 for (int w2 = wave + NTL; w2 < 4; w2 += NTL) v += red[w2 * 256 + r * 64 + lane];
                 const int ci = ti * 16 + (lane >> 4) * 4 + r;
-                if (ci < CIN && co < COUT) atomicAdd(&dwpw[(long)co * CIN + ci], v);
+                if (ci < CIN && co < COUT) flush_w(dwpw, ws, (long)co * CIN + ci, CIN * COUT, v);
             }
         }
         return;
@@ -539,7 +568,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = ci_base + ti * 16 + (lane >> 4) * 4 + r;
-                if (ci < CIN && co < COUT) atomicAdd(&dwpw[(long)co * CIN + ci], accw[j][r]);
+                if (ci < CIN && co < COUT) flush_w(dwpw, ws, (long)co * CIN + ci, CIN * COUT, accw[j][r]);
             }
         }
     }
@@ -1072,7 +1101,7 @@ static inline int cg_grid(long items) { return ew_grid(items); }
 static inline int wgrad_grid(long ntiles, int cap_blocks) {
     static const int cap_env = env_int("OCRS_WGRAD_CAP", 0);
     if (cap_env > 0) cap_blocks = cap_env;
-    static const int tpb = env_int("OCRS_WGRAD_TPB", 8);  // minimum tiles per block (each block flushes one full weight-gradient partial)
+    static const int tpb = env_int("OCRS_WGRAD_TPB", 4);  // minimum tiles per block (each block flushes one full weight-gradient partial)
     long g = ntiles / tpb;
     if (g < 1) g = 1;
     if (g > cap_blocks) g = cap_blocks;
@@ -1113,10 +1142,19 @@ int ocrs_bn_bwd_finalize(const double* gsum, long count, int C, const float* gam
 }
 
 }  // extern "C" (templates need C++ linkage)
+static inline int wgrad_grid(long ntiles, int cap_blocks);
+template <int CIN, int COUT>
+static int pw_bwd_gx(int N, int H, int W) {
+    using Cfg = PwBwdCfg<CIN, COUT>;
+    const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
+    // one-chunk configs (levels 0-1): as many blocks as are resident (3 per CU at that register budget); deeper levels: the
+    // tiles-per-block rule of wgrad_grid (they are latency-bound: more, shorter blocks)
+    return wgrad_grid(tg.ntiles, (Cfg::NKD == 1 && CIN <= 32) ? 3 * kNumCU : 2048);
+}
 template <class T, int CIN, int COUT, bool PPOOL>
 static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
-                         int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int N, int H,
-                         int W, hipStream_t st) {
+                         int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int N,
+                         int H, int W, hipStream_t st) {
     using Cfg = PwBwdCfg<CIN, COUT>;
     constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
     const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + Cfg::mid_el(TPP)) * sizeof(T) + 15) & ~15) +
@@ -1131,11 +1169,13 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
-    // every block flushes one weight-gradient partial with float atomics onto the same few addresses: no more blocks than are resident
-    // (3 per CU at the fast path's register budget) for the one-chunk configs, 2048 otherwise
-    const int gx = wgrad_grid(tg.ntiles, (Cfg::NKD == 1 && CIN <= 32) ? 3 * kNumCU : 2048);
+    const int gx = pw_bwd_gx<CIN, COUT>(N, H, W);
     hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT, PPOOL>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
-                       wpk_d, (T*)du, dwpw, tg);
+                       wpk_d, (T*)du, dwpw, ws, tg);
+    if (ws) {
+        const int ne = CIN * COUT;
+        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, gx >= 128 ? 16 : (gx >= 16 ? 4 : 1)), dim3(256), 0, st, ws, gx, ne, dwpw);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -1152,8 +1192,16 @@ extern "C" {
 // Pointwise-conv backward of a DepthwiseConv block: du = Wpw^T dz (written, [P][Cin]); dwpw += u^T dz (accumulated, master layout
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
+// ws: workspace of ocrs_pw_bwd_ws_floats() floats (deterministic two-stage weight-gradient reduction) or null (float atomics).
+long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W) {
+#define X(CI, CO) \
+    if (Cin == CI && Cout == CO) return (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO;
+    PW_BWD_COMBOS(X)
+#undef X
+    return 0;
+}
 int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2, int pooled,
-                const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, int Cout, int N, int H, int W,
+                const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N, int H, int W,
                 int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(xa && tra && wdw && g1 && z && bn && coef && wpk_d && du && dwpw && (Cb == 0 || trb));
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
@@ -1162,7 +1210,7 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     // pipelined pool-routed variant: bf16, one K chunk (Cin = Cout <= 32: the second conv of a Down block, models.py:52-54)
 #define XP(CI)                                                                                                                            \
     if (pooled && dtype == 1 && Cin == CI && Cout == CI)                                                                                  \
-        return launch_pw_bwd<bf16, CI, CI, true>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
+        return launch_pw_bwd<bf16, CI, CI, true>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st);
 #ifdef OCRS_PW_ONLY_16
     XP(16)
 #else
@@ -1171,8 +1219,8 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 #undef XP
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \
-        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st) \
-                          : launch_pw_bwd<float, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, N, H, W, st);
+        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st) \
+                          : launch_pw_bwd<float, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st);
     PW_BWD_COMBOS(X)
 #undef X
     return OCRS_ERR_ARG;

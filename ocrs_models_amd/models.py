@@ -214,8 +214,10 @@ class _DetRun:
         Ca, Cb = a.C, (b.C if b is not None else 0)
         wpk_d = self.pack(wpw, 0, C, r.Cin, C, 0, r.Cin, 1)
         du = self.empty(N, H, W, r.Cin)
+        ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
         L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
-                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), C, N, H, W, self.dt)
+                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W,
+                 self.dt)
         gxa = self.empty(N, H, W, Ca) if need_gx else None
         gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
         L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),
