@@ -64,8 +64,10 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw,
                 float* ws, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of the depthwise 3x3 conv (dL/dx~ split at channel Ca into gxa|gxb; dwdw [C][1][3][3] accumulated). */
+/*   ws: ocrs_dw_bwd_ws_floats() floats of workspace (per-block partials, two-stage reduction) or NULL (float atomics). */
+long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W);
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du,
-                void* gxa, void* gxb, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);
+                void* gxa, void* gxb, float* dwdw, float* ws, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
                      const float* bn, const float* coef, float* du_ws, float* dwpw, float* dwdw, int N, int H, int W, int dtype,
                      hipStream_t st);

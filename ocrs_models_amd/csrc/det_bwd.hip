@@ -580,7 +580,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 template <class T, int CG>
 __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
-                                                T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/, Tiling2 tg) {
+                                                T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
+                                                float* __restrict__ ws /*[gridDim.x][C][9] block partials or null*/, Tiling2 tg) {
     // slab of SC = CG*8 channels per block (grid.y); 4 channels per thread -> 36 dW accumulators; tile 8 x (16/CG) pixels
     constexpr int TH = 8, TW = 16 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
     constexpr int NIT = (HP * CG + 255) / 256;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
         const float* src = s_red + (t * 4 + (c & 3)) * 256 + (c >> 2);
         float v = 0.f;
         for (int m = 0; m < 256 / CQ; ++m) v += src[m * CQ];
-        atomicAdd(&dwdw[(cb + c) * 9 + t], v);
+        flush_w(dwdw, ws, (cb + c) * 9 + t, C * 9, v);
     }
 }
 
@@ -1227,22 +1228,34 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 }
 
 // Depthwise-conv backward: gxa/gxb (either may be null) receive dL/dx~ split at channel Ca; dwdw accumulated in master layout [C][1][3][3].
+static void dw_bwd_grid(int C, int N, int H, int W, int& gx, int& gy, int& cg) {
+    cg = C >= 32 ? 4 : C / 8;
+    gy = C / (cg * 8);
+    const Tiling2 tg = make_tiling2(N, H, W, 16 / cg, 8);
+    gx = persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1);
+}
+// ws: ocrs_dw_bwd_ws_floats() floats (per-block partials of dwdw, summed by a second kernel) or null (float atomics).
+long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W) {
+    int gx, gy, cg;
+    dw_bwd_grid(C, N, H, W, gx, gy, cg);
+    return (long)gx * C * 9;
+}
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du, void* gxa, void* gxb,
-                float* dwdw, int N, int H, int W, int dtype, hipStream_t st) {
+                float* dwdw, float* ws, int N, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(xa && tra && wdw && du && dwdw && (Ca + Cb) % 8 == 0 && Ca % 4 == 0 && (Cb == 0 || trb));
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int C = Ca + Cb;
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31) && (C < 32 || C % 32 == 0) && Ca % 8 == 0);
-    const int cg = C >= 32 ? 4 : C / 8;
-    const int gy = C / (cg * 8);
+    int gx, gy, cg;
+    dw_bwd_grid(C, N, H, W, gx, gy, cg);
 #define DWB(T_, CG_)                                                                                                                      \
     {                                                                                                                                     \
         const Tiling2 tg = make_tiling2(N, H, W, 16 / CG_, 8);                                                                            \
         const int HP = (16 / CG_ + 2) * 10;                                                                                               \
         const size_t smem = (HP * CG_ * 8 + 9 * CG_ * 8 + 36 * 256) * sizeof(float);                                                                \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
-        hipLaunchKernelGGL((k_dw_bwd<T_, CG_>), dim3(persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1), gy), dim3(256), smem, st, x, tra, trb, wdw, \
-                           (const T_*)du, (T_*)gxa, (T_*)gxb, dwdw, tg);                                                                   \
+        hipLaunchKernelGGL((k_dw_bwd<T_, CG_>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, dwdw, ws, \
+                           tg);                                                                                                           \
     }
     if (dtype == 1) {
         if (cg == 1) DWB(bf16, 1) else if (cg == 2) DWB(bf16, 2) else DWB(bf16, 4)
@@ -1250,6 +1263,7 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         if (cg == 1) DWB(float, 1) else if (cg == 2) DWB(float, 2) else DWB(float, 4)
     }
 #undef DWB
+    if (ws) hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((C * 9 + 255) / 256, gx >= 128 ? 16 : (gx >= 16 ? 4 : 1)), dim3(256), 0, st, ws, gx, C * 9, dwdw);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -220,8 +220,9 @@ class _DetRun:
                  self.dt)
         gxa = self.empty(N, H, W, Ca) if need_gx else None
         gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
+        ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
         L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),
-                 ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.0.weight"]), N, H, W, self.dt)
+                 ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), N, H, W, self.dt)
         return gxa, gxb
 
     def backward(self, gpred):
