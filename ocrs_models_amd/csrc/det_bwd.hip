@@ -130,18 +130,22 @@ __global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __re
     if (e >= nelem) return;
     const int per = (nb + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = b0;
-    for (; b + 1 < b1; b += 2) {
+    for (; b + 3 < b1; b += 4) {  // four independent loads in flight
         s0 += ws[(long)b * nelem + e];
         s1 += ws[(long)(b + 1) * nelem + e];
+        s2 += ws[(long)(b + 2) * nelem + e];
+        s3 += ws[(long)(b + 3) * nelem + e];
     }
-    if (b < b1) s0 += ws[(long)b * nelem + e];
+    for (; b < b1; ++b) s0 += ws[(long)b * nelem + e];
+    const float s = (s0 + s1) + (s2 + s3);
     if (gridDim.y == 1)
-        dw[e] += s0 + s1;
+        dw[e] += s;
     else
-        atomicAdd(&dw[e], s0 + s1);
+        atomicAdd(&dw[e], s);
 }
+static inline int partial_chunks(int nb) { return nb >= 512 ? 64 : (nb >= 128 ? 32 : (nb >= 16 ? 8 : 1)); }
 
 template <int CIN, int COUT>
 struct PwBwdCfg {
@@ -1121,7 +1125,10 @@ int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z
     OCRS_CHECK_ARG(g1 && z && bn && saved && gsum && C % 8 == 0 && C <= 256);
     if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     const long P = (long)N * H * W;
-    const int grid = cg_grid(P * (C / 8));
+    // every block ends with 2C fp64 atomics onto the same addresses: at the deep levels (tens of thousands of pixels) give each thread
+    // at least 8 items instead of launching 2048 nearly idle blocks (those launches were 60 us of pure flush)
+    long gl = (P * (C / 8) + 256 * 8 - 1) / (256 * 8);
+    const int grid = (int)(gl < 8 ? 8 : (gl > kNumCU * 8 ? kNumCU * 8 : gl));
     const size_t smem = 2 * C * sizeof(float);
     if (dtype == 1) {
         GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
@@ -1175,7 +1182,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                        wpk_d, (T*)du, dwpw, ws, tg);
     if (ws) {
         const int ne = CIN * COUT;
-        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, gx >= 128 ? 16 : (gx >= 16 ? 4 : 1)), dim3(256), 0, st, ws, gx, ne, dwpw);
+        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, ne, dwpw);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1263,7 +1270,7 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         if (cg == 1) DWB(float, 1) else if (cg == 2) DWB(float, 2) else DWB(float, 4)
     }
 #undef DWB
-    if (ws) hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((C * 9 + 255) / 256, gx >= 128 ? 16 : (gx >= 16 ? 4 : 1)), dim3(256), 0, st, ws, gx, C * 9, dwdw);
+    if (ws) hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((C * 9 + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, C * 9, dwdw);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

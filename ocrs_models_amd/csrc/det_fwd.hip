@@ -467,7 +467,8 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
     const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) +
                         (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16 + (MT <= 2 ? MT * 8 * 256 : 0)) * sizeof(float);
-    const int grid = persistent_grid(tg.ntiles, 8);
+    static const int fwd_tpb = env_int("OCRS_FWD_TPB", 1);  // minimum tiles per block (every block ends with 2*COUT fp64 atomics)
+    const int grid = persistent_grid(tg.ntiles / fwd_tpb > 0 ? tg.ntiles / fwd_tpb : 1, 8);
     hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
