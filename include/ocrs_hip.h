@@ -66,8 +66,12 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 /* autograd of the depthwise 3x3 conv (dL/dx~ split at channel Ca into gxa|gxb; dwdw [C][1][3][3] accumulated). */
 /*   ws: ocrs_dw_bwd_ws_floats() floats of workspace (per-block partials, two-stage reduction) or NULL (float atomics). */
 long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W);
+/*   gsum_a / gsum_b (nullable, need ws): ALSO accumulate the BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Ca] / [2][Cb] fp64,
+ *   zeroed by the caller before the first consumer) of the blocks that produced source a / b -- this replaces their ocrs_bn_bwd_reduce
+ *   when every consumer of that block output is a depthwise conv; saved_a / saved_b = those blocks' saved [mean | rstd]. */
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du,
-                void* gxa, void* gxb, float* dwdw, float* ws, int N, int H, int W, int dtype, hipStream_t st);
+                void* gxa, void* gxb, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
+                int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
                      const float* bn, const float* coef, float* du_ws, float* dwpw, float* dwdw, int N, int H, int W, int dtype,
                      hipStream_t st);

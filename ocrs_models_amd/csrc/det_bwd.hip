@@ -581,11 +581,16 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 // ----------------------------------------------------------------------------------------------
 // depthwise backward: dx~[p][c] = sum_tap w[c][tap] * du[p - off(tap)][c];  dW[c][tap] = sum_p x~[p][c] * du[p - off(tap)][c]
 // 4 channels per thread (weights, transform and the 36 dW partials live in registers).
-template <class T, int CG>
-__global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+// STATS: additionally accumulate, for the PRODUCER blocks of the two sources, the BatchNorm-backward reductions of the gradient this
+// kernel computes (sum ghat and sum ghat*(z - mean), ghat = dx~ * [bn(z) > 0]): the input x is that producer's raw z, so its
+// k_bn_bwd_reduce pass over (g, z) -- 2.1 ms of the step -- disappears.  Partials go to workspace rows 9..10 (stat_mask bit 0 / 1 =
+// source a / b wants them); k_dw_partials_reduce scales by rstd and adds them to the producers' gsum [2][C] (fp64).
+template <class T, int CG, bool STATS>
+__global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
-                                                float* __restrict__ ws /*[gridDim.x][C][9] block partials or null*/, Tiling2 tg) {
+                                                float* __restrict__ ws /*[gridDim.x][C][9 (+2)] block partials or null*/,
+                                                const float* __restrict__ saved_a, const float* __restrict__ saved_b, int stat_mask, Tiling2 tg) {
     // slab of SC = CG*8 channels per block (grid.y); 4 channels per thread -> 36 dW accumulators; tile 8 x (16/CG) pixels
     constexpr int TH = 8, TW = 16 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
     constexpr int NIT = (HP * CG + 255) / 256;
@@ -619,6 +624,15 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
     const T* xsrc = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
     T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
     const int xp = in_a ? x.Ca : x.Cb;
+    float mu[STATS ? 4 : 1], st1[STATS ? 4 : 1], st2[STATS ? 4 : 1];
+    if constexpr (STATS) {
+        const bool on = in_a ? (stat_mask & 1) : (stat_mask & 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mu[i] = on ? (in_a ? saved_a[c0 + i] : saved_b[c0 - x.Ca + i]) : 0.f;
+            st1[i] = st2[i] = 0.f;
+        }
+    }
 
     // Software pipeline: the raw du halo vectors AND this thread's x quad of the NEXT tile are in flight while the current tile is
     // computed.  Loads are unconditional (invalid items read element 0 and are zeroed at use: a load under a divergent branch makes
@@ -670,10 +684,18 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
             }
         }
         const bool valid = cur.ok >> 31;
-        float xv[4];
+        float xv[4], zc[STATS ? 4 : 1];
+        bool pos[STATS ? 4 : 1];
         unpack4(cur.x, xv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = valid ? max_lo(fmaf(xv[i], sc[i], sh[i]), lo[i]) : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const float pre = fmaf(xv[i], sc[i], sh[i]);
+            if constexpr (STATS) {
+                zc[i] = xv[i] - mu[i];
+                pos[i] = valid && pre > 0.f;
+            }
+            xv[i] = valid ? max_lo(pre, lo[i]) : 0.f;
+        }
         __builtin_amdgcn_sched_barrier(0);
         const bool more = t + ts.step < ts.end;
         if (more) issue(cur, tile_origin2<TW, TH>(tg, (int)(t + ts.step)));
@@ -693,23 +715,71 @@ __global__ __launch_bounds__(256) void k_dw_bwd(Src2<T> x, const float* __restri
             }
         }
         if (valid && gdst) store4(gdst + (((long)org.n * H + org.h0) * W + org.w0) * xp + xoff, g[0], g[1], g[2], g[3]);
+        if constexpr (STATS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gh = pos[i] ? Elem<T>::round(g[i]) : 0.f;  // the producer's pw_bwd reads the STORED (rounded) gradient
+                st1[i] += gh;
+                st2[i] = fmaf(gh, zc[i], st2[i]);
+            }
+        }
     }
     __syncthreads();
     // block reduction of the 36 per-thread partials through LDS (plain stores, then a strided sum): cheap in registers,
     // runs once per persistent block
-    float* s_red = s_w + 9 * SC;  // [36][256]
+    constexpr int NROW = STATS ? 11 : 9;  // per-channel partial rows: 9 taps (+ the two BatchNorm-backward sums)
+    float* s_red = s_w + 9 * SC;  // [NROW*4][256]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) s_red[(t * 4 + i) * 256 + tid] = acc[t][i];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s_red[(36 + i) * 256 + tid] = st1[i];
+            s_red[(40 + i) * 256 + tid] = st2[i];
+        }
+    }
     __syncthreads();
-    for (int j = tid; j < 9 * SC; j += 256) {
+    for (int j = tid; j < NROW * SC; j += 256) {
         const int t = j / SC, c = j - t * SC;
         const float* src = s_red + (t * 4 + (c & 3)) * 256 + (c >> 2);
         float v = 0.f;
         for (int m = 0; m < 256 / CQ; ++m) v += src[m * CQ];
-        flush_w(dwdw, ws, (cb + c) * 9 + t, C * 9, v);
+        if (t < 9)
+            flush_w(dwdw, ws, (cb + c) * 9 + t, C * NROW, v);
+        else
+            ws[(long)blockIdx.x * (C * NROW) + C * t + cb + c] = v;  // rows 9, 10: [C] each (STATS requires a workspace)
     }
+}
+// second stage of k_dw_bwd's flush: dwdw[e] += sum_b ws[b][e] (e < 9C); with stats (nrow = 11) rows 9/10 are scaled (row 10 by rstd)
+// and added to the producers' BatchNorm-backward sums gsum_a [2][Ca] / gsum_b [2][Cb] (fp64), if requested.
+__global__ __launch_bounds__(256) void k_dw_partials_reduce(const float* __restrict__ ws, int nb, int C, int Ca, int nrow, float* __restrict__ dwdw,
+                                                            double* __restrict__ gsum_a, double* __restrict__ gsum_b,
+                                                            const float* __restrict__ saved_a, const float* __restrict__ saved_b) {
+    const int e = blockIdx.x * 256 + threadIdx.x, nelem = C * nrow;
+    if (e >= nelem) return;
+    const int per = (nb + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        s0 += ws[(long)b * nelem + e];
+        s1 += ws[(long)(b + 1) * nelem + e];
+        s2 += ws[(long)(b + 2) * nelem + e];
+        s3 += ws[(long)(b + 3) * nelem + e];
+    }
+    for (; b < b1; ++b) s0 += ws[(long)b * nelem + e];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (e < 9 * C) {
+        atomicAdd(&dwdw[e], v);
+        return;
+    }
+    const int which = (e - 9 * C) / C, c = (e - 9 * C) % C, Cb = C - Ca;
+    if (c < Ca) {
+        if (gsum_a) atomicAdd(&gsum_a[which * Ca + c], (double)(which ? v * saved_a[Ca + c] : v));
+    } else if (gsum_b)
+        atomicAdd(&gsum_b[which * Cb + (c - Ca)], (double)(which ? v * saved_b[Cb + (c - Ca)] : v));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1245,10 +1315,18 @@ static void dw_bwd_grid(int C, int N, int H, int W, int& gx, int& gy, int& cg) {
 long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W) {
     int gx, gy, cg;
     dw_bwd_grid(C, N, H, W, gx, gy, cg);
-    return (long)gx * C * 9;
+    return (long)gx * C * 11;
 }
+// gsum_a / gsum_b (nullable; need ws): the producer blocks of source a / b get their BatchNorm-backward sums
+// [sum ghat | sum ghat*zhat] ([2][Ca] / [2][Cb] fp64, ACCUMULATED: zero them before the first consumer) from this pass instead of
+// ocrs_bn_bwd_reduce; saved_a / saved_b = those producers' saved [mean | rstd].  Valid when the source is that block's raw z
+// with its BatchNorm+ReLU load transform (not for pooled / ConvTranspose outputs).
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du, void* gxa, void* gxb,
-                float* dwdw, float* ws, int N, int H, int W, int dtype, hipStream_t st) {
+                float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int N, int H, int W, int dtype,
+                hipStream_t st) {
+    const int stat_mask = (gsum_a ? 1 : 0) | (gsum_b ? 2 : 0);
+    OCRS_CHECK_ARG(!stat_mask || ws);
+    OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
     OCRS_CHECK_ARG(xa && tra && wdw && du && dwdw && (Ca + Cb) % 8 == 0 && Ca % 4 == 0 && (Cb == 0 || trb));
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int C = Ca + Cb;
@@ -1259,10 +1337,14 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     {                                                                                                                                     \
         const Tiling2 tg = make_tiling2(N, H, W, 16 / CG_, 8);                                                                            \
         const int HP = (16 / CG_ + 2) * 10;                                                                                               \
-        const size_t smem = (HP * CG_ * 8 + 9 * CG_ * 8 + 36 * 256) * sizeof(float);                                                                \
+        const size_t smem = (HP * CG_ * 8 + 9 * CG_ * 8 + 44 * 256) * sizeof(float);                                                      \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
-        hipLaunchKernelGGL((k_dw_bwd<T_, CG_>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, dwdw, ws, \
-                           tg);                                                                                                           \
+        if (stat_mask)                                                                                                                    \
+            hipLaunchKernelGGL((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
+                               dwdw, ws, saved_a, saved_b, stat_mask, tg);                                                                \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((k_dw_bwd<T_, CG_, false>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
+                               dwdw, ws, saved_a, saved_b, 0, tg);                                                                        \
     }
     if (dtype == 1) {
         if (cg == 1) DWB(bf16, 1) else if (cg == 2) DWB(bf16, 2) else DWB(bf16, 4)
@@ -1270,7 +1352,11 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         if (cg == 1) DWB(float, 1) else if (cg == 2) DWB(float, 2) else DWB(float, 4)
     }
 #undef DWB
-    if (ws) hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((C * 9 + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, C * 9, dwdw);
+    if (ws) {
+        const int nrow = stat_mask ? 11 : 9;
+        hipLaunchKernelGGL(k_dw_partials_reduce, dim3((C * nrow + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
+                           gsum_b, saved_a, saved_b);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

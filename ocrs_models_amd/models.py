@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -61,10 +63,14 @@ class Up(nn.Module):
 class _Act:
     """NHWC activation + the per-channel load transform its consumers must apply."""
 
-    __slots__ = ("t", "tr", "C", "H", "W")
+    __slots__ = ("t", "tr", "C", "H", "W", "src", "other_use")
 
-    def __init__(self, t, tr, C, H, W):
+    def __init__(self, t, tr, C, H, W, src=None):
         self.t, self.tr, self.C, self.H, self.W = t, tr, C, H, W
+        # src: prefix of the DepthwiseConv block whose raw (pre-BatchNorm) output this is (None for pooled / ConvTranspose outputs);
+        # other_use: it is also consumed by something that is not a depthwise conv (max-pool, ConvTranspose, head).  A block output
+        # consumed ONLY by depthwise convs gets its BatchNorm-backward sums from those consumers' dw_bwd pass (no bn_bwd_reduce).
+        self.src, self.other_use = src, False
 
 
 class _BlockRec:
@@ -101,6 +107,8 @@ class _DetRun:
         self.dt = _DT[self.dtype]
         self.N = x.shape[0]
         self.recs = {}
+        self.fused = {}  # block prefix -> fp64 [2][C] BatchNorm-backward sums accumulated by its consumers' dw_bwd
+        self.fuse_bn_bwd = os.environ.get("OCRS_FUSE_BN_BWD", "1") != "0"
         self.x = x
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -142,7 +150,7 @@ class _DetRun:
         r = _BlockRec()
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
         self.recs[prefix] = r
-        return _Act(z, tr, Cout, H, W)
+        return _Act(z, tr, Cout, H, W, src=prefix)
 
     def block_c1(self, prefix, img, H, W):
         L, P, N = self.L, self.P, self.N
@@ -153,7 +161,7 @@ class _DetRun:
         r = _BlockRec()
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, None, None, z, tr, saved, 1, 8, H, W
         self.recs[prefix] = r
-        return _Act(z, tr, 8, H, W)
+        return _Act(z, tr, 8, H, W, src=prefix)
 
     def double(self, prefix, a, b, Cout):
         y = self.block(f"{prefix}.seq.0", a, b, Cout)
@@ -172,6 +180,7 @@ class _DetRun:
             y = self.double(f"down.{i}.seq.0", cur, None, w[i + 1])
             Hp, Wp = y.H // 2, y.W // 2
             pooled = self.empty(N, Hp, Wp, y.C)
+            y.other_use = True
             L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, self.dt)
             cur = _Act(pooled, _identity_tr(y.C, self.dev), y.C, Hp, Wp)
             skips.append(cur)
@@ -182,11 +191,13 @@ class _DetRun:
             Cup, Cout = w[i + 1], w[i]
             wpk = self.pack(P[f"up.{i}.up.weight"], 1, 4 * Cup, 4 * Cout, Cup, 0, 0, 0)
             t = self.empty(N, skip.H, skip.W, Cout)
+            up.other_use = True
             L.convt_fwd(ptr(up.t), ptr(up.tr), ptr(wpk), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W, self.dt)
             ta = _Act(t, _identity_tr(Cout, self.dev), Cout, skip.H, skip.W)
             self.convt[i] = (up, ta)
             up = self.double(f"up.{i}.contract", ta, skip, Cout)
         pred = self.empty(N, 1, H, W, dtype=torch.float32)
+        up.other_use = True
         L.head_fwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(P["out_conv.0.bias"]), ptr(pred), N * H * W, self.dt)
         self.head_in = up
         self.pred = pred
@@ -199,8 +210,10 @@ class _DetRun:
         """-> (gxa, gxb): dL/d(block input), split at the concat boundary."""
         L, P, N, r = self.L, self.P, self.N, self.recs[prefix]
         C, H, W = r.Cout, r.H, r.W
-        gsum = self.empty(2 * C, dtype=torch.float64)
-        L.bn_bwd_reduce(ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(r.saved), ptr(gsum), C, N, H, W, self.dt)
+        gsum = self.fused.pop(prefix, None)  # BatchNorm-backward sums already produced by this block's consumers (their dw_bwd)?
+        if gsum is None:
+            gsum = self.empty(2 * C, dtype=torch.float64)
+            L.bn_bwd_reduce(ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(r.saved), ptr(gsum), C, N, H, W, self.dt)
         coef = self.empty(3, C, dtype=torch.float32)
         L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(P[f"{prefix}.seq.2.weight"]), ptr(r.saved), ptr(coef),
                           ptr(self.G[f"{prefix}.seq.2.weight"]), ptr(self.G[f"{prefix}.seq.2.bias"]))
@@ -221,8 +234,18 @@ class _DetRun:
         gxa = self.empty(N, H, W, Ca) if need_gx else None
         gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
         ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
+
+        def stat_target(act):
+            """(saved, gsum) of the block that produced `act` if this pass may produce its BatchNorm-backward sums."""
+            if act is None or act.src is None or act.other_use or not need_gx or not self.fuse_bn_bwd:
+                return None, None
+            if act.src not in self.fused:
+                self.fused[act.src] = torch.zeros(2 * act.C, dtype=torch.float64, device=self.dev)
+            return self.recs[act.src].saved, self.fused[act.src]
+        sva, gsa = stat_target(a)
+        svb, gsb = stat_target(b)
         L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),
-                 ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), N, H, W, self.dt)
+                 ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), N, H, W, self.dt)
         return gxa, gxb
 
     def backward(self, gpred):

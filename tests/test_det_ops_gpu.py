@@ -29,6 +29,7 @@ def make_run(dev, dtype, N, P, Bf):
 
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
+    r.fused, r.fuse_bn_bwd = {}, True
     return r
 
 
@@ -119,6 +120,54 @@ def test_dwpw_block_fwd_bwd(dev, dtype, Ca, Cb, Cout):
         assert rel(nchw(gxb), gxt[:, Ca:]) < gt, "gxb"
     for k in P:
         assert rel(run.G[k], Pr[k].grad) < gt, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C0,Ca,Cb,Cc", [(8, 8, 8, 8), (8, 16, 0, 16), (16, 32, 32, 32), (32, 64, 0, 64)])
+def test_fused_bn_bwd_sums_match_reduce_pass(dev, dtype, C0, Ca, Cb, Cc):
+    """Blocks A (and B) feed block C directly: C's depthwise-backward pass produces A's / B's BatchNorm-backward sums (ocrs_dw_bwd
+    gsum_a/gsum_b).  The resulting gradients must equal the ones obtained with the separate ocrs_bn_bwd_reduce pass (same arithmetic,
+    different summation order -> 1e-5 fp32; in bf16 both read the same rounded gradient -> 1e-3)."""
+    from ocrs_models_amd.models import _Act
+
+    g = torch.Generator().manual_seed(77 + Ca + Cb)
+    N, H, W = 2, 19, 26
+
+    def mk(pfx, cin, cout, P, Bf):
+        P[f"{pfx}.seq.0.weight"] = (torch.randn(cin, 1, 3, 3, generator=g) / 3).to(dev)
+        P[f"{pfx}.seq.1.weight"] = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(dev)
+        P[f"{pfx}.seq.2.weight"] = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev)
+        P[f"{pfx}.seq.2.bias"] = (0.1 * torch.randn(cout, generator=g)).to(dev)
+        Bf[f"{pfx}.seq.2.running_mean"] = torch.zeros(cout, device=dev)
+        Bf[f"{pfx}.seq.2.running_var"] = torch.ones(cout, device=dev)
+        Bf[f"{pfx}.seq.2.num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=dev)
+
+    P, Bf = {}, {}
+    mk("A", C0, Ca, P, Bf)
+    if Cb:
+        mk("B", C0, Cb, P, Bf)
+    mk("C", Ca + Cb, Cc, P, Bf)
+    x0 = _Act(nhwc(torch.randn(N, C0, H, W, generator=g).to(dev), dtype), rand_tr(C0, dev, g), C0, H, W)
+    gy = nhwc(torch.randn(N, Cc, H, W, generator=g).to(dev), dtype)
+    res = {}
+    for fuse in (True, False):
+        run = make_run(dev, dtype, N, P, {k: v.clone() for k, v in Bf.items()})
+        run.fuse_bn_bwd = fuse
+        a = run.block("A", x0, None, Ca)
+        b = run.block("B", x0, None, Cb) if Cb else None
+        run.block("C", a, b, Cc)
+        run.G = {k: torch.zeros_like(v) for k, v in P.items()}
+        gxa, gxb = run.block_bwd("C", gy, None, 0)
+        assert ("A" in run.fused) == fuse
+        run.block_bwd("A", gxa, None, 0)
+        if Cb:
+            run.block_bwd("B", gxb, None, 0)
+        assert not run.fused
+        torch.cuda.synchronize()
+        res[fuse] = {k: v.clone() for k, v in run.G.items()}
+    tol = 1e-5 if dtype == torch.float32 else 1e-3
+    for k in P:
+        assert rel(res[True][k], res[False][k]) < tol, k
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
