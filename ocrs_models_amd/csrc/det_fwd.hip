@@ -467,8 +467,11 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
     const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) +
                         (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16 + (MT <= 2 ? MT * 8 * 256 : 0)) * sizeof(float);
-    static const int fwd_tpb = env_int("OCRS_FWD_TPB", 1);  // minimum tiles per block (every block ends with 2*COUT fp64 atomics)
-    const int grid = persistent_grid(tg.ntiles / fwd_tpb > 0 ? tg.ntiles / fwd_tpb : 1, 8);
+    // every block ends with 2*COUT same-address fp64 atomics (~15 ns each, serialised): at the middle levels (a few thousand tiles)
+    // two tiles per block halve that tail; below that parallelism matters more (measured: OCRS_FWD_TPB sweep, profiles/README.md)
+    static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);
+    const int tpb = fwd_tpb > 0 ? fwd_tpb : (tg.ntiles >= 2048 ? 2 : 1);
+    const int grid = persistent_grid(tg.ntiles / tpb > 0 ? tg.ntiles / tpb : 1, 8);
     hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;

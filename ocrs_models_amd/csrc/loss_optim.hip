@@ -26,27 +26,105 @@ struct LossState {            // device-resident, one per loss call
 
 __device__ __forceinline__ unsigned loss_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
+// log(1 - p) for p in [0, 1] with log1p accuracy from ONE logf: log1p(x) = log(u) - ((u - 1) - x) / u, u = fl(1 + x)  (x = -p).
+// (OCML's log1pf costs ~3x a logf; the loss forward was VALU-bound on it.)  p = 1 -> -inf (clamped by the caller).
+__device__ __forceinline__ float log1p_neg(float p) {
+    const float u = 1.f - p;
+    if (u <= 0.f) return -__builtin_inff();
+    return logf(u) - ((u - 1.f) + p) / u;
+}
+
+// The elementwise loss kernels walk the pixels in quads (16-byte loads / stores of pred, target, lpx, gpred; 4-byte of cls) when the
+// buffers are 16-byte aligned (VEC = 4), else one by one (VEC = 1).  The < 4 tail elements are done by the last quad-loop thread.
+template <int VEC>
+struct Quad {
+    float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Quad<VEC> ldq(const float* p, long q) {
+    Quad<VEC> r;
+    if constexpr (VEC == 4) {
+        const float4 a = reinterpret_cast<const float4*>(p)[q];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    } else
+        r.v[0] = p[q];
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void stq(float* p, long q, const Quad<VEC>& r) {
+    if constexpr (VEC == 4)
+        reinterpret_cast<float4*>(p)[q] = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    else
+        p[q] = r.v[0];
+}
+template <int VEC>
+struct QuadB {
+    unsigned char v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ QuadB<VEC> ldqb(const unsigned char* p, long q) {
+    QuadB<VEC> r;
+    if constexpr (VEC == 4) {
+        const unsigned a = reinterpret_cast<const unsigned*>(p)[q];
+        r.v[0] = a & 255; r.v[1] = (a >> 8) & 255; r.v[2] = (a >> 16) & 255; r.v[3] = a >> 24;
+    } else
+        r.v[0] = p[q];
+    return r;
+}
+template <int VEC>
+__device__ __forceinline__ void stqb(unsigned char* p, long q, const QuadB<VEC>& r) {
+    if constexpr (VEC == 4)
+        reinterpret_cast<unsigned*>(p)[q] = r.v[0] | (r.v[1] << 8) | (r.v[2] << 16) | ((unsigned)r.v[3] << 24);
+    else
+        p[q] = r.v[0];
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ lpx,
                                                  unsigned char* __restrict__ cls, LossState* __restrict__ stt, long P) {
     unsigned long long np = 0, nn = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+    const long nq = P / VEC;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const Quad<VEC> pq = ldq<VEC>(pred, q), tq = ldq<VEC>(target, q);
+        Quad<VEC> lq;
+        QuadB<VEC> cq;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float p = pq.v[e], t0 = tq.v[e];
+            const unsigned char c = t0 > 0.5f ? 1 : (t0 < 0.5f ? 2 : 0);
+            const float t = fminf(fmaxf(t0, 0.f), 1.f);
+            lq.v[e] = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1p_neg(p), -100.f));
+            cq.v[e] = c;
+            np += c == 1;
+            nn += c == 2;
+        }
+        stq<VEC>(lpx, q, lq);
+        stqb<VEC>(cls, q, cq);
+    }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) {  // tail
+        const long i = nq * VEC + threadIdx.x;
         const float p = pred[i], t0 = target[i];
         const unsigned char c = t0 > 0.5f ? 1 : (t0 < 0.5f ? 2 : 0);
         const float t = fminf(fmaxf(t0, 0.f), 1.f);
-        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(log1pf(-p), -100.f);
-        lpx[i] = -(t * lp + (1.f - t) * l1p);
+        lpx[i] = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1p_neg(p), -100.f));
         cls[i] = c;
         np += c == 1;
         nn += c == 2;
     }
+    // one pair of global atomics per BLOCK: same-address atomics serialise at ~15 ns each (8192 waves x 2 were 0.24 ms)
+    __shared__ unsigned s_cnt[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) {
         np += __shfl_xor(np, o, 64);
         nn += __shfl_xor(nn, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (np) atomicAdd(&stt->cnt[0], np);
-        if (nn) atomicAdd(&stt->cnt[1], nn);
+        atomicAdd(&s_cnt[0], (unsigned)np);
+        atomicAdd(&s_cnt[1], (unsigned)nn);
     }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&stt->cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
 __global__ void k_select_init(LossState* stt) {
@@ -66,6 +144,7 @@ __device__ __forceinline__ void pass_bits(int pass, int& shift, int& nb) {
     nb = pass == 0 ? 2048 : 1024;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
                                                      const LossState* __restrict__ stt, unsigned* __restrict__ hist /*[2][2048]*/, int pass,
                                                      long P) {
@@ -76,13 +155,20 @@ __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ l
     pass_bits(pass, shift, nb);
     const unsigned pf0 = stt->prefix[0], pf1 = stt->prefix[1];
     const int hs = shift + (pass == 0 ? 11 : 10);  // bits above the current digit
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
-        const unsigned char c = cls[i];
-        if (!c) continue;
-        const unsigned key = loss_key(lpx[i]);
+    auto visit = [&](unsigned char c, float v) {
+        if (!c) return;
+        const unsigned key = loss_key(v);
         const unsigned pf = c == 1 ? pf0 : pf1;
         if (pass == 0 || (key >> hs) == pf) atomicAdd(&s_h[(c - 1) * 2048 + ((key >> shift) & (nb - 1))], 1u);
+    };
+    const long nq = P / VEC;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const QuadB<VEC> cq = ldqb<VEC>(cls, q);
+        const Quad<VEC> lq = ldq<VEC>(lpx, q);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) visit(cq.v[e], lq.v[e]);
     }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) visit(cls[nq * VEC + threadIdx.x], lpx[nq * VEC + threadIdx.x]);
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
@@ -131,28 +217,41 @@ __global__ __launch_bounds__(256) void k_select_scan(LossState* __restrict__ stt
     for (int i = tid; i < 2048; i += 256) h[i] = 0;  // ready for the next pass
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void k_topk_sum(const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
                                                   LossState* __restrict__ stt, long P) {
     const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
     double s0 = 0.0, s1 = 0.0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
-        const unsigned char c = cls[i];
-        if (!c) continue;
-        const float v = lpx[i];
+    auto visit = [&](unsigned char c, float v) {
+        if (!c) return;
         const unsigned key = loss_key(v);
         if (c == 1) {
             if (key > t0) s0 += (double)v;
         } else {
             if (key > t1) s1 += (double)v;
         }
+    };
+    const long nq = P / VEC;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const QuadB<VEC> cq = ldqb<VEC>(cls, q);
+        const Quad<VEC> lq = ldq<VEC>(lpx, q);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) visit(cq.v[e], lq.v[e]);
     }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) visit(cls[nq * VEC + threadIdx.x], lpx[nq * VEC + threadIdx.x]);
+    __shared__ double s_sum[2][4];
     for (int o = 32; o > 0; o >>= 1) {
         s0 += __shfl_xor(s0, o, 64);
         s1 += __shfl_xor(s1, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (s0 != 0.0) atomicAdd(&stt->sum_gt[0], s0);
-        if (s1 != 0.0) atomicAdd(&stt->sum_gt[1], s1);
+        s_sum[0][threadIdx.x >> 6] = s0;
+        s_sum[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {  // one global atomic per block and class
+        const double v = (s_sum[threadIdx.x][0] + s_sum[threadIdx.x][1]) + (s_sum[threadIdx.x][2] + s_sum[threadIdx.x][3]);
+        if (v != 0.0) atomicAdd(&stt->sum_gt[threadIdx.x], v);
     }
 }
 
@@ -171,26 +270,34 @@ __global__ void k_loss_final(LossState* stt, float* loss_out) {
 }
 
 // d loss / d pred: weight * (p - t) / max(p (1 - p), 1e-12)   (ATen binary_cross_entropy_backward)
+template <int VEC>
 __global__ __launch_bounds__(256) void k_bce_bwd(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ lpx,
                                                  const unsigned char* __restrict__ cls, const LossState* __restrict__ stt,
                                                  const float* __restrict__ gout, float* __restrict__ gpred, long P) {
     const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
     const float f0 = stt->frac[0], f1 = stt->frac[1];
     const float s = gout[0] * stt->inv2k;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
-        const unsigned char c = cls[i];
-        float g = 0.f;
-        if (c) {
-            const unsigned key = loss_key(lpx[i]);
-            const unsigned thr = c == 1 ? t0 : t1;
-            const float wgt = key > thr ? 1.f : (key == thr ? (c == 1 ? f0 : f1) : 0.f);
-            if (wgt != 0.f) {
-                const float p = pred[i];
-                const float t = fminf(fmaxf(target[i], 0.f), 1.f);
-                g = s * wgt * (p - t) / fmaxf((1.f - p) * p, 1e-12f);
-            }
-        }
-        gpred[i] = g;
+    auto grad = [&](unsigned char c, float l, float p, float tg) -> float {
+        if (!c) return 0.f;
+        const unsigned key = loss_key(l);
+        const unsigned thr = c == 1 ? t0 : t1;
+        const float wgt = key > thr ? 1.f : (key == thr ? (c == 1 ? f0 : f1) : 0.f);
+        if (wgt == 0.f) return 0.f;
+        const float t = fminf(fmaxf(tg, 0.f), 1.f);
+        return s * wgt * (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+    };
+    const long nq = P / VEC;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const QuadB<VEC> cq = ldqb<VEC>(cls, q);
+        const Quad<VEC> lq = ldq<VEC>(lpx, q), pq = ldq<VEC>(pred, q), tq = ldq<VEC>(target, q);
+        Quad<VEC> gq;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) gq.v[e] = grad(cq.v[e], lq.v[e], pq.v[e], tq.v[e]);
+        stq<VEC>(gpred, q, gq);
+    }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) {
+        const long i = nq * VEC + threadIdx.x;
+        gpred[i] = grad(cls[i], lpx[i], pred[i], target[i]);
     }
 }
 
@@ -270,14 +377,26 @@ int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, un
     LossState* stt = (LossState*)state;
     if (hipMemsetAsync(state, 0, sizeof(LossState), st) != hipSuccess) return OCRS_ERR_HIP;
     if (hipMemsetAsync(hist, 0, 2 * 2048 * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
-    const int grid = ew_grid(P);
-    hipLaunchKernelGGL(k_bce_fwd, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
+    int grid = ew_grid((P + 3) / 4);
+    if (grid > 1024) grid = 1024;  // streaming kernels that end in same-address atomics: 4 blocks per CU are plenty
+    const bool vec = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(lpx)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(cls) & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_bce_fwd<4>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
+    else
+        hipLaunchKernelGGL(k_bce_fwd<1>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
     hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, st, stt);
     for (int pass = 0; pass < 3; ++pass) {
-        hipLaunchKernelGGL(k_select_hist, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
+        if (vec)
+            hipLaunchKernelGGL(k_select_hist<4>, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
+        else
+            hipLaunchKernelGGL(k_select_hist<1>, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
         hipLaunchKernelGGL(k_select_scan, dim3(2), dim3(256), 0, st, stt, (unsigned*)hist, pass);
     }
-    hipLaunchKernelGGL(k_topk_sum, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
+    if (vec)
+        hipLaunchKernelGGL(k_topk_sum<4>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
+    else
+        hipLaunchKernelGGL(k_topk_sum<1>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1), 0, st, stt, loss_out);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -287,7 +406,12 @@ int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, un
 int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* lpx, const unsigned char* cls, const void* state,
                           const float* gout, float* gpred, long P, hipStream_t st) {
     OCRS_CHECK_ARG(pred && target && lpx && cls && state && gout && gpred && P > 0);
-    hipLaunchKernelGGL(k_bce_bwd, dim3(ew_grid(P)), dim3(256), 0, st, pred, target, lpx, cls, (const LossState*)state, gout, gpred, P);
+    const bool vec = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(lpx) |
+                       reinterpret_cast<uintptr_t>(gpred)) & 15) == 0 && (reinterpret_cast<uintptr_t>(cls) & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_bce_bwd<4>, dim3(ew_grid((P + 3) / 4)), dim3(256), 0, st, pred, target, lpx, cls, (const LossState*)state, gout, gpred, P);
+    else
+        hipLaunchKernelGGL(k_bce_bwd<1>, dim3(ew_grid(P)), dim3(256), 0, st, pred, target, lpx, cls, (const LossState*)state, gout, gpred, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
