@@ -51,10 +51,54 @@ __global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int
 // D[cout][pixel] = sum_cin Wpw[cout][cin] * u[pixel][cin],  u = dw3x3(x~)   (channels = MFMA M, pixels = MFMA N)
 // so each lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 // ----------------------------------------------------------------------------------------------
-template <int CG>
-struct FwdTile {  // 8-row tiles; width chosen so that TP = 256 / CG pixels: 8x32, 8x16, 8x8
-    static constexpr int TH = 8, TW = 32 / CG, TP = TH * TW;
+// Tile geometry: every thread computes the depthwise output of PX horizontally adjacent pixels for one group of 8 channels.
+//   PX = 2 (COUT <= 64): the two pixels share 6 of their 9 taps and all 72 weights -> 12 + 9 LDS vector reads per pair instead of
+//   2 x (9 + 9): the kernel is LDS-bandwidth bound at the top levels (SQ_LDS_IDX_ACTIVE 77 % of the kernel's cycles), this removes
+//   ~40 % of that traffic.  Tiles: CG=1 16x32, CG=2 16x16, CG=4 8x16 pixels (PX = 1, COUT > 64: 8x32 / 8x16 / 8x8).
+template <int CG, int PX>
+struct FwdTile {
+    static constexpr int TP = PX * 256 / CG;
+    static constexpr int TW = (PX == 2 && CG == 4) ? 16 : (PX == 2 ? 32 / CG : 32 / CG);
+    static constexpr int TH = TP / TW;
 };
+template <int MT>
+struct FwdPx {
+    static constexpr int PX = MT <= 4 ? 2 : 1;
+};
+// LDS pitch (elements) of the depthwise-output tile [TP][CG*8 + pad]: 16-byte aligned rows, conflict-free fragment reads
+template <class T, int CG>
+struct FwdPitch {
+    static constexpr int V = CG * 8 + (Elem<T>::is_bf16 ? 8 : 4);
+};
+
+// u0/u1 = depthwise 3x3 of two horizontally adjacent pixels (tx, tx+1) for 8 channels, from the HaloStager's planar LDS tile:
+// 3 rows x 4 columns of inputs, each row's 3 weight vectors read once.
+template <int CG, int TW, int TH>
+__device__ __forceinline__ void dw2_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
+                                             float (&u0)[8], float (&u1)[8]) {
+    constexpr int HWp = TW + 2;
+    constexpr int PLANE = HaloTile<TW, TH>::HP * CG * 4;
+    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u0[i] = u1[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float w[3][8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load8(s_w + (r * 3 + c) * CIN + c0, w[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* q = xc + (r * HWp + c) * CG * 4;
+            const float4 lo4 = *reinterpret_cast<const float4*>(q), hi4 = *reinterpret_cast<const float4*>(q + PLANE);
+            const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (c < 3) u0[i] = fmaf(w[c][i], v[i], u0[i]);
+                if (c > 0) u1[i] = fmaf(w[c - 1][i], v[i], u1[i]);
+            }
+        }
+    }
+}
 
 #ifndef OCRS_PIPE_BLOCKS
 #define OCRS_PIPE_BLOCKS 3
@@ -64,21 +108,17 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
                                                                     const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
                                                                     const void* __restrict__ wpk, T* __restrict__ z,
                                                                     double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg) {
-    using FT = FwdTile<CG>;
+    constexpr int PX = FwdPx<MT>::PX;
+    using FT = FwdTile<CG, PX>;
     constexpr int TW = FT::TW, TH = FT::TH, TP = FT::TP;
     constexpr int PTW = TP / 64;
     constexpr int KS = CG * 2;  // fp32 k-steps (of 4) per chunk
-    constexpr int PITCH = Mma<T>::LDS_PITCH;
+    constexpr int PITCH = FwdPitch<T, CG>::V;
     constexpr int HP = HaloTile<TW, TH>::HP;
-    constexpr bool LANE_STATS = false;  // (per-lane sums across tiles in REGISTERS cost 16 long-lived VGPRs -> spills)
-    // BN partial sums: MT <= 2 (levels 0-2, where the kernel is VALU-bound): every lane accumulates its 8 values per channel tile in
-    // its OWN LDS slot with fire-and-forget ds_add_f32 (8 instructions per tile instead of 32 DPP adds + 8 masked atomics);
-    // the 64 slots per channel are summed once at the end.  Larger MT: per-tile DPP row reduction.
-    constexpr bool LDS_STATS = false;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* tile = reinterpret_cast<T*>(smem);                                                   // [TP][PITCH]  dw output (MFMA operand)
-    float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // [HP][CG*8]   transformed input + halo
-    float* s_par = xs + HP * CG * 8;                                                         // [12][CIN]: tr(3) | wdw(9, tap-major)
+    float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // 2 planes [HP*CG][4]: transformed input + halo
+    float* s_par = xs + HP * CG * 8;                                                         // [12][CIN]: tr(3, HaloStager layout) | wdw(9, tap-major)
     float* s_stat = s_par + 12 * CIN;                                                        // [2][MT*16]
     const int H = tg.H, W = tg.W;
 
@@ -89,28 +129,13 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
         s_par[3 * CIN + i] = wdw[c * 9 + t];
     }
     for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
-    float* s_lane = s_stat + 2 * MT * 16;  // [MT*8][256] (LDS_STATS only)
-    if constexpr (LDS_STATS)
-        for (int i = tid; i < MT * 8 * 256; i += 256) s_lane[i] = 0.f;
     __syncthreads();
     const HaloStager<T, CG, TW, TH> stager(tid, W);
 
     const int nkc = CG < 4 ? 1 : CIN / (CG * 8);  // CG = min(CIN/8, 4): fewer than 4 groups means a single chunk
-    const int pxl = tid / CG, cg = tid % CG;
-    const int ty = pxl / TW, tx = pxl % TW;
-    // output pixels of this lane (MFMA N index): fixed position inside every tile
-    int oty[PTW], otx[PTW];
-#pragma unroll
-    for (int a = 0; a < PTW; ++a) {
-        const int q = (wave * PTW + a) * 16 + (lane & 15);
-        oty[a] = q / TW;
-        otx[a] = q % TW;
-    }
-    float ls1[LANE_STATS ? MT : 1][4], ls2[LANE_STATS ? MT : 1][4];
-#pragma unroll
-    for (int b = 0; b < (LANE_STATS ? MT : 1); ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ls1[b][r] = ls2[b][r] = 0.f;
+    const int pgrp = tid / CG, cg = tid % CG;     // pixel (PX = 1) or pixel pair (PX = 2) of this thread
+    const int ty = pgrp / (TW / PX), tx = (pgrp % (TW / PX)) * PX;
+    const int pxl = ty * TW + tx;
 
     TileSched ts(tg.ntiles);
     constexpr bool PIPE = CG < 4 && Elem<T>::is_bf16;  // single-chunk bf16 configs (levels 0-1): register-prefetch the next tile
@@ -144,9 +169,16 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
             } else
                 stager.stage(x, s_par, kc * CG * 8, org, H, W, xs, tid);
             tile_barrier<PIPE>();  // xs ready; all readers of the previous xs / tile passed a barrier since
-            float u[8];
-            dw_from_lds<CG, TW, TH>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);  // (scalar-loaded weights for CG==1 spill SGPRs -> slower)
-            store8_opaque(tile + pxl * PITCH + cg * 8, u);
+            if constexpr (PX == 2) {
+                float u0[8], u1[8];
+                dw2_from_lds<CG, TW, TH>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u0, u1);
+                store8_opaque(tile + pxl * PITCH + cg * 8, u0);
+                store8_opaque(tile + (pxl + 1) * PITCH + cg * 8, u1);
+            } else {
+                float u[8];
+                dw_from_lds<CG, TW, TH>(xs, s_par + 3 * CIN, CIN, (kc * CG + cg) * 8, cg, ty, tx, u);
+                store8_opaque(tile + pxl * PITCH + cg * 8, u);
+            }
             tile_barrier<PIPE>();
             typename Mma<T>::Frag pf[PTW];
 #pragma unroll
@@ -170,49 +202,23 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < PTW; ++a) {
-                const bool ov = org.h0 + oty[a] < H && org.w0 + otx[a] < W;
+                const int q = (wave * PTW + a) * 16 + (lane & 15);  // output pixel of this lane (MFMA N index)
+                const int oty = q / TW, otx = q % TW;
+                const bool ov = org.h0 + oty < H && org.w0 + otx < W;
                 if (ov && m0 < COUT) {
                     const f32x4 v = acc[a][b];
-                    store4(z + (tile_base + (long)oty[a] * W + otx[a]) * COUT + m0, v[0], v[1], v[2], v[3]);
+                    store4(z + (tile_base + (long)oty * W + otx) * COUT + m0, v[0], v[1], v[2], v[3]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float q = Elem<T>::round(v[r]);  // statistics of what the consumer will read
-                        s1[r] += q;
-                        s2[r] = fmaf(q, q, s2[r]);
+                        const float qv = Elem<T>::round(v[r]);  // statistics of what the consumer will read
+                        s1[r] += qv;
+                        s2[r] = fmaf(qv, qv, s2[r]);
                     }
                 }
             }
-            if constexpr (LDS_STATS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(&s_lane[(b * 8 + r) * 256 + tid], s1[r]);
-                    atomicAdd(&s_lane[(b * 8 + 4 + r) * 256 + tid], s2[r]);
-                }
-            } else if constexpr (LANE_STATS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ls1[b][r] += s1[r];
-                    ls2[b][r] += s2[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
-                    if ((lane & 15) == 0) {
-                        atomicAdd(&s_stat[m0 + r], a1);
-                        atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
-                    }
-                }
-            }
-        }
-    }
-    if constexpr (LANE_STATS) {
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            const int m0 = b * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float a1 = quad16_sum(ls1[b][r]), a2 = quad16_sum(ls2[b][r]);
+                const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
                 if ((lane & 15) == 0) {
                     atomicAdd(&s_stat[m0 + r], a1);
                     atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
@@ -221,20 +227,6 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
         }
     }
     __syncthreads();
-    if constexpr (LDS_STATS) {
-        for (int c = tid; c < COUT; c += 256) {
-            const int b = c >> 4, q = (c & 15) >> 2, r = c & 3;  // channel c lives in lanes [q*16, q*16+16) of every wave, register r
-            float a1 = 0.f, a2 = 0.f;
-            for (int w = 0; w < 4; ++w)
-                for (int l = 0; l < 16; ++l) {
-                    a1 += s_lane[(b * 8 + r) * 256 + w * 64 + q * 16 + l];
-                    a2 += s_lane[(b * 8 + 4 + r) * 256 + w * 64 + q * 16 + l];
-                }
-            atomicAdd(&gstat[c], (double)a1);
-            atomicAdd(&gstat[COUT + c], (double)a2);
-        }
-        return;
-    }
     for (int c = tid; c < COUT; c += 256) {
         atomicAdd(&gstat[c], (double)s_stat[c]);
         atomicAdd(&gstat[COUT + c], (double)s_stat[MT * 16 + c]);
@@ -460,13 +452,13 @@ long ocrs_pack_frags_bytes(int K, int M, int dtype) { return (long)((K + 31) / 3
 template <class T, int CG, int MT>
 static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
                            double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
-    using FT = FwdTile<CG>;
+    using FT = FwdTile<CG, FwdPx<MT>::PX>;
     constexpr int TP = FT::TP;
     const int CIN = Ca + Cb;
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
-    const size_t smem = ((TP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) +
-                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16 + (MT <= 2 ? MT * 8 * 256 : 0)) * sizeof(float);
+    const size_t smem = ((TP * FwdPitch<T, CG>::V * sizeof(T) + 15) & ~15) +
+                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16) * sizeof(float);
     // every block ends with 2*COUT same-address fp64 atomics (~15 ns each, serialised): at the middle levels (a few thousand tiles)
     // two tiles per block halve that tail; below that parallelism matters more (measured: OCRS_FWD_TPB sweep, profiles/README.md)
     static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);
