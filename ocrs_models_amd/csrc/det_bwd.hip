@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     // The max-pool-routed gradient (gs.pooled) needs 3 more z vectors per thread: those stay synchronous at the top of the tile.
     constexpr bool PIPE = Cfg::NKD == 1 && CIN <= 32 && Elem<T>::is_bf16;
     typename HaloStager<T, CGI, TW, TH>::Pending pend;
-    Raw8<T> zr, g1r, g2r, zo[PPOOL ? 3 : 1];
+    Raw8<T> zr, g1r, g2r;
     typename Mma<T>::Frag wfd[PIPE ? MTD : 1];
     const int opix = ty * W + tx;
     const bool has_g2 = gs.g2 != nullptr;
@@ -246,11 +246,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             gv_pre = ld;
             const T* zp = ld ? z + (tb + opix) * COUT + cg * 8 : z;
             zr = load8_raw(zp);
-            // the other three window elements: horizontal / vertical / diagonal neighbour (static register indices)
-            const int dxo = (tx & 1) ? -COUT : COUT, dyo = (ty & 1) ? -W * COUT : W * COUT;
-            zo[0] = load8_raw(ld ? zp + dxo : z);
-            zo[1] = load8_raw(ld ? zp + dyo : z);
-            zo[2] = load8_raw(ld ? zp + dxo + dyo : z);
+            // (the other three window elements are fetched by the lanes tid^CGM, tid^32, tid^(32|CGM) of this wave as THEIR own z:
+            //  they are exchanged with ds_bpermute at use time instead of three more global loads per thread)
             const long pp = ((long)o.n * Hp + (h >> 1)) * Wp + (w >> 1);
             g1r = load8_raw(ld ? gs.g1 + pp * COUT + cg * 8 : gs.g1);
             g2r = load8_raw(ld && has_g2 ? gs.g2 + pp * COUT + cg * 8 : gs.g1);
@@ -289,6 +286,20 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 const bool gv_cur = gv_pre;
                 float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 const int c0 = cg * 8;
+                // PPOOL: the other three elements of this pixel's 2x2 pool window are the "own" z of the lanes tid^CGM (horizontal),
+                // tid^32 (vertical: TW * CGM = 32) and tid^(32|CGM) of the same wave: exchanged with ds_bpermute -- by ALL lanes,
+                // before any divergent branch -- instead of three more global loads per thread.
+                Raw8<T> zq[PPOOL ? 3 : 1];
+                if constexpr (PPOOL) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int lm = ((j + 1) & 1 ? CGM : 0) | ((j + 1) & 2 ? 32 : 0);
+                        zq[j].a.x = __shfl_xor((int)zr.a.x, lm, 64);
+                        zq[j].a.y = __shfl_xor((int)zr.a.y, lm, 64);
+                        zq[j].a.z = __shfl_xor((int)zr.a.z, lm, 64);
+                        zq[j].a.w = __shfl_xor((int)zr.a.w, lm, 64);
+                    }
+                }
                 if (cg < CGO && pv) {
                     float gh[8], zv[8];
                     if constexpr (PPOOL) {
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                         for (int j = 0; j < 3; ++j) {
                             const bool earlier = (own ^ (j + 1)) < own;  // window index of neighbour j is own ^ (j+1)
                             float zn[8];
-                            unpack8(zo[j], zn);
+                            unpack8(zq[j], zn);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const float yo = fmaxf(fmaf(zn[i], s_bn[c0 + i], s_bn[COUT + c0 + i]), 0.f);
