@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     const bool has_g2 = gs.g2 != nullptr;
     const int own = ((ty & 1) << 1) | (tx & 1);  // position inside the 2x2 pool window (tile origins are even)
     bool gv_pre = false;                         // PPOOL: this thread's pixel lies inside a pool window (floor mode)
-    auto issue_tile = [&](long tn) {
-        const TileOrg o = tile_origin2<TW, TH>(tg, (int)tn);
+    auto issue_tile = [&](const TileOrg& o) {
         stager.issue(pend, x, 0, o, H, W, tid);
         const long tb = ((long)o.n * H + o.h0) * W + o.w0;
         if constexpr (PPOOL) {
@@ -259,16 +258,17 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             g2r = load8_raw((ld && has_g2 ? gs.g2 + tb * COUT : gs.g1) + off);
         }
     };
+    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // PIPE: one tile decode per tile
     if constexpr (PIPE) {
 #pragma unroll
         for (int b = 0; b < MTD; ++b) {
             wfd[b] = Mma<T>::load_w(wpk_d, (long)b, lane);
             asm volatile("" : "+v"(wfd[b].q.x), "+v"(wfd[b].q.y), "+v"(wfd[b].q.z), "+v"(wfd[b].q.w));
         }
-        if (ts.first < ts.end) issue_tile(ts.first);
+        if (ts.first < ts.end) issue_tile(org_next);
     }
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        const TileOrg org = PIPE ? org_next : tile_origin2<TW, TH>(tg, (int)t);
         PixIdx px;
         px.n = org.n;
         px.h = org.h0 + ty;
@@ -349,7 +349,10 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 if (cg < CGO) store8_opaque(tileD + pxl * PITCH + cg * 8, dz);  // natural layout: dgrad operand AND (transpose-read) wgrad operand
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t + ts.step < ts.end) issue_tile(t + ts.step);
+            if (t + ts.step < ts.end) {
+                org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+                issue_tile(org_next);
+            }
             lds_barrier();
             {
                 typename Mma<T>::Frag pf[PTW];
@@ -681,9 +684,10 @@ __global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __res
     };
     Pre cur;  // consumed at the top of an iteration (commit + x transform), then immediately refilled for the next tile
     TileSched ts(tg.ntiles);
-    if (ts.first < ts.end) issue(cur, tile_origin2<TW, TH>(tg, (int)ts.first));
+    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // one tile decode (2 integer divisions) per tile
+    if (ts.first < ts.end) issue(cur, org_next);
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        const TileOrg org = org_next;
         lds_barrier();  // previous tile's readers of ds are done
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
@@ -709,7 +713,10 @@ __global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __res
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool more = t + ts.step < ts.end;
-        if (more) issue(cur, tile_origin2<TW, TH>(tg, (int)(t + ts.step)));
+        if (more) {
+            org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+            issue(cur, org_next);
+        }
         lds_barrier();
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         // tap k pairs x~[p] with du[p - off(k)]: halo index (ty + 2 - k/3, tx + 2 - k%3).  Unconditional: an out-of-image pixel of a

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
     typename HaloStager<T, CG, TW, TH>::Pending pend;
     typename Mma<T>::Frag wfr[PIPE ? MT : 1];  // PIPE: pointwise weight fragments are tile-invariant -> registers (a global load inside
                                                 // the loop would make the compiler wait vmcnt(0), i.e. for the prefetch as well)
+    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // PIPE: one tile decode per tile
     if constexpr (PIPE) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
@@ -149,10 +150,10 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
             // consume the load HERE: otherwise its first use inside the loop carries a vmcnt(0) (PIPE implies bf16: Frag = uint4)
             asm volatile("" : "+v"(wfr[b].q.x), "+v"(wfr[b].q.y), "+v"(wfr[b].q.z), "+v"(wfr[b].q.w));
         }
-        if (ts.first < ts.end) stager.issue(pend, x, 0, tile_origin2<TW, TH>(tg, (int)ts.first), H, W, tid);
+        if (ts.first < ts.end) stager.issue(pend, x, 0, org_next, H, W, tid);
     }
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        const TileOrg org = PIPE ? org_next : tile_origin2<TW, TH>(tg, (int)t);
         f32x4 acc[PTW][MT];
 #pragma unroll
         for (int a = 0; a < PTW; ++a)
@@ -165,7 +166,10 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
                 // their HBM latency hides under the tap / MFMA / store phases below
                 stager.commit(pend, s_par, 0, xs, tid);
                 __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads behind ALL of this tile's commit waits
-                if (t + ts.step < ts.end) stager.issue(pend, x, 0, tile_origin2<TW, TH>(tg, (int)(t + ts.step)), H, W, tid);
+                if (t + ts.step < ts.end) {
+                    org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+                    stager.issue(pend, x, 0, org_next, H, W, tid);
+                }
             } else
                 stager.stage(x, s_par, kc * CG * 8, org, H, W, xs, tid);
             tile_barrier<PIPE>();  // xs ready; all readers of the previous xs / tile passed a barrier since
