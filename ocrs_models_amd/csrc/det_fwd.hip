@@ -546,6 +546,133 @@ int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, in
 }
 
 }  // extern "C" (templates need C++ linkage)
+// ConvTranspose2d forward for the top levels (bf16, Cup = 16 / 32): 2-D tiles of 8 x 16 quad positions.  The transformed input tile
+// (+1 halo row / column: a quad position (qy, qx) reads inputs (qy - dy, qx - dx), dy, dx in {0,1}) is staged ONCE in LDS in bf16
+// NHWC order and every MFMA pixel-operand fragment is a single ds_read_b128 straight from it (k = d*Cup + c: 8 consecutive channels of one
+// neighbour); packed weight fragments are cached in LDS; the next tile's input is register-prefetched.  Replaces per-chunk
+// global gathers (each input pixel fetched 4x) + two barriers per 32-wide K chunk: level 0 0.52 -> 0.25 ms.
+template <int CUP, int COUT>
+struct CtfCfg {
+    static constexpr int TH = 8, TW = 16, TPOS = TH * TW;                 // quad positions per tile
+    static constexpr int XH = TH + 1, XW = TW + 1, XP = XH * XW;           // input tile with the top / left halo
+    static constexpr int NKC = 4 * CUP / 32, MT = 4 * COUT / 16;           // K chunks of 32, M tiles of 16 (M = (parity, cout))
+    static constexpr int XI = XP * CUP / 8, NXI = (XI + 255) / 256;       // 16-byte staging items
+    static constexpr int XPITCH = CUP + 8;                                 // elements: rows of 48 / 80 B keep the b128 reads spread over banks
+    static constexpr int SMEM = (XP * XPITCH + NKC * MT * 64 * 8) * 2 + 3 * CUP * 4 + 4 * COUT * 4;
+};
+template <int CUP, int COUT>
+__global__ __launch_bounds__(256) void k_convt_fwd_tile(const bf16* __restrict__ x, const float* __restrict__ tr, const void* __restrict__ wpk,
+                                                        const float* __restrict__ bias, bf16* __restrict__ out, int h, int w, int H, int W,
+                                                        Tiling2 tg) {
+    using C = CtfCfg<CUP, COUT>;
+    constexpr int TW = C::TW, TH = C::TH, XW = C::XW, MT = C::MT, NKC = C::NKC, XPITCH = C::XPITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* xs = reinterpret_cast<bf16*>(smem);                              // [XP][XPITCH]
+    uint4* s_wf = reinterpret_cast<uint4*>(xs + C::XP * XPITCH);           // [NKC*MT][64] packed weight fragments
+    float* s_tr = reinterpret_cast<float*>(s_wf + NKC * MT * 64);          // [CUP/8][3][8]
+    float* s_bias = s_tr + 3 * CUP;                                        // [4*COUT] bias per M row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        Src2<bf16> xsrc{x, nullptr, CUP, 0};
+        fill_tr8(s_tr, xsrc, tr, nullptr, CUP, tid);
+        for (int i = tid; i < NKC * MT * 64; i += 256) s_wf[i] = reinterpret_cast<const uint4*>(wpk)[i];
+        for (int i = tid; i < 4 * COUT; i += 256) s_bias[i] = bias[i % COUT];
+    }
+    // tile-invariant staging descriptors: item it -> halo pixel (hy, hx), channel group
+    int xoff[C::NXI], xyx[C::NXI];
+#pragma unroll
+    for (int j = 0; j < C::NXI; ++j) {
+        const int it = tid + j * 256, hp = it / (CUP / 8), cg8 = it % (CUP / 8);
+        const int hy = hp / XW, hx = hp % XW;
+        xoff[j] = (hy * w + hx) * CUP + cg8 * 8;
+        xyx[j] = hy | (hx << 16);
+    }
+    Raw8<bf16> xr[C::NXI];
+    unsigned okx = 0;
+    auto issue = [&](const TileOrg& o) {  // o = (n, qy0, qx0); halo corner = input pixel (qy0 - 1, qx0 - 1)
+        const bf16* xb = x + (((long)o.n * h + (o.h0 - 1)) * w + (o.w0 - 1)) * CUP;
+        okx = 0;
+#pragma unroll
+        for (int j = 0; j < C::NXI; ++j) {
+            const int iy = o.h0 - 1 + (xyx[j] & 0xffff), ix = o.w0 - 1 + (xyx[j] >> 16);
+            const bool ok = (C::XI % 256 == 0 || tid + j * 256 < C::XI) && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+            xr[j] = load8_raw(ok ? xb + xoff[j] : x);
+            okx |= ok ? 1u << j : 0u;
+        }
+    };
+    // this lane's two N tiles (pixels) per wave: quad position q = (wave*2 + a)*16 + (lane & 15); operand k-group kg = lane >> 4
+    const int kg = lane >> 4;
+    TileSched ts(tg.ntiles);
+    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));
+    if (ts.first < ts.end) issue(org_next);
+    __syncthreads();
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = org_next;
+#pragma unroll
+        for (int j = 0; j < C::NXI; ++j) {
+            const int it = tid + j * 256;
+            if (C::XI % 256 == 0 || it < C::XI) {
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (okx & (1u << j)) {
+                    const float* tp = s_tr + (it % (CUP / 8)) * 24;
+                    float sc[8], sh[8], lo[8];
+                    unpack8(xr[j], v);
+                    load8(tp, sc);
+                    load8(tp + 8, sh);
+                    load8(tp + 16, lo);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                }
+                store8_opaque(xs + (it / (CUP / 8)) * XPITCH + (it % (CUP / 8)) * 8, v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + ts.step < ts.end) {
+            org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+            issue(org_next);
+        }
+        lds_barrier();
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int k0 = kc * 32 + kg * 8, d = k0 / CUP, c0 = k0 % CUP;  // neighbour d = dy*2 + dx, channels c0..c0+7
+            uint4 pf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int q = (wave * 2 + a) * 16 + (lane & 15), qy = q / TW, qx = q % TW;
+                // input (qy - dy, qx - dx) = halo pixel (qy + 1 - dy, qx + 1 - dx)
+                pf[a] = *reinterpret_cast<const uint4*>(xs + ((qy + 1 - (d >> 1)) * XW + (qx + 1 - (d & 1))) * XPITCH + c0);
+            }
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const uint4 wf = s_wf[(kc * MT + b) * 64 + lane];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, pf[a]), acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int q = (wave * 2 + a) * 16 + (lane & 15), qy = org.h0 + q / TW, qx = org.w0 + q % TW;
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int m0 = b * 16 + kg * 4, par = m0 / COUT, o0 = m0 % COUT;
+                const int Y = 2 * qy + (par >> 1), X = 2 * qx + (par & 1);
+                if (qy <= h && qx <= w && Y < H && X < W) {
+                    const f32x4 v = acc[a][b];
+                    store4(out + (((long)org.n * H + Y) * W + X) * COUT + o0, v[0] + s_bias[m0], v[1] + s_bias[m0 + 1], v[2] + s_bias[m0 + 2],
+                           v[3] + s_bias[m0 + 3]);
+                }
+            }
+        }
+        lds_barrier();  // all fragment reads done before the next commit overwrites xs
+    }
+}
+
 template <class T>
 static int dispatch_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h,
                               int w, int H, int W, hipStream_t st) {
@@ -577,6 +704,17 @@ int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float*
                    int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && tr && wpk && bias && out);
     OCRS_CHECK_ARG(Cup % 8 == 0 && Cout % 8 == 0 && (H == 2 * h || H == 2 * h + 1) && (W == 2 * w || W == 2 * w + 1));
+#define CTF_CASE(CU_, CO_)                                                                                                                \
+    if (dtype == 1 && Cup == CU_ && Cout == CO_) {                                                                                       \
+        using CC = CtfCfg<CU_, CO_>;                                                                                                      \
+        const Tiling2 tg = make_tiling2(N, h + 1, w + 1, CC::TW, CC::TH); /* quad positions: (h+1) x (w+1) */                             \
+        hipLaunchKernelGGL((k_convt_fwd_tile<CU_, CO_>), dim3(persistent_grid(tg.ntiles, 4)), dim3(256), CC::SMEM, st, (const bf16*)x, tr, wpk, bias, \
+                           (bf16*)out, h, w, H, W, tg);                                                                                   \
+        OCRS_LAUNCH_CHECK();                                                                                                              \
+        return OCRS_OK;                                                                                                                   \
+    }
+    CTF_CASE(16, 8) CTF_CASE(32, 16) CTF_CASE(32, 32)
+#undef CTF_CASE
     return dtype == 1 ? dispatch_convt_fwd<bf16>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st)
                       : dispatch_convt_fwd<float>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st);
 }
