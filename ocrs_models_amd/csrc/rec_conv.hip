@@ -472,6 +472,124 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad(const T* __restrict__ dz,
         }
 }
 
+// bf16 variant on the LDS transpose read (see lds_tr8 in common.h): both tiles are staged in their NATURAL NHWC order with plain 16-byte
+// stores (dz tile [128 px][Cout], input halo [10 x 18 px][32 ci]) and the K = pixel operands are produced by ds_read_b64_tr_b16 --
+// no transposing ds_write_b16 scatters, no shifted copies -- and the next tile's loads are register-prefetched under the 144 MFMAs.
+// Same decomposition and accumulator layout as k_conv3x3_wgrad (so the flush is shared).
+template <int COUT_MAX>
+__global__ __launch_bounds__(256) void k_conv3x3_wgrad_tr(const bf16* __restrict__ dz, int Cout, const bf16* __restrict__ x, int Cin,
+                                                          float* __restrict__ dW, int N, int H, int W, float* __restrict__ ws) {
+    constexpr int TH = 8, TW = 16;
+    constexpr int DP = COUT_MAX + 8;   // dz tile pitch (elements)
+    constexpr int XP = 40;             // halo pitch: 32 ci + 8
+    constexpr int NDI = 128 * (COUT_MAX / 8) / 256, NXI = 3;  // 16-byte staging items per thread (dz; x halo: 180 px * 4 groups = 720)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* dzs = reinterpret_cast<bf16*>(smem);   // [128][DP]
+    bf16* xh = dzs + 128 * DP;                   // [180][XP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci_base = blockIdx.y * 32;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntiles = N * tiles_x * tiles_y;
+    const int CG8 = Cout / 8;  // 8-channel groups of dz actually present (<= COUT_MAX / 8)
+    f32x4 acc[36];
+#pragma unroll
+    for (int j = 0; j < 36; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // zero the tiles once: channel columns >= Cout of the dz tile stay zero
+    for (int i = tid * 8; i < 128 * DP + 180 * XP; i += 256 * 8) *reinterpret_cast<uint4*>(dzs + i) = make_uint4(0, 0, 0, 0);
+    Raw8<bf16> dr[NDI], xr[NXI];
+    unsigned okd = 0, okx = 0;
+    auto issue = [&](long t) {
+        const int tpi = tiles_x * tiles_y;
+        const int n = (int)t / tpi, r = (int)t - n * tpi;
+        const int h0 = (r / tiles_x) * TH, w0 = (r % tiles_x) * TW;
+        okd = okx = 0;
+#pragma unroll
+        for (int j = 0; j < NDI; ++j) {
+            const int it = tid + j * 256, px = it / (COUT_MAX / 8), g8 = it % (COUT_MAX / 8);
+            const int h = h0 + px / TW, w = w0 + px % TW;
+            const bool ok = h < H && w < W && g8 < CG8;
+            dr[j] = load8_raw(ok ? dz + (((long)n * H + h) * W + w) * Cout + g8 * 8 : dz);
+            okd |= ok ? 1u << j : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int it = tid + j * 256, hp = it >> 2, g8 = it & 3;
+            const int h = h0 + hp / 18 - 1, w = w0 + hp % 18 - 1;
+            const bool ok = it < 720 && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            xr[j] = load8_raw(ok ? x + (((long)n * H + h) * W + w) * Cin + ci_base + g8 * 8 : x);
+            okx |= ok ? 1u << j : 0u;
+        }
+    };
+    // tile-invariant operand addresses
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int prow = 4 * kg + (i16 >> 2), pcol = (i16 & 3) * 4;
+    TileSched ts(ntiles);
+    if (ts.first < ts.end) issue(ts.first);
+    __syncthreads();
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+#pragma unroll
+        for (int j = 0; j < NDI; ++j) {
+            const int it = tid + j * 256, px = it / (COUT_MAX / 8), g8 = it % (COUT_MAX / 8);
+            *reinterpret_cast<uint4*>(dzs + px * DP + g8 * 8) = (okd & (1u << j)) ? dr[j].a : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int it = tid + j * 256;
+            if (it < 720) *reinterpret_cast<uint4*>(xh + (it >> 2) * XP + (it & 3) * 8) = (okx & (1u << j)) ? xr[j].a : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + ts.step < ts.end) issue(t + ts.step);
+        lds_barrier();
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int p = pc * 32 + prow, ty = p >> 4, tx = p & 15;  // this lane's supplied position (second read: next tile row)
+            bf16x8 fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16* ap = dzs + p * DP + (wave + 4 * a) * 16 + pcol;
+                fa[a] = lds_tr8(ap, ap + 16 * DP);
+            }
+#pragma unroll
+            for (int tj = 0; tj < 18; ++tj) {
+                const int tap = tj >> 1, ky = tap / 3, kx = tap % 3;
+                const bf16* bp = xh + ((ty + ky) * 18 + tx + kx) * XP + (tj & 1) * 16 + pcol;
+                const bf16x8 fb = lds_tr8(bp, bp + 18 * XP);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[tj * 2 + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb, acc[tj * 2 + a], 0, 0, 0);
+            }
+        }
+        lds_barrier();
+    }
+    // ---- flush (same accumulator layout as k_conv3x3_wgrad)
+    if (ws) {
+        float* wb = ws + (long)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+        for (int tj = 0; tj < 18; ++tj)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int ci = ci_base + (tj & 1) * 16 + (lane & 15), tap = tj >> 1;
+                const int co0 = (wave + 4 * a) * 16 + (lane >> 4) * 4;
+                if (co0 < Cout) {
+                    const f32x4 v = acc[tj * 2 + a];
+                    *reinterpret_cast<float4*>(wb + ((long)tap * Cin + ci) * Cout + co0) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 18; ++tj)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ci = ci_base + (tj & 1) * 16 + (lane & 15), tap = tj >> 1;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int co = (wave + 4 * a) * 16 + (lane >> 4) * 4 + r4;
+                if (co < Cout && ci < Cin) atomicAdd(&dW[((long)co * Cin + ci) * 9 + tap], acc[tj * 2 + a][r4]);
+            }
+        }
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // first layer: Conv2d(1,32,3,pad 1,bias) + ReLU + MaxPool2d(2) (models.py:180-187).  One thread per (pooled pixel, 8 out channels).
 template <class T>
@@ -956,7 +1074,24 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
             return OCRS_ERR_HIP;
         attr_set = true;
     }
-    if (dtype == 1)
+    static const int use_tr = env_int("OCRS_WGRAD3X3_TR", 1);
+    if (dtype == 1 && use_tr) {
+        static bool attr2 = false;
+        if (!attr2) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad_tr<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
+                    hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad_tr<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) !=
+                    hipSuccess)
+                return OCRS_ERR_HIP;
+            attr2 = true;
+        }
+        if (Cout > 64)
+            hipLaunchKernelGGL(k_conv3x3_wgrad_tr<128>, dim3((int)gx, gy), dim3(256), (128 * 136 + 180 * 40) * 2, st, (const bf16*)dz, Cout, (const bf16*)x,
+                               Cin, dW, N, H, W, ws);
+        else
+            hipLaunchKernelGGL(k_conv3x3_wgrad_tr<64>, dim3((int)gx, gy), dim3(256), (128 * 72 + 180 * 40) * 2, st, (const bf16*)dz, Cout, (const bf16*)x,
+                               Cin, dW, N, H, W, ws);
+    } else if (dtype == 1)
         hipLaunchKernelGGL(k_conv3x3_wgrad<bf16>, dim3((int)gx, gy), dim3(256), (128 * 136 + 96 * 168) * 2, st, (const bf16*)dz, Cout, (const bf16*)x, Cin,
                            dW, N, H, W, ws);
     else
