@@ -819,22 +819,18 @@ __global__ __launch_bounds__(256) void k_c1_bwd_a(const float* __restrict__ img,
     for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-        const PixIdx px = decode_pixel(p, H, W);
+    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256) {  // wave-uniform trip count (nb3x3 shuffles)
+        const long p = base + threadIdx.x;
+        const bool active = p < P;
+        const PixIdx px = decode_pixel(active ? p : 0, H, W);
+        float nb[9];
+        nb3x3(img, px, H, W, active, threadIdx.x & 63, nb);
+        if (!active) continue;
         float gh[8], zv[8];
         load_ghat8(gs, z, 8, s_bn, p, px, H, W, 0, gh, zv);
         float u = 0.f;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int hh = px.h + dy - 1;
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ww = px.w + dx - 1;
-                if (ww < 0 || ww >= W) continue;
-                u = fmaf(wd[dy * 3 + dx], img[((long)px.n * H + hh) * W + ww], u);
-            }
-        }
+        for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[k], u);
         u = Elem<T>::round(u);
         float d = 0.f;
 #pragma unroll
@@ -860,20 +856,16 @@ __global__ __launch_bounds__(256) void k_c1_bwd_b(const float* __restrict__ img,
     if (threadIdx.x < 9) s_acc[threadIdx.x] = 0.f;
     __syncthreads();
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-        const PixIdx px = decode_pixel(p, H, W);
+    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256) {  // wave-uniform trip count (nb3x3 shuffles)
+        const long p = base + threadIdx.x;
+        const bool active = p < P;
+        const PixIdx px = decode_pixel(active ? p : 0, H, W);
+        float nb[9];  // du at (h + ey - 1, w + ex - 1); tap (dy, dx) pairs img[p] with du[p - off] = nb[(2 - dy) * 3 + (2 - dx)]
+        nb3x3(du, px, H, W, active, threadIdx.x & 63, nb);
+        if (!active) continue;
         const float xv = img[p];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int hh = px.h - (dy - 1);
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ww = px.w - (dx - 1);
-                if (ww < 0 || ww >= W) continue;
-                acc[dy * 3 + dx] = fmaf(xv, du[((long)px.n * H + hh) * W + ww], acc[dy * 3 + dx]);
-            }
-        }
+        for (int k = 0; k < 9; ++k) acc[k] = fmaf(xv, nb[8 - k], acc[k]);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {

@@ -252,20 +252,16 @@ __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ i
 #pragma unroll
     for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
-        const PixIdx px = decode_pixel(p, H, W);
+    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256) {  // wave-uniform trip count (nb3x3 shuffles)
+        const long p = base + threadIdx.x;
+        const bool active = p < P;
+        const PixIdx px = decode_pixel(active ? p : 0, H, W);
+        float nb[9];
+        nb3x3(img, px, H, W, active, threadIdx.x & 63, nb);
+        if (!active) continue;
         float u = 0.f;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int hh = px.h + dy - 1;
-            if (hh < 0 || hh >= H) continue;
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ww = px.w + dx - 1;
-                if (ww < 0 || ww >= W) continue;
-                u = fmaf(wd[dy * 3 + dx], img[((long)px.n * H + hh) * W + ww], u);
-            }
-        }
+        for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[k], u);
         u = Elem<T>::round(u);
         float o[8];
 #pragma unroll
