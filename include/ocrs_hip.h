@@ -31,6 +31,8 @@ typedef struct ihipStream_t* hipStream_t;
  * mode 1: ConvTranspose2d forward effective weight (src = W[Cup][Cout][3][3], K = 4*Cup, M = 4*Cout, K2 = Cup). */
 int ocrs_pack_frags(const float* src, int mode, int K, int M, int K2, long s1, long s2, long sm, void* out, int dtype, hipStream_t st);
 long ocrs_pack_frags_bytes(int K, int M, int dtype);
+/* All weight packs of a step in one launch: table = device int64 [n][9] = { src, out, mode, K, M, K2, s1, s2, sm }. */
+int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, int dtype, hipStream_t st);
 
 /* ------------------------------------------------------------------ detection forward ------- */
 /* DepthwiseConv block up to its pre-BatchNorm output: conv2d(groups=C, 3x3, pad 1) -> conv2d(1x1)

@@ -15,10 +15,10 @@
 //           k = d*Cup + c (d = dy*2+dx), m = q*Cout + o (q = py*2+px) -> W[c][o][py+2dy][px+2dx] or 0
 // ----------------------------------------------------------------------------------------------
 template <class T>
-__global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out) {
+__device__ __forceinline__ void pack_frags_body(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out,
+                                                long idx) {
     const int MT = (M + 15) / 16;
     const int nkc = (K + 31) / 32;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)nkc * MT * 64) return;
     const int lane = (int)(idx & 63);
     const long frag = idx >> 6;
@@ -42,6 +42,18 @@ __global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int
         v[j] = x;
     }
     store8(out + idx * 8, v);
+}
+template <class T>
+__global__ void k_pack_frags(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out) {
+    pack_frags_body<T>(src, mode, K, M, K2, s1, s2, sm, out, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// all weight packs of a train step in ONE launch (they were 74 launches x 4.4 us): blockIdx.y = table row
+//   table [n][9] int64 = { src, out, mode, K, M, K2, s1, s2, sm }
+template <class T>
+__global__ void k_pack_frags_multi(const long long* __restrict__ table) {
+    const long long* r = table + (long)blockIdx.y * 9;
+    pack_frags_body<T>(reinterpret_cast<const float*>(r[0]), (int)r[2], (int)r[3], (int)r[4], (int)r[5], (long)r[6], (long)r[7], (long)r[8],
+                       reinterpret_cast<T*>(r[1]), (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -441,6 +453,19 @@ int ocrs_pack_frags(const float* src, int mode, int K, int M, int K2, long s1, l
         hipLaunchKernelGGL(k_pack_frags<bf16>, dim3(grid), dim3(256), 0, st, src, mode, K, M, K2, s1, s2, sm, (bf16*)out);
     else
         hipLaunchKernelGGL(k_pack_frags<float>, dim3(grid), dim3(256), 0, st, src, mode, K, M, K2, s1, s2, sm, (float*)out);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// table: device int64 [n][9] = { src ptr, out ptr, mode, K, M, K2, s1, s2, sm } (the arguments of ocrs_pack_frags per row);
+// max_frag_threads = max over rows of ceil(K/32) * ceil(M/16) * 64.
+int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(table && n > 0 && max_frag_threads > 0);
+    const dim3 grid((unsigned)((max_frag_threads + 255) / 256), (unsigned)n);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_pack_frags_multi<bf16>, grid, dim3(256), 0, st, table);
+    else
+        hipLaunchKernelGGL(k_pack_frags_multi<float>, grid, dim3(256), 0, st, table);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

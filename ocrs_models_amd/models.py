@@ -116,10 +116,46 @@ class _DetRun:
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
 
     def pack(self, src, mode, K, M, K2, s1, s2, sm):
+        """MFMA weight fragments of one layer: from this step's multi-pack buffer (prepack) or, outside a full forward, packed here."""
+        hit = getattr(self, "packs", {}).get((src.data_ptr(), mode, K, M, s2, sm))
+        if hit is not None:
+            return hit
         nbytes = self.L.pack_frags_bytes(K, M, self.dt)
         out = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
         self.L.pack_frags(ptr(src), mode, K, M, K2, s1, s2, sm, ptr(out), self.dt)
         return out
+
+    def prepack(self):
+        """All weight-fragment packs of the step (25 forward + 24 backward pointwise, 6+6 ConvTranspose) in ONE launch.  The table of
+        (source pointer, layout) rows is built once per module / dtype and reused while the parameter storage stays in place."""
+        P, w = self.P, DEPTH_SCALE
+        cache = getattr(self.mod, "_pack_cache", None)
+        key = (self.dt, tuple(p.data_ptr() for p in P.values()))
+        if cache is None or cache[0] != key:
+            rows = []  # (src tensor, mode, K, M, K2, s1, s2, sm)
+            for name in self.names:
+                if name.endswith(".seq.1.weight") and P[name].dim() == 4 and P[name].shape[1] > 1:
+                    cout, cin = P[name].shape[0], P[name].shape[1]
+                    rows.append((P[name], 0, cin, cout, cin, 0, 1, cin))   # forward:  W   (K = Cin,  M = Cout)
+                    rows.append((P[name], 0, cout, cin, cout, 0, cin, 1))  # backward: W^T (K = Cout, M = Cin)
+            for i in range(6):
+                Cup, Cout = w[i + 1], w[i]
+                rows.append((P[f"up.{i}.up.weight"], 1, 4 * Cup, 4 * Cout, Cup, 0, 0, 0))
+                rows.append((P[f"up.{i}.up.weight"], 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout))
+            sizes = [self.L.pack_frags_bytes(r[2], r[3], self.dt) for r in rows]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + ((n + 255) // 256) * 256)
+            buf = torch.empty(offs[-1], dtype=torch.uint8, device=self.dev)
+            table = torch.tensor([[r[0].data_ptr(), buf.data_ptr() + o, r[1], r[2], r[3], r[4], r[5], r[6], r[7]] for r, o in zip(rows, offs)],
+                                 dtype=torch.int64).to(self.dev)
+            views = {(r[0].data_ptr(), r[1], r[2], r[3], r[6], r[7]): buf[o:o + n] for r, o, n in zip(rows, offs, sizes)}
+            maxthr = max(((r[2] + 31) // 32) * ((r[3] + 15) // 16) * 64 for r in rows)
+            cache = (key, table, buf, views, len(rows), maxthr)
+            self.mod._pack_cache = cache
+        _, table, _, views, n, maxthr = cache
+        self.L.pack_frags_multi(ptr(table), n, maxthr, self.dt)
+        self.packs = views
 
     def bn_tr(self, prefix, gstat, count, C):
         P, Bf = self.P, self.Bf
@@ -173,6 +209,7 @@ class _DetRun:
         H, W = x.shape[2], x.shape[3]
         if H < 64 or W < 64:
             raise RuntimeError(f"DetectionModel needs H, W >= 64 (six 2x2 poolings), got {H}x{W}")
+        self.prepack()
         a0 = self.block_c1("in_conv.seq.0", x, H, W)
         cur = self.block("in_conv.seq.1", a0, None, w[0])
         skips = [cur]
