@@ -32,28 +32,31 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s mea
 
 
 def alg_bytes(name, a, sz):
-    """Algorithmic HBM bytes of one launch of a kernel family, from its C-ABI arguments.
+    """Algorithmic HBM bytes of one launch of a kernel family, from its C-ABI arguments (looked up BY NAME in include/ocrs_hip.h).
 
     SURVEY.md 8(d) model: a fused pass reads its inputs once and writes its outputs once.
     """
-    if name == "dwpw_fwd":  # (xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, dt)
-        return a[11] * a[12] * a[13] * (a[2] + a[3] + a[10]) * sz
-    if name == "pw_bwd":  # (xa,xb,Ca,Cb,tra,trb,wdw,g1,g2,pooled,z,bn,coef,wpk_d,du,dwpw,Cout,N,H,W,dt): g + z + x in, du out
-        P, cin, cout = a[17] * a[18] * a[19], a[2] + a[3], a[16]
-        g = cout / 4 if a[9] else cout * (2 if a[8] else 1)
+    from ocrs_models_amd._lib import ARG_NAMES
+
+    v = dict(zip(ARG_NAMES["ocrs_" + name], a))
+    if name == "dwpw_fwd":  # x (Ca+Cb) in, z (Cout) out
+        return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
+    if name == "pw_bwd":  # g (+g2, or a quarter-size pooled g) + z + x in, du out
+        P, cin, cout = v["N"] * v["H"] * v["W"], v["Ca"] + v["Cb"], v["Cout"]
+        g = cout / 4 if v["pooled"] else cout * (2 if v["g2"] else 1)
         return P * (g + cout + 2 * cin) * sz
-    if name == "dw_bwd":  # (xa,xb,Ca,Cb,tra,trb,wdw,du,gxa,gxb,dwdw,N,H,W,dt): du + x in, gx out
-        return a[11] * a[12] * a[13] * 3 * (a[2] + a[3]) * sz
-    if name == "bn_bwd_reduce":  # (g1,g2,pooled,z,bn,saved,gsum,C,N,H,W,dt)
-        P, c = a[8] * a[9] * a[10], a[7]
-        g = c / 4 if a[2] else c * (2 if a[1] else 1)
+    if name == "dw_bwd":  # du + x in, dL/dx out
+        return v["N"] * v["H"] * v["W"] * 3 * (v["Ca"] + v["Cb"]) * sz
+    if name == "bn_bwd_reduce":
+        P, c = v["N"] * v["H"] * v["W"], v["C"]
+        g = c / 4 if v["pooled"] else c * (2 if v["g2"] else 1)
         return P * (g + c) * sz
-    if name == "convt_fwd":  # (x,tr,wpk,bias,out,Cup,Cout,N,h,w,H,W,dt)
-        return a[7] * (a[8] * a[9] * a[5] + a[10] * a[11] * a[6]) * sz
-    if name == "convt_bwd":  # (x,tr,g,wpk_d,dx,dW,dbias,Cup,Cout,N,h,w,H,W,dt): x + g in, dx out
-        return a[9] * (2 * a[10] * a[11] * a[7] + a[12] * a[13] * a[8]) * sz
-    if name == "maxpool_fwd":  # (z,tr,out,C,N,H,W,dt)
-        return a[4] * a[5] * a[6] * a[3] * 1.25 * sz
+    if name == "convt_fwd":  # x in, out out
+        return v["N"] * (v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
+    if name == "convt_bwd":  # x + g in, dx out
+        return v["N"] * (2 * v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
+    if name == "maxpool_fwd":
+        return v["N"] * v["H"] * v["W"] * v["C"] * 1.25 * sz
     return 0.0
 
 

@@ -36,7 +36,9 @@ int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, 
 
 /* ------------------------------------------------------------------ detection forward ------- */
 /* DepthwiseConv block up to its pre-BatchNorm output: conv2d(groups=C, 3x3, pad 1) -> conv2d(1x1)
- * (ocrs_models/models.py:11-22) with the channel concat of models.py:89 folded in (xa|xb). */
+ * (ocrs_models/models.py:11-22) with the channel concat of models.py:89 folded in (xa|xb).
+ * gstat [2][Cout] fp64 (sum z | sum z^2) is ACCUMULATED: the caller zeroes it (one memset for all layers of a step);
+ * the same holds for gsum of ocrs_bn_bwd_reduce. */
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
                   void* z, double* gstat, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */

@@ -44,9 +44,11 @@ def parse_header(path: str = HEADER_PATH):
                 else:
                     raise RuntimeError(f"unparsed argument {a!r} of {name}")
         sigs[name] = ("i" if res == "int" else "l", sig)
+        ARG_NAMES[name] = [re.sub(r"\[.*", "", a.strip().split()[-1].lstrip("*")) for a in args.split(",")] if args not in ("", "void") else []
     return sigs
 
 
+ARG_NAMES = {}  # ocrs_* -> parameter names in ABI order (for tools that read call arguments by name: bench.py's byte model)
 SIGNATURES = parse_header()
 
 _ERR = {1: "bad argument", 2: "HIP launch/runtime error"}

@@ -1199,11 +1199,10 @@ extern "C" int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* tr
 
 extern "C" {
 
-// Sum of ghat and ghat*zhat over all pixels (BatchNorm2d backward reductions).  gsum [2][C] double, zeroed here.
+// Sum of ghat and ghat*zhat over all pixels (BatchNorm2d backward reductions).  gsum [2][C] double, ACCUMULATED (caller zeroes).
 int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z, const float* bn, const float* saved, double* gsum, int C,
                        int N, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(g1 && z && bn && saved && gsum && C % 8 == 0 && C <= 256);
-    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     const long P = (long)N * H * W;
     // every block ends with 2C fp64 atomics onto the same addresses: at the deep levels (tens of thousands of pixels) give each thread
     // at least 8 items instead of launching 2048 nearly idle blocks (those launches were 60 us of pure flush)

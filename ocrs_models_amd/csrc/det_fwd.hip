@@ -515,24 +515,23 @@ extern "C" {
 //   xa/xb : NHWC inputs (xb may be null; channel concat [xa | xb] as torch.cat at models.py:89), Ca, Cb multiples of 8
 //   tra/trb : [3][Ca] / [3][Cb] load transforms of the inputs (producer BN+ReLU, or identity)
 //   wdw   : depthwise weights in the reference layout [Cin][1][3][3]; wpk: pointwise weights packed by ocrs_pack_frags(K=Cin, M=Cout)
-//   z     : [P][Cout] pre-BN output; gstat: [2][Cout] double, sum z and sum z^2 (zeroed here)
+//   z     : [P][Cout] pre-BN output; gstat: [2][Cout] double, sum z and sum z^2 ACCUMULATED (the caller zeroes it: one
+//           memset for all layers of a step instead of one per launch)
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
                   void* z, double* gstat, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG(xa && tra && wdw && wpk && z && gstat && (Cb == 0 || trb));
     OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
-    if (hipMemsetAsync(gstat, 0, 2 * Cout * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
     return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st)
                       : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st);
 }
 
-// First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] (zeroed here).
+// First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] accumulated (caller zeroes).
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st) {
     OCRS_CHECK_ARG(img && wdw && wpw && z && gstat);
-    if (hipMemsetAsync(gstat, 0, 16 * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     const long P = (long)N * H * W;
     const int grid = ew_grid(P);
     if (dtype == 1)
