@@ -893,28 +893,38 @@ struct CtwCfg {
     static constexpr int XI = TPOS * CUP / 8, GI = GH * GW * COUT / 8;  // 16-byte staging items
     static constexpr int NXI = (XI + 255) / 256, NGI = (GI + 255) / 256;
     static constexpr int XS_EL = TPOS * CUP, GS_EL = GH * GW * COUT;
-    static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8) * 2 + 3 * CUP * 4;
-    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4;
+    // fused dgrad: dx[c] = sum_{tap,o} g[2i+ky][2j+kx][o] * W[c][o][tap]: K = 9*COUT in chunks of 32, M = CUP, N = positions
+    static constexpr int DKC = (9 * COUT + 31) / 32, DNT = TPOS / 16 / 4;  // K chunks, N tiles (of 16 positions) per wave
+    static constexpr int WD_EL = DKC * MT * 64 * 8;                          // cached packed dgrad weight fragments (bf16 elements)
+    static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8 + WD_EL) * 2 + 3 * CUP * 4;
+    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4 + 256 * 8 * 4;
     static constexpr int SMEM = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
-    static constexpr int PART = CUP * NT * 16;  // floats per block partial: [CUP][NT*16]
+    static constexpr int PART = CUP * NT * 16 + COUT;  // floats per block partial: dW [CUP][NT*16] | dbias [COUT]
 };
 
+// The same staged tiles also give (fused, levels 0-2): the input gradient dx (dgrad GEMM, pixel operand = one ds_read_b128 per
+// fragment straight from the natural-layout g region, packed weights cached in LDS) and dbias = sum of g (every output pixel is owned by
+// exactly one tile).  One kernel + one reduce replace k_convt_dgrad + wgrad + k_channel_sum: g is read from HBM once instead of 3 times.
 template <int CUP, int COUT>
 __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__ x, const float* __restrict__ tr /*[3][CUP]*/, const bf16* __restrict__ g,
-                                                        float* __restrict__ ws, int h, int w, int H, int W, Tiling2 tg) {
+                                                        const void* __restrict__ wpk_d, bf16* __restrict__ dx, float* __restrict__ ws, int h, int w,
+                                                        int H, int W, Tiling2 tg) {
     using C = CtwCfg<CUP, COUT>;
     constexpr int TW = C::TW, TH = C::TH, GW = C::GW, MT = C::MT, NTW = C::NTW, KW = C::KW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* xs = reinterpret_cast<bf16*>(smem);   // [TPOS][CUP]
     bf16* gsm = xs + C::XS_EL;                  // [GH*GW][COUT]
     bf16* zero8 = gsm + C::GS_EL;               // 8 zero elements (padding columns of the last N tile)
-    float* s_tr = reinterpret_cast<float*>(zero8 + 8);  // [CUP/8][3][8]
+    uint4* s_wd = reinterpret_cast<uint4*>(zero8 + 8);  // [DKC*MT][64] packed dgrad weight fragments
+    float* s_tr = reinterpret_cast<float*>(s_wd + C::DKC * MT * 64);  // [CUP/8][3][8]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         Src2<bf16> xsrc{x, nullptr, CUP, 0};
         fill_tr8(s_tr, xsrc, tr, nullptr, CUP, tid);
         if (tid < 4) reinterpret_cast<unsigned*>(zero8)[tid] = 0u;
+        for (int i = tid; i < C::DKC * MT * 64; i += 256) s_wd[i] = reinterpret_cast<const uint4*>(wpk_d)[i];
     }
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dbias partial of this thread's channel group (tid % (COUT/8))
     // ---- tile-invariant staging descriptors
     int xoff[C::NXI], goff[C::NGI], gyx[C::NGI];
 #pragma unroll
@@ -970,8 +980,12 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     };
     TileSched ts(tg.ntiles);
     if (ts.first < ts.end) issue(ts.first);
-    __syncthreads();  // s_tr, zero8
+    __syncthreads();  // s_tr, zero8, s_wd
     for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
+        // output pixels owned by this tile (for dbias): the 2TH x 2TW block, plus the extra halo row / column for the last tile of
+        // each direction (H = 2h+1 / W = 2w+1 leave one more output row / column than 2 * tiles * T{H,W} can own otherwise)
+        const int own_h = org.h0 + TH >= h ? C::GH : 2 * TH, own_w = org.w0 + TW >= w ? C::GW : 2 * TW;
         // commit the prefetched tile: x~ = max(x*scale+shift, lo) rounded to bf16 (what the forward MFMA consumed), g as is
 #pragma unroll
         for (int j = 0; j < C::NXI; ++j) {
@@ -995,6 +1009,12 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
         for (int j = 0; j < C::NGI; ++j) {
             const int it = tid + j * 256;
             if (C::GI % 256 == 0 || it < C::GI) *reinterpret_cast<uint4*>(gsm + it * 8) = (okg & (1u << j)) ? gr[j].a : make_uint4(0, 0, 0, 0);
+            if ((okg & (1u << j)) && (gyx[j] & 0xffff) < own_h && (gyx[j] >> 16) < own_w) {
+                float gv[8];
+                unpack8(gr[j], gv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum[i] += gv[i];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t + ts.step < ts.end) issue(t + ts.step);
@@ -1008,6 +1028,30 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
             const bf16x8 bfr = lds_tr8(bp, b_ptr[q] ? bp + 2 * GW * COUT : zero8);
 #pragma unroll
             for (int a = 0; a < MT; ++a) acc[a][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr, acc[a][q], 0, 0, 0);
+        }
+        // ---- dgrad: this wave's DNT tiles of 16 positions
+#pragma unroll
+        for (int a = 0; a < C::DNT; ++a) {
+            const int n = (wave * C::DNT + a) * 16 + i16, ii = n / TW, jj = n % TW;
+            f32x4 dacc[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) dacc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < C::DKC; ++kc) {
+                const int k0 = kc * 32 + kg * 8, tap = k0 / COUT, o0 = k0 % COUT;
+                const bf16* gp = k0 < C::NCOL ? gsm + ((2 * ii + tap / 3) * GW + 2 * jj + tap % 3) * COUT + o0 : zero8;
+                const uint4 pf = *reinterpret_cast<const uint4*>(gp);
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    dacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, s_wd[(kc * MT + b) * 64 + lane]),
+                                                                      __builtin_bit_cast(bf16x8, pf), dacc[b], 0, 0, 0);
+            }
+            const int i = org.h0 + ii, jx = org.w0 + jj;
+            if (i < h && jx < w) {
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    store4(dx + (((long)org.n * h + i) * w + jx) * CUP + b * 16 + kg * 4, dacc[b][0], dacc[b][1], dacc[b][2], dacc[b][3]);
+            }
         }
         lds_barrier();  // all operand reads done before the next commit overwrites the tiles
     }
@@ -1023,6 +1067,18 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
                 for (int r = 0; r < 4; ++r) red[(((ks - 1) * C::NW + nh) * MT * NTW + a * NTW + q) * 256 + r * 64 + lane] = acc[a][q][r];
     }
     __syncthreads();
+    {   // dbias: threads with the same channel group (tid % (COUT/8)) are summed through LDS (behind the wgrad reduction area)
+        float* bred = red + (KW - 1) * MT * NTW * C::NW * 256;  // [256][8]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bred[tid * 8 + i] = bsum[i];
+        __syncthreads();
+        if (tid < COUT) {
+            const int cg8 = tid / 8, i = tid % 8;
+            float v = 0.f;
+            for (int t2 = cg8; t2 < 256; t2 += COUT / 8) v += bred[t2 * 8 + i];
+            ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + tid] = v;
+        }
+    }
     if (ks == 0) {
         float* part = ws + (long)blockIdx.x * C::PART;
 #pragma unroll
@@ -1039,14 +1095,22 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     }
 }
 // dW[(c*COUT + o)*9 + tap] += sum over block partials of ws[b][c][tap*COUT + o];  grid (ceil(CUP*NCOL/256), partial chunks)
-__global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restrict__ ws, int nblocks, int CUP, int COUT, int NT16, float* __restrict__ dW) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= CUP * 9 * COUT) return;
-    const int c = e / (9 * COUT), n = e - c * 9 * COUT;
+__global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restrict__ ws, int nblocks, int CUP, int COUT, int NT16, float* __restrict__ dW,
+                                                            float* __restrict__ dbias) {
+    const int e = blockIdx.x * 256 + threadIdx.x, part = CUP * NT16 + COUT;
+    if (e >= CUP * 9 * COUT + COUT) return;
     const int per = (nblocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    if (e >= CUP * 9 * COUT) {  // dbias [COUT]
+        const int o = e - CUP * 9 * COUT;
+        float sb = 0.f;
+        for (int b = b0; b < b1; ++b) sb += ws[(long)b * part + CUP * NT16 + o];
+        atomicAdd(&dbias[o], sb);
+        return;
+    }
+    const int c = e / (9 * COUT), n = e - c * 9 * COUT;
     float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += ws[((long)b * CUP + c) * NT16 + n];
+    for (int b = b0; b < b1; ++b) s += ws[(long)b * part + c * NT16 + n];
     const int tap = n / COUT, o = n - tap * COUT;
     atomicAdd(&dW[((long)c * COUT + o) * 9 + tap], s);
 }
@@ -1401,13 +1465,31 @@ static int convt_wgrad_tr_grid(int Cout, int N, int h, int w) {
 }
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
     const long a = ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype);
-    const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * Cup * ((9 * Cout + 15) / 16 * 16) : 0;
+    const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * (Cup * ((9 * Cout + 15) / 16 * 16) + Cout) : 0;
     return a > b ? a : b;
 }
 
 int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup, int Cout,
                    int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
+    if (ws && convt_wgrad_tr_ok(Cup, Cout, dtype)) {
+        // levels 0-2 (bf16): ONE tiled kernel produces dx, the weight-gradient partials and the bias-gradient partials; one reduce
+#define CTW_CASE(CU_, CO_)                                                                                                                   \
+    if (Cup == CU_ && Cout == CO_) {                                                                                                         \
+        using CC = CtwCfg<CU_, CO_>;                                                                                                         \
+        const Tiling2 tg = make_tiling2(N, h, w, CC::TW, CC::TH);                                                                            \
+        const int nb = convt_wgrad_tr_grid(Cout, N, h, w);                                                                                   \
+        hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, wpk_d, (bf16*)dx, ws, \
+                           h, w, H, W, tg);                                                                                                  \
+        const int ne = CU_ * 9 * CO_ + CO_;                                                                                                  \
+        hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 255) / 256, nb >= 64 ? 16 : 1), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW, \
+                           dbias);                                                                                                           \
+    }
+        CTW_CASE(16, 8) CTW_CASE(32, 16) CTW_CASE(32, 32)
+#undef CTW_CASE
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
     const int MT_total = Cup / 16;
     const long P = (long)N * h * w;
     const long ntiles = (P + 63) / 64;
@@ -1433,19 +1515,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_DISPATCH
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
-    if (ws && convt_wgrad_tr_ok(Cup, Cout, dtype)) {
-#define CTW_CASE(CU_, CO_)                                                                                                                   \
-    if (Cup == CU_ && Cout == CO_) {                                                                                                         \
-        using CC = CtwCfg<CU_, CO_>;                                                                                                         \
-        const Tiling2 tg = make_tiling2(N, h, w, CC::TW, CC::TH);                                                                            \
-        const int nb = convt_wgrad_tr_grid(Cout, N, h, w);                                                                                   \
-        hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, ws, h, w, H, W, tg); \
-        const int ne = CU_ * 9 * CO_;                                                                                                        \
-        hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 255) / 256, nb >= 64 ? 16 : 1), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW); \
-    }
-        CTW_CASE(16, 8) CTW_CASE(32, 16) CTW_CASE(32, 32)
-#undef CTW_CASE
-    } else {
+    {
         const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;
     }
