@@ -7,4 +7,4 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 python tools/pmc_summary.py gpurun_out/pmc1 "$1" > gpurun_out/pmc_sq.txt 2>&1
 python tools/pmc_summary.py gpurun_out/pmc2 "$1" >> gpurun_out/pmc_sq.txt 2>&1
 find gpurun_out/pmc1 gpurun_out/pmc2 -name "*.csv" -size +2M -delete
-tail -5 gpurun_out/pmc1.log gpurun_out/pmc2.log
+tail -n 2 gpurun_out/pmc1.log gpurun_out/pmc2.log
