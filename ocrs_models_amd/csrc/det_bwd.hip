@@ -308,27 +308,33 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                         unpack8(zr, zv);
                         unpack8(g1r, ga);
                         unpack8(g2r, gb);
-                        bool win[8];
-                        float ym[8];
+                        // win  <=>  ym > max(0, earlier neighbours)  &&  ym >= max(later neighbours)   (ym = relu(bn(z)); "> 0" is the
+                        // ReLU mask).  Kept in float max/mul form: per-channel bool chains compile to scalar mask arithmetic and made
+                        // this kernel issue 3x the SALU instructions of its non-pooled twin.
+                        float ym[8], be[8], bl[8], scv[8], shv[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            const float y = fmaf(zv[i], s_bn[c0 + i], s_bn[COUT + c0 + i]);
-                            win[i] = gv_cur && y > 0.f;
-                            ym[i] = fmaxf(y, 0.f);
+                            scv[i] = s_bn[c0 + i];
+                            shv[i] = s_bn[COUT + c0 + i];
+                            ym[i] = max_lo(fmaf(zv[i], scv[i], shv[i]), 0.f);
+                            be[i] = 0.f;
+                            bl[i] = 0.f;
                         }
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
-                            const bool earlier = (own ^ (j + 1)) < own;  // window index of neighbour j is own ^ (j+1)
+                            const float ef = (own ^ (j + 1)) < own ? 1.f : 0.f, lf = 1.f - ef;  // neighbour j has window index own ^ (j+1)
                             float zn[8];
                             unpack8(zq[j], zn);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
-                                const float yo = fmaxf(fmaf(zn[i], s_bn[c0 + i], s_bn[COUT + c0 + i]), 0.f);
-                                win[i] = win[i] && (earlier ? ym[i] > yo : ym[i] >= yo);
+                                const float yo = max_lo(fmaf(zn[i], scv[i], shv[i]), 0.f);
+                                be[i] = max_lo(yo * ef, be[i]);
+                                bl[i] = max_lo(yo * lf, bl[i]);
                             }
                         }
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) gh[i] = win[i] ? (has_g2 ? ga[i] + gb[i] : ga[i]) : 0.f;
+                        for (int i = 0; i < 8; ++i)
+                            gh[i] = (gv_cur && ym[i] > be[i] && ym[i] >= bl[i]) ? (has_g2 ? ga[i] + gb[i] : ga[i]) : 0.f;
                     } else if (gs.pooled)
                         load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
                     else {
