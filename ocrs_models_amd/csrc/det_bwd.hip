@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             g2r = load8_raw((ld && has_g2 ? gs.g2 + tb * COUT : gs.g1) + off);
         }
     };
-    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // PIPE: one tile decode per tile
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);  // PIPE: origin of the prefetched tile, no divisions in the loop
+    TileOrg org_next = tit.org();
     if constexpr (PIPE) {
 #pragma unroll
         for (int b = 0; b < MTD; ++b) {
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             }
             __builtin_amdgcn_sched_barrier(0);
             if (t + ts.step < ts.end) {
-                org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+                tit.next();
+                org_next = tit.org();
                 issue_tile(org_next);
             }
             lds_barrier();
@@ -690,7 +692,8 @@ __global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __res
     };
     Pre cur;  // consumed at the top of an iteration (commit + x transform), then immediately refilled for the next tile
     TileSched ts(tg.ntiles);
-    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // one tile decode (2 integer divisions) per tile
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);  // origin of the tile being prefetched, advanced without divisions
+    TileOrg org_next = tit.org();
     if (ts.first < ts.end) issue(cur, org_next);
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = org_next;
@@ -720,7 +723,8 @@ __global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __res
         __builtin_amdgcn_sched_barrier(0);
         const bool more = t + ts.step < ts.end;
         if (more) {
-            org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+            tit.next();
+            org_next = tit.org();
             issue(cur, org_next);
         }
         lds_barrier();

@@ -109,6 +109,47 @@ __device__ __forceinline__ void nb3x3(const float* __restrict__ img, const PixId
     }
 }
 
+// Tile origins along a TileSched without divisions in the loop: the schedule's step is constant, so the origin advances by a fixed
+// (images, tile rows, tile columns) triple with two carries -- ~10 scalar instructions instead of two integer divisions (~45) per tile
+// (k_dw_bwd issued more SALU than VALU instructions, most of them tile bookkeeping).
+template <int TW, int TH>
+struct TileIter {
+    int n, ty, tx, sn, sy, sx, tiles_x, tiles_y;
+    __device__ __forceinline__ TileIter(const Tiling2& tg, long first, long step) {
+        const int tpi = tg.tiles_x * tg.tiles_y;
+        tiles_x = tg.tiles_x;
+        tiles_y = tg.tiles_y;
+        n = (int)first / tpi;
+        const int r = (int)first - n * tpi;
+        ty = r / tiles_x;
+        tx = r - ty * tiles_x;
+        sn = (int)step / tpi;
+        const int rs = (int)step - sn * tpi;
+        sy = rs / tiles_x;
+        sx = rs - sy * tiles_x;
+    }
+    __device__ __forceinline__ TileOrg org() const {
+        TileOrg o;
+        o.n = n;
+        o.h0 = ty * TH;
+        o.w0 = tx * TW;
+        return o;
+    }
+    __device__ __forceinline__ void next() {
+        tx += sx;
+        if (tx >= tiles_x) {
+            tx -= tiles_x;
+            ++ty;
+        }
+        ty += sy;
+        if (ty >= tiles_y) {
+            ty -= tiles_y;
+            ++n;
+        }
+        n += sn;
+    }
+};
+
 // two-source (channel-concatenated) activation: channels [0,Ca) from a, [Ca,Ca+Cb) from b.
 // This is how torch.cat((upscaled, skip), 1) (models.py:89) is consumed without materialising it.
 template <class T>

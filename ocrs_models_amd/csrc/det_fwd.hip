@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
     typename HaloStager<T, CG, TW, TH>::Pending pend;
     typename Mma<T>::Frag wfr[PIPE ? MT : 1];  // PIPE: pointwise weight fragments are tile-invariant -> registers (a global load inside
                                                 // the loop would make the compiler wait vmcnt(0), i.e. for the prefetch as well)
-    TileOrg org_next = tile_origin2<TW, TH>(tg, (int)(ts.first < ts.end ? ts.first : 0));  // PIPE: one tile decode per tile
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);  // PIPE: origin of the prefetched tile, no divisions in the loop
+    TileOrg org_next = tit.org();
     if constexpr (PIPE) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
                 stager.commit(pend, s_par, 0, xs, tid);
                 __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads behind ALL of this tile's commit waits
                 if (t + ts.step < ts.end) {
-                    org_next = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+                    tit.next();
+                    org_next = tit.org();
                     stager.issue(pend, x, 0, org_next, H, W, tid);
                 }
             } else
