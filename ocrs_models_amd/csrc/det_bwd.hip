@@ -607,8 +607,11 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 // kernel computes (sum ghat and sum ghat*(z - mean), ghat = dx~ * [bn(z) > 0]): the input x is that producer's raw z, so its
 // k_bn_bwd_reduce pass over (g, z) -- 2.1 ms of the step -- disappears.  Partials go to workspace rows 9..10 (stat_mask bit 0 / 1 =
 // source a / b wants them); k_dw_partials_reduce scales by rstd and adds them to the producers' gsum [2][C] (fp64).
+#ifndef OCRS_DW_BLOCKS
+#define OCRS_DW_BLOCKS 3
+#endif
 template <class T, int CG, bool STATS>
-__global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
                                                 float* __restrict__ ws /*[gridDim.x][C][9 (+2)] block partials or null*/,
@@ -733,6 +736,7 @@ __global__ __launch_bounds__(256, 3) void k_dw_bwd(Src2<T> x, const float* __res
         // partial tile has x~ = 0, so it adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
+            if (k % 3 == 0 && k) __builtin_amdgcn_sched_barrier(0);  // at most 3 taps (6 LDS vector reads) in flight: hoisting all 18 costs 70 VGPRs
             const float4 d4 = *reinterpret_cast<const float4*>(ds + ((ty + 2 - k / 3) * (TW + 2) + (tx + 2 - k % 3)) * SC + q * 4);
             const float4 w4 = *reinterpret_cast<const float4*>(s_w + k * SC + q * 4);
             const float d[4] = {d4.x, d4.y, d4.z, d4.w}, wk[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -1389,7 +1393,8 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 
 // Depthwise-conv backward: gxa/gxb (either may be null) receive dL/dx~ split at channel Ca; dwdw accumulated in master layout [C][1][3][3].
 static void dw_bwd_grid(int C, int N, int H, int W, int& gx, int& gy, int& cg) {
-    cg = C >= 32 ? 4 : C / 8;
+    static const int cg_max = env_int("OCRS_DW_CG", 4);  // channel groups (of 8) per block: 4 -> 8x4-pixel tiles, 2 -> 8x8, 1 -> 8x16
+    cg = C / 8 < cg_max ? C / 8 : cg_max;
     gy = C / (cg * 8);
     const Tiling2 tg = make_tiling2(N, H, W, 16 / cg, 8);
     gx = persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1);
