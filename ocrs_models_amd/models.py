@@ -109,6 +109,9 @@ class _DetRun:
         self.recs = {}
         self.fused = {}  # block prefix -> fp64 [2][C] BatchNorm-backward sums accumulated by its consumers' dw_bwd
         self.fuse_bn_bwd = os.environ.get("OCRS_FUSE_BN_BWD", "1") != "0"
+        # fused pointwise+depthwise backward kernel (csrc/det_blk.hip): correct (tests/test_det_ops_gpu.py) but, at 168 VGPRs with spills
+        # and 1.4x dgrad work, still slower than the two pipelined kernels it replaces (level 0: 1.30 vs 1.08 ms) -> opt-in for now
+        self.fuse_blk = os.environ.get("OCRS_FUSE_BLK", "0") == "1"
         self.x = x
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -274,14 +277,6 @@ class _DetRun:
         a, b = r.a, r.b
         Ca, Cb = a.C, (b.C if b is not None else 0)
         wpk_d = self.pack(wpw, 0, C, r.Cin, C, 0, r.Cin, 1)
-        du = self.empty(N, H, W, r.Cin)
-        ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
-        L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
-                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W,
-                 self.dt)
-        gxa = self.empty(N, H, W, Ca) if need_gx else None
-        gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
-        ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
 
         def stat_target(act):
             """(saved, gsum) of the block that produced `act` if this pass may produce its BatchNorm-backward sums."""
@@ -290,6 +285,25 @@ class _DetRun:
             if act.src not in self.fused:
                 self.fused[act.src] = self.zeros64(2 * act.C)
             return self.recs[act.src].saved, self.fused[act.src]
+        if self.fuse_blk and L.blk_bwd_supported(r.Cin, C, pooled, self.dt):
+            # top levels: pointwise + depthwise backward in ONE kernel (du never reaches HBM)
+            gxa = self.empty(N, H, W, Ca) if need_gx else None
+            gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
+            sva, gsa = stat_target(a)
+            svb, gsb = stat_target(b)
+            ws = self.empty(L.blk_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
+            L.blk_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
+                      ptr(g2), ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
+                      ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
+            return gxa, gxb
+        du = self.empty(N, H, W, r.Cin)
+        ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
+        L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
+                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W,
+                 self.dt)
+        gxa = self.empty(N, H, W, Ca) if need_gx else None
+        gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
+        ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
         sva, gsa = stat_target(a)
         svb, gsb = stat_target(b)
         L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),

@@ -29,7 +29,7 @@ def make_run(dev, dtype, N, P, Bf):
 
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
-    r.fused, r.fuse_bn_bwd = {}, True
+    r.fused, r.fuse_bn_bwd, r.fuse_blk = {}, True, False
     return r
 
 
@@ -168,6 +168,57 @@ def test_fused_bn_bwd_sums_match_reduce_pass(dev, dtype, C0, Ca, Cb, Cc):
     tol = 1e-5 if dtype == torch.float32 else 1e-3
     for k in P:
         assert rel(res[True][k], res[False][k]) < tol, k
+
+
+@pytest.mark.parametrize("C0,Ca,Cb,Cc", [(8, 8, 8, 8), (8, 8, 0, 16), (8, 16, 0, 8), (8, 16, 0, 16), (8, 8, 8, 16)])
+def test_fused_block_backward_kernel_matches_separate_kernels(dev, C0, Ca, Cb, Cc):
+    """ocrs_blk_bwd (pointwise + depthwise backward of a block in one kernel, du kept in LDS; opt-in) against the default
+    ocrs_pw_bwd + ocrs_dw_bwd pair on the same inputs: input gradients, all weight gradients and the producers' fused
+    BatchNorm-backward sums (through the producers' parameter gradients).  bf16: both paths round du differently (the fused kernel
+    keeps it in fp32) -> 2e-2 on gradients."""
+    from ocrs_models_amd.models import _Act
+
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5 + Ca + 3 * Cb + 7 * Cc)
+    N, H, W = 2, 21, 37
+
+    def mk(pfx, cin, cout, P, Bf):
+        P[f"{pfx}.seq.0.weight"] = (torch.randn(cin, 1, 3, 3, generator=g) / 3).to(dev)
+        P[f"{pfx}.seq.1.weight"] = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(dev)
+        P[f"{pfx}.seq.2.weight"] = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev)
+        P[f"{pfx}.seq.2.bias"] = (0.1 * torch.randn(cout, generator=g)).to(dev)
+        Bf[f"{pfx}.seq.2.running_mean"] = torch.zeros(cout, device=dev)
+        Bf[f"{pfx}.seq.2.running_var"] = torch.ones(cout, device=dev)
+        Bf[f"{pfx}.seq.2.num_batches_tracked"] = torch.zeros((), dtype=torch.int64, device=dev)
+
+    P, Bf = {}, {}
+    mk("A", C0, Ca, P, Bf)
+    if Cb:
+        mk("B", C0, Cb, P, Bf)
+    mk("C", Ca + Cb, Cc, P, Bf)
+    x0 = _Act(nhwc(torch.randn(N, C0, H, W, generator=g).to(dev), dtype), rand_tr(C0, dev, g), C0, H, W)
+    gy1 = nhwc(torch.randn(N, Cc, H, W, generator=g).to(dev), dtype)
+    gy2 = nhwc(torch.randn(N, Cc, H, W, generator=g).to(dev), dtype)
+    res = {}
+    for fuse in (True, False):
+        run = make_run(dev, dtype, N, P, {k: v.clone() for k, v in Bf.items()})
+        run.fuse_blk = fuse
+        a = run.block("A", x0, None, Ca)
+        b = run.block("B", x0, None, Cb) if Cb else None
+        run.block("C", a, b, Cc)
+        run.G = {k: torch.zeros_like(v) for k, v in P.items()}
+        gxa, gxb = run.block_bwd("C", gy1, gy2, 0)
+        out = {"gxa": gxa.float().clone()}
+        if Cb:
+            out["gxb"] = gxb.float().clone()
+        run.block_bwd("A", gxa, None, 0, need_gx=False)  # (A's own input gradient is not needed: also exercises the unfused tail)
+        if Cb:
+            run.block_bwd("B", gxb, None, 0, need_gx=False)
+        torch.cuda.synchronize()
+        out.update({k: v.clone() for k, v in run.G.items()})
+        res[fuse] = out
+    for k in res[True]:
+        assert rel(res[True][k], res[False][k]) < 2e-2, k
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
