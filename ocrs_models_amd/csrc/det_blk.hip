@@ -38,7 +38,7 @@ struct BlkCfg {
 };
 
 #ifndef OCRS_BLK_BLOCKS
-#define OCRS_BLK_BLOCKS 3
+#define OCRS_BLK_BLOCKS 2  // 3 blocks/CU (168 VGPRs) spills inside the tile loop: measured 1.1-3x slower
 #endif
 template <int CIN, int COUT, bool STATS>
 __global__ __launch_bounds__(256, OCRS_BLK_BLOCKS) void k_blk_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
