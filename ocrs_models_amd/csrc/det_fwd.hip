@@ -115,8 +115,8 @@ __device__ __forceinline__ void dw2_from_lds(const float* xs, const float* s_w /
 #ifndef OCRS_PIPE_BLOCKS
 #define OCRS_PIPE_BLOCKS 3
 #endif
-template <class T, int CG, int MT>
-__global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS : (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+template <class T, int CG, int MT, bool ONE /* Cin == CG*8: a single K chunk (always true for CG < 4) */>
+__global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS : (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                                     const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
                                                                     const void* __restrict__ wpk, T* __restrict__ z,
                                                                     double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg) {
@@ -144,13 +144,13 @@ __global__ __launch_bounds__(256, (CG < 4 && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCK
     __syncthreads();
     const HaloStager<T, CG, TW, TH> stager(tid, W);
 
-    const int nkc = CG < 4 ? 1 : CIN / (CG * 8);  // CG = min(CIN/8, 4): fewer than 4 groups means a single chunk
+    const int nkc = ONE ? 1 : CIN / (CG * 8);
     const int pgrp = tid / CG, cg = tid % CG;     // pixel (PX = 1) or pixel pair (PX = 2) of this thread
     const int ty = pgrp / (TW / PX), tx = (pgrp % (TW / PX)) * PX;
     const int pxl = ty * TW + tx;
 
     TileSched ts(tg.ntiles);
-    constexpr bool PIPE = CG < 4 && Elem<T>::is_bf16;  // single-chunk bf16 configs (levels 0-1): register-prefetch the next tile
+    constexpr bool PIPE = ONE && Elem<T>::is_bf16;  // single-chunk bf16 configs (Cin <= 32, levels 0-2): register-prefetch the next tile
     typename HaloStager<T, CG, TW, TH>::Pending pend;
     typename Mma<T>::Frag wfr[PIPE ? MT : 1];  // PIPE: pointwise weight fragments are tile-invariant -> registers (a global load inside
                                                 // the loop would make the compiler wait vmcnt(0), i.e. for the prefetch as well)
@@ -476,7 +476,7 @@ int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, 
 long ocrs_pack_frags_bytes(int K, int M, int dtype) { return (long)((K + 31) / 32) * ((M + 15) / 16) * 64 * 8 * (dtype == 1 ? 2 : 4); }
 
 }  // extern "C" (templates need C++ linkage)
-template <class T, int CG, int MT>
+template <class T, int CG, int MT, bool ONE>
 static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
                            double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
     using FT = FwdTile<CG, FwdPx<MT>::PX>;
@@ -491,7 +491,7 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);
     const int tpb = fwd_tpb > 0 ? fwd_tpb : (tg.ntiles >= 2048 ? 2 : 1);
     const int grid = persistent_grid(tg.ntiles / tpb > 0 ? tg.ntiles / tpb : 1, 8);
-    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
+    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT, ONE>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -505,9 +505,12 @@ static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, con
     const int CIN = Ca + Cb;
     const int cg = CIN >= 32 ? 4 : CIN / 8;
     const int mt = (COUT + 15) / 16;
-#define DWPW_CASE(CG_, MT_) \
-    if (cg == CG_ && mt == MT_) return launch_dwpw_fwd<T, CG_, MT_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
-    DWPW_CASE(1, 1) DWPW_CASE(2, 1) DWPW_CASE(2, 2) DWPW_CASE(4, 1) DWPW_CASE(4, 2) DWPW_CASE(4, 4) DWPW_CASE(4, 8) DWPW_CASE(4, 16)
+#define DWPW_CASE(CG_, MT_, ONE_) \
+    if (cg == CG_ && mt == MT_ && (CIN == CG_ * 8) == ONE_) \
+        return launch_dwpw_fwd<T, CG_, MT_, ONE_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
+    DWPW_CASE(1, 1, true) DWPW_CASE(2, 1, true) DWPW_CASE(2, 2, true)
+    DWPW_CASE(4, 1, true) DWPW_CASE(4, 2, true) DWPW_CASE(4, 4, true)  // Cin == 32: pipelined single-chunk variants
+    DWPW_CASE(4, 1, false) DWPW_CASE(4, 2, false) DWPW_CASE(4, 4, false) DWPW_CASE(4, 8, false) DWPW_CASE(4, 16, false)
 #undef DWPW_CASE
     return OCRS_ERR_ARG;
 }
