@@ -180,7 +180,7 @@ __device__ __forceinline__ void apply_tr8(float (&v)[8], const float* tr, int C,
 // transform parameters) is the same for every item and every tile; the halo coordinates (hy, hx) of each item are
 // tile-invariant too.  Per item this leaves: 2 adds + 2 unsigned compares (bounds), one 24-bit multiply + one 64-bit add
 // (address), the load, the transform and two LDS stores -- ~40 VALU instructions instead of ~130 (the index decode, the
-// 64-bit pixel arithmetic and the parameter addressing of stage_halo were ~2/3 of the forward kernel's VALU work).
+// 64-bit pixel arithmetic and the parameter addressing of the first, per-item version were ~2/3 of the forward kernel's VALU work).
 // s_tr8: transform parameters interleaved per 8-channel group: [CIN/8][3][8] (scale | shift | lo) -> 6 aligned ds_read_b128.
 template <class T>
 __device__ __forceinline__ void fill_tr8(float* s_tr8, const Src2<T>& x, const float* __restrict__ tra, const float* __restrict__ trb, int CIN,

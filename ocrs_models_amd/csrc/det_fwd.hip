@@ -58,7 +58,7 @@ __global__ void k_pack_frags_multi(const long long* __restrict__ table) {
 
 // ----------------------------------------------------------------------------------------------
 // fused depthwise+pointwise forward.
-//   CG  = channel groups (of 8) per K-chunk = min(CIN,32)/8   -> tile = TP = 256/CG pixels, one (pixel, group) per thread
+//   CG  = channel groups (of 8) per K-chunk = min(CIN,32)/8   -> tile = TP = PX*256/CG pixels, PX pixels x one group per thread
 //   MT  = ceil(COUT/16) output-channel tiles, every wave computes all MT tiles for its 16*PTW pixels
 // D[cout][pixel] = sum_cin Wpw[cout][cin] * u[pixel][cin],  u = dw3x3(x~)   (channels = MFMA M, pixels = MFMA N)
 // so each lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
@@ -70,7 +70,7 @@ __global__ void k_pack_frags_multi(const long long* __restrict__ table) {
 template <int CG, int PX>
 struct FwdTile {
     static constexpr int TP = PX * 256 / CG;
-    static constexpr int TW = (PX == 2 && CG == 4) ? 16 : (PX == 2 ? 32 / CG : 32 / CG);
+    static constexpr int TW = (PX == 2 && CG == 4) ? 16 : 32 / CG;
     static constexpr int TH = TP / TW;
 };
 template <int MT>
