@@ -109,6 +109,10 @@ int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* l
 int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st);
 /* weight gradients of Conv2d / Linear / GRU (autograd of the calls above). */
+/* Split-bf16 (bf16x3) weight-gradient GEMM for fp32 operands: dW [CA][CB] += A^T B over P rows (throughput mode of the GRU / Linear
+ * weight gradients, train_rec.py:140 backward of models.py:264-268); <= ~1.1e-5 relative error per product, fp32 accumulation. */
+long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P);
+int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st);
 long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
 int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,
                       int wA, int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);

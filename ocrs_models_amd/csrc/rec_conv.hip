@@ -1033,6 +1033,114 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     return OCRS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") weight-gradient GEMM for fp32 operands:  dW[ra][cb] += sum_p A[p][ra] * B[p][cb]   (K = P rows).
+// The GRU / Linear weight gradients of the CRNN are fp32 (the reference keeps the GRU in fp32 under autocast, models.py:264-266) and
+// were the largest item of the CRNN step on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 is 1/16 of the bf16 rate).  In THROUGHPUT mode
+// they run here as  a*b ~ ah*bh + ah*bl + al*bh  with  ah = bf16(a), al = bf16(a - ah)  (dropped term and residuals <= ~1.1e-5 relative
+// per product, fp32 accumulation: the same order as the summation-order noise of an fp32 dot product of K = 25856 terms); parity
+// (fp32) mode keeps the exact-fp32 kernel.  Operands are staged in natural [row][channel] order as hi / lo bf16 planes and read with
+// the LDS transpose read (K = rows).  Block = 128 x 128 outputs, a contiguous range of 32-row chunks; partials -> workspace in the
+// layout of k_wgrad_gather_reduce (ntaps = 1).
+__global__ __launch_bounds__(256) void k_wgrad_gemm_x3(const float* __restrict__ A, int ldA, int CA, const float* __restrict__ B, int ldB, int CB, long P,
+                                                       float* __restrict__ ws, int tiles_a, int chunks_per_block) {
+    constexpr int BM = 128, BN = 128, KC = 32, PA = BM + 8;  // pitch (elements) of the bf16 planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ah = reinterpret_cast<bf16*>(smem);  // [KC][PA]
+    bf16* Al = Ah + KC * PA;
+    bf16* Bh = Al + KC * PA;
+    bf16* Bl = Bh + KC * PA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ta = blockIdx.y % tiles_a, tb = blockIdx.y / tiles_a;
+    const int a0 = ta * BM, b0 = tb * BN;
+    const long nchunks = (P + KC - 1) / KC;
+    const long c_first = (long)blockIdx.x * chunks_per_block, c_end = c_first + chunks_per_block < nchunks ? c_first + chunks_per_block : nchunks;
+    // staging map: 4 float4 of A and 4 of B per thread and chunk: f = tid + 256*j -> row f/32, columns (f%32)*4..+3
+    float4 ra[4], rb[4];
+    auto issue = [&](long c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + j * 256, row = f >> 5, col = (f & 31) * 4;
+            const long p = c * KC + row;
+            const bool oka = p < P && a0 + col < CA, okb = p < P && b0 + col < CB;  // CA, CB multiples of 4 (checked by the host)
+            ra[j] = oka ? *reinterpret_cast<const float4*>(A + p * ldA + a0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = okb ? *reinterpret_cast<const float4*>(B + p * ldB + b0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto split_store = [&](const float4& v, bf16* hi, bf16* lo, int off) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        float h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = Elem<bf16>::round(x[i]);
+            l[i] = x[i] - h[i];
+        }
+        *reinterpret_cast<uint2*>(hi + off) = make_uint2(pack2bf(h[0], h[1]), pack2bf(h[2], h[3]));
+        *reinterpret_cast<uint2*>(lo + off) = make_uint2(pack2bf(l[0], l[1]), pack2bf(l[2], l[3]));
+    };
+    const int wm = wave & 1, wn = wave >> 1;  // 2 x 2 waves, each 4 x 4 MFMA tiles of 16 x 16
+    const int prow = 4 * (lane >> 4) + ((lane & 15) >> 2), pcol = (lane & 3) * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c_first < c_end) issue(c_first);
+    for (long c = c_first; c < c_end; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + j * 256, off = (f >> 5) * PA + (f & 31) * 4;
+            split_store(ra[j], Ah, Al, off);
+            split_store(rb[j], Bh, Bl, off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < c_end) issue(c + 1);
+        lds_barrier();
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = prow * PA + (wm * 4 + i) * 16 + pcol;
+            ah[i] = lds_tr8(Ah + o, Ah + o + 16 * PA);
+            al[i] = lds_tr8(Al + o, Al + o + 16 * PA);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = prow * PA + (wn * 4 + j) * 16 + pcol;
+            const bf16x8 bh = lds_tr8(Bh + o, Bh + o + 16 * PA), bl = lds_tr8(Bl + o, Bl + o + 16 * PA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            }
+        }
+        lds_barrier();
+    }
+    // partial -> ws[blockIdx.x][cb][ra] (CA8-padded rows), 4 consecutive ra per lane
+    const int CA8 = (CA + 7) & ~7;
+    float* wb = ws + (long)blockIdx.x * CB * CA8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r0 = a0 + (wm * 4 + i) * 16 + (lane >> 4) * 4, cb = b0 + (wn * 4 + j) * 16 + (lane & 15);
+            if (r0 < CA8 && cb < CB) {
+                const f32x4 v = acc[i][j];
+                *reinterpret_cast<float4*>(wb + (long)cb * CA8 + r0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+static void wgrad_x3_grid(int CA, int CB, long P, int& gx, int& gy, int& tiles_a, int& cpb) {
+    tiles_a = (CA + 127) / 128;
+    gy = tiles_a * ((CB + 127) / 128);
+    const long nchunks = (P + 31) / 32;
+    long g = 512 / gy;
+    if (g < 1) g = 1;
+    if (g > nchunks) g = nchunks;
+    cpb = (int)((nchunks + g - 1) / g);
+    gx = (int)((nchunks + cpb - 1) / cpb);
+}
+
 static int wgrad3x3_gx(int Cin, int N, int H, int W) {
     const int ntiles = N * ((W + 15) / 16) * ((H + 7) / 8);
     const int gy = Cin / 32;
@@ -1054,6 +1162,27 @@ __global__ __launch_bounds__(256) void k_wgrad3x3_reduce(const float* __restrict
         const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((long)Cout * Cin));
         dW[((long)co * Cin + ci) * 9 + tap] += s;
     }
+}
+
+// Split-bf16 weight-gradient GEMM for fp32 operands (throughput mode of the GRU / Linear weight gradients):
+//   dW [CA][CB] += A^T B,  A [P][ldA] (first CA columns), B [P][ldB] (first CB columns), CA, CB, ldA, ldB multiples of 4.
+//   ws: ocrs_wgrad_gemm_x3_ws_floats() floats.  Products carry <= ~1.1e-5 relative error (see k_wgrad_gemm_x3), fp32 accumulation.
+long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P) {
+    int gx, gy, ta, cpb;
+    wgrad_x3_grid(CA, CB, P, gx, gy, ta, cpb);
+    return (long)gx * CB * ((CA + 7) & ~7);
+}
+int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st) {
+    OCRS_CHECK_ARG(A && B && dW && ws && P > 0 && CA % 4 == 0 && CB % 4 == 0 && ldA % 4 == 0 && ldB % 4 == 0 && ldA >= CA && ldB >= CB);
+    OCRS_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    int gx, gy, ta, cpb;
+    wgrad_x3_grid(CA, CB, P, gx, gy, ta, cpb);
+    hipLaunchKernelGGL(k_wgrad_gemm_x3, dim3(gx, gy), dim3(256), 4 * 32 * 136 * 2, st, A, ldA, CA, B, ldB, CB, P, ws, ta, cpb);
+    const int CA8 = (CA + 7) & ~7;
+    const long n = (long)CB * CA8;
+    hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, ws, gx, CA, CA8, CB, 1, dW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
 }
 
 // workspace (floats) for the atomic-free flush of ocrs_conv3x3_wgrad

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -41,6 +43,7 @@ class _RecRun:
         self.dev = x.device
         self.dtype = dtype
         self.dt = _DT[self.dtype]
+        self.x3 = os.environ.get("OCRS_GRU_X3", "1") != "0"  # split-bf16 GEMMs for the fp32 GRU weight gradients in throughput mode
         self.x = x
         self.N, _, self.H, self.W = x.shape
         self.ncls = self.P["output.0.weight"].shape[0]
@@ -174,9 +177,16 @@ class _RecRun:
     def wgrad(self, A, ldA, CA, B, ldB, CB, dW, N, hA, wA, HB, WB, padh, padw, KH, KW, dt):
         """dW += A^T (gathered) B with the deterministic two-stage flush (workspace from the caching allocator)."""
         L = self.L
-        ws = self.empty(L.wgrad_gather_ws_floats(CA, CB, KH * KW, N * hA * wA, dt), dtype=torch.float32)
         a_ptr = A if isinstance(A, int) else ptr(A)
         b_ptr = B if isinstance(B, int) else ptr(B)
+        if dt == 0 and self.dt == 1 and self.x3 and KH * KW == 1 and CA % 4 == 0 and CB % 4 == 0 and ldA % 4 == 0 and ldB % 4 == 0:
+            # throughput (autocast) mode: the fp32 GRU weight gradients as split-bf16 (bf16x3) GEMMs -- ~1e-5 relative per product, fp32
+            # accumulation; parity mode (self.dt == 0) keeps the exact-fp32 MFMA kernel
+            P = N * hA * wA
+            ws = self.empty(L.wgrad_gemm_x3_ws_floats(CA, CB, P), dtype=torch.float32)
+            L.wgrad_gemm_x3(a_ptr, ldA, CA, b_ptr, ldB, CB, ptr(dW), ptr(ws), P)
+            return
+        ws = self.empty(L.wgrad_gather_ws_floats(CA, CB, KH * KW, N * hA * wA, dt), dtype=torch.float32)
         L.wgrad_gather(a_ptr, ldA, CA, None, b_ptr, ldB, CB, ptr(dW), ptr(ws), N, hA, wA, HB, WB, 1, padh, padw, KH, KW, dt)
 
     def bn_pool_bwd(self, prefix, g, z, tr, saved, C, H, W, PH, PW):

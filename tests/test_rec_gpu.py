@@ -262,3 +262,30 @@ def test_recognition_eval_mode(dev):
         lp = m(x.to(dev))
     assert lp.shape == (26, 3, 97)
     assert rel(lp, lp_o) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,CA,ldA,CB,ldB", [(25856, 1536, 1536, 256, 256), (4001, 768, 1536, 256, 512), (77, 100, 128, 36, 40)])
+def test_split_bf16_wgrad_gemm(dev, P, CA, ldA, CB, ldB):
+    """ocrs_wgrad_gemm_x3 (bf16x3 emulation of the fp32 GRU weight-gradient GEMMs, throughput mode only) against a float64 matmul:
+    products carry <= ~1.1e-5 relative error, fp32 accumulation -> the result must be within 5e-5 of the exact one relative to
+    ||A||.||B|| (column-wise), i.e. fp32-GEMM class; also checks accumulation into dW and ragged sizes / leading dimensions."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    g = torch.Generator().manual_seed(P % 97 + CA)
+    A = torch.randn(P, ldA, generator=g).to(dev)
+    B = torch.randn(P, ldB, generator=g).to(dev)
+    dW0 = torch.randn(CA, CB, generator=g).to(dev)
+    dW = dW0.clone()
+    ws = torch.empty(L.wgrad_gemm_x3_ws_floats(CA, CB, P), dtype=torch.float32, device=dev)
+    L.wgrad_gemm_x3(ptr(A), ldA, CA, ptr(B), ldB, CB, ptr(dW), ptr(ws), P)
+    torch.cuda.synchronize()
+    ref = dW0.double() + A[:, :CA].double().T @ B[:, :CB].double()
+    scale = A[:, :CA].double().norm(dim=0)[:, None] * B[:, :CB].double().norm(dim=0)[None, :]
+    err = ((dW.double() - ref).abs() / scale).max().item()
+    assert err < 5e-5, err
+    # and it is at least as good as ~1e-4 x the bf16-operand GEMM would be (sanity: not accidentally single-bf16)
+    bf = A[:, :CA].bfloat16().float().T @ B[:, :CB].bfloat16().float()
+    err_bf = (((dW0 + bf).double() - ref).abs() / scale).max().item()
+    assert err < 0.05 * err_bf, (err, err_bf)
