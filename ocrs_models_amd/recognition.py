@@ -179,10 +179,18 @@ class _RecRun:
         L = self.L
         a_ptr = A if isinstance(A, int) else ptr(A)
         b_ptr = B if isinstance(B, int) else ptr(B)
-        if dt == 0 and self.dt == 1 and self.x3 and KH * KW == 1 and CA % 4 == 0 and CB % 4 == 0 and ldA % 4 == 0 and ldB % 4 == 0:
+        if (dt == 0 and self.dt == 1 and self.x3 and KH * KW == 1 and padw == 0 and N == 1 and (hA, wA) == (HB, WB) and CA % 4 == 0
+                and CB % 4 == 0 and ldA % 4 == 0 and ldB % 4 == 0):
             # throughput (autocast) mode: the fp32 GRU weight gradients as split-bf16 (bf16x3) GEMMs -- ~1e-5 relative per product, fp32
-            # accumulation; parity mode (self.dt == 0) keeps the exact-fp32 MFMA kernel
-            P = N * hA * wA
+            # accumulation; parity mode (self.dt == 0) keeps the exact-fp32 MFMA kernel.
+            # A row (t, n) pairs with B row (t - padh, n) (the h_{t-1} / h_{t+1} operand of the recurrent weights): a plain GEMM over the
+            # overlapping rows after shifting one of the two base pointers by |padh| * wA rows.
+            shift = padh * wA
+            P = hA * wA - abs(shift)
+            if shift > 0:
+                a_ptr += 4 * shift * ldA
+            elif shift < 0:
+                b_ptr += 4 * (-shift) * ldB
             ws = self.empty(L.wgrad_gemm_x3_ws_floats(CA, CB, P), dtype=torch.float32)
             L.wgrad_gemm_x3(a_ptr, ldA, CA, b_ptr, ldB, CB, ptr(dW), ptr(ws), P)
             return

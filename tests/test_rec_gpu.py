@@ -244,6 +244,11 @@ def test_recognition_bf16_autocast_mode(dev):
         errs.append(compare_to_golden(G, f"rec1/f32/grad/{k}", p.grad, 0, atol=1e-7))
         floors.append(golden_vs_golden(G, f"rec1/bf16/grad/{k}", f"rec1/f32/grad/{k}"))
     assert float(np.median(errs)) < 1.5 * float(np.median(floors)) + 1e-2, (float(np.median(errs)), float(np.median(floors)))
+    # the fp32 part of the net (GRU, Linear: exact-fp32 or split-bf16 GEMMs) must hold PER TENSOR, not only in the median: their error is
+    # what the bf16 conv stack feeds them, i.e. bounded by the reference's own bf16-vs-fp32 difference for that tensor
+    for (k, _), e_k, f_k in zip(m.named_parameters(), errs, floors):
+        if k.startswith(("gru.", "output.")):
+            assert e_k < 2.0 * f_k + 2e-2, (k, e_k, f_k)
 
 
 def test_recognition_eval_mode(dev):
