@@ -31,6 +31,19 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
 
 
+# ABI argument names the byte model below reads, per kernel family (tests/test_abi.py checks them against include/ocrs_hip.h so that an
+# ABI change cannot silently corrupt the roofline figure)
+ALG_BYTES_ARGS = {
+    "dwpw_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout", "pooled", "g2"),
+    "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
+    "bn_bwd_reduce": ("N", "H", "W", "C", "pooled", "g2"),
+    "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
+    "convt_bwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
+    "maxpool_fwd": ("N", "H", "W", "C"),
+}
+
+
 def alg_bytes(name, a, sz):
     """Algorithmic HBM bytes of one launch of a kernel family, from its C-ABI arguments (looked up BY NAME in include/ocrs_hip.h).
 

@@ -46,3 +46,20 @@ def test_state_dict_contract_matches_reference_keys():
 
     sd = oa.DetectionModel().state_dict()
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(n, s) for n, s, _ in detection_specs()]
+
+
+def test_bench_byte_model_reads_existing_abi_arguments():
+    """bench.py's roofline byte model looks C-ABI call arguments up by name: every name it uses must exist in the header's signature
+    of that entry point (an ABI change once shifted positional indices and silently corrupted roofline.achieved)."""
+    import bench
+    from ocrs_models_amd._lib import ARG_NAMES
+
+    assert set(bench.ALG_BYTES_ARGS) == set(bench.FAMILIES)
+    for fam, names in bench.ALG_BYTES_ARGS.items():
+        have = ARG_NAMES["ocrs_" + fam]
+        for n in names:
+            assert n in have, (fam, n, have)
+    # and the model returns a positive number for a plausible call of each family
+    for fam in bench.FAMILIES:
+        args = [8 if n in ("Ca", "Cb", "C", "Cout", "Cup") else (64 if n in ("H", "W", "h", "w") else (2 if n == "N" else 0)) for n in ARG_NAMES["ocrs_" + fam]]
+        assert bench.alg_bytes(fam, args, 2) > 0, fam
