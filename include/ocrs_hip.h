@@ -113,6 +113,10 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
  * weight gradients, train_rec.py:140 backward of models.py:264-268); <= ~1.1e-5 relative error per product, fp32 accumulation. */
 long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P);
 int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st);
+/* Split-bf16 GEMM for fp32 operands (GRU input projections and their input gradients in throughput mode, models.py:264-266):
+ * out [P][ldo] = X [P][ldx] (K columns) * W (+ bias), W[m][k] = Wm[m * ldw + k] (km = 0) or Wm[k * ldw + m] (km = 1). */
+int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P,
+                 hipStream_t st);
 long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
 int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,
                       int wA, int HB, int WB, int stride, int padh, int padw, int KH, int KW, int dtype, hipStream_t st);

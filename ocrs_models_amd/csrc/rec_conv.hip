@@ -957,6 +957,121 @@ static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int 
     return OCRS_OK;
 }
 
+// Split-bf16 GEMM for fp32 operands (the GRU input projections gi = x W_ih^T + b and their input gradients dx = dgi W_ih, throughput mode):
+//   out[p][m] = sum_k X[p][k] * W(m, k) (+ bias[m]),   W(m, k) = KM ? Wm[k * ldw + m] : Wm[m * ldw + k]   (master layout, no packing).
+// Same a*b ~ ah*bh + ah*bl + al*bh arithmetic as k_wgrad_gemm_x3.  Block = 128 pixels x 128 outputs, K in chunks of 32 staged as hi / lo
+// bf16 planes; the pixel operand and the [m][k] weight operand are direct ds_read_b128 fragments, the [k][m] weight operand comes
+// through the LDS transpose read.  Next chunk register-prefetched.
+template <bool KM>
+__global__ __launch_bounds__(256) void k_gemm_x3(const float* __restrict__ X, int ldx, const float* __restrict__ Wm, int ldw, const float* __restrict__ bias,
+                                                 float* __restrict__ out, int ldo, int K, int M, long P) {
+    constexpr int BP = 128, BM = 128, KC = 32, PK = KC + 8, PM = BM + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Xh = reinterpret_cast<bf16*>(smem);  // [BP][PK]
+    bf16* Xl = Xh + BP * PK;
+    bf16* Wh = Xl + BP * PK;                   // KM ? [KC][PM] : [BM][PK]
+    bf16* Wl = Wh + (KM ? KC * PM : BM * PK);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long p0 = (long)blockIdx.x * BP;
+    const int m0 = blockIdx.y * BM;
+    float4 rx[4], rw[4];
+    auto issue = [&](int kc) {
+        const int k0 = kc * KC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + j * 256;
+            {
+                const int px = f >> 3, k4 = (f & 7) * 4;
+                rx[j] = p0 + px < P ? *reinterpret_cast<const float4*>(X + (p0 + px) * ldx + k0 + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (KM) {
+                const int k = f >> 5, m4 = (f & 31) * 4;
+                rw[j] = m0 + m4 < M ? *reinterpret_cast<const float4*>(Wm + (long)(k0 + k) * ldw + m0 + m4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int m = f >> 3, k4 = (f & 7) * 4;
+                rw[j] = m0 + m < M ? *reinterpret_cast<const float4*>(Wm + (long)(m0 + m) * ldw + k0 + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto split_store = [&](const float4& v, bf16* hi, bf16* lo, int off) {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        float h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = Elem<bf16>::round(x[i]);
+            l[i] = x[i] - h[i];
+        }
+        *reinterpret_cast<uint2*>(hi + off) = make_uint2(pack2bf(h[0], h[1]), pack2bf(h[2], h[3]));
+        *reinterpret_cast<uint2*>(lo + off) = make_uint2(pack2bf(l[0], l[1]), pack2bf(l[2], l[3]));
+    };
+    const int wm = wave & 1, wn = wave >> 1;  // 2 x 2 waves: 4 m-tiles x 4 pixel-tiles each
+    const int i16 = lane & 15, kg = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nkc = K / KC;
+    issue(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + j * 256;
+            split_store(rx[j], Xh, Xl, (f >> 3) * PK + (f & 7) * 4);
+            if (KM)
+                split_store(rw[j], Wh, Wl, (f >> 5) * PM + (f & 31) * 4);
+            else
+                split_store(rw[j], Wh, Wl, (f >> 3) * PK + (f & 7) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nkc) issue(kc + 1);
+        lds_barrier();
+        bf16x8 wh[4], wl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (KM) {
+                // K order must match the pixel operand's direct reads (lane group kg holds k = 8kg .. 8kg+7): rows 8kg + 0..3, then + 4..7
+                const int o = (8 * kg + (i16 >> 2)) * PM + (wm * 4 + i) * 16 + (i16 & 3) * 4;
+                wh[i] = lds_tr8(Wh + o, Wh + o + 4 * PM);
+                wl[i] = lds_tr8(Wl + o, Wl + o + 4 * PM);
+            } else {
+                const int o = ((wm * 4 + i) * 16 + i16) * PK + kg * 8;
+                wh[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wh + o));
+                wl[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Wl + o));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = ((wn * 4 + j) * 16 + i16) * PK + kg * 8;
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + o));
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xl + o));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh, acc[i][j], 0, 0, 0);
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (wm * 4 + i) * 16 + kg * 4;
+        if (m >= M) continue;
+        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bs = *reinterpret_cast<const float4*>(bias + m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long p = p0 + (wn * 4 + j) * 16 + i16;
+            if (p < P) {
+                const f32x4 v = acc[i][j];
+                *reinterpret_cast<float4*>(out + p * ldo + m) = make_float4(v[0] + bs.x, v[1] + bs.y, v[2] + bs.z, v[3] + bs.w);
+            }
+        }
+    }
+}
+
+
 extern "C" {
 
 // Implicit-GEMM convolution / GEMM:  out[n][ho][wo][m] = sum_{ky,kx,c} W[m][(ky,kx,c)] * x[n][ho+ky-padh][wo+kx-padw][c]  (+bias, ReLU)
@@ -1181,6 +1296,21 @@ int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB,
     const int CA8 = (CA + 7) & ~7;
     const long n = (long)CB * CA8;
     hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, ws, gx, CA, CA8, CB, 1, dW);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Split-bf16 GEMM for fp32 operands: out [P][ldo] (first M columns) = X [P][ldx] (first K columns) * W (+ bias [M]);
+//   km = 0: W[m][k] at Wm[m * ldw + k];  km = 1: W[k][m] at Wm[k * ldw + m].   K % 32 == 0, M % 4 == 0, 16-byte aligned rows.
+int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P,
+                 hipStream_t st) {
+    OCRS_CHECK_ARG(X && Wm && out && P > 0 && K > 0 && K % 32 == 0 && M % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && ldx >= K && ldo >= M);
+    OCRS_CHECK_ARG(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wm) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
+    const dim3 grid((unsigned)((P + 127) / 128), (unsigned)((M + 127) / 128));
+    if (km)
+        hipLaunchKernelGGL(k_gemm_x3<true>, grid, dim3(256), (2 * 128 * 40 + 2 * 32 * 136) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P);
+    else
+        hipLaunchKernelGGL(k_gemm_x3<false>, grid, dim3(256), (4 * 128 * 40) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

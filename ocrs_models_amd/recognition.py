@@ -90,6 +90,15 @@ class _RecRun:
                           kh, kw, pad, pad, self.dt)
         return out, gstat
 
+    def gemm_x3(self, x, ldx, K, w, ldw, km, bias, M, ldo, rows):
+        """Throughput-mode fp32 GEMM as split-bf16 (see csrc/rec_conv.hip::k_gemm_x3): W straight from the master layout."""
+        out = self.empty(rows, ldo, dtype=torch.float32)
+        self.L.gemm_x3(ptr(x), ldx, K, ptr(w), ldw, km, ptr(bias), ptr(out), ldo, M, rows)
+        return out
+
+    def use_x3(self, K, M):
+        return self.dt == 1 and self.x3 and K % 32 == 0 and M % 4 == 0
+
     def gemm(self, x, ldx, K, wpk, bias, M, ldo, rows):
         """fp32 GEMM: out[rows][ldo] = x[rows][K] @ W^T (+bias), W given as packed fragments (K, M)."""
         out = self.empty(rows, ldo, dtype=torch.float32)
@@ -138,7 +147,10 @@ class _RecRun:
             b_ih = torch.cat([P["gru.bias_ih" + s] for s in sfx], 0)
             b_hh = torch.cat([P["gru.bias_hh" + s] for s in sfx], 0)
             w_hh = torch.stack([P["gru.weight_hh" + s] for s in sfx], 0).contiguous()  # (2, 768, 256)
-            gi = self.gemm(xin, I, I, self.pack(w_ih, I, 1536, I, 0, 1, I, dt=0), b_ih, 1536, 1536, rows)
+            if self.use_x3(I, 1536):
+                gi = self.gemm_x3(xin, I, I, w_ih, I, 0, b_ih, 1536, 1536, rows)  # W_ih [1536][I]
+            else:
+                gi = self.gemm(xin, I, I, self.pack(w_ih, I, 1536, I, 0, 1, I, dt=0), b_ih, 1536, 1536, rows)
             nfl = 8 * 48 * 64 * 8
             whh_pk = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
             for d in (0, 1):
@@ -269,7 +281,10 @@ class _RecRun:
                            T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
             L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
             L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
-            dout = self.gemm(dgi, 1536, 1536, self.pack(gl["w_ih"], 1536, I, 1536, 0, I, 1, dt=0), None, I, I, rows)
+            if self.use_x3(1536, I):
+                dout = self.gemm_x3(dgi, 1536, 1536, gl["w_ih"], I, 1, None, I, I, rows)  # dx = dgi W_ih: W(m, k) = W_ih[k][m]
+            else:
+                dout = self.gemm(dgi, 1536, 1536, self.pack(gl["w_ih"], 1536, I, 1536, 0, I, 1, dt=0), None, I, I, rows)
             stage_done(f"gru.bias_hh_l{layer}")
         dseq = dout  # [T][N][128] fp32
         # ---- conv.20 (BN, no ReLU) + AvgPool ----

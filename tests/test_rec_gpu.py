@@ -294,3 +294,26 @@ def test_split_bf16_wgrad_gemm(dev, P, CA, ldA, CB, ldB):
     bf = A[:, :CA].bfloat16().float().T @ B[:, :CB].bfloat16().float()
     err_bf = (((dW0 + bf).double() - ref).abs() / scale).max().item()
     assert err < 0.05 * err_bf, (err, err_bf)
+
+
+@pytest.mark.parametrize("P,K,M,km", [(25856, 128, 1536, 0), (3000, 512, 1536, 0), (25856, 1536, 128, 1), (777, 1536, 512, 1), (130, 64, 36, 0)])
+def test_split_bf16_gemm(dev, P, K, M, km):
+    """ocrs_gemm_x3 (bf16x3 emulation of the fp32 GRU projection / input-gradient GEMMs, throughput mode only) against float64:
+    within 5e-5 of the exact result relative to ||x_row||.||w_col||, both weight layouts, bias, ragged P and M."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    g = torch.Generator().manual_seed(P + K + M)
+    X = torch.randn(P, K, generator=g).to(dev)
+    W = (torch.randn(K, M, generator=g) if km else torch.randn(M, K, generator=g)).to(dev)
+    bias = torch.randn(M, generator=g).to(dev)
+    ldo = M + 4
+    out = torch.full((P, ldo), 7.0, device=dev)
+    L.gemm_x3(ptr(X), K, K, ptr(W), M if km else K, km, ptr(bias), ptr(out), ldo, M, P)
+    torch.cuda.synchronize()
+    Wkm = W.double() if km else W.double().T
+    ref = X.double() @ Wkm + bias.double()
+    scale = X.double().norm(dim=1)[:, None] * Wkm.norm(dim=0)[None, :]
+    err = ((out[:, :M].double() - ref).abs() / scale).max().item()
+    assert err < 5e-5, err
+    assert float((out[:, M:] - 7.0).abs().max()) == 0.0  # columns beyond M untouched
