@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 // k_bn_bwd_reduce pass over (g, z) -- 2.1 ms of the step -- disappears.  Partials go to workspace rows 9..10 (stat_mask bit 0 / 1 =
 // source a / b wants them); k_dw_partials_reduce scales by rstd and adds them to the producers' gsum [2][C] (fp64).
 #ifndef OCRS_DW_BLOCKS
-#define OCRS_DW_BLOCKS 3
+#define OCRS_DW_BLOCKS 2  // two pixels per thread need ~200 VGPRs: 3 blocks/CU spills inside the tile loop (measured 1.5x slower), 2 wins
 #endif
 template <class T, int CG, bool STATS>
 __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
@@ -616,12 +616,15 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
                                                 float* __restrict__ ws /*[gridDim.x][C][9 (+2)] block partials or null*/,
                                                 const float* __restrict__ saved_a, const float* __restrict__ saved_b, int stat_mask, Tiling2 tg) {
-    // slab of SC = CG*8 channels per block (grid.y); 4 channels per thread -> 36 dW accumulators; tile 8 x (16/CG) pixels
-    constexpr int TH = 8, TW = 16 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
+    // slab of SC = CG*8 channels per block (grid.y); a thread owns 4 channels (36 dW accumulators) of TWO horizontally adjacent pixels:
+    // the pair shares 6 of its 9 du taps and all weights (12 + 9 LDS vector reads instead of 36), and the tile doubles to
+    // 8 x (32/CG) pixels (halo re-read 1.33-1.56x instead of 1.4-1.875x, per-tile bookkeeping amortised over twice the pixels)
+    constexpr int TH = 8, TW = 32 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
     constexpr int NIT = (HP * CG + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     float* ds = s_mem;           // [HP][SC] du tile + halo (fp32, 0 outside the image)
     float* s_w = ds + HP * SC;   // [9][SC] weights, tap-major
+    float* s_mu = s_w + 9 * SC;  // [SC] saved mean of the producer(s) (STATS)
     const int C = x.Ca + x.Cb;
     const int H = tg.H, W = tg.W;
     const int cb = blockIdx.y * SC;
@@ -630,8 +633,14 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         const int t = i / SC, c = i - t * SC;
         s_w[i] = wdw[(cb + c) * 9 + t];
     }
-    const int pxl = tid / CQ, q = tid % CQ;
-    const int ty = pxl / TW, tx = pxl % TW;
+    if (STATS)
+        for (int c = tid; c < SC; c += 256) {
+            const int cc = cb + c;
+            const bool ia = cc < x.Ca, on = ia ? (stat_mask & 1) : (stat_mask & 2);
+            s_mu[c] = on ? (ia ? saved_a[cc] : saved_b[cc - x.Ca]) : 0.f;
+        }
+    const int ppair = tid / CQ, q = tid % CQ;
+    const int ty = ppair / (TW / 2), tx = (ppair % (TW / 2)) * 2;  // left pixel of the pair
     const int c0 = cb + q * 4;
     float acc[9][4], sc[4], sh[4], lo[4];
 #pragma unroll
@@ -649,17 +658,13 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     const T* xsrc = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
     T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
     const int xp = in_a ? x.Ca : x.Cb;
-    float mu[STATS ? 4 : 1], st1[STATS ? 4 : 1], st2[STATS ? 4 : 1];
+    float st1[STATS ? 4 : 1], st2[STATS ? 4 : 1];
     if constexpr (STATS) {
-        const bool on = in_a ? (stat_mask & 1) : (stat_mask & 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mu[i] = on ? (in_a ? saved_a[c0 + i] : saved_b[c0 - x.Ca + i]) : 0.f;
-            st1[i] = st2[i] = 0.f;
-        }
+        for (int i = 0; i < 4; ++i) st1[i] = st2[i] = 0.f;
     }
 
-    // Software pipeline: the raw du halo vectors AND this thread's x quad of the NEXT tile are in flight while the current tile is
+    // Software pipeline: the raw du halo vectors AND this thread's two x quads of the NEXT tile are in flight while the current tile is
     // computed.  Loads are unconditional (invalid items read element 0 and are zeroed at use: a load under a divergent branch makes
     // hipcc put vmcnt(0) in front of the next load) and the barriers order LDS only (__syncthreads() would drain the prefetch).
     // Tile-invariant per-thread halo coordinates / offsets are hoisted.
@@ -671,11 +676,11 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         hyx[j] = hy | (hx << 16);
         poff[j] = (hy * W + hx) * C + cb + g8 * 8;  // element offset from the halo's corner pixel (fits 32 bits: <= 10 rows)
     }
-    const int xoff = (ty * W + tx) * xp;  // this thread's pixel, relative to the tile origin
+    const int xoff = (ty * W + tx) * xp;  // this thread's left pixel, relative to the tile origin
     struct Pre {
         Raw8<T> du[NIT];
-        Raw4<T> x;
-        unsigned ok;  // bit j: du item j inside the image; bit 31: this thread's pixel inside the image
+        Raw4<T> x[2];
+        unsigned ok;  // bit j: du item j inside the image; bits 30 / 31: left / right pixel inside the image
     };
     auto issue = [&](Pre& pr, const TileOrg& o) {
         const long corner = ((long)o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);
@@ -688,10 +693,11 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
             pr.du[j] = load8_raw(ok ? dub + poff[j] : du);
             pr.ok |= ok ? 1u << j : 0u;
         }
-        const bool valid = o.h0 + ty < H && o.w0 + tx < W;
-        const long org_pix = ((long)o.n * H + o.h0) * W + o.w0;
-        pr.x = load4_raw(valid ? xsrc + org_pix * xp + xoff : xsrc);
-        pr.ok |= valid ? 0x80000000u : 0u;
+        const bool v0 = o.h0 + ty < H && o.w0 + tx < W, v1 = v0 && o.w0 + tx + 1 < W;
+        const T* xb = xsrc + (((long)o.n * H + o.h0) * W + o.w0) * xp + xoff;
+        pr.x[0] = load4_raw(v0 ? xb : xsrc);
+        pr.x[1] = load4_raw(v1 ? xb + xp : xsrc);
+        pr.ok |= (v0 ? 0x40000000u : 0u) | (v1 ? 0x80000000u : 0u);
     };
     Pre cur;  // consumed at the top of an iteration (commit + x transform), then immediately refilled for the next tile
     TileSched ts(tg.ntiles);
@@ -710,18 +716,17 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
                 store8(ds + it * 8, v);
             }
         }
-        const bool valid = cur.ok >> 31;
-        float xv[4], zc[STATS ? 4 : 1];
-        bool pos[STATS ? 4 : 1];
-        unpack4(cur.x, xv);
+        const bool valid[2] = {(cur.ok & 0x40000000u) != 0, (cur.ok & 0x80000000u) != 0};
+        float xv[2][4], zr[STATS ? 2 : 1][4];  // transformed input x~ (0 outside the image) / raw input of the two pixels
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float pre = fmaf(xv[i], sc[i], sh[i]);
-            if constexpr (STATS) {
-                zc[i] = xv[i] - mu[i];
-                pos[i] = valid && pre > 0.f;
+        for (int e = 0; e < 2; ++e) {
+            float r[4];
+            unpack4(cur.x[e], r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (STATS) zr[e][i] = r[i];
+                xv[e][i] = valid[e] ? max_lo(fmaf(r[i], sc[i], sh[i]), lo[i]) : 0.f;
             }
-            xv[i] = valid ? max_lo(pre, lo[i]) : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool more = t + ts.step < ts.end;
@@ -731,36 +736,59 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
             issue(cur, org_next);
         }
         lds_barrier();
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
-        // tap k pairs x~[p] with du[p - off(k)]: halo index (ty + 2 - k/3, tx + 2 - k%3).  Unconditional: an out-of-image pixel of a
-        // partial tile has x~ = 0, so it adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
+        float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // tap k = (ky, kx) pairs x~[p] with du[p - off(k)] = halo (ty + 2 - ky, tx' + 2 - kx).  Window column c (halo column tx + c) serves
+        // the left pixel with kx = 2 - c (c <= 2) and the right pixel with kx = 3 - c (c >= 1).  An out-of-image pixel has x~ = 0, so it
+        // adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (k % 3 == 0 && k) __builtin_amdgcn_sched_barrier(0);  // at most 3 taps (6 LDS vector reads) in flight: hoisting all 18 costs 70 VGPRs
-            const float4 d4 = *reinterpret_cast<const float4*>(ds + ((ty + 2 - k / 3) * (TW + 2) + (tx + 2 - k % 3)) * SC + q * 4);
-            const float4 w4 = *reinterpret_cast<const float4*>(s_w + k * SC + q * 4);
-            const float d[4] = {d4.x, d4.y, d4.z, d4.w}, wk[4] = {w4.x, w4.y, w4.z, w4.w};
+        for (int ky = 0; ky < 3; ++ky) {
+            __builtin_amdgcn_sched_barrier(0);  // one row of taps (4 + 3 LDS vector reads) in flight at a time (register pressure)
+            const float* drow = ds + ((ty + 2 - ky) * (TW + 2) + tx) * SC + q * 4;
+            float wk[3][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                g[i] = fmaf(wk[i], d[i], g[i]);
-                acc[k][i] = fmaf(xv[i], d[i], acc[k][i]);
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 w4 = *reinterpret_cast<const float4*>(s_w + (ky * 3 + kx) * SC + q * 4);
+                wk[kx][0] = w4.x; wk[kx][1] = w4.y; wk[kx][2] = w4.z; wk[kx][3] = w4.w;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 d4 = *reinterpret_cast<const float4*>(drow + c * SC);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c <= 2) {
+                        g[0][i] = fmaf(wk[2 - c][i], d[i], g[0][i]);
+                        acc[ky * 3 + 2 - c][i] = fmaf(xv[0][i], d[i], acc[ky * 3 + 2 - c][i]);
+                    }
+                    if (c >= 1) {
+                        g[1][i] = fmaf(wk[3 - c][i], d[i], g[1][i]);
+                        acc[ky * 3 + 3 - c][i] = fmaf(xv[1][i], d[i], acc[ky * 3 + 3 - c][i]);
+                    }
+                }
             }
         }
-        if (valid && gdst) store4(gdst + (((long)org.n * H + org.h0) * W + org.w0) * xp + xoff, g[0], g[1], g[2], g[3]);
+        if (gdst) {
+            T* gp = gdst + (((long)org.n * H + org.h0) * W + org.w0) * xp + xoff;
+            if (valid[0]) store4(gp, g[0][0], g[0][1], g[0][2], g[0][3]);
+            if (valid[1]) store4(gp + xp, g[1][0], g[1][1], g[1][2], g[1][3]);
+        }
         if constexpr (STATS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float gh = pos[i] ? Elem<T>::round(g[i]) : 0.f;  // the producer's pw_bwd reads the STORED (rounded) gradient
-                st1[i] += gh;
-                st2[i] = fmaf(gh, zc[i], st2[i]);
-            }
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // the producer's pw_bwd reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask for sums
+                    const float gh = xv[e][i] > 0.f ? Elem<T>::round(g[e][i]) : 0.f;
+                    st1[i] += gh;
+                    st2[i] = fmaf(gh, zr[e][i] - s_mu[q * 4 + i], st2[i]);
+                }
         }
     }
     __syncthreads();
     // block reduction of the 36 per-thread partials through LDS (plain stores, then a strided sum): cheap in registers,
     // runs once per persistent block
     constexpr int NROW = STATS ? 11 : 9;  // per-channel partial rows: 9 taps (+ the two BatchNorm-backward sums)
-    float* s_red = s_w + 9 * SC;  // [NROW*4][256]
+    float* s_red = s_mu + SC;  // [NROW*4][256]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1396,7 +1424,7 @@ static void dw_bwd_grid(int C, int N, int H, int W, int& gx, int& gy, int& cg) {
     static const int cg_max = env_int("OCRS_DW_CG", 4);  // channel groups (of 8) per block: 4 -> 8x4-pixel tiles, 2 -> 8x8, 1 -> 8x16
     cg = C / 8 < cg_max ? C / 8 : cg_max;
     gy = C / (cg * 8);
-    const Tiling2 tg = make_tiling2(N, H, W, 16 / cg, 8);
+    const Tiling2 tg = make_tiling2(N, H, W, 32 / cg, 8);
     gx = persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1);
 }
 // ws: ocrs_dw_bwd_ws_floats() floats (per-block partials of dwdw, summed by a second kernel) or null (float atomics).
@@ -1423,9 +1451,9 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     dw_bwd_grid(C, N, H, W, gx, gy, cg);
 #define DWB(T_, CG_)                                                                                                                      \
     {                                                                                                                                     \
-        const Tiling2 tg = make_tiling2(N, H, W, 16 / CG_, 8);                                                                            \
-        const int HP = (16 / CG_ + 2) * 10;                                                                                               \
-        const size_t smem = (HP * CG_ * 8 + 9 * CG_ * 8 + 44 * 256) * sizeof(float);                                                      \
+        const Tiling2 tg = make_tiling2(N, H, W, 32 / CG_, 8);                                                                            \
+        const int HP = (32 / CG_ + 2) * 10;                                                                                               \
+        const size_t smem = (HP * CG_ * 8 + 10 * CG_ * 8 + 44 * 256) * sizeof(float);                                                     \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         if (stat_mask)                                                                                                                    \
             hipLaunchKernelGGL((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
