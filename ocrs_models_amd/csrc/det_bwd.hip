@@ -1385,8 +1385,26 @@ extern "C" {
 // Pointwise-conv backward of a DepthwiseConv block: du = Wpw^T dz (written, [P][Cin]); dwpw += u^T dz (accumulated, master layout
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
+void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 255) / 256, partial_chunks(nb)), dim3(256), 0, st, ws, nb, nelem, dw);
+}
+// det_pw2.hip: two-pixel-per-thread pipelined kernel for bf16, Cin, Cout <= 32 (levels 0-2)
+long det_pw2_supported(int Cin, int Cout, int dtype);
+long det_pw2_ws_floats(int Cin, int Cout, int N, int H, int W);
+int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                   int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
+                   int H, int W, hipStream_t st);
+
 // ws: workspace of ocrs_pw_bwd_ws_floats() floats (deterministic two-stage weight-gradient reduction) or null (float atomics).
 long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W) {
+    if (det_pw2_supported(Cin, Cout, 1)) {  // (dtype is not known here: cover both kernels)
+        const long a = det_pw2_ws_floats(Cin, Cout, N, H, W);
+#define X(CI, CO) \
+    if (Cin == CI && Cout == CO) { const long b = (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO; return a > b ? a : b; }
+        PW_BWD_COMBOS(X)
+#undef X
+        return a;
+    }
 #define X(CI, CO) \
     if (Cin == CI && Cout == CO) return (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO;
     PW_BWD_COMBOS(X)
@@ -1400,6 +1418,9 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
+    static const int use_pw2 = env_int("OCRS_PW2", 1);
+    if (use_pw2 && det_pw2_supported(Cin, Cout, dtype))
+        return det_pw2_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, st);
     // pipelined pool-routed variant: bf16, one K chunk (Cin = Cout <= 32: the second conv of a Down block, models.py:52-54)
 #define XP(CI)                                                                                                                            \
     if (pooled && dtype == 1 && Cin == CI && Cout == CI)                                                                                  \

@@ -321,6 +321,35 @@ __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*
     }
 }
 
+// u0/u1 = depthwise 3x3 of two horizontally adjacent pixels (tx, tx+1) for 8 channels, from the HaloStager's planar LDS tile:
+// 3 rows x 4 columns of inputs, each row's 3 weight vectors read once.
+template <int CG, int TW, int TH>
+__device__ __forceinline__ void dw2_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
+                                             float (&u0)[8], float (&u1)[8]) {
+    constexpr int HWp = TW + 2;
+    constexpr int PLANE = HaloTile<TW, TH>::HP * CG * 4;
+    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u0[i] = u1[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float w[3][8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) load8(s_w + (r * 3 + c) * CIN + c0, w[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* q = xc + (r * HWp + c) * CG * 4;
+            const float4 lo4 = *reinterpret_cast<const float4*>(q), hi4 = *reinterpret_cast<const float4*>(q + PLANE);
+            const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (c < 3) u0[i] = fmaf(w[c][i], v[i], u0[i]);
+                if (c > 0) u1[i] = fmaf(w[c - 1][i], v[i], u1[i]);
+            }
+        }
+    }
+}
+
 // Gradient w.r.t. a block's post-activation output y, in one of two forms:
 //   direct : g1[p][C] (+ g2[p][C])                         (one or two consumers of y)
 //   pooled : g1[pp][C] (+ g2[pp][C]) at half resolution; y went through MaxPool2d(2) (models.py:54),
