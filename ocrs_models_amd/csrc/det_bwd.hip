@@ -3,7 +3,8 @@
 // Backward of one DepthwiseConv block  x~ -> u = dw3x3(x~) -> z = pw(u) -> y = relu(bn(z)):
 //   k_bn_bwd_reduce    sum ghat, sum ghat*zhat                 (ghat = dL/dy * [y>0], through a 2x2 max-pool if needed)
 //   k_bn_bwd_finalize  -> dz = A*ghat + B*z + C per channel, dgamma, dbeta
-//   k_pw_bwd           dz tile + recomputed u tile in LDS; MFMA dgrad (du = Wpw^T dz) and wgrad (dWpw += u^T dz)
+//   k_pw_bwd           dz tile + recomputed u tile in LDS; MFMA dgrad (du = Wpw^T dz) and wgrad (dWpw += u^T dz): fp32 and the deep
+//                      (Cin or Cout > 32) bf16 levels; bf16 levels 0-2 run k_pw_bwd2 (det_pw2.hip)
 //   k_dw_bwd           dx~ = dw3x3^T(du), dWdw
 // plus ConvTranspose2d dgrad / wgrad, head backward, first-block (1->8) backward.
 #include "det_common.h"
@@ -167,11 +168,11 @@ struct PwBwdCfg {
     static constexpr int TPP_F = TP + 4;
     static constexpr int TH = 8, TW = TP / 8;  // 8x32 / 8x16 / 8x8 pixel tiles
     static constexpr int HP = (TW + 2) * (TH + 2);
-    // elements of the LDS region behind tileD: transposed dz / u tiles, or (pipelined bf16 path) the natural-layout u tile [TP][40]
-    __host__ __device__ static constexpr int mid_el(int tpp) { return (WTO + WTI) * 16 * tpp > TP * 40 ? (WTO + WTI) * 16 * tpp : TP * 40; }
+    // elements of the LDS region behind tileD: the transposed dz / u tiles
+    __host__ __device__ static constexpr int mid_el(int tpp) { return (WTO + WTI) * 16 * tpp; }
 };
 
-template <class T, int CIN, int COUT, bool PPOOL /* pipelined max-pool-routed gradient source (PIPE configs only) */>
+template <class T, int CIN, int COUT>
 __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
                                                 const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     T* tileD = reinterpret_cast<T*>(smem);               // [TP][PITCH]
     T* dzT = tileD + TP * PITCH;                         // [WTO*16][TPP]
     T* uT = dzT + WTO * 16 * TPP;                        // [WTI*16][TPP]
-    T* tileU = dzT;                                      // pipelined bf16 path instead: natural-layout u tile [TP][PITCH]
     float* xs = reinterpret_cast<float*>(smem + (((TP * PITCH + Cfg::mid_el(TPP)) * sizeof(T) + 15) & ~15));  // [HP][CGI*8]
     float* s_par = xs + Cfg::HP * CGI * 8;
     float* s_trx = s_par;                // [CIN/8][3][8] (HaloStager layout)
@@ -224,52 +224,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     for (int j = 0; j < NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     TileSched ts(tg.ntiles);
-    // PIPE (levels 0-1 in bf16: one K chunk on both sides): software pipeline over tiles.  The raw x halo items and this thread's
-    // (z, g1, g2) vectors of the NEXT tile are in flight while the current tile is computed; loads are unconditional, barriers order
-    // LDS only, the dgrad weight fragments live in registers (a global load inside the loop would force vmcnt(0)).
-    // The max-pool-routed gradient (gs.pooled) needs 3 more z vectors per thread: those stay synchronous at the top of the tile.
-    constexpr bool PIPE = Cfg::NKD == 1 && CIN <= 32 && Elem<T>::is_bf16;
-    typename HaloStager<T, CGI, TW, TH>::Pending pend;
-    Raw8<T> zr, g1r, g2r;
-    typename Mma<T>::Frag wfd[PIPE ? MTD : 1];
-    const int opix = ty * W + tx;
-    const bool has_g2 = gs.g2 != nullptr;
-    const int own = ((ty & 1) << 1) | (tx & 1);  // position inside the 2x2 pool window (tile origins are even)
-    bool gv_pre = false;                         // PPOOL: this thread's pixel lies inside a pool window (floor mode)
-    auto issue_tile = [&](const TileOrg& o) {
-        stager.issue(pend, x, 0, o, H, W, tid);
-        const long tb = ((long)o.n * H + o.h0) * W + o.w0;
-        if constexpr (PPOOL) {
-            const int Hp = H >> 1, Wp = W >> 1, h = o.h0 + ty, w = o.w0 + tx;
-            const bool ld = cg < CGO && h < 2 * Hp && w < 2 * Wp;
-            gv_pre = ld;
-            const T* zp = ld ? z + (tb + opix) * COUT + cg * 8 : z;
-            zr = load8_raw(zp);
-            // (the other three window elements are fetched by the lanes tid^CGM, tid^32, tid^(32|CGM) of this wave as THEIR own z:
-            //  they are exchanged with ds_bpermute at use time instead of three more global loads per thread)
-            const long pp = ((long)o.n * Hp + (h >> 1)) * Wp + (w >> 1);
-            g1r = load8_raw(ld ? gs.g1 + pp * COUT + cg * 8 : gs.g1);
-            g2r = load8_raw(ld && has_g2 ? gs.g2 + pp * COUT + cg * 8 : gs.g1);
-        } else if (!gs.pooled) {
-            const bool ld = o.h0 + ty < H && o.w0 + tx < W && cg < CGO;
-            const int off = ld ? opix * COUT + cg * 8 : 0;
-            zr = load8_raw((ld ? z + tb * COUT : z) + off);
-            g1r = load8_raw((ld ? gs.g1 + tb * COUT : gs.g1) + off);
-            g2r = load8_raw((ld && has_g2 ? gs.g2 + tb * COUT : gs.g1) + off);
-        }
-    };
-    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);  // PIPE: origin of the prefetched tile, no divisions in the loop
-    TileOrg org_next = tit.org();
-    if constexpr (PIPE) {
-#pragma unroll
-        for (int b = 0; b < MTD; ++b) {
-            wfd[b] = Mma<T>::load_w(wpk_d, (long)b, lane);
-            asm volatile("" : "+v"(wfd[b].q.x), "+v"(wfd[b].q.y), "+v"(wfd[b].q.z), "+v"(wfd[b].q.w));
-        }
-        if (ts.first < ts.end) issue_tile(org_next);
-    }
     for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = PIPE ? org_next : tile_origin2<TW, TH>(tg, (int)t);
+        const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
         PixIdx px;
         px.n = org.n;
         px.h = org.h0 + ty;
@@ -282,137 +238,7 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 #pragma unroll
             for (int b = 0; b < MTD; ++b) accd[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        if constexpr (PIPE) {
-            {
-                const bool gv_cur = gv_pre;
-                float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const int c0 = cg * 8;
-                // PPOOL: the other three elements of this pixel's 2x2 pool window are the "own" z of the lanes tid^CGM (horizontal),
-                // tid^32 (vertical: TW * CGM = 32) and tid^(32|CGM) of the same wave: exchanged with ds_bpermute -- by ALL lanes,
-                // before any divergent branch -- instead of three more global loads per thread.
-                Raw8<T> zq[PPOOL ? 3 : 1];
-                if constexpr (PPOOL) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int lm = ((j + 1) & 1 ? CGM : 0) | ((j + 1) & 2 ? 32 : 0);
-                        zq[j].a.x = __shfl_xor((int)zr.a.x, lm, 64);
-                        zq[j].a.y = __shfl_xor((int)zr.a.y, lm, 64);
-                        zq[j].a.z = __shfl_xor((int)zr.a.z, lm, 64);
-                        zq[j].a.w = __shfl_xor((int)zr.a.w, lm, 64);
-                    }
-                }
-                if (cg < CGO && pv) {
-                    float gh[8], zv[8];
-                    if constexpr (PPOOL) {
-                        // gradient routed through MaxPool2d(2): to the FIRST maximal element of the window, and through the ReLU
-                        float ga[8], gb[8];
-                        unpack8(zr, zv);
-                        unpack8(g1r, ga);
-                        unpack8(g2r, gb);
-                        // win  <=>  ym > max(0, earlier neighbours)  &&  ym >= max(later neighbours)   (ym = relu(bn(z)); "> 0" is the
-                        // ReLU mask).  Kept in float max/mul form: per-channel bool chains compile to scalar mask arithmetic and made
-                        // this kernel issue 3x the SALU instructions of its non-pooled twin.
-                        float ym[8], be[8], bl[8], scv[8], shv[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            scv[i] = s_bn[c0 + i];
-                            shv[i] = s_bn[COUT + c0 + i];
-                            ym[i] = max_lo(fmaf(zv[i], scv[i], shv[i]), 0.f);
-                            be[i] = 0.f;
-                            bl[i] = 0.f;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const float ef = (own ^ (j + 1)) < own ? 1.f : 0.f, lf = 1.f - ef;  // neighbour j has window index own ^ (j+1)
-                            float zn[8];
-                            unpack8(zq[j], zn);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const float yo = max_lo(fmaf(zn[i], scv[i], shv[i]), 0.f);
-                                be[i] = max_lo(yo * ef, be[i]);
-                                bl[i] = max_lo(yo * lf, bl[i]);
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            gh[i] = (gv_cur && ym[i] > be[i] && ym[i] >= bl[i]) ? (has_g2 ? ga[i] + gb[i] : ga[i]) : 0.f;
-                    } else if (gs.pooled)
-                        load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
-                    else {
-                        float ga[8], gb[8];
-                        unpack8(zr, zv);
-                        unpack8(g1r, ga);
-                        unpack8(g2r, gb);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float gsum = has_g2 ? ga[i] + gb[i] : ga[i];
-                            gh[i] = fmaf(zv[i], s_bn[c0 + i], s_bn[COUT + c0 + i]) > 0.f ? gsum : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
-                }
-                stager.commit(pend, s_trx, 0, xs, tid);
-                if (cg < CGO) store8_opaque(tileD + pxl * PITCH + cg * 8, dz);  // natural layout: dgrad operand AND (transpose-read) wgrad operand
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + ts.step < ts.end) {
-                tit.next();
-                org_next = tit.org();
-                issue_tile(org_next);
-            }
-            lds_barrier();
-            {
-                typename Mma<T>::Frag pf[PTW];
-#pragma unroll
-                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
-#pragma unroll
-                for (int b = 0; b < MTD; ++b)
-#pragma unroll
-                    for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wfd[b], pf[a], accd[a][b]);
-#pragma unroll
-                for (int a = 0; a < PTW; ++a) {
-                    const int oq = (wave * PTW + a) * 16 + (lane & 15);
-                    const int qh = org.h0 + oq / TW, qw = org.w0 + oq % TW;
-                    const long po = ((long)org.n * H + qh) * W + qw;
-#pragma unroll
-                    for (int b = 0; b < MTD; ++b) {
-                        const int m0 = b * 16 + (lane >> 4) * 4;
-                        if (qh < H && qw < W && m0 < CIN) {
-                            const f32x4 v = accd[a][b];
-                            store4(du + po * CIN + m0, v[0], v[1], v[2], v[3]);
-                        }
-                    }
-                }
-                if (cg < CGI) {
-                    float u[8];
-                    dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, cg * 8, cg, ty, tx, u);
-                    float uz[8];  // (a select, not an `if (!pv)` block writing u: the branch form costs 60 VGPRs)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) uz[i] = pv ? u[i] : 0.f;
-                    store8_opaque(tileU + pxl * PITCH + cg * 8, uz);
-                }
-            }
-            lds_barrier();
-            if constexpr (Elem<T>::is_bf16) {
-                // wgrad: K = pixels; both operands come straight from the natural-layout tiles through the LDS transpose read.
-                // The WTI*WTO (1, 2 or 4) output tiles x TP/32 k-steps are spread over all four waves (tile = wave % NT).
-                constexpr int NTL = WTI * WTO, KSTRIDE = 4 / NTL;
-                const int ti = (wave % NTL) % WTI, to = (wave % NTL) / WTI;
-                const int prow = 4 * (lane >> 4) + ((lane & 15) >> 2), pcol = (lane & 3) * 4;
-                static_assert((TP / 32) % KSTRIDE == 0, "k-steps divide evenly over the waves");
-#pragma unroll
-                for (int m = 0; m < (TP / 32) / KSTRIDE; ++m) {
-                    const int pc = wave / NTL + m * KSTRIDE;
-                    const T* ua = tileU + (pc * 32 + prow) * PITCH + ti * 16 + pcol;
-                    const T* da = tileD + (pc * 32 + prow) * PITCH + to * 16 + pcol;
-                    const bf16x8 fa = lds_tr8(ua, ua + 16 * PITCH), fb = lds_tr8(da, da + 16 * PITCH);
-                    accw[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, accw[0], 0, 0, 0);
-                }
-            }
-            lds_barrier();
-            continue;
-        } else if constexpr (Cfg::NKD == 1 && CIN <= 32) {
+        if constexpr (Cfg::NKD == 1 && CIN <= 32) {
             // ---- fast path (levels 0-1: one K chunk on both sides): ALL global loads of the tile are issued before the first barrier
             // (g, z for dz and the input halo for the depthwise recompute), 3 barriers per tile instead of 5.
             {
@@ -563,28 +389,6 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
         __syncthreads();
     }
     // ---- flush weight gradient (master layout [COUT][CIN])
-    if constexpr (PIPE) {
-        // the 4/NTL waves that split K for the same output tile are summed through LDS first: same-address float atomics are the
-        // expensive part of the flush (2048 blocks x 4 waves onto 256 addresses cost +0.5 ms per launch)
-        constexpr int NTL = WTI * WTO;
-        float* red = reinterpret_cast<float*>(smem);  // [4][256]
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = accw[0][r];
-        __syncthreads();
-        if (wave < NTL) {
-            const int ti = wave % WTI, to = wave / WTI;
-            const int co = to * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = accw[0][r];
-                for (int w2 = wave + NTL; w2 < 4; w2 += NTL) v += red[w2 * 256 + r * 64 + lane];
-                const int ci = ti * 16 + (lane >> 4) * 4 + r;
-                if (ci < CIN && co < COUT) flush_w(dwpw, ws, (long)co * CIN + ci, CIN * COUT, v);
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int tt = wave + 4 * j;
@@ -1340,11 +1144,11 @@ template <int CIN, int COUT>
 static int pw_bwd_gx(int N, int H, int W) {
     using Cfg = PwBwdCfg<CIN, COUT>;
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
-    // one-chunk configs (levels 0-1): as many blocks as are resident (3 per CU at that register budget); deeper levels: the
-    // tiles-per-block rule of wgrad_grid (they are latency-bound: more, shorter blocks)
+    // one-chunk configs (fp32 parity mode at levels 0-2): as many blocks as are resident; deeper levels: the tiles-per-block rule of
+    // wgrad_grid (they are latency-bound: more, shorter blocks)
     return wgrad_grid(tg.ntiles, (Cfg::NKD == 1 && CIN <= 32) ? 3 * kNumCU : 2048);
 }
-template <class T, int CIN, int COUT, bool PPOOL>
+template <class T, int CIN, int COUT>
 static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                          int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int N,
                          int H, int W, hipStream_t st) {
@@ -1354,7 +1158,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                         (Cfg::HP * Cfg::CGI * 8 + 12 * CIN + 6 * COUT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT, PPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess)
             return OCRS_ERR_HIP;
         attr_set = true;
@@ -1363,7 +1167,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
     const int gx = pw_bwd_gx<CIN, COUT>(N, H, W);
-    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT, PPOOL>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
+    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
                        wpk_d, (T*)du, dwpw, ws, tg);
     if (ws) {
         const int ne = CIN * COUT;
@@ -1421,20 +1225,10 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     static const int use_pw2 = env_int("OCRS_PW2", 1);
     if (use_pw2 && det_pw2_supported(Cin, Cout, dtype))
         return det_pw2_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, st);
-    // pipelined pool-routed variant: bf16, one K chunk (Cin = Cout <= 32: the second conv of a Down block, models.py:52-54)
-#define XP(CI)                                                                                                                            \
-    if (pooled && dtype == 1 && Cin == CI && Cout == CI)                                                                                  \
-        return launch_pw_bwd<bf16, CI, CI, true>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st);
-#ifdef OCRS_PW_ONLY_16
-    XP(16)
-#else
-    XP(8) XP(16) XP(32)
-#endif
-#undef XP
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \
-        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st) \
-                          : launch_pw_bwd<float, CI, CO, false>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st);
+        return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st) \
+                          : launch_pw_bwd<float, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st);
     PW_BWD_COMBOS(X)
 #undef X
     return OCRS_ERR_ARG;
