@@ -85,13 +85,16 @@ def pmc_traffic(family):
         return {"traffic": None}
     tot, n = 0.0, 0.0
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith("k_" + family + "<") or r["kernel"] == "k_" + family:
+        if r["kernel"].startswith(FAMILY_KERNELS.get(family, ("k_" + family + "<",))) or r["kernel"] == "k_" + family:
             tot += (float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9
             n += float(r["launches_per_step"])
     return {"traffic": round(tot / n) if n else None, "traffic_source": os.path.basename(files[-1])}
 
 
 FAMILIES = ["dwpw_fwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce", "convt_fwd", "convt_bwd", "maxpool_fwd"]
+# kernels launched by one C-ABI call of a family (for the PMC traffic lookup)
+FAMILY_KERNELS = {"pw_bwd": ("k_pw_bwd<", "k_pw_bwd2<"), "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
+                  "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<")}
 
 
 def cpu_baseline(steps=3, B=2, H=1024, W=1024):
