@@ -93,7 +93,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
                    int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
 /* autograd of out_conv + sigmoid. */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
-                  long P, int dtype, hipStream_t st);
+                  const float* saved, double* gsum, long P, int dtype, hipStream_t st);
 
 /* ------------------------------------------------------------------ detection loss ---------- */
 /* balanced_cross_entropy_loss (ocrs_models/train_detection.py:225-263), forward and backward. */

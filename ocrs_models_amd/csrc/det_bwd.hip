@@ -1044,17 +1044,22 @@ __global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, fl
 template <class T>
 __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
                                                   const float* __restrict__ pred, const float* __restrict__ gpred, T* __restrict__ gy,
-                                                  float* __restrict__ dw, float* __restrict__ db, long P) {
-    __shared__ float s_acc[9];
-    if (threadIdx.x < 9) s_acc[threadIdx.x] = 0.f;
+                                                  float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ saved /*[2][8] or null*/,
+                                                  double* __restrict__ gsum /*[2][8] or null*/, long P) {
+    // gsum != null: also the BatchNorm-backward sums (sum ghat, sum ghat*zhat) of the block that produced z -- this kernel is that
+    // block's only consumer and already reads z, so its k_bn_bwd_reduce pass (0.24 ms at 32x1024^2) is not needed
+    __shared__ float s_acc[25];
+    if (threadIdx.x < 25) s_acc[threadIdx.x] = 0.f;
     __syncthreads();
-    float wv[8], sc[8], sh[8], lo[8], acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float wv[8], sc[8], sh[8], lo[8], mu[8], acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st1[8], st2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         wv[i] = w[i];
         sc[i] = tr[i];
         sh[i] = tr[8 + i];
         lo[i] = tr[16 + i];
+        mu[i] = gsum ? saved[i] : 0.f;
+        st1[i] = st2[i] = 0.f;
     }
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
         const float pr = pred[p];
@@ -1063,9 +1068,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const
         load8(z + p * 8, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float xv = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
+            const float pre = fmaf(v[i], sc[i], sh[i]);
+            const float xv = fmaxf(pre, lo[i]);
             acc[i] = fmaf(gl, xv, acc[i]);
             o[i] = gl * wv[i];
+            const float gh = pre > 0.f ? Elem<T>::round(o[i]) : 0.f;  // what the block's pw_bwd will read back
+            st1[i] += gh;
+            st2[i] = fmaf(gh, v[i] - mu[i], st2[i]);
         }
         acc[8] += gl;
         store8(gy + p * 8, o);
@@ -1075,9 +1084,23 @@ __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const
         const float a = wave_sum(acc[i]);
         if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
     }
+    if (gsum) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = wave_sum(st1[i]), b = wave_sum(st2[i]);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&s_acc[9 + i], a);
+                atomicAdd(&s_acc[17 + i], b);
+            }
+        }
+    }
     __syncthreads();
     if (threadIdx.x < 8) atomicAdd(&dw[threadIdx.x], s_acc[threadIdx.x]);
     if (threadIdx.x == 8) atomicAdd(db, s_acc[8]);
+    if (gsum && threadIdx.x >= 9 && threadIdx.x < 25) {
+        const int i = threadIdx.x - 9;  // 0..7: sum ghat, 8..15: sum ghat*(z - mean) -> * rstd
+        atomicAdd(&gsum[i], (double)(i < 8 ? s_acc[threadIdx.x] : s_acc[threadIdx.x] * saved[8 + (i - 8)]));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1387,15 +1410,17 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
     return OCRS_OK;
 }
 
-// Head backward: gy [P][8] written (dtype T); dw [8], db [1] accumulated.
-int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db, long P,
-                  int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && dw && db && P > 0);
-    const int grid = ew_grid(P);
+// Head backward: gy [P][8] written (dtype T); dw [8], db [1] accumulated.  saved / gsum (nullable): also accumulate the BatchNorm-backward
+// sums [2][8] (fp64, caller-zeroed) of the block that produced z (saved = its [mean | rstd]) -- replaces that block's ocrs_bn_bwd_reduce.
+int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
+                  const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && dw && db && P > 0 && (!gsum || saved));
+    int grid = ew_grid(P);
+    if (grid > 1024) grid = 1024;  // streaming kernel ending in same-address atomics: 4 blocks per CU are plenty
     if (dtype == 1)
-        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, dw, db, P);
+        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, dw, db, saved, gsum, P);
     else
-        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, dw, db, P);
+        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, dw, db, saved, gsum, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -334,8 +334,12 @@ class _DetRun:
         gpred = gpred.contiguous().float()
         up = self.head_in
         g = self.empty(N, H, W, 8)
+        sv = gs_head = None
+        if self.fuse_bn_bwd and up.src is not None:  # the head is this block's only consumer and reads its z anyway
+            sv, gs_head = self.recs[up.src].saved, self.zeros64(16)
+            self.fused[up.src] = gs_head
         L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(self.G["out_conv.0.weight"]),
-                   ptr(self.G["out_conv.0.bias"]), N * H * W, self.dt)
+                   ptr(self.G["out_conv.0.bias"]), ptr(sv), ptr(gs_head), N * H * W, self.dt)
         stage_done("out_conv")
         skip_g = [[] for _ in range(7)]
         for i in range(6):

@@ -373,11 +373,21 @@ def test_head(dev, dtype):
     ref.backward(gp)
     gy = run.empty(N, H, W, 8)
     dw, db = torch.zeros_like(w), torch.zeros_like(b)
-    run.L.head_bwd(ptr(zs), ptr(tr), ptr(w), ptr(pred), ptr(gp), ptr(gy), ptr(dw), ptr(db), N * H * W, run.dt)
+    # also ask for the BatchNorm-backward sums of the block that produced z (the head is its only consumer)
+    saved = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)  # [mean | rstd]
+    gsum = torch.zeros(16, dtype=torch.float64, device=dev)
+    run.L.head_bwd(ptr(zs), ptr(tr), ptr(w), ptr(pred), ptr(gp), ptr(gy), ptr(dw), ptr(db), ptr(saved), ptr(gsum), N * H * W, run.dt)
     torch.cuda.synchronize()
     tol = TOL[dtype]
     assert rel(nchw(gy), xt.grad) < 5 * tol
     assert rel(dw, wr.grad) < 1e-4 and rel(db, brr.grad) < 1e-4
+    # reference sums from the STORED gradient: ghat = gy * [z*scale+shift > 0], zhat = (z - mean) * rstd
+    gyf = nchw(gy).double()
+    pre = zr.double() * tr[0].double().view(1, -1, 1, 1) + tr[1].double().view(1, -1, 1, 1)
+    gh = torch.where(pre > 0, gyf, torch.zeros_like(gyf))
+    zh = (zr.double() - saved[0].double().view(1, -1, 1, 1)) * saved[1].double().view(1, -1, 1, 1)
+    ref_sums = torch.cat([gh.sum((0, 2, 3)), (gh * zh).sum((0, 2, 3))])
+    assert rel(gsum, ref_sums) < 1e-5
 
 
 @pytest.mark.parametrize("shape,ppos", [((2, 1, 64, 64), 0.1), ((1, 1, 100, 136), 0.3), ((3, 1, 33, 47), 0.7), ((2, 1, 40, 40), 0.0)])
