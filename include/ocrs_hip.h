@@ -153,6 +153,18 @@ int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, c
 /* preds.argmax(-1) + ctc_greedy_decode_text's collapse (train_rec.py:52; datasets/util.py:147-177). */
 int ocrs_ctc_greedy_decode(const float* lp, const long long* in_len, int* amax, int* labels, int* lens, int T, int N, int C, hipStream_t st);
 
+/* ------------------------------------------------------------------ input pipeline ----------- */
+/* transform_image (ocrs_models/datasets/util.py:27-35): out[i] = float(img_u8[i]) / 255 - 0.5; both pointers 16-byte aligned. */
+int ocrs_transform_image_u8(const void* img_u8, void* out, long n, int dtype, hipStream_t st);
+/* collate_samples, image part (ocrs_models/train_rec.py:285-299): B crops of H rows, crop b = (H, widths[b]) row-major starting at element
+ * offs[b] of `packed` (kind 0: uint8, transform_image fused; kind 1: fp32 already transformed) -> out (B,1,H,Wpad), right-padded with 0.0. */
+int ocrs_collate_pad(const void* packed, const long long* offs, const int* widths, void* out, int B, int H, int Wpad, int kind, int dtype,
+                     hipStream_t st);
+/* torchvision resize(img, [oh, ow], antialias=True) on a float tensor (ocrs_models/datasets/hiertext.py:288-294) =
+ * F.interpolate(mode="bilinear", antialias=True, align_corners=False): in [planes][h][w] -> out [planes][oh][ow]; ws = planes*h*ow floats. */
+int ocrs_resize_aa(const float* in, float* ws, float* out, int planes, int h, int w, int oh, int ow, hipStream_t st);
+long ocrs_resize_aa_ws_floats(int planes, int h, int ow);
+
 /* ------------------------------------------------------------------ optimiser ---------------- */
 /* table [nt][5] int64 {param, grad, exp_avg, exp_avg_sq, numel}; chunks [nchunks][2] int32 {tensor, chunk of ocrs_opt_chunk()}. */
 int ocrs_opt_chunk(void);

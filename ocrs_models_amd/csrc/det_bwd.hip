@@ -424,10 +424,13 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     // the pair shares 6 of its 9 du taps and all weights (12 + 9 LDS vector reads instead of 36), and the tile doubles to
     // 8 x (32/CG) pixels (halo re-read 1.33-1.56x instead of 1.4-1.875x, per-tile bookkeeping amortised over twice the pixels)
     constexpr int TH = 8, TW = 32 / CG, HP = (TW + 2) * (TH + 2), SC = CG * 8, CQ = 2 * CG;
+    // pixel pitch of the du tile = 1.5 x SC floats: with the pair mapping a 16-lane group reads (16 / CQ) pixel PAIRS, i.e. every other
+    // pixel; at pitch SC those land on the same banks two by two (PMC: 40 % of this kernel's LDS cycles were conflicts)
+    constexpr int PS = SC + SC / 2;
     constexpr int NIT = (HP * CG + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    float* ds = s_mem;           // [HP][SC] du tile + halo (fp32, 0 outside the image)
-    float* s_w = ds + HP * SC;   // [9][SC] weights, tap-major
+    float* ds = s_mem;           // [HP][PS] du tile + halo (fp32, 0 outside the image)
+    float* s_w = ds + HP * PS;   // [9][SC] weights, tap-major
     float* s_mu = s_w + 9 * SC;  // [SC] saved mean of the producer(s) (STATS)
     const int C = x.Ca + x.Cb;
     const int H = tg.H, W = tg.W;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
             if (HP * CG % 256 == 0 || j < NIT - 1 || it < HP * CG) {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (cur.ok & (1u << j)) unpack8(cur.du[j], v);
-                store8(ds + it * 8, v);
+                store8(ds + (it / CG) * PS + (it % CG) * 8, v);
             }
         }
         const bool valid[2] = {(cur.ok & 0x40000000u) != 0, (cur.ok & 0x80000000u) != 0};
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             __builtin_amdgcn_sched_barrier(0);  // one row of taps (4 + 3 LDS vector reads) in flight at a time (register pressure)
-            const float* drow = ds + ((ty + 2 - ky) * (TW + 2) + tx) * SC + q * 4;
+            const float* drow = ds + ((ty + 2 - ky) * (TW + 2) + tx) * PS + q * 4;
             float wk[3][4];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 d4 = *reinterpret_cast<const float4*>(drow + c * SC);
+                const float4 d4 = *reinterpret_cast<const float4*>(drow + c * PS);
                 const float d[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1291,7 +1294,7 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     {                                                                                                                                     \
         const Tiling2 tg = make_tiling2(N, H, W, 32 / CG_, 8);                                                                            \
         const int HP = (32 / CG_ + 2) * 10;                                                                                               \
-        const size_t smem = (HP * CG_ * 8 + 10 * CG_ * 8 + 44 * 256) * sizeof(float);                                                     \
+        const size_t smem = (HP * CG_ * 12 + 10 * CG_ * 8 + 44 * 256) * sizeof(float);                                                    \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         if (stat_mask)                                                                                                                    \
             hipLaunchKernelGGL((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \

@@ -1,5 +1,6 @@
 """Recognition training step, the body of the reference's ``train()`` loop (ocrs_models/train_rec.py:107-153):
-bf16 autocast forward + CTC loss, accuracy stats, NaN guard, backward, clip_grad_norm_(4.0), Adam step."""
+bf16 autocast forward + CTC loss, accuracy stats, NaN guard, backward, clip_grad_norm_(4.0), Adam step -- and the validation loop
+``test()`` (ocrs_models/train_rec.py:163-217): eval-mode forward, CTC loss, greedy decode + character error rate."""
 from __future__ import annotations
 
 import math
@@ -52,4 +53,36 @@ def train(epoch: int, device, dataloader, model, optimizer):
         total_norm += gn
         n += 1
     print(f"Mean grad norm {float(total_norm.item()) / max(n, 1)}")
+    return float(mean_loss.item()) / max(n, 1), stats
+
+
+def test(device, dataloader, model, preview: int = 10):
+    """Validation loop with the reference's signature and return value (mean loss, RecognitionAccuracyStats) (train_rec.py:163-217).
+
+    Like the reference's, it runs outside autocast (fp32 kernels) and in eval mode; the first batch's first ``preview`` predictions are
+    printed next to their targets.
+    """
+    from .text import DEFAULT_ALPHABET, ctc_greedy_decode_text, decode_text
+
+    model.eval()
+    stats = RecognitionAccuracyStats()
+    loss_fn = CTCLoss()
+    mean_loss = torch.zeros((), device=device)
+    n = 0
+    with torch.no_grad():
+        for batch_idx, batch in enumerate(dataloader):
+            input_lengths = batch["image_width"].div(4, rounding_mode="floor")
+            img = batch["image"].to(device, non_blocking=True)
+            text_seq = batch["text_seq"].to(device, non_blocking=True)
+            target_lengths = batch["text_len"]
+            pred_seq = model(img)
+            stats.update(batch["text_seq"], target_lengths.tolist(), pred_seq, input_lengths.tolist())
+            if batch_idx == 0 and preview:
+                amax = pred_seq[:, : min(preview, pred_seq.shape[1]), :].argmax(-1).T.cpu()
+                for i in range(amax.shape[0]):
+                    target_text = decode_text(batch["text_seq"][i], list(DEFAULT_ALPHABET))
+                    pred_text = ctc_greedy_decode_text(amax[i][: int(input_lengths[i])], list(DEFAULT_ALPHABET))
+                    print(f'Sample test prediction "{pred_text}" target "{target_text}"')
+            mean_loss += loss_fn(pred_seq, text_seq, input_lengths, target_lengths)
+            n += 1
     return float(mean_loss.item()) / max(n, 1), stats

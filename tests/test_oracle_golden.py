@@ -168,3 +168,20 @@ def test_bce_and_pool_kats():
 def test_balanced_bce_k0_is_nan():
     p = torch.full((1, 1, 4, 4), 0.3)
     assert torch.isnan(olosses.balanced_bce(p, torch.zeros(1, 1, 4, 4)))
+
+
+@pytest.mark.parametrize("h,w,oh,ow", [(37, 211, 64, 364), (120, 900, 64, 480), (64, 400, 64, 400), (20, 9, 64, 28), (200, 3000, 64, 800), (5, 40, 64, 512)])
+def test_resize_weights_restatement_matches_aten_operator(h, w, oh, ow):
+    """oracle/input_pipe.py: the explicit antialias weights (what the HIP kernel implements) against the ATen operator torchvision's
+    resize(antialias=True) dispatches to (hiertext.py:294; torchvision itself is absent -> parity unpinned, see the module header)."""
+    from oracle import input_pipe as oip
+
+    x = torch.rand(1, h, w, generator=torch.Generator().manual_seed(h + w)) - 0.5
+    assert (oip.resize_aa(x, [oh, ow]) - oip.resize_aa_explicit(x, [oh, ow])).abs().max().item() < 5e-7
+
+
+def test_line_output_width_rule():
+    from oracle import input_pipe as oip
+
+    assert oip.line_output_width(64, 400) == 400 and oip.line_output_width(32, 3) == 10 and oip.line_output_width(10, 1000) == 800
+    assert oip.line_output_width(37, 211) == int(64 * (211 / 37))

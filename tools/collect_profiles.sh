@@ -13,6 +13,6 @@ bash tools/run_trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step.txt $OUT
 # 4. HBM traffic (two separate PMC passes)
 bash tools/run_pmc_hbm.sh ${TAG}_pmc_hbm.csv > $OUT/pmc_hbm.log 2>&1; cp gpurun_out/${TAG}_pmc_hbm.csv $OUT/
 # 5. SQ counters of the three big families
-bash tools/run_pmc_sq.sh "k_dwpw_fwd<bf16, [12], 1>|k_pw_bwd<bf16, (8|16), (8|16), (false|true)>|k_dw_bwd<bf16, [12], true>" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
+bash tools/run_pmc_sq.sh "k_dwpw_fwd<bf16, [12], 1, true>|k_pw_bwd2<(8|16), (8|16), (false|true)>|k_dw_bwd<bf16, [12], true>" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
 rm -rf gpurun_out/ks gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc_f gpurun_out/pmc_w
 ls -la $OUT; tail -c 600 $OUT/${TAG}_bench.json
