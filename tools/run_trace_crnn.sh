@@ -9,7 +9,8 @@ rows=list(csv.DictReader(open(f)))
 out=open('gpurun_out/crnn_stats.txt','w')
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 for r in rows[:40]:
-    out.write(f"{re.sub(r'\(.*','',r['Name'])[:70]:70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/5e3:10.1f} us/step {float(r['AverageNs'])/1e3:9.1f} us {r['Percentage']}\n")
+    nm = re.sub(r'[(].*', '', r['Name'])[:70]
+    out.write(f"{nm:70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/5e3:10.1f} us/step {float(r['AverageNs'])/1e3:9.1f} us {r['Percentage']}\n")
 out.write(f"total per step us: {tot/5e3}\n")
 PY
 find gpurun_out/trace_crnn -name "*kernel_trace.csv" -delete
