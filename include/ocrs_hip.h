@@ -47,8 +47,9 @@ int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void*
 /* nn.BatchNorm2d training statistics (models.py:23): sums -> tr [3][C], saved mean|rstd [2][C], running stats, num_batches_tracked. */
 int ocrs_bn_finalize(const double* gstat, long count, int C, const float* gamma, const float* beta, float eps, float momentum, float* tr,
                      float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st);
-/* nn.MaxPool2d(2) (models.py:54) over relu(bn(z)). */
-int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int dtype, hipStream_t st);
+/* nn.MaxPool2d(2) (models.py:54) over relu(bn(z)).  raw = 0: out = the window maximum; raw = 1: out = the pre-BatchNorm z of the selected
+ * element (first maximum), to be consumed through the producer's load transform `tr` like any block output. */
+int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int raw, int dtype, hipStream_t st);
 /* nn.ConvTranspose2d(k=3, s=2) + crop (models.py:76-78, 82-87). */
 int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h, int w,
                    int H, int W, int dtype, hipStream_t st);

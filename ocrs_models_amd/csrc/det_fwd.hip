@@ -297,7 +297,11 @@ __global__ void k_bn_finalize(const double* __restrict__ gstat, long count, int 
 }
 
 // MaxPool2d(2) (models.py:54) over relu(bn(z)); floor output size.
-template <class T>
+// RAW = false: out = max over the window of act(z).  RAW = true: out = the PRE-BatchNorm z of the element with the largest act(z) (first
+// one on ties), so that the pooled tensor is consumed exactly like a block output (consumers apply the producer's load transform, which
+// reproduces act(z_sel) = the max bit for bit) and the depthwise-backward passes that read it can produce the producer's
+// BatchNorm-backward sums (the gradient only lands on the selected elements) -- no separate bn_bwd_reduce pass over the full-size z.
+template <class T, bool RAW>
 __global__ __launch_bounds__(256) void k_maxpool_fwd(const T* __restrict__ z, const float* __restrict__ tr, T* __restrict__ out, int C, int H,
                                                      int W, long Pp) {
     const int CG = C / 8;
@@ -308,16 +312,24 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd(const T* __restrict__ z, co
         const int c0 = (int)(it - pp * CG) * 8;
         const PixIdx q = decode_pixel(pp, Hp, Wp);
         const long base = ((long)q.n * H + 2 * q.h) * W + 2 * q.w;
-        float m[8];
+        float m[8], zr[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float v[8];
+            float v[8], a[8];
             load8(z + (base + (long)(k >> 1) * W + (k & 1)) * C + c0, v);
-            apply_tr8(v, tr, C, c0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) m[i] = k == 0 ? v[i] : fmaxf(m[i], v[i]);
+            for (int i = 0; i < 8; ++i) a[i] = v[i];
+            apply_tr8(a, tr, C, c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (k == 0 || a[i] > m[i]) {
+                    m[i] = a[i];
+                    zr[i] = v[i];
+                }
+            }
         }
-        store8(out + pp * C + c0, m);
+        if (RAW) store8(out + pp * C + c0, zr);
+        else store8(out + pp * C + c0, m);
     }
 }
 
@@ -528,15 +540,20 @@ int ocrs_bn_finalize(const double* gstat, long count, int C, const float* gamma,
     return OCRS_OK;
 }
 
-// MaxPool2d(2) over relu(bn(z))  (models.py:54).  out: [N][H/2][W/2][C]
-int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(z && tr && out && C % 8 == 0 && H >= 2 && W >= 2);
+// MaxPool2d(2) over relu(bn(z))  (models.py:54).  out: [N][H/2][W/2][C]; raw = 1: the selected elements' pre-BatchNorm z instead of the max
+int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int raw, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && out && C % 8 == 0 && H >= 2 && W >= 2 && (raw == 0 || raw == 1));
     const long Pp = (long)N * (H / 2) * (W / 2);
     const int grid = ew_grid(Pp * (C / 8));
-    if (dtype == 1)
-        hipLaunchKernelGGL(k_maxpool_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, (bf16*)out, C, H, W, Pp);
-    else
-        hipLaunchKernelGGL(k_maxpool_fwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, (float*)out, C, H, W, Pp);
+#define OCRS_POOL(T_, R_) hipLaunchKernelGGL((k_maxpool_fwd<T_, R_>), dim3(grid), dim3(256), 0, st, (const T_*)z, tr, (T_*)out, C, H, W, Pp)
+    if (dtype == 1) {
+        if (raw) OCRS_POOL(bf16, true);
+        else OCRS_POOL(bf16, false);
+    } else {
+        if (raw) OCRS_POOL(float, true);
+        else OCRS_POOL(float, false);
+    }
+#undef OCRS_POOL
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

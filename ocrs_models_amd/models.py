@@ -232,8 +232,11 @@ class _DetRun:
             Hp, Wp = y.H // 2, y.W // 2
             pooled = self.empty(N, Hp, Wp, y.C)
             y.other_use = True
-            L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, self.dt)
-            cur = _Act(pooled, _identity_tr(y.C, self.dev), y.C, Hp, Wp)
+            # the pooled tensor holds the SELECTED elements' pre-BatchNorm z: consumers apply y's load transform (= the max, exactly), and
+            # the depthwise-backward passes that read it produce y's BatchNorm-backward sums (src = y's block; the gradient lands only
+            # on the selected elements), so no bn_bwd_reduce pass over the full-size z is needed for pooled blocks
+            L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, 1, self.dt)
+            cur = _Act(pooled, y.tr, y.C, Hp, Wp, src=y.src)
             skips.append(cur)
         up = skips[6]
         self.convt = {}

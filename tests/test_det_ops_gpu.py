@@ -245,7 +245,7 @@ def test_block_bwd_through_maxpool(dev, dtype):
     xs = nhwc(x, dtype)
     out = run.block(pfx, _Act(xs, tr, C, H, W), None, Cout)
     pooled = run.empty(N, H // 2, W // 2, Cout)
-    run.L.maxpool_fwd(ptr(out.t), ptr(out.tr), ptr(pooled), Cout, N, H, W, run.dt)
+    run.L.maxpool_fwd(ptr(out.t), ptr(out.tr), ptr(pooled), Cout, N, H, W, 0, run.dt)
     torch.cuda.synchronize()
     # reference built on OUR z so that arg-max ties/ordering are identical
     zr = nchw(out.t).requires_grad_(True)
@@ -254,6 +254,15 @@ def test_block_bwd_through_maxpool(dev, dtype):
     pr = F.max_pool2d(y, 2)
     tol = TOL[dtype]
     assert rel(nchw(pooled), pr) < 5 * tol
+    # raw mode (what the model uses): the SELECTED elements' pre-BatchNorm z; through the producer's load transform it reproduces the max
+    praw = run.empty(N, H // 2, W // 2, Cout)
+    run.L.maxpool_fwd(ptr(out.t), ptr(out.tr), ptr(praw), Cout, N, H, W, 1, run.dt)
+    torch.cuda.synchronize()
+    act = torch.maximum(praw.float() * out.tr[0] + out.tr[1], out.tr[2])
+    assert rel(act, pooled.float()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    # ... and every raw value is one of the four z of its window
+    zwin = out.t.float().reshape(N, H, W, Cout)[:, : H // 2 * 2, : W // 2 * 2].reshape(N, H // 2, 2, W // 2, 2, Cout)
+    assert bool(((zwin - praw.float()[:, :, None, :, None, :]) == 0).any(dim=4).any(dim=2).all())
     g1 = nhwc(torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev), dtype)
     g2 = nhwc(torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev), dtype)
     pr.backward(nchw(g1) + nchw(g2))
