@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
     for (int j = 0; j < NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     TileSched ts(tg.ntiles);
+    GhatPend<T> gp;        // (g, z) loads of the next dz chunk (generic path)
+    bool have_gp = false;  // gp already holds chunk 0 of the tile that starts (issued during the previous tile's wgrad phase)
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = tile_origin2<TW, TH>(tg, (int)t);
         PixIdx px;
@@ -306,13 +308,21 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             __syncthreads();
             continue;
         }
-        // ---- A: dz chunks -> tileD (dgrad operand) + dzT (wgrad operand) ; dgrad MFMA
-        for (int kc = 0; kc < Cfg::NKD; ++kc) {
+        // ---- A: dz chunks -> tileD (dgrad operand) + dzT (wgrad operand) ; dgrad MFMA.
+        // Software-pipelined: the (g, z) loads of chunk kc+1 are in flight while chunk kc goes through LDS and the MFMAs (these
+        // deep-level launches are latency-bound: exposed, the loads were 40 % of their time).  In the dgrad blocks the prefetch is issued
+        // AFTER the chunk's weight-fragment loads: vector loads retire in order, so a weight load issued behind the prefetch would wait
+        // for it.
+        const bool gact = cg < CGO && pv;
+        if (!have_gp) issue_ghat8(gp, gs, z, COUT, p, px, H, W, cg * 8, gact);
+        have_gp = false;
+        for (int kc = 0; kc < Cfg::NKD; ++kc) {  // (compile-time trip count: with run-time bounds -- e.g. only the cout range a wgrad-only
+                                                 // block needs -- hipcc's code for this loop got 15-20 % slower)
             float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const int c0 = (kc * CGO + cg) * 8;
-            if (cg < CGO && pv) {
+            if (gact) {
                 float gh[8], zv[8];
-                load_ghat8(gs, z, COUT, s_bn, p, px, H, W, c0, gh, zv);
+                finish_ghat8(gp, gs, COUT, s_bn, px, H, W, c0, gh, zv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) dz[i] = fmaf(s_cf[c0 + i], gh[i], fmaf(s_cf[COUT + c0 + i], zv[i], s_cf[2 * COUT + c0 + i]));
             }
@@ -325,18 +335,41 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
                 }
             }
             __syncthreads();
+            const int c0n = ((kc + 1) * CGO + cg) * 8;
             if (do_dgrad) {
                 typename Mma<T>::Frag pf[PTW];
+                if constexpr (Elem<T>::is_bf16) {
+                    typename Mma<T>::Frag wf[MTD];
 #pragma unroll
-                for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
+                    for (int b = 0; b < MTD; ++b) wf[b] = Mma<T>::load_w(wpk_d, (long)kc * MTD + b, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kc + 1 < Cfg::NKD) issue_ghat8(gp, gs, z, COUT, p, px, H, W, c0n, gact);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int b = 0; b < MTD; ++b) {
-                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk_d, (long)kc * MTD + b, lane);
+                    for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
 #pragma unroll
-                    for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wf, pf[a], accd[a][b]);
+                    for (int b = 0; b < MTD; ++b)
+#pragma unroll
+                        for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wf[b], pf[a], accd[a][b]);
+                } else {
+                    if (kc + 1 < Cfg::NKD) issue_ghat8(gp, gs, z, COUT, p, px, H, W, c0n, gact);
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(tileD, PITCH, (wave * PTW + a) * 16, lane, CGO * 8);
+#pragma unroll
+                    for (int b = 0; b < MTD; ++b) {
+                        const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk_d, (long)kc * MTD + b, lane);
+#pragma unroll
+                        for (int a = 0; a < PTW; ++a) accd[a][b] = Mma<T>::template mma<CGO * 2>(wf, pf[a], accd[a][b]);
+                    }
                 }
+            } else if (kc + 1 < Cfg::NKD) {
+                issue_ghat8(gp, gs, z, COUT, p, px, H, W, c0n, gact);
             }
         }
+        // first input-halo chunk of phase C: in flight during the du stores
+        typename HaloStager<T, CGI, TW, TH>::Pending hp;
+        const int kcc0 = ci_base / (CGI * 8), kcc1 = (ci_base + Cfg::CIB) / (CGI * 8);
+        stager.issue(hp, x, kcc0 * CGI * 8, org, H, W, tid);
         // ---- B: store du
         if (do_dgrad) {
 #pragma unroll
@@ -359,9 +392,10 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             }
         }
         // ---- C: recompute u = dw3x3(x~) for this block's cin range -> uT (input tile + halo staged once in LDS)
-        for (int kc = ci_base / (CGI * 8); kc < (ci_base + Cfg::CIB) / (CGI * 8); ++kc) {
+        for (int kc = kcc0; kc < kcc1; ++kc) {
             __syncthreads();  // xs free (previous chunk / previous tile readers done)
-            stager.stage(x, s_trx, kc * CGI * 8, org, H, W, xs, tid);
+            stager.commit(hp, s_trx, kc * CGI * 8, xs, tid);
+            if (kc + 1 < kcc1) stager.issue(hp, x, (kc + 1) * CGI * 8, org, H, W, tid);  // next chunk: in flight during the tap phase
             __syncthreads();
             if (cg < CGI) {
                 const int c0 = (kc * CGI + cg) * 8;
@@ -372,6 +406,16 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
             }
         }
         __syncthreads();
+        if (t + ts.step < ts.end) {  // chunk 0 of the NEXT tile: in flight during the wgrad MFMAs
+            const TileOrg on = tile_origin2<TW, TH>(tg, (int)(t + ts.step));
+            PixIdx pn;
+            pn.n = on.n;
+            pn.h = on.h0 + ty;
+            pn.w = on.w0 + tx;
+            const bool pvn = pn.h < H && pn.w < W;
+            issue_ghat8(gp, gs, z, COUT, pix_linear(pn, H, W), pn, H, W, cg * 8, cg < CGO && pvn);
+            have_gp = true;
+        }
         // ---- D: wgrad MFMA over the pixel dimension
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {

@@ -418,3 +418,74 @@ __device__ __forceinline__ void load_ghat8(const GradSrc<T>& gs, const T* z, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) gh[i] = win[i] ? g[i] : 0.f;
 }
+
+// The same in two halves for software pipelining: issue_ghat8() only ISSUES the global loads (raw registers; UNCONDITIONAL, inactive
+// threads read the tensors' first elements -- a load under a divergent branch would make hipcc drain vmcnt before the next load),
+// finish_ghat8() does the arithmetic one phase later.  gs.pooled / gs.g2 are kernel-uniform.
+template <class T>
+struct GhatPend {
+    Raw8<T> z, g1, g2, zo0, zo1, zo2;  // (named members, not an array: an array here ends up in scratch)
+};
+template <class T>
+__device__ __forceinline__ void issue_ghat8(GhatPend<T>& pd, const GradSrc<T>& gs, const T* z, int C, long p, const PixIdx& px, int H, int W,
+                                            int c0, bool act) {
+    // Straight-line code on purpose (addresses are selected, loads are not branched over): with the loads under `if (gs.g2)` /
+    // `if (gs.pooled)` hipcc routed the conditionally-defined registers through scratch with a vmcnt(0) behind each load.  Without a
+    // second gradient g2 re-reads g1, without pooling the three window loads re-read one element of z: cache hits, results unused.
+    const bool pooled = gs.pooled != 0;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int ph = px.h >> 1, pw = px.w >> 1;
+    const bool inw = act && (!pooled || (px.h < 2 * Hp && px.w < 2 * Wp));
+    const long pg = pooled ? ((long)px.n * Hp + ph) * Wp + pw : p;
+    const T* g2b = gs.g2 ? gs.g2 : gs.g1;
+    pd.z = load8_raw(act ? z + p * C + c0 : z);
+    pd.g1 = load8_raw(inw ? gs.g1 + pg * C + c0 : gs.g1);
+    pd.g2 = load8_raw(inw ? g2b + pg * C + c0 : g2b);
+    const bool wz = inw && pooled;
+    const int own = ((px.h & 1) << 1) | (px.w & 1);
+    const long base = ((long)px.n * H + 2 * ph) * W + 2 * pw;
+    // the three OTHER elements of the window, in window order
+    const int k0 = own <= 0 ? 1 : 0, k1 = own <= 1 ? 2 : 1, k2 = own <= 2 ? 3 : 2;
+    pd.zo0 = load8_raw(wz ? z + (base + (long)(k0 >> 1) * W + (k0 & 1)) * C + c0 : z);
+    pd.zo1 = load8_raw(wz ? z + (base + (long)(k1 >> 1) * W + (k1 & 1)) * C + c0 : z);
+    pd.zo2 = load8_raw(wz ? z + (base + (long)(k2 >> 1) * W + (k2 & 1)) * C + c0 : z);
+}
+template <class T>
+__device__ __forceinline__ void finish_ghat8(const GhatPend<T>& pd, const GradSrc<T>& gs, int C, const float* bn, const PixIdx& px, int H, int W,
+                                             int c0, float (&gh)[8], float (&zv)[8]) {
+    unpack8(pd.z, zv);
+    float y[8], g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = fmaf(zv[i], bn[c0 + i], bn[C + c0 + i]);
+    unpack8(pd.g1, g);
+    if (gs.g2) {
+        float g2[8];
+        unpack8(pd.g2, g2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] += g2[i];
+    }
+    if (!gs.pooled) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gh[i] = y[i] > 0.f ? g[i] : 0.f;
+        return;
+    }
+    const int Hp = H >> 1, Wp = W >> 1;
+    const bool inw = px.h < 2 * Hp && px.w < 2 * Wp;  // floor mode: the last odd row / column is in no window
+    const int own = ((px.h & 1) << 1) | (px.w & 1);
+    bool win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win[i] = inw && y[i] > 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float zo[8];
+        unpack8(j == 0 ? pd.zo0 : (j == 1 ? pd.zo1 : pd.zo2), zo);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float yo = fmaxf(fmaf(zo[i], bn[c0 + i], bn[C + c0 + i]), 0.f);
+            const float ym = fmaxf(y[i], 0.f);
+            win[i] = win[i] && (j < own ? ym > yo : ym >= yo);  // ties go to the first element of the window
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gh[i] = win[i] ? g[i] : 0.f;
+}
