@@ -86,8 +86,7 @@ int ocrs_blk_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tr
                  float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H,
                  int W, int dtype, hipStream_t st);
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
-                     const float* bn, const float* coef, float* du_ws, float* dwpw, float* dwdw, int N, int H, int W, int dtype,
-                     hipStream_t st);
+                     const float* bn, const float* coef, float* dwpw, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of ConvTranspose2d + crop. */
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype);
 int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup,

@@ -273,8 +273,7 @@ class _DetRun:
                           ptr(self.G[f"{prefix}.seq.2.weight"]), ptr(self.G[f"{prefix}.seq.2.bias"]))
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
         if r.Cin == 1:
-            du = self.empty(N * H * W, dtype=torch.float32)
-            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(du),
+            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef),
                           ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), N, H, W, self.dt)
             return None, None
         a, b = r.a, r.b
