@@ -716,10 +716,11 @@ __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, c
     for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
-    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256) {  // wave-uniform trip count (nb3x3 shuffles)
+    PixIter pit((long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, H, W);
+    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256, pit.next()) {  // wave-uniform trip count (nb3x3 shuffles)
         const long p = base + threadIdx.x;
         const bool active = p < P;
-        const PixIdx px = decode_pixel(active ? p : 0, H, W);
+        const PixIdx px = pit.cur();
         float nb[9];
         nb3x3(img, px, H, W, active, threadIdx.x & 63, nb);
         if (!active) continue;
