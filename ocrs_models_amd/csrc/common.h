@@ -197,6 +197,7 @@ __device__ __forceinline__ float quad16_sum(float v) {
 //   D  : lane l holds D[(l>>4)*4 + r][l&15], r = 0..3                       (both)
 // ----------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // operand of the packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 

@@ -493,7 +493,10 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     const int ppair = tid / CQ, q = tid % CQ;
     const int ty = ppair / (TW / 2), tx = (ppair % (TW / 2)) * 2;  // left pixel of the pair
     const int c0 = cb + q * 4;
-    float acc[9][4], sc[4], sh[4], lo[4];
+    // The 144 FMAs per tile and thread (2 pixels x 4 channels x 9 taps x {dx~, dW}) run as PACKED fp32 FMAs (v_pk_fma_f32: two channels
+    // per instruction, full rate on CDNA3/4): this kernel was ~60 % VALU-busy per SIMD with scalar FMAs.  Channel pairs (0,1) / (2,3).
+    f32x2 acc[9][2];
+    float sc[4], sh[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + i;
@@ -502,9 +505,9 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         sc[i] = trp[0];
         sh[i] = trp[trs];
         lo[i] = trp[2 * trs];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t][i] = 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = (f32x2){0.f, 0.f};
     const bool in_a = c0 < x.Ca;
     const T* xsrc = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
     T* gdst = in_a ? (gxa ? gxa + c0 : nullptr) : (gxb ? gxb + (c0 - x.Ca) : nullptr);
@@ -587,7 +590,8 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
             issue(cur, org_next);
         }
         lds_barrier();
-        float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x2 g[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+        const f32x2 xp2[2][2] = {{{xv[0][0], xv[0][1]}, {xv[0][2], xv[0][3]}}, {{xv[1][0], xv[1][1]}, {xv[1][2], xv[1][3]}}};
         // tap k = (ky, kx) pairs x~[p] with du[p - off(k)] = halo (ty + 2 - ky, tx' + 2 - kx).  Window column c (halo column tx + c) serves
         // the left pixel with kx = 2 - c (c <= 2) and the right pixel with kx = 3 - c (c >= 1).  An out-of-image pixel has x~ = 0, so it
         // adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
@@ -595,33 +599,34 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         for (int ky = 0; ky < 3; ++ky) {
             __builtin_amdgcn_sched_barrier(0);  // one row of taps (4 + 3 LDS vector reads) in flight at a time (register pressure)
             const float* drow = ds + ((ty + 2 - ky) * (TW + 2) + tx) * PS + q * 4;
-            float wk[3][4];
+            f32x2 wk[3][2];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const float4 w4 = *reinterpret_cast<const float4*>(s_w + (ky * 3 + kx) * SC + q * 4);
-                wk[kx][0] = w4.x; wk[kx][1] = w4.y; wk[kx][2] = w4.z; wk[kx][3] = w4.w;
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_w + (ky * 3 + kx) * SC + q * 4);
+                wk[kx][0] = (f32x2){w4[0], w4[1]};
+                wk[kx][1] = (f32x2){w4[2], w4[3]};
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 d4 = *reinterpret_cast<const float4*>(drow + c * PS);
-                const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(drow + c * PS);
+                const f32x2 d[2] = {{d4[0], d4[1]}, {d4[2], d4[3]}};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 2; ++i) {
                     if (c <= 2) {
-                        g[0][i] = fmaf(wk[2 - c][i], d[i], g[0][i]);
-                        acc[ky * 3 + 2 - c][i] = fmaf(xv[0][i], d[i], acc[ky * 3 + 2 - c][i]);
+                        g[0][i] = __builtin_elementwise_fma(wk[2 - c][i], d[i], g[0][i]);
+                        acc[ky * 3 + 2 - c][i] = __builtin_elementwise_fma(xp2[0][i], d[i], acc[ky * 3 + 2 - c][i]);
                     }
                     if (c >= 1) {
-                        g[1][i] = fmaf(wk[3 - c][i], d[i], g[1][i]);
-                        acc[ky * 3 + 3 - c][i] = fmaf(xv[1][i], d[i], acc[ky * 3 + 3 - c][i]);
+                        g[1][i] = __builtin_elementwise_fma(wk[3 - c][i], d[i], g[1][i]);
+                        acc[ky * 3 + 3 - c][i] = __builtin_elementwise_fma(xp2[1][i], d[i], acc[ky * 3 + 3 - c][i]);
                     }
                 }
             }
         }
         if (gdst) {
             T* gp = gdst + (((long)org.n * H + org.h0) * W + org.w0) * xp + xoff;
-            if (valid[0]) store4(gp, g[0][0], g[0][1], g[0][2], g[0][3]);
-            if (valid[1]) store4(gp + xp, g[1][0], g[1][1], g[1][2], g[1][3]);
+            if (valid[0]) store4(gp, g[0][0][0], g[0][0][1], g[0][1][0], g[0][1][1]);
+            if (valid[1]) store4(gp + xp, g[1][0][0], g[1][0][1], g[1][1][0], g[1][1][1]);
         }
         if constexpr (STATS) {
 #pragma unroll
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     // the producer's pw_bwd reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask for sums
-                    const float gh = xv[e][i] > 0.f ? Elem<T>::round(g[e][i]) : 0.f;
+                    const float gh = xv[e][i] > 0.f ? Elem<T>::round(g[e][i >> 1][i & 1]) : 0.f;
                     st1[i] += gh;
                     st2[i] = fmaf(gh, zr[e][i] - s_mu[q * 4 + i], st2[i]);
                 }
@@ -643,7 +648,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_red[(t * 4 + i) * 256 + tid] = acc[t][i];
+        for (int i = 0; i < 4; ++i) s_red[(t * 4 + i) * 256 + tid] = acc[t][i >> 1][i & 1];
     if constexpr (STATS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
