@@ -597,7 +597,6 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         // adds nothing to dW (keeps the 36 accumulators out of divergent control flow).
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            __builtin_amdgcn_sched_barrier(0);  // one row of taps (4 + 3 LDS vector reads) in flight at a time (register pressure)
             const float* drow = ds + ((ty + 2 - ky) * (TW + 2) + tx) * PS + q * 4;
             f32x2 wk[3][2];
 #pragma unroll
