@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restri
 // k_bn_bwd_reduce pass over (g, z) -- 2.1 ms of the step -- disappears.  Partials go to workspace rows 9..10 (stat_mask bit 0 / 1 =
 // source a / b wants them); k_dw_partials_reduce scales by rstd and adds them to the producers' gsum [2][C] (fp64).
 #ifndef OCRS_DW_BLOCKS
-#define OCRS_DW_BLOCKS 2  // two pixels per thread need ~200 VGPRs: 3 blocks/CU spills inside the tile loop (measured 1.5x slower), 2 wins
+#define OCRS_DW_BLOCKS 3  // 168 VGPRs: the per-channel load transform lives in LDS (3 vector reads per tile) instead of 12 registers, and the
+                          // final-reduction scratch aliases the tiles, so that three blocks fit a CU (registers AND LDS)
 #endif
 template <class T, int CG, bool STATS>
 __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     float* ds = s_mem;           // [HP][PS] du tile + halo (fp32, 0 outside the image)
     float* s_w = ds + HP * PS;   // [9][SC] weights, tap-major
     float* s_mu = s_w + 9 * SC;  // [SC] saved mean of the producer(s) (STATS)
+    float* s_trp = s_mu + SC;    // [3][SC] load transform of this block's channel slab: scale | shift | lo
     const int C = x.Ca + x.Cb;
     const int H = tg.H, W = tg.W;
     const int cb = blockIdx.y * SC;
@@ -483,6 +485,10 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     for (int i = tid; i < 9 * SC; i += 256) {
         const int t = i / SC, c = i - t * SC;
         s_w[i] = wdw[(cb + c) * 9 + t];
+    }
+    for (int i = tid; i < 3 * SC; i += 256) {
+        const int k = i / SC, c = cb + (i - k * SC);
+        s_trp[i] = c < x.Ca ? tra[k * x.Ca + c] : trb[k * x.Cb + (c - x.Ca)];
     }
     if (STATS)
         for (int c = tid; c < SC; c += 256) {
@@ -496,16 +502,6 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     // The 144 FMAs per tile and thread (2 pixels x 4 channels x 9 taps x {dx~, dW}) run as PACKED fp32 FMAs (v_pk_fma_f32: two channels
     // per instruction, full rate on CDNA3/4): this kernel was ~60 % VALU-busy per SIMD with scalar FMAs.  Channel pairs (0,1) / (2,3).
     f32x2 acc[9][2];
-    float sc[4], sh[4], lo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + i;
-        const float* trp = c < x.Ca ? tra + c : trb + (c - x.Ca);
-        const int trs = c < x.Ca ? x.Ca : x.Cb;
-        sc[i] = trp[0];
-        sh[i] = trp[trs];
-        lo[i] = trp[2 * trs];
-    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = (f32x2){0.f, 0.f};
     const bool in_a = c0 < x.Ca;
@@ -572,6 +568,17 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
         }
         const bool valid[2] = {(cur.ok & 0x40000000u) != 0, (cur.ok & 0x80000000u) != 0};
         float xv[2][4], zr[STATS ? 2 : 1][4];  // transformed input x~ (0 outside the image) / raw input of the two pixels
+        float sc[4], sh[4], lo[4];
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s_trp + q * 4), b = *reinterpret_cast<const f32x4*>(s_trp + SC + q * 4),
+                        c = *reinterpret_cast<const f32x4*>(s_trp + 2 * SC + q * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = a[i];
+                sh[i] = b[i];
+                lo[i] = c[i];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             float r[4];
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const
     // block reduction of the 36 per-thread partials through LDS (plain stores, then a strided sum): cheap in registers,
     // runs once per persistent block
     constexpr int NROW = STATS ? 11 : 9;  // per-channel partial rows: 9 taps (+ the two BatchNorm-backward sums)
-    float* s_red = s_mu + SC;  // [NROW*4][256]
+    float* s_red = s_mem;  // [NROW*4][256]: aliases the (now dead) tile and parameters
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1323,7 +1330,8 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     {                                                                                                                                     \
         const Tiling2 tg = make_tiling2(N, H, W, 32 / CG_, 8);                                                                            \
         const int HP = (32 / CG_ + 2) * 10;                                                                                               \
-        const size_t smem = (HP * CG_ * 12 + 10 * CG_ * 8 + 44 * 256) * sizeof(float);                                                    \
+        const size_t tile_fl = HP * CG_ * 12 + 13 * CG_ * 8, red_fl = 44 * 256;                                                           \
+        const size_t smem = (tile_fl > red_fl ? tile_fl : red_fl) * sizeof(float);                                                        \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         if (stat_mask)                                                                                                                    \
             hipLaunchKernelGGL((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
