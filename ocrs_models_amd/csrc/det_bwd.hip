@@ -173,7 +173,7 @@ struct PwBwdCfg {
 };
 
 template <class T, int CIN, int COUT>
-__global__ __launch_bounds__(256) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
+__global__ __launch_bounds__(256, ((CIN > 32 || COUT > 32) && CIN * COUT <= 8192 && Elem<T>::is_bf16) ? 2 : 1) void k_pw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw /*master [CIN][9]*/,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][COUT]*/,
                                                 const float* __restrict__ coef /*[3][COUT]*/, const void* __restrict__ wpk_d,
                                                 T* __restrict__ du /*[P][CIN]*/, float* __restrict__ dwpw /*[COUT][CIN]*/,
