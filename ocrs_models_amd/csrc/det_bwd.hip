@@ -727,16 +727,27 @@ __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, c
     for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
-    PixIter pit((long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, H, W);
-    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256, pit.next()) {  // wave-uniform trip count (nb3x3 shuffles)
-        const long p = base + threadIdx.x;
-        const bool active = p < P;
-        const PixIdx px = pit.cur();
+    // software pipeline over the grid-stride loop (see k_dwpw_c1_fwd): the image neighbourhood AND the (g, z) vectors of iteration i+1 are in
+    // flight while iteration i is computed; two buffers, loop unrolled by two
+    const long stride = (long)gridDim.x * 256;
+    PixIter pit((long)blockIdx.x * 256 + threadIdx.x, stride, H, W);
+    long p = (long)blockIdx.x * 256 + threadIdx.x;
+    struct Buf {
+        Nb9 nb;
+        GhatPend<T> gp;
+        PixIdx px;
+    };
+    auto issue = [&](Buf& b, long pp) {
+        const bool act = pp < P;
+        b.px = pit.cur();
+        issue_ghat8(b.gp, gs, z, 8, act ? pp : 0, b.px, H, W, 0, act);
+        nb9_issue(b.nb, img, b.px, H, W, act);
+    };
+    auto compute = [&](const Buf& b) {
         float nb[9];
-        nb3x3(img, px, H, W, active, threadIdx.x & 63, nb);
-        if (!active) continue;
+        nb9_finish(b.nb, nb);
         float gh[8], zv[8];
-        load_ghat8(gs, z, 8, s_bn, p, px, H, W, 0, gh, zv);
+        finish_ghat8(b.gp, gs, 8, s_bn, b.px, H, W, 0, gh, zv);
         float u = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[k], u);
@@ -750,6 +761,19 @@ __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, c
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[8 + k] = fmaf(d, nb[k], acc[8 + k]);
+    };
+    Buf bufA, bufB;
+    issue(bufA, p);
+    while (p < P) {
+        pit.next();
+        issue(bufB, p + stride);
+        compute(bufA);
+        p += stride;
+        if (p >= P) break;
+        pit.next();
+        issue(bufA, p + stride);
+        compute(bufB);
+        p += stride;
     }
 #pragma unroll
     for (int i = 0; i < 17; ++i) {
@@ -1361,7 +1385,8 @@ int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const
     OCRS_CHECK_ARG(img && wdw && wpw && g1 && z && bn && coef && dwpw && dwdw);
     const long P = (long)N * H * W;
     int grid = ew_grid(P);
-    if (grid > 1024) grid = 1024;  // streaming kernel ending in same-address atomics: 4 blocks per CU are plenty
+    const int resident = (dtype == 1 ? 3 : 2) * kNumCU;  // persistent grid-stride kernel: exactly the resident blocks (168 / 217 VGPRs)
+    if (grid > resident) grid = resident;
     if (dtype == 1) {
         GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
         hipLaunchKernelGGL(k_c1_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const bf16*)z, bn, coef, dwpw, dwdw, H, W, P);

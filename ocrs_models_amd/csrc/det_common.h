@@ -132,6 +132,30 @@ __device__ __forceinline__ void nb3x3(const float* __restrict__ img, const PixId
     }
 }
 
+// The same neighbourhood as nine plain loads in two halves (issue now, use one loop iteration later): the streaming first-block kernels
+// are bound by the memory LATENCY of one iteration, not by load count (the 6 extra loads hit the lines the 3 column loads fetch), and
+// nb3x3's whole-wave shifts + edge fix-up loads have to wait for their data on the spot.  Loads are unconditional (out-of-image taps
+// read element 0 and are zeroed in nb9_finish).
+struct Nb9 {
+    float v[9];
+    unsigned ok;
+};
+__device__ __forceinline__ void nb9_issue(Nb9& nb, const float* __restrict__ img, const PixIdx& px, int H, int W, bool active) {
+    const long rowc = ((long)px.n * H + px.h) * W + px.w;
+    nb.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int dy = k / 3 - 1, dx = k % 3 - 1;
+        const bool ok = active && (unsigned)(px.h + dy) < (unsigned)H && (unsigned)(px.w + dx) < (unsigned)W;
+        nb.v[k] = img[ok ? rowc + (long)dy * W + dx : 0];
+        nb.ok |= ok ? 1u << k : 0u;
+    }
+}
+__device__ __forceinline__ void nb9_finish(const Nb9& nb, float (&v)[9]) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = (nb.ok >> k & 1u) ? nb.v[k] : 0.f;
+}
+
 // Tile origins along a TileSched without divisions in the loop: the schedule's step is constant, so the origin advances by a fixed
 // (images, tile rows, tile columns) triple with two carries -- ~10 scalar instructions instead of two integer divisions (~45) per tile
 // (k_dw_bwd issued more SALU than VALU instructions, most of them tile bookkeeping).

@@ -237,14 +237,14 @@ __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ i
 #pragma unroll
     for (int i = 0; i < 8; ++i) wp[i] = wpw[i];
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    PixIter pit((long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, H, W);
-    for (long base = (long)blockIdx.x * 256; base < P; base += (long)gridDim.x * 256, pit.next()) {  // wave-uniform trip count (nb3x3 shuffles)
-        const long p = base + threadIdx.x;
-        const bool active = p < P;
-        const PixIdx px = pit.cur();
+    // software pipeline over the grid-stride loop: the neighbourhood of iteration i+1 is in flight while iteration i is computed and
+    // stored; two buffers, loop unrolled by two (a buffer that a load is still filling cannot be copied without waiting for it)
+    const long stride = (long)gridDim.x * 256;
+    PixIter pit((long)blockIdx.x * 256 + threadIdx.x, stride, H, W);
+    long p = (long)blockIdx.x * 256 + threadIdx.x;
+    auto compute = [&](const Nb9& nbr, long pp) {
         float nb[9];
-        nb3x3(img, px, H, W, active, threadIdx.x & 63, nb);
-        if (!active) continue;
+        nb9_finish(nbr, nb);
         float u = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[k], u);
@@ -257,7 +257,20 @@ __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ i
             s1[i] += q;
             s2[i] = fmaf(q, q, s2[i]);
         }
-        store8(z + p * 8, o);
+        store8(z + pp * 8, o);
+    };
+    Nb9 bufA, bufB;
+    nb9_issue(bufA, img, pit.cur(), H, W, p < P);
+    while (p < P) {
+        pit.next();
+        nb9_issue(bufB, img, pit.cur(), H, W, p + stride < P);
+        compute(bufA, p);
+        p += stride;
+        if (p >= P) break;
+        pit.next();
+        nb9_issue(bufA, img, pit.cur(), H, W, p + stride < P);
+        compute(bufB, p);
+        p += stride;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
