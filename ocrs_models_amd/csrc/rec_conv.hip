@@ -924,6 +924,41 @@ __global__ __launch_bounds__(256) void k_col_sum(const T* __restrict__ a, int ld
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
 }
 
+// The same for C % 4 == 0 and 4-element-aligned rows: a thread owns 4 consecutive columns (one 16 / 8-byte load per row), 64 column quads
+// x 4 row phases per block, four rows in flight per thread; per-block partials pre-reduced in LDS, then C atomics per block (grid <= 2/CU).
+template <class T>
+__global__ __launch_bounds__(256) void k_col_sum4(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows) {
+    extern __shared__ float s_acc[];
+    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
+    __syncthreads();
+    const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const long rstep = (long)gridDim.x * 4;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + cq * 4;
+        if (c < C) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+            long r = (long)blockIdx.x * 4 + ph;
+            for (; r + 3 * rstep < rows; r += 4 * rstep) {
+                float v[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load4(a + (r + u * rstep) * ld + c, v[u]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += (v[0][i] + v[1][i]) + (v[2][i] + v[3][i]);
+            }
+            for (; r < rows; r += rstep) {
+                float v[4];
+                load4(a + r * ld + c, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(&s_acc[c + i], s[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 static inline int ew_grid(long items) {
     long g = (items + 255) / 256;
@@ -1464,6 +1499,18 @@ int ocrs_avgpool_dz(const float* gseq, const void* z, const float* coef, void* d
 // column sums (bias gradients): out[c] += sum_rows a[row][c]
 int ocrs_col_sum(const void* a, int ld, int C, float* out, long rows, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(a && out && C > 0 && ld >= C && rows > 0);
+    const int esz = dtype == 1 ? 2 : 4;
+    if (C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & (4 * esz - 1)) == 0) {
+        long g4 = (rows + 15) / 16;  // >= 4 rows per thread before another block is worth its C trailing atomics
+        if (g4 > 2 * kNumCU) g4 = 2 * kNumCU;
+        if (g4 < 1) g4 = 1;
+        if (dtype == 1)
+            hipLaunchKernelGGL(k_col_sum4<bf16>, dim3((int)g4), dim3(256), C * sizeof(float), st, (const bf16*)a, ld, C, out, rows);
+        else
+            hipLaunchKernelGGL(k_col_sum4<float>, dim3((int)g4), dim3(256), C * sizeof(float), st, (const float*)a, ld, C, out, rows);
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
     long g = (rows + 1) / 2;
     if (g > 1024) g = 1024;
     if (dtype == 1)
