@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_dw_partials_reduce(const float* __restr
 // ----------------------------------------------------------------------------------------------
 // first block (1 -> 8) backward: ONE streaming pass.  dz -> du[p] = sum_c Wpw[c] dz[p][c] stays in a register (the image needs no gradient);
 // dWpw[c] = sum_p u[p] dz[p][c] and dWdw[k] = sum_p du[p] * img[p + off_k] both use the 3x3 neighbourhood of the image that the
-// recompute of u needs anyway (nb3x3).  (A first version wrote du and ran a second kernel that gathered du neighbours: +167 us, +268 MB.)
+// recompute of u needs anyway (Nb9).  (A first version wrote du and ran a second kernel that gathered du neighbours: +167 us, +268 MB.)
 template <class T>
 __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn,

@@ -111,31 +111,11 @@ __device__ __forceinline__ TileOrg tile_origin2(const Tiling2& tg, int tile) {
     return o;
 }
 
-// 3x3 neighbourhood (zero outside the image) of pixel px in a single-channel fp32 image, for kernels whose consecutive lanes hold
-// consecutive pixels: each lane loads only the three values of ITS column (rows h-1, h, h+1); the left / right columns come from the
-// neighbouring lanes with whole-wave DPP shifts (wave_shr:1 / wave_shl:1, gfx9) -- 3 loads per pixel instead of 9.  Lanes whose neighbour
-// lane is not the adjacent pixel of the same row (wave edges, row ends) fetch that column themselves.  Must be executed by ALL 64
-// lanes of the wave (inactive pixels pass active = false).
-__device__ __forceinline__ void nb3x3(const float* __restrict__ img, const PixIdx& px, int H, int W, bool active, int lane, float (&v)[9]) {
-    const long rowc = ((long)px.n * H + px.h) * W + px.w;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-        const int hh = px.h + dy - 1;
-        const bool rv = active && hh >= 0 && hh < H;
-        const float c = rv ? img[rowc + (long)(dy - 1) * W] : 0.f;
-        float l = dpp_f<0x138>(c), r = dpp_f<0x130>(c);  // wave_shr:1 (from lane-1), wave_shl:1 (from lane+1)
-        if (lane == 0 || px.w == 0) l = (rv && px.w > 0) ? img[rowc + (long)(dy - 1) * W - 1] : 0.f;
-        if (lane == 63 || px.w == W - 1) r = (rv && px.w < W - 1) ? img[rowc + (long)(dy - 1) * W + 1] : 0.f;
-        v[dy * 3 + 0] = l;
-        v[dy * 3 + 1] = c;
-        v[dy * 3 + 2] = r;
-    }
-}
-
-// The same neighbourhood as nine plain loads in two halves (issue now, use one loop iteration later): the streaming first-block kernels
-// are bound by the memory LATENCY of one iteration, not by load count (the 6 extra loads hit the lines the 3 column loads fetch), and
-// nb3x3's whole-wave shifts + edge fix-up loads have to wait for their data on the spot.  Loads are unconditional (out-of-image taps
-// read element 0 and are zeroed in nb9_finish).
+// 3x3 neighbourhood (zero outside the image) of pixel px in a single-channel fp32 image as nine plain loads in two halves (issue now, use
+// one loop iteration later): the streaming first-block kernels are bound by the memory LATENCY of one iteration, not by load count (six of
+// the nine loads hit lines the other three fetch).  An earlier version took the left / right columns from the neighbouring lanes with
+// whole-wave DPP shifts (3 loads per pixel), but shifts and edge fix-up loads have to wait for their data on the spot, which exposed a
+// full memory latency per iteration.  Loads are unconditional (out-of-image taps read element 0 and are zeroed in nb9_finish).
 struct Nb9 {
     float v[9];
     unsigned ok;
