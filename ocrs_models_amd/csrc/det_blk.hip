@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, OCRS_BLK_BLOCKS) void k_blk_bwd(Src2<bf16> x, 
         if (tid < C::TP * CGI) {
             const int p = tid / CGI, ty = p / TW, tx = p % TW;
             float u[8], uz[8];
-            dw_from_lds<CGI, TW, TH>(xs, s_wdw, CIN, cgi * 8, cgi, ty, tx, u);
+            dw_from_lds<CGI, TW, TH, false>(xs, s_wdw, CIN, cgi * 8, cgi, ty, tx, u);  // (this kernel stores its tile unswizzled)
             const bool pv = org.h0 + ty < H && org.w0 + tx < W;
 #pragma unroll
             for (int i = 0; i < 8; ++i) uz[i] = pv ? u[i] : 0.f;

@@ -200,6 +200,15 @@ __device__ __forceinline__ void apply_tr8(float (&v)[8], const float* tr, int C,
 // ---- HaloStager: stage x~ = max(x*scale+shift, lo) of a tile's halo region into LDS as fp32; pixels outside the image are written
 // as 0 (that IS the conv's zero padding), so the tap loop needs no bounds checks.  Everything tile-invariant is hoisted out of
 // the persistent tile loop.
+// Bank swizzle of the planar tile (16-byte units = items): the two-pixels-per-thread readers (dw2_from_lds) read every OTHER pixel, i.e. units
+// base + 2*CG*k + cg: that hits half of the 16 bank groups twice (PMC: 28-34 % of the LDS cycles of the forward / pointwise-backward
+// kernels were bank conflicts).  Flipping bit log2(CG) of the unit index in every odd 16-unit block moves the second half of such a
+// read onto the unused bank groups; writers (consecutive units) and one-pixel readers stay conflict-free (a permutation inside a block).
+template <int CG>
+__device__ __forceinline__ int xs_swz(int item) {
+    return item ^ (((item >> 4) & 1) * CG);
+}
+
 // LDS layout: two PLANES of 4 channels, xs[plane][halo pixel * CG + cg][4]: consecutive lanes read consecutive 16-byte words, so the
 // tap loop's ds_read_b128 are bank-conflict free (an [item][8] layout puts lanes i and i+8 on the same banks: measured 25-28 %
 // of all LDS cycles were conflicts).
@@ -231,8 +240,9 @@ struct HaloStager {
     static constexpr int PLANE = NITEMS * 4;  // floats
     static constexpr int NIT = (NITEMS + 255) / 256;
     __device__ static __forceinline__ void put(float* xs, int it, const float (&v)[8]) {
-        store4(xs + it * 4, v[0], v[1], v[2], v[3]);
-        store4(xs + PLANE + it * 4, v[4], v[5], v[6], v[7]);
+        const int o = xs_swz<CG>(it) * 4;
+        store4(xs + o, v[0], v[1], v[2], v[3]);
+        store4(xs + PLANE + o, v[4], v[5], v[6], v[7]);
     }
     int hyx[NIT];   // hy | hx << 16
     int poff[NIT];  // hy * W + hx  (pixel offset from the halo's corner pixel)
@@ -327,18 +337,19 @@ struct HaloStager {
 
 // u[8] = sum over the 9 taps of w[tap][c] * xs[pixel + tap][c] for the thread's (pixel, channel group), all from LDS
 // (xs in the HaloStager's planar layout).
-template <int CG, int TW, int TH>
+template <int CG, int TW, int TH, bool SWZ = true>
 __device__ __forceinline__ void dw_from_lds(const float* xs, const float* s_w /*[9][CIN] tap-major*/, int CIN, int c0, int cg, int ty, int tx,
                                             float (&u)[8]) {
     constexpr int HWp = TW + 2;
     constexpr int PLANE = HaloTile<TW, TH>::HP * CG * 4;
-    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 4;  // top-left tap of this pixel, plane 0
+    const int item0 = (ty * HWp + tx) * CG + cg;  // top-left tap of this pixel
 #pragma unroll
     for (int i = 0; i < 8; ++i) u[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float v[8], wv[8];
-        const float* q = xc + ((t / 3) * HWp + (t % 3)) * CG * 4;
+        const int it = item0 + ((t / 3) * HWp + (t % 3)) * CG;
+        const float* q = xs + (SWZ ? xs_swz<CG>(it) : it) * 4;
         const float4 lo4 = *reinterpret_cast<const float4*>(q), hi4 = *reinterpret_cast<const float4*>(q + PLANE);
         v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w;
         v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
@@ -355,7 +366,7 @@ __device__ __forceinline__ void dw2_from_lds(const float* xs, const float* s_w /
                                              float (&u0)[8], float (&u1)[8]) {
     constexpr int HWp = TW + 2;
     constexpr int PLANE = HaloTile<TW, TH>::HP * CG * 4;
-    const float* xc = xs + ((ty * HWp + tx) * CG + cg) * 4;
+    const int item0 = (ty * HWp + tx) * CG + cg;
 #pragma unroll
     for (int i = 0; i < 8; ++i) u0[i] = u1[i] = 0.f;
 #pragma unroll
@@ -365,7 +376,7 @@ __device__ __forceinline__ void dw2_from_lds(const float* xs, const float* s_w /
         for (int c = 0; c < 3; ++c) load8(s_w + (r * 3 + c) * CIN + c0, w[c]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float* q = xc + (r * HWp + c) * CG * 4;
+            const float* q = xs + xs_swz<CG>(item0 + (r * HWp + c) * CG) * 4;
             const float4 lo4 = *reinterpret_cast<const float4*>(q), hi4 = *reinterpret_cast<const float4*>(q + PLANE);
             const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
