@@ -457,10 +457,11 @@ __global__ __launch_bounds__(256, ((CIN > 32 || COUT > 32) && CIN * COUT <= 8192
 // source a / b wants them); k_dw_partials_reduce scales by rstd and adds them to the producers' gsum [2][C] (fp64).
 #ifndef OCRS_DW_BLOCKS
 #define OCRS_DW_BLOCKS 3  // 168 VGPRs: the per-channel load transform lives in LDS (3 vector reads per tile) instead of 12 registers, and the
-                          // final-reduction scratch aliases the tiles, so that three blocks fit a CU (registers AND LDS)
+                          // final-reduction scratch aliases the tiles, so that three blocks fit a CU (registers AND LDS).  Applies to the
+                          // bf16 STATS variant (every launch of a training step); the fp32 / no-stats variants would spill and keep 2
 #endif
 template <class T, int CG, bool STATS>
-__global__ __launch_bounds__(256, OCRS_DW_BLOCKS) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(256, (Elem<T>::is_bf16 && STATS) ? OCRS_DW_BLOCKS : 2) void k_dw_bwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
                                                 float* __restrict__ ws /*[gridDim.x][C][9 (+2)] block partials or null*/,
