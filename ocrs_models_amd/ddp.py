@@ -24,7 +24,7 @@ from torch import nn
 class GradBucketer:
     def __init__(self, process_group=None, bucket_bytes: int = 1 << 20, average: bool = True):
         self.pg = process_group
-        self.bucket_bytes = bucket_bytes
+        self.bucket_bytes = int(os.environ.get("OCRS_DDP_BUCKET_BYTES", bucket_bytes))  # (env override: measurement knob)
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # OCRS_DDP_FORCE=1: issue the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
