@@ -10,19 +10,25 @@
 #include "det_common.h"
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <class T, int MT, int TH, int TW>
+// WM = waves along M: the four waves tile the block's output WM x (4 / WM) -- WM = 1: every wave computes all MT tiles for a quarter of the
+// pixels; 2: half of the M tiles x half of the pixel tiles; 4: a quarter of the M tiles x all pixel tiles.  Each weight fragment is fetched
+// by 4 / WM waves (the fragments come from L2 -- 72 KB per 32-channel chunk for MT = 8 -- and their re-fetch by every wave was the kernel's
+// largest data stream), each pixel fragment is read from LDS by WM waves.
+template <class T, int MT, int TH, int TW, int WM = 1>
 __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int ldx, const void* __restrict__ wpk, T* __restrict__ out, int ldo,
                                                     const float* __restrict__ bias, int relu, double* __restrict__ gstat, int Cin, int M,
                                                     int MT_total, int N, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw) {
     constexpr int PITCH = Mma<T>::LDS_PITCH;
-    constexpr int NTILES = TH * TW / 16, PTW = NTILES / 4, TPR = TW / 16;  // N-tiles per block / per wave / per tile row
-    static_assert(NTILES % 4 == 0 && TW % 16 == 0, "tile shape");
+    constexpr int NTILES = TH * TW / 16, PTW = NTILES * WM / 4, TPR = TW / 16;  // N-tiles per block / per wave / per tile row
+    constexpr int MTW = MT / WM;                                                // M-tiles per wave
+    static_assert(NTILES % 4 == 0 && TW % 16 == 0 && MT % WM == 0 && (WM == 1 || WM == 2 || WM == 4), "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);  // [(TH+KH-1)*(TW+KW-1)][PITCH]
     const int HWp = TW + KW - 1, HHp = TH + KH - 1, HP = HWp * HHp;
     float* s_stat = reinterpret_cast<float*>(smem + ((HP * PITCH * sizeof(T) + 15) & ~15));  // [2][MT*16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt0 = blockIdx.y * MT;
+    const int mw0 = (wave % WM) * MTW;  // first M tile (within the block's MT) of this wave
     if (gstat) {
         for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
     }
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
     int oty[PTW], otx[PTW];
 #pragma unroll
     for (int a = 0; a < PTW; ++a) {
-        const int q = wave * PTW + a;
+        const int q = (wave / WM) * PTW + a;
         oty[a] = q / TPR;
         otx[a] = (q % TPR) * 16;
     }
@@ -41,11 +47,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
         const int tpi = tiles_x * tiles_y;
         const int n = (int)t / tpi, r = (int)t - n * tpi;
         const int h0 = (r / tiles_x) * TH, w0 = (r % tiles_x) * TW;
-        f32x4 acc[PTW][MT];
+        f32x4 acc[PTW][MTW];
 #pragma unroll
         for (int a = 0; a < PTW; ++a)
 #pragma unroll
-            for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < ncc; ++cc) {
             __syncthreads();  // previous chunk's fragment reads done
             for (int it = tid; it < HP * 4; it += 256) {
@@ -64,8 +70,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
                 for (int a = 0; a < PTW; ++a) pf[a] = Mma<T>::load_p(xs, PITCH, (oty[a] + ky) * HWp + otx[a] + kx, lane, 32);
                 const long kc = (long)tap * ncc + cc;
 #pragma unroll
-                for (int b = 0; b < MT; ++b) {
-                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, kc * MT_total + mt0 + b, lane);
+                for (int b = 0; b < MTW; ++b) {
+                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, kc * MT_total + mt0 + mw0 + b, lane);
 #pragma unroll
                     for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<8>(wf, pf[a], acc[a][b]);
                 }
@@ -73,8 +79,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
         }
         // epilogue
 #pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            const int m0 = (mt0 + b) * 16 + (lane >> 4) * 4;
+        for (int b = 0; b < MTW; ++b) {
+            const int m0 = (mt0 + mw0 + b) * 16 + (lane >> 4) * 4;
             float bs[4] = {0.f, 0.f, 0.f, 0.f};
             if (bias) {
 #pragma unroll
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const float a1 = quad16_sum(s1[r4]), a2 = quad16_sum(s2[r4]);
                     if ((lane & 15) == 0) {
-                        atomicAdd(&s_stat[b * 16 + (lane >> 4) * 4 + r4], a1);
-                        atomicAdd(&s_stat[MT * 16 + b * 16 + (lane >> 4) * 4 + r4], a2);
+                        atomicAdd(&s_stat[(mw0 + b) * 16 + (lane >> 4) * 4 + r4], a1);
+                        atomicAdd(&s_stat[MT * 16 + (mw0 + b) * 16 + (lane >> 4) * 4 + r4], a2);
                     }
                 }
             }
@@ -976,7 +982,8 @@ static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int 
     {                                                                                                                                            \
         const size_t smem = ((HP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + 2 * MT_ * 16 * sizeof(float);                                    \
         const int gy = (MT_total + MT_ - 1) / MT_;                                                                                               \
-        hipLaunchKernelGGL((k_conv_igemm<T, MT_, TH, TW>), dim3(persistent_grid(tiles, gy >= 4 ? 2 : 4), gy), dim3(256), smem, st, (const T*)x, ldx, \
+        constexpr int WM_ = (Elem<T>::is_bf16 && TH > 1) ? (MT_ >= 8 ? 4 : (MT_ >= 4 ? 2 : 1)) : 1; /* measured: 1382 -> 974 us, 270 -> 230 us */ \
+        hipLaunchKernelGGL((k_conv_igemm<T, MT_, TH, TW, WM_>), dim3(persistent_grid(tiles, gy >= 4 ? 2 : 4), gy), dim3(256), smem, st, (const T*)x, ldx, \
                            wpk, (T*)out, ldo, bias, relu, gstat, Cin, M, MT_total, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw);                         \
     }
     if (MT_total % 8 == 0 || MT_total > 8)
