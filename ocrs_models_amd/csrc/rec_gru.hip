@@ -121,20 +121,22 @@ __device__ __forceinline__ float gru_gate_bwd1(const float* __restrict__ saved, 
 //   s >= 1 : dh_total = dout[t] + dhz_prev + W_hh^T dgh[t_prev]  (t_prev = the time processed at step s-1)
 // wT: packed W_hh^T fragments per direction (K=768, M=256): [2][24 chunks][16 mtiles][64][8].  dhz: ping-pong [2][2][N][256].
 // Block = 16 hidden x 16 batch; K = 768 split over the 4 waves (192 each).
-__global__ __launch_bounds__(256) void k_gru_step_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
+// Block = 16 hidden x 16 batch, 512 threads: K = 768 split over the block's EIGHT waves (96 each: the dependent MFMA chain and the slab
+// load per wave are half of the 4-wave version's); threads 0..255 own the (hidden, batch) pairs of the epilogue.
+__global__ __launch_bounds__(512) void k_gru_step_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
                                                       const float* __restrict__ wT, float* __restrict__ dgi, float* __restrict__ dgh,
                                                       float* __restrict__ dhz, int T, int N, int s) {
-    constexpr int GP = 196;  // LDS pitch of a 192-wide slab row
-    __shared__ __attribute__((aligned(16))) float gs[4][16 * GP];
-    __shared__ float red[4][16][17];
+    constexpr int NW = 8, KW_ = 768 / NW, GP = KW_ + 4;  // LDS pitch of a 96-wide slab row
+    __shared__ __attribute__((aligned(16))) float gs[NW][16 * GP];
+    __shared__ float red[NW][16][17];
     const int d = blockIdx.z, jt = blockIdx.x, b0 = blockIdx.y * 16;
     const int t = d == 0 ? T - 1 - s : s;
     const int tq = d == 0 ? t + 1 : t - 1;  // time processed at the previous step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // this thread's epilogue operands (independent of the GEMM): issue their loads first
-    const int jl = tid & 15, bl = tid >> 4;
+    const int jl = tid & 15, bl = (tid >> 4) & 15;
     const int b = b0 + bl, j = jt * 16 + jl;
-    const bool bv = b < N;
+    const bool bv = b < N && tid < 256;
     float e_dout = 0.f, e_dhz = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_hn = 0.f, e_hp = 0.f;
     if (bv) {
         e_dout = dout[((long)t * N + b) * 512 + d * GH + j];
@@ -148,19 +150,19 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(const float* __restrict__ 
         if (tp >= 0 && tp < T) e_hp = out[((long)tp * N + b) * 512 + d * GH + j];
     }
     if (s > 0) {
-        for (int it = lane; it < 16 * 48; it += 64) {
-            const int row = it / 48, c4 = (it % 48) * 4;
+        for (int it = lane; it < 16 * (KW_ / 4); it += 64) {
+            const int row = it / (KW_ / 4), c4 = (it % (KW_ / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + row < N) v = *reinterpret_cast<const float4*>(dgh + ((long)tq * N + b0 + row) * (2 * G3) + d * G3 + wave * 192 + c4);
+            if (b0 + row < N) v = *reinterpret_cast<const float4*>(dgh + ((long)tq * N + b0 + row) * (2 * G3) + d * G3 + wave * KW_ + c4);
             *reinterpret_cast<float4*>(&gs[wave][row * GP + c4]) = v;
         }
         __syncthreads();
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wd = wT + (long)d * 24 * 16 * 64 * 8;
 #pragma unroll
-        for (int kc = 0; kc < 6; ++kc) {
+        for (int kc = 0; kc < KW_ / 32; ++kc) {
             const Mma<float>::Frag pf = Mma<float>::load_p(&gs[wave][kc * 32], GP, 0, lane, 32);
-            const Mma<float>::Frag wf = Mma<float>::load_w(wd, (long)(wave * 6 + kc) * 16 + jt, lane);
+            const Mma<float>::Frag wf = Mma<float>::load_w(wd, (long)(wave * (KW_ / 32) + kc) * 16 + jt, lane);
             acc = Mma<float>::mma<8>(wf, pf, acc);
         }
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(const float* __restrict__ 
     }
     if (!bv) return;
     float dh = e_dout;
-    if (s > 0) dh += e_dhz + red[0][jl][bl] + red[1][jl][bl] + red[2][jl][bl] + red[3][jl][bl];
+    if (s > 0) dh += e_dhz + ((red[0][jl][bl] + red[1][jl][bl]) + (red[2][jl][bl] + red[3][jl][bl])) + ((red[4][jl][bl] + red[5][jl][bl]) + (red[6][jl][bl] + red[7][jl][bl]));
     const float dn_pre = dh * (1.f - e_z) * (1.f - e_n * e_n);
     const float dz = dh * (e_hp - e_n) * e_z * (1.f - e_z);
     const float dr = dn_pre * e_hn * e_r * (1.f - e_r);
@@ -201,7 +203,7 @@ int ocrs_gru_layer_bwd(const float* dout, const float* saved, const float* out, 
                        int N, hipStream_t st) {
     OCRS_CHECK_ARG(dout && saved && out && whhT_pk && dgi && dgh && dhz && T > 0 && N > 0);
     const dim3 grid(GH / 16, (N + 15) / 16, 2);
-    for (int s = 0; s < T; ++s) hipLaunchKernelGGL(k_gru_step_bwd, grid, dim3(256), 0, st, dout, saved, out, whhT_pk, dgi, dgh, dhz, T, N, s);
+    for (int s = 0; s < T; ++s) hipLaunchKernelGGL(k_gru_step_bwd, grid, dim3(512), 0, st, dout, saved, out, whhT_pk, dgi, dgh, dhz, T, N, s);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
