@@ -4,7 +4,7 @@
 //
 // The input projections gi = W_ih x + b_ih for all time steps and both directions are one big GEMM (ocrs_conv_igemm, fp32 MFMA);
 // only the T sequential steps run here, one launch per step (both directions in the same launch, grid.z = 2):
-//   block = 16 hidden units x 3 gates (3 MFMA M-tiles) x 64 batch columns, K = 256 on v_mfma_f32_16x16x4_f32 (exact fp32).
+//   block = 16 hidden units x 3 gates (3 MFMA M-tiles) x 16 batch columns, 8 waves, K = 256 on v_mfma_f32_16x16x4_f32 (exact fp32).
 // Backward (BPTT) mirrors it: one launch per step computes dh_carry = z*dh + W_hh^T dgh (K = 768) and, in its epilogue, the
 // gate derivatives of the NEXT step to process; the weight/input gradients are big GEMMs over all steps afterwards.
 #include "common.h"
@@ -17,22 +17,24 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // gi   [T][N][2*768]  (direction-major: d*768 + gate*256 + j), b_ih already added
 // whh  packed W_hh fragments per direction (K=256, M=768): [2][8 chunks][48 mtiles][64][8] fp32
 // bhh  [2][768];  out [T][N][512] (d*256 + j);  saved [T][N][2][4][256] = r | z | n | gh_n
-// Block = 16 hidden units x 16 batch columns x 3 gates; the K = 256 reduction is SPLIT over the block's 4 waves (64 each, so the
-// dependent MFMA chain is 4x shorter) and combined through LDS; grid = 16 x ceil(N/16) x 2 directions (512 blocks at N = 256).
-static constexpr int SPITCH = 68;  // LDS pitch of a 64-wide fp32 slab row
-__global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ gi, const float* __restrict__ whh, const float* __restrict__ bhh,
+// Block = 16 hidden units x 16 batch columns x 3 gates; the K = 256 reduction is SPLIT over the block's 8 waves (32 each, so the
+// dependent MFMA chain is 8x shorter; a step is pure latency: 6.9 us with 4 waves, 6.6 with 8) and combined through LDS;
+// grid = 16 x ceil(N/16) x 2 directions (512 blocks of 512 threads at N = 256).
+static constexpr int FNW = 8, FKW = GH / FNW;  // forward: K = 256 split over 8 waves (32 each), 512 threads; threads 0..255 own the epilogue pairs
+static constexpr int SPITCH = FKW + 4;         // LDS pitch of a slab row
+__global__ __launch_bounds__(512) void k_gru_step_fwd(const float* __restrict__ gi, const float* __restrict__ whh, const float* __restrict__ bhh,
                                                       float* __restrict__ out, float* __restrict__ saved, int T, int N, int s) {
-    __shared__ __attribute__((aligned(16))) float hs[4][16 * SPITCH];  // per wave: h_prev[16 batch][64 k]
-    __shared__ float red[4][3][16][17];                                // per wave partial gh[gate][hidden][batch]
+    __shared__ __attribute__((aligned(16))) float hs[FNW][16 * SPITCH];  // per wave: h_prev[16 batch][FKW k]
+    __shared__ float red[FNW][3][16][17];                                // per wave partial gh[gate][hidden][batch]
     const int d = blockIdx.z, jt = blockIdx.x, b0 = blockIdx.y * 16;
     const int t = d == 0 ? s : T - 1 - s;
     const int tp = d == 0 ? t - 1 : t + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = s == 0;
     // epilogue operands of this thread's (hidden, batch) pair: independent of the recurrent GEMM, so their loads are issued first
-    const int jl = tid & 15, bl = tid >> 4;
+    const int jl = tid & 15, bl = (tid >> 4) & 15;
     const int b = b0 + bl, j = jt * 16 + jl;
-    const bool bv = b < N;
+    const bool bv = b < N && tid < 256;
     float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, bh_r = 0.f, bh_z = 0.f, bh_n = 0.f, hp = 0.f;
     if (bv) {
         const float* gir = gi + ((long)t * N + b) * (2 * G3) + d * G3;
@@ -46,11 +48,11 @@ __global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ 
         if (!first) hp = out[((long)tp * N + b) * 512 + d * GH + j];
     }
     if (!first) {
-        // this wave's K slab: h_prev[b0 .. b0+16][64*wave .. +64]
-        for (int it = lane; it < 16 * 16; it += 64) {
-            const int row = it >> 4, c4 = (it & 15) * 4;
+        // this wave's K slab: h_prev[b0 .. b0+16][FKW*wave .. +FKW]
+        for (int it = lane; it < 16 * (FKW / 4); it += 64) {
+            const int row = it / (FKW / 4), c4 = (it % (FKW / 4)) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + row < N) v = *reinterpret_cast<const float4*>(out + ((long)tp * N + b0 + row) * 512 + d * GH + wave * 64 + c4);
+            if (b0 + row < N) v = *reinterpret_cast<const float4*>(out + ((long)tp * N + b0 + row) * 512 + d * GH + wave * FKW + c4);
             *reinterpret_cast<float4*>(&hs[wave][row * SPITCH + c4]) = v;
         }
         __syncthreads();
@@ -59,11 +61,11 @@ __global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ 
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wd = whh + (long)d * 8 * 48 * 64 * 8;
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
+        for (int kc = 0; kc < FKW / 32; ++kc) {
             const Mma<float>::Frag pf = Mma<float>::load_p(&hs[wave][kc * 32], SPITCH, 0, lane, 32);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const Mma<float>::Frag wf = Mma<float>::load_w(wd, (long)(wave * 2 + kc) * 48 + g * 16 + jt, lane);
+                const Mma<float>::Frag wf = Mma<float>::load_w(wd, (long)(wave * (FKW / 32) + kc) * 48 + g * 16 + jt, lane);
                 acc[g] = Mma<float>::mma<8>(wf, pf, acc[g]);
             }
         }
@@ -78,7 +80,12 @@ __global__ __launch_bounds__(256) void k_gru_step_fwd(const float* __restrict__ 
     float gh[3] = {0.f, 0.f, 0.f};
     if (!first) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gh[g] = red[0][g][jl][bl] + red[1][g][jl][bl] + red[2][g][jl][bl] + red[3][g][jl][bl];
+        for (int g = 0; g < 3; ++g) {
+            float sum = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < FNW; ++wv) sum += red[wv][g][jl][bl];
+            gh[g] = sum;
+        }
     }
     const float rv = sigmoidf_(gi_r + gh[0] + bh_r);
     const float zv = sigmoidf_(gi_z + gh[1] + bh_z);
@@ -120,7 +127,6 @@ __device__ __forceinline__ float gru_gate_bwd1(const float* __restrict__ saved, 
 //   s == 0 : dh_total = dout[t]                                 (no GEMM)
 //   s >= 1 : dh_total = dout[t] + dhz_prev + W_hh^T dgh[t_prev]  (t_prev = the time processed at step s-1)
 // wT: packed W_hh^T fragments per direction (K=768, M=256): [2][24 chunks][16 mtiles][64][8].  dhz: ping-pong [2][2][N][256].
-// Block = 16 hidden x 16 batch; K = 768 split over the 4 waves (192 each).
 // Block = 16 hidden x 16 batch, 512 threads: K = 768 split over the block's EIGHT waves (96 each: the dependent MFMA chain and the slab
 // load per wave are half of the 4-wave version's); threads 0..255 own the (hidden, batch) pairs of the epilogue.
 __global__ __launch_bounds__(512) void k_gru_step_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
@@ -192,7 +198,7 @@ extern "C" {
 int ocrs_gru_layer_fwd(const float* gi, const float* whh_pk, const float* bhh, float* out, float* saved, int T, int N, hipStream_t st) {
     OCRS_CHECK_ARG(gi && whh_pk && bhh && out && T > 0 && N > 0);
     const dim3 grid(GH / 16, (N + 15) / 16, 2);
-    for (int s = 0; s < T; ++s) hipLaunchKernelGGL(k_gru_step_fwd, grid, dim3(256), 0, st, gi, whh_pk, bhh, out, saved, T, N, s);
+    for (int s = 0; s < T; ++s) hipLaunchKernelGGL(k_gru_step_fwd, grid, dim3(512), 0, st, gi, whh_pk, bhh, out, saved, T, N, s);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
