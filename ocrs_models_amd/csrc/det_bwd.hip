@@ -125,10 +125,12 @@ __device__ __forceinline__ void flush_w(float* __restrict__ dw, float* __restric
     else
         atomicAdd(&dw[idx], v);
 }
-// dw[e] += sum_b ws[b][e];  grid (ceil(nelem/256), chunks of partials)
-__global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __restrict__ ws, int nb, int nelem, float* __restrict__ dw) {
+// dw[(e / cin) * ldw + e % cin] += sum_b ws[b][e]  (ldw = cin: plain dw[e]);  grid (ceil(nelem/256), chunks of partials)
+__global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __restrict__ ws, int nb, int nelem, float* __restrict__ dw, int cin,
+                                                               int ldw) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nelem) return;
+    const int eo = ldw == cin ? e : (e / cin) * ldw + e % cin;
     const int per = (nb + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __re
     for (; b < b1; ++b) s0 += ws[(long)b * nelem + e];
     const float s = (s0 + s1) + (s2 + s3);
     if (gridDim.y == 1)
-        dw[e] += s;
+        dw[eo] += s;
     else
-        atomicAdd(&dw[e], s);
+        atomicAdd(&dw[eo], s);
 }
 static inline int partial_chunks(int nb) { return nb >= 512 ? 64 : (nb >= 128 ? 32 : (nb >= 16 ? 8 : 1)); }
 
@@ -1258,7 +1260,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                        wpk_d, (T*)du, dwpw, ws, tg);
     if (ws) {
         const int ne = CIN * COUT;
-        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, ne, dwpw);
+        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, ne, dwpw, CIN, CIN);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1276,15 +1278,17 @@ extern "C" {
 // Pointwise-conv backward of a DepthwiseConv block: du = Wpw^T dz (written, [P][Cin]); dwpw += u^T dz (accumulated, master layout
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
-void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 255) / 256, partial_chunks(nb)), dim3(256), 0, st, ws, nb, nelem, dw);
+void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 255) / 256, partial_chunks(nb)), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
 }
 // det_pw2.hip: two-pixel-per-thread pipelined kernel for bf16, Cin, Cout <= 32 (levels 0-2)
 long det_pw2_supported(int Cin, int Cout, int dtype);
 long det_pw2_ws_floats(int Cin, int Cout, int N, int H, int W);
 int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
-                   int H, int W, hipStream_t st);
+                   int H, int W, int ldu, int ldw, hipStream_t st);
+// a 64-channel concat input (32 | 32) is handled as two k_pw_bwd2<32, Cout> launches, one per source (see ocrs_pw_bwd)
+static bool pw2_split_ok(int Ca, int Cb, int Cout, int dtype) { return Ca == 32 && Cb == 32 && det_pw2_supported(32, Cout, dtype); }
 
 // ws: workspace of ocrs_pw_bwd_ws_floats() floats (deterministic two-stage weight-gradient reduction) or null (float atomics).
 long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W) {
@@ -1296,11 +1300,12 @@ long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W) {
 #undef X
         return a;
     }
+    const long half = (Cin == 64 && det_pw2_supported(32, Cout, 1)) ? det_pw2_ws_floats(32, Cout, N, H, W) : 0;  // two-launch split (32 | 32)
 #define X(CI, CO) \
-    if (Cin == CI && Cout == CO) return (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO;
+    if (Cin == CI && Cout == CO) { const long b = (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO; return b > half ? b : half; }
     PW_BWD_COMBOS(X)
 #undef X
-    return 0;
+    return half;
 }
 int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2, int pooled,
                 const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N, int H, int W,
@@ -1311,7 +1316,20 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
     static const int use_pw2 = env_int("OCRS_PW2", 1);
     if (use_pw2 && det_pw2_supported(Cin, Cout, dtype))
-        return det_pw2_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, st);
+        return det_pw2_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, Cin, Cin, st);
+    static const int use_split = env_int("OCRS_PW2_SPLIT", 1);
+    if (use_pw2 && use_split && pw2_split_ok(Ca, Cb, Cout, dtype)) {
+        // cat(32 | 32) -> Cout: z = Wpw[:, :32] u_a + Wpw[:, 32:] u_b, so du and dWpw separate by source; dz is the same for both.  Two launches of the
+        // tuned two-pixel kernel (each re-reads g and z: 512 instead of 384 B per pixel) beat the generic 64-channel path (392 -> ~270 us at
+        // level 2).  Per half: depthwise weights [32][9], packed W^T fragments (M tiles 2h, 2h+1), du / dWpw columns 32h.., row strides 64.
+        const char* wp = static_cast<const char*>(wpk_d);
+        const size_t half_frag_bytes = 2 * 64 * 8 * sizeof(bf16);  // two M tiles of one K chunk
+        OCRS_CHECK_ARG(Cout <= 32);
+        int rc = det_pw2_launch(xa, nullptr, 32, 0, tra, nullptr, wdw, g1, g2, pooled, z, bn, coef, wp, du, dwpw, ws, Cout, N, H, W, 64, 64, st);
+        if (rc != OCRS_OK) return rc;
+        return det_pw2_launch(xb, nullptr, 32, 0, trb, nullptr, wdw + 32 * 9, g1, g2, pooled, z, bn, coef, wp + half_frag_bytes,
+                              static_cast<bf16*>(du) + 32, dwpw + 32, ws, Cout, N, H, W, 64, 64, st);
+    }
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \
         return dtype == 1 ? launch_pw_bwd<bf16, CI, CO>(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, N, H, W, st) \

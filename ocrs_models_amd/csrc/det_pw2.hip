@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 3) void k_pw_bwd2(Src2<bf16> x, const float* _
                                                     const float* __restrict__ wdw /*master [CIN][9]*/, const bf16* __restrict__ g1,
                                                     const bf16* __restrict__ g2, const bf16* __restrict__ z, const float* __restrict__ bn,
                                                     const float* __restrict__ coef, const void* __restrict__ wpk_d, bf16* __restrict__ du,
-                                                    float* __restrict__ dwpw, float* __restrict__ ws, Tiling2 tg) {
+                                                    float* __restrict__ dwpw, float* __restrict__ ws, Tiling2 tg, int ldu /*du row stride*/, int ldw /*dwpw row stride*/) {
     using C = Pw2Cfg<CIN, COUT>;
     constexpr int TW = C::TW, TH = C::TH, CGI = C::CGI, CGO = C::CGO, CGM = C::CGM, PD = C::PD, PU = C::PU, MTD = C::MTD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void k_pw_bwd2(Src2<bf16> x, const float* _
             const typename Mma<bf16>::Frag pf = Mma<bf16>::load_p(tileD, PD, n0, lane, CGO * 8);
             const int oq = n0 + (lane & 15), qh = org.h0 + oq / TW, qw = org.w0 + oq % TW;
             const bool ov = qh < H && qw < W;
-            bf16* dst = du + (((long)org.n * H + qh) * W + qw) * CIN + (lane >> 4) * 4;
+            bf16* dst = du + (((long)org.n * H + qh) * W + qw) * ldu + (lane >> 4) * 4;
 #pragma unroll
             for (int b = 0; b < MTD; ++b) {
                 const f32x4 v = Mma<bf16>::template mma<8>(wfd[b], pf, (f32x4){0.f, 0.f, 0.f, 0.f});
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void k_pw_bwd2(Src2<bf16> x, const float* _
                 if (ws)
                     ws[(long)blockIdx.x * (CIN * COUT) + co * CIN + ci] = v;
                 else
-                    atomicAdd(&dwpw[co * CIN + ci], v);
+                    atomicAdd(&dwpw[co * ldw + ci], v);
             }
         }
     }
@@ -272,11 +272,13 @@ long det_pw2_supported(int Cin, int Cout, int dtype) {
 }
 long det_pw2_ws_floats(int Cin, int Cout, int N, int H, int W) { return (long)pw2_grid(Cin, Cout, N, H, W) * Cin * Cout; }
 
-void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, hipStream_t st);  // det_bwd.hip
+void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st);  // det_bwd.hip
 
 int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                  int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
-                 int H, int W, hipStream_t st) {
+                 int H, int W, int ldu, int ldw, hipStream_t st) {
+    // ldu / ldw: row strides (elements) of du [P][ldu] and dwpw [Cout][ldw]: Cin for a whole block, larger when this launch handles one
+    // half of a concat block's input channels (the caller offsets wdw / wpk_d / du / dwpw to the half)
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG(xa && tra && wdw && g1 && z && bn && coef && wpk_d && du && dwpw && (Cb == 0 || (xb && trb)));
     OCRS_CHECK_ARG(det_pw2_supported(Cin, Cout, 1) && Ca % 8 == 0 && Cb % 8 == 0 && (long)N * H * W < (1L << 31));
@@ -288,14 +290,14 @@ int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
         const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);                                                                           \
         if (pooled)                                                                                                                         \
             hipLaunchKernelGGL((k_pw_bwd2<CI_, CO_, true>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
-                               (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg);                                                   \
+                               (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg, ldu, ldw);                                                   \
         else                                                                                                                                \
             hipLaunchKernelGGL((k_pw_bwd2<CI_, CO_, false>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
-                               (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg);                                                   \
+                               (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg, ldu, ldw);                                                   \
     }
     PW2_CASE(8, 8) PW2_CASE(8, 16) PW2_CASE(16, 8) PW2_CASE(16, 16) PW2_CASE(16, 32) PW2_CASE(32, 16) PW2_CASE(32, 32)
 #undef PW2_CASE
-    if (ws) k_wgrad_partials_reduce_launch(ws, nb, Cin * Cout, dwpw, st);
+    if (ws) k_wgrad_partials_reduce_launch(ws, nb, Cin * Cout, dwpw, Cin, ldw, st);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
