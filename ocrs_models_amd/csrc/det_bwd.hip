@@ -1094,7 +1094,16 @@ __global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, fl
     const long nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long p = gtid / CG; p < P; p += nthr / CG) {
+    const long step = nthr / CG;
+    long p = gtid / CG;
+    for (; p + 3 * step < P; p += 4 * step) {  // 4 independent loads in flight per thread (the grid is small: see the launcher)
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8(g + (p + u * step) * C + c0, v[u]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += (v[0][i] + v[1][i]) + (v[2][i] + v[3][i]);
+    }
+    for (; p < P; p += step) {
         float v[8];
         load8(g + p * C + c0, v);
 #pragma unroll
@@ -1484,7 +1493,10 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
         if (rc != OCRS_OK) return rc;
     }
     const long Pout = (long)N * H * W;
-    const int gs = cg_grid(Pout * (Cout / 8));
+    // every block ends in Cout same-address global atomics (~15 ns each, serialised): 2048 blocks cost 30 us of atomics on a tensor that
+    // streams in 10 us -> at most 2 blocks per CU, each thread keeping 4 loads in flight
+    int gs = cg_grid((Pout * (Cout / 8) + 3) / 4);
+    if (gs > 2 * kNumCU) gs = 2 * kNumCU;
     if (dtype == 1)
         hipLaunchKernelGGL(k_channel_sum<bf16>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const bf16*)g, dbias, Cout, Pout);
     else
