@@ -1296,6 +1296,11 @@ long det_pw2_ws_floats(int Cin, int Cout, int N, int H, int W);
 int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
                    int H, int W, int ldu, int ldw, hipStream_t st);
+// det_pw8.hip: eight-wave kernel for the deep levels (bf16, Cin, Cout in {64, 128, 256}); same tiling and workspace rule as k_pw_bwd
+long det_pw8_supported(int Cin, int Cout, int dtype);
+int det_pw8_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                   int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
+                   int H, int W, int gx, hipStream_t st);
 // a 64-channel concat input (32 | 32) is handled as two k_pw_bwd2<32, Cout> launches, one per source (see ocrs_pw_bwd)
 static bool pw2_split_ok(int Ca, int Cb, int Cout, int dtype) { return Ca == 32 && Cb == 32 && det_pw2_supported(32, Cout, dtype); }
 
@@ -1338,6 +1343,13 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         if (rc != OCRS_OK) return rc;
         return det_pw2_launch(xb, nullptr, 32, 0, trb, nullptr, wdw + 32 * 9, g1, g2, pooled, z, bn, coef, wp + half_frag_bytes,
                               static_cast<bf16*>(du) + 32, dwpw + 32, ws, Cout, N, H, W, 64, 64, st);
+    }
+    if (det_pw8_supported(Cin, Cout, dtype)) {
+#define X(CI, CO)                 \
+    if (Cin == CI && Cout == CO)  \
+        return det_pw8_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, pw_bwd_gx<CI, CO>(N, H, W), st);
+        PW_BWD_COMBOS(X)
+#undef X
     }
 #define X(CI, CO)                                                                                                                         \
     if (Cin == CI && Cout == CO)                                                                                                          \

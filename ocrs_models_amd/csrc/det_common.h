@@ -233,12 +233,12 @@ __device__ __forceinline__ float max_lo(float v, float lo) {
     return r;
 }
 
-template <class T, int CG, int TW, int TH>
+template <class T, int CG, int TW, int TH, int NT = 256 /* threads per block */>
 struct HaloStager {
     using HT = HaloTile<TW, TH>;
     static constexpr int NITEMS = HT::HP * CG;
     static constexpr int PLANE = NITEMS * 4;  // floats
-    static constexpr int NIT = (NITEMS + 255) / 256;
+    static constexpr int NIT = (NITEMS + NT - 1) / NT;
     __device__ static __forceinline__ void put(float* xs, int it, const float (&v)[8]) {
         const int o = xs_swz<CG>(it) * 4;
         store4(xs + o, v[0], v[1], v[2], v[3]);
@@ -251,7 +251,7 @@ struct HaloStager {
         cg = tid % CG;
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            const int hp = (tid + j * 256) / CG;
+            const int hp = (tid + j * NT) / CG;
             const int hy = hp / HT::HW_, hx = hp - hy * HT::HW_;
             hyx[j] = hy | (hx << 16);
             poff[j] = hy * W + hx;
@@ -275,16 +275,16 @@ struct HaloStager {
         const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            if (NITEMS % 256 != 0 && j == NIT - 1 && tid + j * 256 >= NITEMS) break;
+            if (NITEMS % NT != 0 && j == NIT - 1 && tid + j * NT >= NITEMS) break;
             const int h = org.h0 - 1 + (hyx[j] & 0xffff), w = org.w0 - 1 + (hyx[j] >> 16);
             if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
                 float v[8];
                 load8(base + __umul24(poff[j], pitch), v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
-                put(xs, tid + j * 256, v);
+                put(xs, tid + j * NT, v);
             } else
-                put(xs, tid + j * 256, zero8);
+                put(xs, tid + j * NT, zero8);
         }
     }
 
@@ -308,7 +308,7 @@ struct HaloStager {
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
             const int h = org.h0 - 1 + (hyx[j] & 0xffff), w = org.w0 - 1 + (hyx[j] >> 16);
-            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && (NITEMS % 256 == 0 || j < NIT - 1 || tid + j * 256 < NITEMS);
+            const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && (NITEMS % NT == 0 || j < NIT - 1 || tid + j * NT < NITEMS);
             pd.raw[j] = load8_raw(ok ? base + __umul24(poff[j], pitch) : dummy);
             pd.ok |= ok ? 1u << j : 0u;
         }
@@ -322,15 +322,15 @@ struct HaloStager {
         const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NIT; ++j) {
-            if (NITEMS % 256 != 0 && j == NIT - 1 && tid + j * 256 >= NITEMS) break;
+            if (NITEMS % NT != 0 && j == NIT - 1 && tid + j * NT >= NITEMS) break;
             if (pd.ok & (1u << j)) {
                 float v[8];
                 unpack8(pd.raw[j], v);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
-                put(xs, tid + j * 256, v);
+                put(xs, tid + j * NT, v);
             } else
-                put(xs, tid + j * 256, zero8);
+                put(xs, tid + j * NT, zero8);
         }
     }
 };
