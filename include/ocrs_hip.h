@@ -89,8 +89,11 @@ int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const
                      const float* bn, const float* coef, float* dwpw, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of ConvTranspose2d + crop. */
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype);
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup,
-                   int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
+/* saved / gsum (nullable; need ocrs_convt_bwd_stats_supported): x is the raw output of a block consumed ONLY by this ConvTranspose -> its
+ * BatchNorm-backward sums [2][Cup] (fp64, ACCUMULATED; saved = the block's [mean | rstd]) come from this pass instead of ocrs_bn_bwd_reduce. */
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws,
+                   const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
+long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
 /* autograd of out_conv + sigmoid. */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
                   const float* saved, double* gsum, long P, int dtype, hipStream_t st);

@@ -808,19 +808,23 @@ struct CtwCfg {
     // fused dgrad: dx[c] = sum_{tap,o} g[2i+ky][2j+kx][o] * W[c][o][tap]: K = 9*COUT in chunks of 32, M = CUP, N = positions
     static constexpr int DKC = (9 * COUT + 31) / 32, DNT = TPOS / 16 / 4;  // K chunks, N tiles (of 16 positions) per wave
     static constexpr int WD_EL = DKC * MT * 64 * 8;                          // cached packed dgrad weight fragments (bf16 elements)
-    static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8 + WD_EL) * 2 + 3 * CUP * 4;
-    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4 + 256 * 8 * 4;
+    static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8 + WD_EL) * 2 + 3 * CUP * 4 + XS_EL * 2 + CUP * 4;  // + raw x tile and means (STATS)
+    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4 + 256 * 8 * 4 + 2 * CUP * 4;
     static constexpr int SMEM = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
-    static constexpr int PART = CUP * NT * 16 + COUT;  // floats per block partial: dW [CUP][NT*16] | dbias [COUT]
+    static constexpr int PART = CUP * NT * 16 + COUT + 2 * CUP;  // floats per block partial: dW [CUP][NT*16] | dbias [COUT] | BN sums [2][CUP]
 };
 
 // The same staged tiles also give (fused, levels 0-2): the input gradient dx (dgrad GEMM, pixel operand = one ds_read_b128 per
 // fragment straight from the natural-layout g region, packed weights cached in LDS) and dbias = sum of g (every output pixel is owned by
 // exactly one tile).  One kernel + one reduce replace k_convt_dgrad + wgrad + k_channel_sum: g is read from HBM once instead of 3 times.
-template <int CUP, int COUT>
+// STATS: x is the raw (pre-BatchNorm) output of a block whose ONLY consumer is this ConvTranspose, so dx is that block's complete output
+// gradient: the kernel also produces the block's BatchNorm-backward sums (sum ghat, sum ghat * (z - mean); ghat = dx * [bn(z) > 0], the
+// raw z comes from a second, untransformed copy of the staged tile) -- no k_bn_bwd_reduce pass over (dx, z).
+template <int CUP, int COUT, bool STATS>
 __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__ x, const float* __restrict__ tr /*[3][CUP]*/, const bf16* __restrict__ g,
-                                                        const void* __restrict__ wpk_d, bf16* __restrict__ dx, float* __restrict__ ws, int h, int w,
-                                                        int H, int W, Tiling2 tg) {
+                                                        const void* __restrict__ wpk_d, bf16* __restrict__ dx, float* __restrict__ ws,
+                                                        const float* __restrict__ saved /*[2][CUP] mean | rstd (STATS)*/, int h, int w, int H, int W,
+                                                        Tiling2 tg) {
     using C = CtwCfg<CUP, COUT>;
     constexpr int TW = C::TW, TH = C::TH, GW = C::GW, MT = C::MT, NTW = C::NTW, KW = C::KW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -829,7 +833,17 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     bf16* zero8 = gsm + C::GS_EL;               // 8 zero elements (padding columns of the last N tile)
     uint4* s_wd = reinterpret_cast<uint4*>(zero8 + 8);  // [DKC*MT][64] packed dgrad weight fragments
     float* s_tr = reinterpret_cast<float*>(s_wd + C::DKC * MT * 64);  // [CUP/8][3][8]
+    float* s_mu = s_tr + 3 * CUP;                                      // [CUP] saved mean (STATS)
+    bf16* xraw = reinterpret_cast<bf16*>(s_mu + CUP);                  // [TPOS][CUP] untransformed copy of the x tile (STATS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (STATS && tid < CUP) s_mu[tid] = saved[tid];
+    float st1[STATS ? MT : 1][4], st2[STATS ? MT : 1][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st1[b][r] = st2[b][r] = 0.f;
+    }
     {
         Src2<bf16> xsrc{x, nullptr, CUP, 0};
         fill_tr8(s_tr, xsrc, tr, nullptr, CUP, tid);
@@ -915,6 +929,7 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
                     for (int i = 0; i < 8; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
                 }
                 store8(xs + it * 8, v);
+                if constexpr (STATS) *reinterpret_cast<uint4*>(xraw + it * 8) = (okx & (1u << j)) ? xr[j].a : make_uint4(0, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -963,6 +978,24 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
 #pragma unroll
                 for (int b = 0; b < MT; ++b)
                     store4(dx + (((long)org.n * h + i) * w + jx) * CUP + b * 16 + kg * 4, dacc[b][0], dacc[b][1], dacc[b][2], dacc[b][3]);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) {
+                        const int c0 = b * 16 + kg * 4;  // this lane's 4 channels of M tile b
+                        const uint2 zr = *reinterpret_cast<const uint2*>(xraw + n * CUP + c0);
+                        const float zv[4] = {__uint_as_float(zr.x << 16), __uint_as_float(zr.x & 0xffff0000u), __uint_as_float(zr.y << 16),
+                                             __uint_as_float(zr.y & 0xffff0000u)};
+                        const float* tp = s_tr + (c0 >> 3) * 24 + (c0 & 7);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // the producer's pw_bwd reads the STORED (rounded) gradient; bn(z) > 0 <=> the ReLU passes
+                            const bool on = fmaf(zv[r], tp[r], tp[8 + r]) > 0.f;
+                            const float gh = on ? Elem<bf16>::round(dacc[b][r]) : 0.f;
+                            st1[b][r] += gh;
+                            st2[b][r] = fmaf(gh, zv[r] - s_mu[c0 + r], st2[b][r]);
+                        }
+                    }
+                }
             }
         }
         lds_barrier();  // all operand reads done before the next commit overwrites the tiles
@@ -970,6 +1003,7 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     // ---- block reduction over the KW k-waves (same N half), then the block partial -> ws[block][CUP][NT*16]
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [(KW-1)][NW][MT*NTW][256]
+    if (STATS && tid < 2 * CUP) red[(KW - 1) * MT * NTW * C::NW * 256 + 256 * 8 + tid] = 0.f;  // sst (see below), zeroed before the barrier that follows
     if (ks > 0) {
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -981,8 +1015,23 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     __syncthreads();
     {   // dbias: threads with the same channel group (tid % (COUT/8)) are summed through LDS (behind the wgrad reduction area)
         float* bred = red + (KW - 1) * MT * NTW * C::NW * 256;  // [256][8]
+        float* sst = bred + 256 * 8;                            // [2][CUP] BatchNorm-backward sums of the block (STATS)
 #pragma unroll
         for (int i = 0; i < 8; ++i) bred[tid * 8 + i] = bsum[i];
+        if constexpr (STATS) {
+            // channel c = b*16 + kg*4 + r is shared by the 16 lanes of a kg group in every wave: sum over those lanes, then 16 LDS atomics
+            // per wave onto 2*CUP addresses (once per block)
+#pragma unroll
+            for (int b = 0; b < MT; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = quad16_sum(st1[b][r]), a2 = quad16_sum(st2[b][r]);
+                    if (i16 == 0) {
+                        atomicAdd(&sst[b * 16 + kg * 4 + r], a1);
+                        atomicAdd(&sst[CUP + b * 16 + kg * 4 + r], a2);
+                    }
+                }
+        }
         __syncthreads();
         if (tid < COUT) {
             const int cg8 = tid / 8, i = tid % 8;
@@ -990,6 +1039,7 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
             for (int t2 = cg8; t2 < 256; t2 += COUT / 8) v += bred[t2 * 8 + i];
             ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + tid] = v;
         }
+        if (STATS && tid < 2 * CUP) ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + COUT + tid] = sst[tid];
     }
     if (ks == 0) {
         float* part = ws + (long)blockIdx.x * C::PART;
@@ -1007,12 +1057,20 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     }
 }
 // dW[(c*COUT + o)*9 + tap] += sum over block partials of ws[b][c][tap*COUT + o];  grid (ceil(CUP*NCOL/256), partial chunks)
+// With gsum (nullable): the per-block BatchNorm-backward sums [2][CUP] are added to gsum (fp64; row 1 scaled by rstd = saved[CUP + c]).
 __global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restrict__ ws, int nblocks, int CUP, int COUT, int NT16, float* __restrict__ dW,
-                                                            float* __restrict__ dbias) {
-    const int e = blockIdx.x * 256 + threadIdx.x, part = CUP * NT16 + COUT;
-    if (e >= CUP * 9 * COUT + COUT) return;
+                                                            float* __restrict__ dbias, const float* __restrict__ saved, double* __restrict__ gsum) {
+    const int e = blockIdx.x * 256 + threadIdx.x, part = CUP * NT16 + COUT + 2 * CUP, ne = CUP * 9 * COUT + COUT;
+    if (e >= ne + (gsum ? 2 * CUP : 0)) return;
     const int per = (nblocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    if (e >= ne) {  // BatchNorm-backward sums
+        const int idx = e - ne, which = idx / CUP, c = idx - which * CUP;
+        float sb = 0.f;
+        for (int b = b0; b < b1; ++b) sb += ws[(long)b * part + CUP * NT16 + COUT + idx];
+        atomicAdd(&gsum[idx], (double)(which ? sb * saved[CUP + c] : sb));
+        return;
+    }
     if (e >= CUP * 9 * COUT) {  // dbias [COUT]
         const int o = e - CUP * 9 * COUT;
         float sb = 0.f;
@@ -1450,13 +1508,23 @@ static int convt_wgrad_tr_grid(int Cout, int N, int h, int w) {
 }
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
     const long a = ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype);
-    const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * (Cup * ((9 * Cout + 15) / 16 * 16) + Cout) : 0;
+    const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * (Cup * ((9 * Cout + 15) / 16 * 16) + Cout + 2 * Cup) : 0;
     return a > b ? a : b;
 }
 
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws, int Cup, int Cout,
-                   int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
+// 1 if ocrs_convt_bwd can also produce the BatchNorm-backward sums of the block that produced x (saved / gsum arguments)
+// (not for (32, 16): with the sums that instantiation needs 208 + 80 registers -> one block per CU, 122 -> 225 us; its block keeps the
+// 86-us ocrs_bn_bwd_reduce pass)
+long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
+    return convt_wgrad_tr_ok(Cup, Cout, dtype) && !(Cup == 32 && Cout == 16) ? 1 : 0;
+}
+
+// saved / gsum (nullable, need ws and ocrs_convt_bwd_stats_supported): x is the raw output of a block consumed ONLY by this ConvTranspose;
+// its BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws,
+                   const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
+    OCRS_CHECK_ARG(!gsum || (saved && ws && ocrs_convt_bwd_stats_supported(Cup, Cout, dtype)));
     if (ws && convt_wgrad_tr_ok(Cup, Cout, dtype)) {
         // levels 0-2 (bf16): ONE tiled kernel produces dx, the weight-gradient partials and the bias-gradient partials; one reduce
 #define CTW_CASE(CU_, CO_)                                                                                                                   \
@@ -1464,11 +1532,15 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
         using CC = CtwCfg<CU_, CO_>;                                                                                                         \
         const Tiling2 tg = make_tiling2(N, h, w, CC::TW, CC::TH);                                                                            \
         const int nb = convt_wgrad_tr_grid(Cout, N, h, w);                                                                                   \
-        hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, wpk_d, (bf16*)dx, ws, \
-                           h, w, H, W, tg);                                                                                                  \
-        const int ne = CU_ * 9 * CO_ + CO_;                                                                                                  \
+        if (gsum)                                                                                                                            \
+            hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_, true>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, wpk_d,   \
+                               (bf16*)dx, ws, saved, h, w, H, W, tg);                                                                        \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_, false>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, wpk_d,  \
+                               (bf16*)dx, ws, saved, h, w, H, W, tg);                                                                        \
+        const int ne = CU_ * 9 * CO_ + CO_ + (gsum ? 2 * CU_ : 0);                                                                           \
         hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 255) / 256, nb >= 64 ? 16 : 1), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW, \
-                           dbias);                                                                                                           \
+                           dbias, saved, gsum);                                                                                              \
     }
         CTW_CASE(16, 8) CTW_CASE(32, 16) CTW_CASE(32, 32)
 #undef CTW_CASE

@@ -353,8 +353,13 @@ class _DetRun:
             wpk_d = self.pack(P[f"up.{i}.up.weight"], 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
             dx = self.empty(N, up_in.H, up_in.W, Cup)
             ws = self.empty(L.convt_bwd_ws_floats(Cup, Cout, N, up_in.H, up_in.W, self.dt), dtype=torch.float32)
+            sv = gs_up = None
+            if self.fuse_bn_bwd and up_in.src is not None and L.convt_bwd_stats_supported(Cup, Cout, self.dt):
+                # the ConvTranspose is this block's only consumer and stages its z anyway: it also produces the block's BatchNorm-backward sums
+                sv, gs_up = self.recs[up_in.src].saved, self.zeros64(2 * Cup)
+                self.fused[up_in.src] = gs_up
             L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
-                        ptr(self.G[f"up.{i}.up.bias"]), ptr(ws), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+                        ptr(self.G[f"up.{i}.up.bias"]), ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
             stage_done(f"up.{i}")
             g = dx
         skip_g[6].append(g)

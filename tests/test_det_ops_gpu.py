@@ -352,11 +352,28 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
     dx = run.empty(N, h, w, Cup)
     dW, db = torch.zeros_like(Wt), torch.zeros_like(bias)
     ws = torch.empty(run.L.convt_bwd_ws_floats(Cup, Cout, N, h, w, run.dt), device=dev)
-    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), ptr(ws), Cup, Cout, N, h, w, H, W, run.dt)
+    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), ptr(ws), None, None, Cup, Cout, N, h, w, H, W, run.dt)
     torch.cuda.synchronize()
     assert rel(nchw(dx), xt.grad) < 10 * tol, "dgrad"
     assert rel(dW, Wr.grad) < 10 * tol, "wgrad"
     assert rel(db, br.grad) < 10 * tol, "dbias"
+    if run.L.convt_bwd_stats_supported(Cup, Cout, run.dt):
+        # the same pass can produce the BatchNorm-backward sums of the block that produced x (the ConvTranspose is its only consumer):
+        # reference from the STORED gradient, ghat = dx * [x*scale+shift > 0], zhat = (x - mean) * rstd; everything else unchanged
+        saved = torch.stack([0.1 * torch.randn(Cup, generator=g), 1 + 0.2 * torch.rand(Cup, generator=g)]).to(dev)  # [mean | rstd]
+        gsum = torch.zeros(2 * Cup, dtype=torch.float64, device=dev)
+        dx2 = run.empty(N, h, w, Cup)
+        dW2, db2 = torch.zeros_like(Wt), torch.zeros_like(bias)
+        run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx2), ptr(dW2), ptr(db2), ptr(ws), ptr(saved), ptr(gsum), Cup, Cout, N, h, w, H, W,
+                        run.dt)
+        torch.cuda.synchronize()
+        assert torch.equal(dx2, dx) and rel(dW2, dW) < 1e-5 and rel(db2, db) < 1e-5
+        dxf, xf = nchw(dx2).double(), nchw(xs).double()
+        pre = xf * tr[0].double().view(1, -1, 1, 1) + tr[1].double().view(1, -1, 1, 1)
+        gh = torch.where(pre > 0, dxf, torch.zeros_like(dxf))
+        zh = (xf - saved[0].double().view(1, -1, 1, 1)) * saved[1].double().view(1, -1, 1, 1)
+        ref_sums = torch.cat([gh.sum((0, 2, 3)), (gh * zh).sum((0, 2, 3))])
+        assert rel(gsum, ref_sums) < 1e-4, "BatchNorm-backward sums"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
