@@ -38,9 +38,14 @@ int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, 
 /* DepthwiseConv block up to its pre-BatchNorm output: conv2d(groups=C, 3x3, pad 1) -> conv2d(1x1)
  * (ocrs_models/models.py:11-22) with the channel concat of models.py:89 folded in (xa|xb).
  * gstat [2][Cout] fp64 (sum z | sum z^2) is ACCUMULATED: the caller zeroes it (one memset for all layers of a step);
- * the same holds for gsum of ocrs_bn_bwd_reduce. */
+ * the same holds for gsum of ocrs_bn_bwd_reduce.
+ * gamma / pooled (nullable; need ocrs_dwpw_fwd_pool_supported): also write nn.MaxPool2d(2) (models.py:54) of the block output in its
+ * pre-BatchNorm form -- the z of each window's selected element (max z for gamma >= 0, min z for gamma < 0: relu(bn(.)) is monotone in z
+ * with the sign of the BatchNorm weight) -- to pooled [N][H/2][W/2][Cout]; consumers read it through the block's load transform.
+ */
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
-                  void* z, double* gstat, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+                  void* z, double* gstat, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout); /* 1 / 0 */
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st);

@@ -86,11 +86,13 @@ struct FwdPitch {
 #ifndef OCRS_PIPE_BLOCKS
 #define OCRS_PIPE_BLOCKS 3
 #endif
-template <class T, int CG, int MT, bool ONE /* Cin == CG*8: a single K chunk (always true for CG < 4) */>
+template <class T, int CG, int MT, bool ONE /* Cin == CG*8: a single K chunk (always true for CG < 4) */, bool POOL = false /* also write the 2x2 max-pool */>
 __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS : (MT <= 4 ? 4 : 2)) void k_dwpw_fwd(Src2<T> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                                     const float* __restrict__ wdw /*master [CIN][1][3][3]*/,
                                                                     const void* __restrict__ wpk, T* __restrict__ z,
-                                                                    double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg) {
+                                                                    double* __restrict__ gstat /*[2][COUT]*/, int CIN, int COUT, Tiling2 tg,
+                                                                    const float* __restrict__ gamma /*[COUT] or null*/,
+                                                                    T* __restrict__ pooled /*[N][H/2][W/2][COUT] or null*/) {
     constexpr int PX = FwdPx<MT>::PX;
     using FT = FwdTile<CG, PX>;
     constexpr int TW = FT::TW, TH = FT::TH, TP = FT::TP;
@@ -211,6 +213,39 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
                 if ((lane & 15) == 0) {
                     atomicAdd(&s_stat[m0 + r], a1);
                     atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
+                }
+            }
+            // ---- fused MaxPool2d(2) (models.py:54) in its pre-BatchNorm form: the consumer sees relu(bn(z)), monotone in z with the sign of
+            // gamma (known before the batch statistics are), so the window's selected element is max z (gamma >= 0) or min z (gamma < 0); its z
+            // is written to `pooled` and read through this block's load transform like any block output (see k_maxpool_fwd<T, true>, which
+            // this replaces at levels 0-2: the full-size z is not read again).  A 2x2 window = this lane's pixel, the next lane's (same row:
+            // an N tile is 16 consecutive pixels of a tile row) and the same two lanes of the N tile one row below (same wave: rows per
+            // wave are even).  Ties between different z can only differ from k_maxpool_fwd's first-maximum rule where bn(z) rounds to the
+            // same value; the selected VALUE, which is all consumers see, then differs by that rounding.
+            if constexpr (POOL && PX == 2 && TW >= 16) {
+                {
+                    constexpr int TPR = TW / 16;
+                    float sg[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sg[r] = (m0 + r < COUT && gamma[m0 + r] < 0.f) ? -1.f : 1.f;
+                    const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+                    for (int a = 0; a < PTW; ++a) {
+                        const int q = (wave * PTW + a) * 16 + (lane & 15);
+                        const int oty = q / TW, otx = q % TW;
+                        if ((oty & 1) == 0) {  // (compile-time after unrolling: a / TPR is the row within the wave)
+                            float m4[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v0 = sg[r] * Elem<T>::round(acc[a][b][r]), v1 = sg[r] * Elem<T>::round(acc[a + TPR][b][r]);
+                                const float vv = fmaxf(v0, v1);
+                                m4[r] = sg[r] * fmaxf(vv, __shfl_xor(vv, 1, 64));
+                            }
+                            const int ph = (org.h0 + oty) >> 1, pw = (org.w0 + otx) >> 1;
+                            if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
+                                store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
+                        }
+                    }
                 }
             }
         }
@@ -475,7 +510,7 @@ long ocrs_pack_frags_bytes(int K, int M, int dtype) { return (long)((K + 31) / 3
 }  // extern "C" (templates need C++ linkage)
 template <class T, int CG, int MT, bool ONE>
 static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                           double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
+                           double* gstat, int COUT, int N, int H, int W, const float* gamma, void* pooled, hipStream_t st) {
     using FT = FwdTile<CG, FwdPx<MT>::PX>;
     constexpr int TP = FT::TP;
     const int CIN = Ca + Cb;
@@ -488,7 +523,15 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);
     const int tpb = fwd_tpb > 0 ? fwd_tpb : (tg.ntiles >= 2048 ? 2 : 1);
     const int grid = persistent_grid(tg.ntiles / tpb > 0 ? tg.ntiles / tpb : 1, 8);
-    hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT, ONE>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg);
+    if (pooled) {
+        if constexpr (FwdPx<MT>::PX == 2 && FT::TW >= 16)
+            hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT, ONE, true>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg,
+                               gamma, (T*)pooled);
+        else
+            return OCRS_ERR_ARG;  // (ocrs_dwpw_fwd_pool_supported)
+    } else
+        hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT, ONE, false>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg,
+                           gamma, (T*)pooled);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -498,13 +541,13 @@ extern "C" {
 
 template <class T>
 static int dispatch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                             double* gstat, int COUT, int N, int H, int W, hipStream_t st) {
+                             double* gstat, int COUT, int N, int H, int W, const float* gamma, void* pooled, hipStream_t st) {
     const int CIN = Ca + Cb;
     const int cg = CIN >= 32 ? 4 : CIN / 8;
     const int mt = (COUT + 15) / 16;
 #define DWPW_CASE(CG_, MT_, ONE_) \
     if (cg == CG_ && mt == MT_ && (CIN == CG_ * 8) == ONE_) \
-        return launch_dwpw_fwd<T, CG_, MT_, ONE_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, st);
+        return launch_dwpw_fwd<T, CG_, MT_, ONE_>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, COUT, N, H, W, gamma, pooled, st);
     DWPW_CASE(1, 1, true) DWPW_CASE(2, 1, true) DWPW_CASE(2, 2, true)
     DWPW_CASE(4, 1, true) DWPW_CASE(4, 2, true) DWPW_CASE(4, 4, true)  // Cin == 32: pipelined single-chunk variants
     DWPW_CASE(4, 1, false) DWPW_CASE(4, 2, false) DWPW_CASE(4, 4, false) DWPW_CASE(4, 8, false) DWPW_CASE(4, 16, false)
@@ -519,15 +562,21 @@ extern "C" {
 //   wdw   : depthwise weights in the reference layout [Cin][1][3][3]; wpk: pointwise weights packed by ocrs_pack_frags(K=Cin, M=Cout)
 //   z     : [P][Cout] pre-BN output; gstat: [2][Cout] double, sum z and sum z^2 ACCUMULATED (the caller zeroes it: one
 //           memset for all layers of a step instead of one per launch)
+// 1 if ocrs_dwpw_fwd can also write the 2x2-max-pooled (pre-BatchNorm) output: two-pixel tile configurations, Cout <= 64
+long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) { return Cout <= 64 && (Cin < 32 || Cin % 32 == 0) ? 1 : 0; }
+
+//   gamma / pooled (nullable, need ocrs_dwpw_fwd_pool_supported): also write MaxPool2d(2) of the block output in its pre-BatchNorm form
+//           (the selected element's z, chosen by the sign of the BatchNorm weight gamma [Cout]) to pooled [N][H/2][W/2][Cout]
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
-                  void* z, double* gstat, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+                  void* z, double* gstat, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
     const int Cin = Ca + Cb;
+    OCRS_CHECK_ARG(!pooled || (gamma && ocrs_dwpw_fwd_pool_supported(Cin, Cout)));
     OCRS_CHECK_ARG(xa && tra && wdw && wpk && z && gstat && (Cb == 0 || trb));
     OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
-    return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st)
-                      : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st);
+    return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st)
+                      : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st);
 }
 
 // First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] accumulated (caller zeroes).

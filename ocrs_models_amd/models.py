@@ -112,6 +112,9 @@ class _DetRun:
         # fused pointwise+depthwise backward kernel (csrc/det_blk.hip): correct (tests/test_det_ops_gpu.py) but, at 168 VGPRs with spills
         # and 1.4x dgrad work, still slower than the two pipelined kernels it replaces (level 0: 1.30 vs 1.08 ms) -> opt-in for now
         self.fuse_blk = os.environ.get("OCRS_FUSE_BLK", "0") == "1"
+        # max-pool written by the producing block's forward kernel (levels 0-2) instead of a separate pass over the full-size z
+        self.fuse_pool = os.environ.get("OCRS_FUSE_POOL", "1") != "0"
+        self.pooled_by_block = None
         self.x = x
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -186,7 +189,9 @@ class _DetRun:
         return tr, saved
 
     # -- forward ---------------------------------------------------------------------------------
-    def block(self, prefix, a, b, Cout):
+    def block(self, prefix, a, b, Cout, pool=False):
+        """-> the block's output activation (raw z + load transform); with pool=True also ``self.pooled_by_block``: the 2x2 max-pooled
+        (pre-BatchNorm) output written by the same kernel, or None when that configuration has no fused pooling"""
         L, P, N = self.L, self.P, self.N
         H, W = a.H, a.W
         Cin = a.C + (b.C if b is not None else 0)
@@ -194,8 +199,12 @@ class _DetRun:
         wpk = self.pack(wpw, 0, Cin, Cout, Cin, 0, 1, Cin)
         z = self.empty(N, H, W, Cout)
         gstat = self.zeros64(2 * Cout)
+        pooled = gamma = None
+        if pool and self.fuse_pool and L.dwpw_fwd_pool_supported(Cin, Cout):
+            pooled, gamma = self.empty(N, H // 2, W // 2, Cout), P[f"{prefix}.seq.2.weight"]
+        self.pooled_by_block = pooled
         L.dwpw_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, b.C if b is not None else 0, ptr(a.tr),
-                   ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), Cout, N, H, W, self.dt)
+                   ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
         tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, Cout)
         r = _BlockRec()
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
@@ -213,9 +222,9 @@ class _DetRun:
         self.recs[prefix] = r
         return _Act(z, tr, 8, H, W, src=prefix)
 
-    def double(self, prefix, a, b, Cout):
+    def double(self, prefix, a, b, Cout, pool=False):
         y = self.block(f"{prefix}.seq.0", a, b, Cout)
-        return self.block(f"{prefix}.seq.1", y, None, Cout)
+        return self.block(f"{prefix}.seq.1", y, None, Cout, pool=pool)
 
     def forward(self):
         L, P, N, w = self.L, self.P, self.N, DEPTH_SCALE
@@ -228,14 +237,16 @@ class _DetRun:
         cur = self.block("in_conv.seq.1", a0, None, w[0])
         skips = [cur]
         for i in range(6):
-            y = self.double(f"down.{i}.seq.0", cur, None, w[i + 1])
+            y = self.double(f"down.{i}.seq.0", cur, None, w[i + 1], pool=True)
             Hp, Wp = y.H // 2, y.W // 2
-            pooled = self.empty(N, Hp, Wp, y.C)
+            pooled = self.pooled_by_block  # levels 0-2: written by the block's own forward kernel
             y.other_use = True
             # the pooled tensor holds the SELECTED elements' pre-BatchNorm z: consumers apply y's load transform (= the max, exactly), and
             # the depthwise-backward passes that read it produce y's BatchNorm-backward sums (src = y's block; the gradient lands only
             # on the selected elements), so no bn_bwd_reduce pass over the full-size z is needed for pooled blocks
-            L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, 1, self.dt)
+            if pooled is None:
+                pooled = self.empty(N, Hp, Wp, y.C)
+                L.maxpool_fwd(ptr(y.t), ptr(y.tr), ptr(pooled), y.C, N, y.H, y.W, 1, self.dt)
             cur = _Act(pooled, y.tr, y.C, Hp, Wp, src=y.src)
             skips.append(cur)
         up = skips[6]

@@ -29,7 +29,7 @@ def make_run(dev, dtype, N, P, Bf):
 
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
-    r.fused, r.fuse_bn_bwd, r.fuse_blk = {}, True, False
+    r.fused, r.fuse_bn_bwd, r.fuse_blk, r.fuse_pool, r.pooled_by_block = {}, True, False, True, None
     return r
 
 
@@ -243,7 +243,8 @@ def test_block_bwd_through_maxpool(dev, dtype):
           f"{pfx}.seq.2.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=dev)}
     run = make_run(dev, dtype, N, P, Bf)
     xs = nhwc(x, dtype)
-    out = run.block(pfx, _Act(xs, tr, C, H, W), None, Cout)
+    out = run.block(pfx, _Act(xs, tr, C, H, W), None, Cout, pool=True)
+    pfused = run.pooled_by_block  # the same max-pool written by the block's own forward kernel (None if that configuration has none)
     pooled = run.empty(N, H // 2, W // 2, Cout)
     run.L.maxpool_fwd(ptr(out.t), ptr(out.tr), ptr(pooled), Cout, N, H, W, 0, run.dt)
     torch.cuda.synchronize()
@@ -263,6 +264,13 @@ def test_block_bwd_through_maxpool(dev, dtype):
     # ... and every raw value is one of the four z of its window
     zwin = out.t.float().reshape(N, H, W, Cout)[:, : H // 2 * 2, : W // 2 * 2].reshape(N, H // 2, 2, W // 2, 2, Cout)
     assert bool(((zwin - praw.float()[:, :, None, :, None, :]) == 0).any(dim=4).any(dim=2).all())
+    if pfused is not None:
+        # fused form: selection by the sign of gamma on z itself (no batch statistics needed); it may differ from the first-maximum rule only
+        # where two different z give the same activation (both clamped by the ReLU, or equal after rounding): same activation either way
+        assert bool(((zwin - pfused.float()[:, :, None, :, None, :]) == 0).any(dim=4).any(dim=2).all())
+        actf = torch.maximum(pfused.float() * out.tr[0] + out.tr[1], out.tr[2])
+        assert rel(actf, act) < (1e-6 if dtype == torch.float32 else 4e-3)
+        assert (actf == act).float().mean().item() > 0.999
     g1 = nhwc(torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev), dtype)
     g2 = nhwc(torch.randn(N, Cout, H // 2, W // 2, generator=g).to(dev), dtype)
     pr.backward(nchw(g1) + nchw(g2))
