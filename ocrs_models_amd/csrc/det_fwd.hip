@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
                             for (int r = 0; r < 4; ++r) {
                                 const float v0 = sg[r] * Elem<T>::round(acc[a][b][r]), v1 = sg[r] * Elem<T>::round(acc[a + TPR][b][r]);
                                 const float vv = fmaxf(v0, v1);
-                                m4[r] = sg[r] * fmaxf(vv, __shfl_xor(vv, 1, 64));
+                                m4[r] = sg[r] * fmaxf(vv, dpp_f<0xB1>(vv));  // quad_perm [1,0,3,2]: the horizontally adjacent pixel (lane ^ 1), no LDS
                             }
                             const int ph = (org.h0 + oty) >> 1, pw = (org.w0 + otx) >> 1;
                             if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
