@@ -1079,8 +1079,17 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restr
         return;
     }
     const int c = e / (9 * COUT), n = e - c * 9 * COUT;
-    float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += ws[(long)b * part + c * NT16 + n];
+    const float* src = ws + c * NT16 + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {  // four independent loads in flight (the partials of one element are a block apart)
+        s0 += src[(long)b * part];
+        s1 += src[(long)(b + 1) * part];
+        s2 += src[(long)(b + 2) * part];
+        s3 += src[(long)(b + 3) * part];
+    }
+    for (; b < b1; ++b) s0 += src[(long)b * part];
+    const float s = (s0 + s1) + (s2 + s3);
     const int tap = n / COUT, o = n - tap * COUT;
     atomicAdd(&dW[((long)c * COUT + o) * 9 + tap], s);
 }
@@ -1504,7 +1513,9 @@ static bool convt_wgrad_tr_ok(int Cup, int Cout, int dtype) {
 }
 static int convt_wgrad_tr_grid(int Cout, int N, int h, int w) {
     const int TH = Cout >= 32 ? 4 : 8;
-    return persistent_grid((long)N * ((w + 15) / 16) * ((h + TH - 1) / TH), 4);
+    // resident blocks only (register-bound: 3 per CU for Cout = 8, 2 for Cout >= 16): every block ends with a full weight-gradient partial
+    // (5-37 KB) that the reduce kernel reads back
+    return persistent_grid((long)N * ((w + 15) / 16) * ((h + TH - 1) / TH), Cout >= 16 ? 2 : 3);
 }
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
     const long a = ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype);
