@@ -1433,7 +1433,10 @@ static void dw_bwd_grid(int C, int N, int H, int W, int& gx, int& gy, int& cg) {
     cg = C / 8 < cg_max ? C / 8 : cg_max;
     gy = C / (cg * 8);
     const Tiling2 tg = make_tiling2(N, H, W, 32 / cg, 8);
-    gx = persistent_grid(tg.ntiles, 8 / gy > 0 ? 8 / gy : 1);
+    // 3 blocks per CU are resident (k_dw_bwd's launch bounds): a grid of exactly that many blocks (all y-slabs together) has no partial last
+    // round -- with 8 per CU the 2048 blocks ran as 2.67 rounds of 768
+    static const int bpc = env_int("OCRS_DW_BPC", 3);
+    gx = persistent_grid(tg.ntiles, bpc / gy > 0 ? bpc / gy : 1);
 }
 // ws: ocrs_dw_bwd_ws_floats() floats (per-block partials of dwdw, summed by a second kernel) or null (float atomics).
 long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W) {

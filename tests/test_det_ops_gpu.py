@@ -127,7 +127,7 @@ def test_dwpw_block_fwd_bwd(dev, dtype, Ca, Cb, Cout):
 def test_fused_bn_bwd_sums_match_reduce_pass(dev, dtype, C0, Ca, Cb, Cc):
     """Blocks A (and B) feed block C directly: C's depthwise-backward pass produces A's / B's BatchNorm-backward sums (ocrs_dw_bwd
     gsum_a/gsum_b).  The resulting gradients must equal the ones obtained with the separate ocrs_bn_bwd_reduce pass (same arithmetic,
-    different summation order -> 1e-5 fp32; in bf16 both read the same rounded gradient -> 1e-3)."""
+    different summation order -> 1e-5 fp32; bf16: see the tolerance note below)."""
     from ocrs_models_amd.models import _Act
 
     g = torch.Generator().manual_seed(77 + Ca + Cb)
@@ -165,7 +165,11 @@ def test_fused_bn_bwd_sums_match_reduce_pass(dev, dtype, C0, Ca, Cb, Cc):
         assert not run.fused
         torch.cuda.synchronize()
         res[fuse] = {k: v.clone() for k, v in run.G.items()}
-    tol = 1e-5 if dtype == torch.float32 else 1e-3
+    # bf16: the two runs repeat the FORWARD as well, and its BatchNorm statistics are float atomics (order-dependent in the last bits): a
+    # last-bit change of a load transform flips a few bf16 roundings downstream, which moves these small gradient tensors by up to 1.1e-3
+    # run to run on identical inputs (tools/experiments/flake_probe.py; ocrs_pw_bwd / ocrs_dw_bwd themselves are bitwise reproducible,
+    # tools/experiments/det_probe.py) -> 5e-3
+    tol = 1e-5 if dtype == torch.float32 else 5e-3
     for k in P:
         assert rel(res[True][k], res[False][k]) < tol, k
 
