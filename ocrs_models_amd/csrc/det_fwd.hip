@@ -522,7 +522,10 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     // two tiles per block halve that tail; below that parallelism matters more (measured: OCRS_FWD_TPB sweep, profiles/README.md)
     static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);
     const int tpb = fwd_tpb > 0 ? fwd_tpb : (tg.ntiles >= 2048 ? 2 : 1);
-    const int grid = persistent_grid(tg.ntiles / tpb > 0 ? tg.ntiles / tpb : 1, 8);
+    // 4 blocks per CU are resident (registers <= 128, LDS 36 KB): a grid of exactly the resident blocks runs as ONE round (8 per CU = two rounds, each
+    // block with its own prologue and 2*COUT fp64 atomics at the end: 4.66 -> 4.52 ms per step over all forward launches)
+    static const int fwd_bpc = env_int("OCRS_FWD_BPC", 4);
+    const int grid = persistent_grid(tg.ntiles / tpb > 0 ? tg.ntiles / tpb : 1, fwd_bpc);
     if (pooled) {
         if constexpr (FwdPx<MT>::PX == 2 && FT::TW >= 16)
             hipLaunchKernelGGL((k_dwpw_fwd<T, CG, MT, ONE, true>), dim3(grid), dim3(256), smem, st, x, tra, trb, wdw, wpk, (T*)z, gstat, CIN, COUT, tg,
