@@ -65,7 +65,12 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
                                                    int T, int N, int C, int Lpad, int Smax) {
     __shared__ float row[2][256 * CTC_SPT + 2];
     const int n = blockIdx.x;
-    const int Ti = (int)in_len[n], L = (int)tg_len[n];
+    // device-side lengths are clamped to the tensor extents (torch raises for input_lengths > T / target_lengths > Lpad on host lengths --
+    // losses.py does the same check there; lengths that only exist on the device cannot raise without a sync, so they must not go out of bounds)
+    int Ti = (int)in_len[n], L = (int)tg_len[n];
+    Ti = Ti > T ? T : Ti;
+    L = L < 0 ? 0 : (L > Lpad ? Lpad : L);
+    L = 2 * L + 1 > Smax ? (Smax - 1) / 2 : L;
     const int S = 2 * L + 1;
     const int* tg = targets + (long)n * Lpad;
     float* al = alpha + (long)n * T * Smax;
@@ -139,7 +144,12 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
     __shared__ float row[2][256 * CTC_SPT + 2];
     extern __shared__ float s_occ[];  // [C]
     const int n = blockIdx.x;
-    const int Ti = (int)in_len[n], L = (int)tg_len[n];
+    // device-side lengths are clamped to the tensor extents (torch raises for input_lengths > T / target_lengths > Lpad on host lengths --
+    // losses.py does the same check there; lengths that only exist on the device cannot raise without a sync, so they must not go out of bounds)
+    int Ti = (int)in_len[n], L = (int)tg_len[n];
+    Ti = Ti > T ? T : Ti;
+    L = L < 0 ? 0 : (L > Lpad ? Lpad : L);
+    L = 2 * L + 1 > Smax ? (Smax - 1) / 2 : L;
     const int S = 2 * L + 1;
     const int* tg = targets + (long)n * Lpad;
     const float* al = alpha + (long)n * T * Smax;

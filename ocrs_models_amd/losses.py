@@ -49,21 +49,25 @@ def balanced_cross_entropy_loss(pred: torch.Tensor, target: torch.Tensor) -> tor
     return _BalancedBCE.apply(pred, target)
 
 
+MAX_CTC_STATES = 768  # csrc/rec_seq.hip: CTC_SPT (3) states per thread x 256 threads
+
+
 class _CTC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_probs, targets, in_len, tg_len):
+    def forward(ctx, log_probs, targets, in_len, tg_len, smax=None):
         L = lib()
         lp = log_probs.contiguous().float()
         T, N, C = lp.shape
         tg = targets.contiguous().to(torch.int32)
         Lpad = tg.shape[1]
-        Smax = 2 * Lpad + 1
+        Smax = smax or 2 * Lpad + 1
         dev = lp.device
         alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
         nll = torch.empty(N, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
         ctx.save_for_backward(lp, tg, in_len, tg_len, alpha, nll)
+        ctx.smax = Smax
         return loss
 
     @staticmethod
@@ -72,8 +76,8 @@ class _CTC(torch.autograd.Function):
         T, N, C = lp.shape
         grad = torch.empty_like(lp)
         g = gout.contiguous().float().reshape(1)
-        lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], 2 * tg.shape[1] + 1)
-        return grad, None, None, None
+        lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
+        return grad, None, None, None, None
 
 
 class CTCLoss(torch.nn.Module):
@@ -94,6 +98,21 @@ class CTCLoss(torch.nn.Module):
         if targets.dim() != 2:
             raise RuntimeError("targets must be (N, Lpad) padded label rows (the layout collate_samples produces)")
         dev = log_probs.device
-        il = torch.as_tensor(input_lengths, dtype=torch.int64).to(dev, non_blocking=True)
-        tl = torch.as_tensor(target_lengths, dtype=torch.int64).to(dev, non_blocking=True)
-        return _CTC.apply(log_probs, targets.to(dev), il, tl)
+        il = torch.as_tensor(input_lengths, dtype=torch.int64)
+        tl = torch.as_tensor(target_lengths, dtype=torch.int64)
+        T, N = log_probs.shape[0], log_probs.shape[1]
+        smax = None
+        if il.shape != (N,) or tl.shape != (N,) or targets.shape[0] != N:
+            raise RuntimeError(f"input_lengths / target_lengths / targets must have batch size {N}")
+        if not il.is_cuda and not tl.is_cuda and N > 0:
+            # host lengths (what the reference passes, train_rec.py:110-113): validate like torch.nn.functional.ctc_loss, no device sync
+            if int(il.max()) > T or int(il.min()) < 0:
+                raise RuntimeError(f"Expected input_lengths to have value at most {T}, but got value {int(il.max())} (while checking arguments for ctc_loss)")
+            if int(tl.max()) > targets.shape[1] or int(tl.min()) < 0:
+                raise RuntimeError(f"Expected tensor to have size at least {int(tl.max())} at dimension 1, but got size {tuple(targets.shape)} "
+                                   "(while checking arguments for ctc_loss)")
+            smax = 2 * int(tl.max()) + 1  # lattice width from the real lengths, not from the padding
+        if (smax or 2 * targets.shape[1] + 1) > MAX_CTC_STATES:
+            raise RuntimeError(f"CTC lattices wider than {MAX_CTC_STATES} states (targets longer than {(MAX_CTC_STATES - 1) // 2} labels) are not "
+                               "supported by the LDS-resident alpha/beta kernels; pass host-side target_lengths so that the padding does not count")
+        return _CTC.apply(log_probs, targets.to(dev), il.to(dev, non_blocking=True), tl.to(dev, non_blocking=True), smax)

@@ -389,18 +389,29 @@ class _DetRun:
         return [self.G[k] for k in self.names]
 
 
+def _check_versions(ctx):
+    """Backward reads the LIVE parameters (run.P aliases them): refuse, like stock autograd's version-counter check, when one was
+    modified in place (e.g. optimizer.step()) between this forward and its backward."""
+    for p, v in zip(ctx.params, ctx.versions):
+        if p._version != v:
+            raise RuntimeError("one of the parameters needed for gradient computation has been modified by an inplace operation "
+                               "(e.g. optimizer.step()) between forward and backward")
+
+
 class _DetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, names, *params):
         run = _DetRun(mod, x, names, [p.detach() for p in params], mod.training)
         pred = run.forward()
         ctx.run = run
+        ctx.params = params
+        ctx.versions = [p._version for p in params]
         return pred
 
     @staticmethod
     def backward(ctx, gpred):
+        _check_versions(ctx)
         grads = ctx.run.backward(gpred)
-        ctx.run = None
         return (None, None, None, *grads)
 
 

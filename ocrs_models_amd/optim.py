@@ -38,6 +38,14 @@ class Adam(torch.optim.Optimizer):
         self._tables = {}
         self.grad_scale = None  # optional device fp32[1] multiplied into every gradient (fused clip)
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}  # the moment tensors were replaced: cached pointer tables are stale
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
@@ -54,7 +62,15 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if not p.is_cuda or p.dtype != torch.float32 or not p.grad.is_contiguous():
                     raise RuntimeError("ocrs_models_amd.optim.Adam needs contiguous fp32 CUDA parameters and gradients")
-            key = tuple(p.grad.data_ptr() for p in ps) + tuple(p.data_ptr() for p in ps)
+                if torch.is_tensor(st["step"]):  # state restored by load_state_dict() from a stock torch.optim.Adam checkpoint
+                    st["step"] = int(st["step"].item())
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
+                        st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
+            # the pointer table is keyed on EVERY pointer it holds: after optimizer.load_state_dict() (train_detection.py:206-215) torch
+            # replaces exp_avg / exp_avg_sq while the flat gradient buffer usually comes back at the same address
+            key = (tuple(p.grad.data_ptr() for p in ps) + tuple(p.data_ptr() for p in ps)
+                   + tuple(self.state[p]["exp_avg"].data_ptr() for p in ps) + tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in ps))
             tb = self._tables.get(gi)
             if tb is None or tb[0] != key:
                 t = _Table(ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps])

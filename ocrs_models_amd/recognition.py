@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from ._lib import lib, ptr
-from .models import _DT, _identity_tr
+from .models import _DT, _check_versions, _identity_tr
 
 _coef_cache: dict = {}
 
@@ -326,12 +326,14 @@ class _RecFn(torch.autograd.Function):
     def forward(ctx, x, mod, names, dtype, *params):
         run = _RecRun(mod, x, names, [p.detach() for p in params], mod.training, dtype)
         ctx.run = run
+        ctx.params = params
+        ctx.versions = [p._version for p in params]
         return run.forward()
 
     @staticmethod
     def backward(ctx, g):
+        _check_versions(ctx)
         grads = ctx.run.backward(g)
-        ctx.run = None
         return (None, None, None, None, *grads)
 
 

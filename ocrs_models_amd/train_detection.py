@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import torch
 
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401  (train_detection.py:198-215)
 from .losses import balanced_cross_entropy_loss
 from .models import DetectionModel
 from .optim import Adam

@@ -7,6 +7,7 @@ import math
 
 import torch
 
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401  (shared with train_detection, train_rec.py:9)
 from .losses import CTCLoss
 from .optim import Adam, clip_grad_norm_
 from .text import RecognitionAccuracyStats
@@ -14,6 +15,11 @@ from .text import RecognitionAccuracyStats
 
 def make_optimizer(model, lr: float = 1e-3) -> Adam:
     return Adam(model.parameters(), lr=lr)  # train_rec.py:381-382
+
+
+def make_scheduler(optimizer) -> torch.optim.lr_scheduler.ReduceLROnPlateau:
+    """train_rec.py:383-385: stepped once per epoch on the validation loss."""
+    return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.1, patience=3)
 
 
 def train_step(model, optimizer, batch: dict, device, stats: RecognitionAccuracyStats | None = None, loss_fn=None, check_nan: bool = True,
