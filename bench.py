@@ -8,17 +8,25 @@ step = forward + balanced BCE + zero_grad + backward (+ RCCL gradient all-reduce
 synthetic greyscale tiles, B=32 x 1x1024x1024 per GPU (weak scaling), bf16 activations / fp32 accumulate+params,
 random-init weights (seed 1234 as train_detection.py:337).  Prints ONE JSON line on rank 0.
 
-Extra objects in the line:
-  roofline     -- the dominant kernel family timed live with HIP events on the launch stream over the timed
-                  region; achieved = algorithmic bytes (DESIGN.md "Algorithmic bytes") / event time.
-  cpu_baseline -- oracle/ (the CPU restatement of the reference, stock ATen CPU ops) timed on this host, N=1 only.
-  crnn         -- line-crops/s of the CRNN recognition train step (configs[2]) once that path exists.
+Objects in the line besides the contract fields (all byte / flop models are SURVEY.md 8(d)'s, restated in DESIGN.md 5):
+  roofline     -- the dominant PASS of the step (the DepthwiseConv-block backward: every launch belonging to one block's backward),
+                  timed live with HIP events on the launch stream over the timed region.  achieved = algorithmic bytes / event time
+                  with 8(d)'s byte model: a block backward reads saved input, saved output and grad-out once and writes grad-in once
+                  = 2 (Cin + Cout) elements per pixel.  Also: whole_step_frac (3 * sizeof * sum(in+out) of the whole net / step time /
+                  8 TB/s), traffic + traffic_ratio (HBM bytes from the committed PMC passes / algorithmic bytes), and `passes`
+                  (forward-block and ConvTranspose passes, event-timed in the last warm-up step).
+  fp32_exact   -- the same step in the fp32 parity mode (a few steps).
+  crnn         -- line-crops/s of the CRNN recognition train step (configs[2], at the legal crop height 64) with its own roofline
+                  (conv MFMA TF/s vs the 2.5 PF dense bf16 peak; GRU us per time step vs the 1.45 us kernel-boundary floor) and the
+                  exact-fp32 GRU number; `crnn_config5`: the width-bucketed variable-width workload of configs[4] (N > 1 or --rec-config5).
+  cpu_baseline -- oracle/ (CPU restatement of the reference, stock ATen CPU ops) on this host, N=1 only, 8(d) protocol.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,109 +36,191 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s measured achievable (float4 copy)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (same guide)
+KERNEL_BOUNDARY_US = 1.45   # dependent kernel boundary, same stream (same guide, price list row "boundary")
+DEPTH_SCALE = [8, 16, 32, 32, 64, 128, 256]  # models.py:112
 
 
-# ABI argument names the byte model below reads, per kernel family (tests/test_abi.py checks them against include/ocrs_hip.h so that an
+# ------------------------------------------------------------------------------------------------ byte model
+def det_alg_elems_per_image(H: int, W: int) -> int:
+    """sum over the fused passes of the detection net of (input elements + output elements), per image (every a1 block,
+    max-pool, ConvTranspose, the head and the loss is one pass that reads its inputs once and writes its output once; concat is free).
+    1024 x 1024 -> 277.9 M (the survey's figure); bytes fwd+bwd = 3 * sizeof(dtype) * this."""
+    w = DEPTH_SCALE
+    hs, ws = [H], [W]
+    for _ in range(6):
+        hs.append(hs[-1] // 2)
+        ws.append(ws[-1] // 2)
+    px = [h * v for h, v in zip(hs, ws)]
+    tot = px[0] * ((1 + w[0]) + (w[0] + w[0]))                       # in_conv
+    for i in range(6):
+        tot += px[i] * ((w[i] + w[i + 1]) + (w[i + 1] + w[i + 1]))    # down[i] DoubleConv at level i
+        tot += w[i + 1] * (px[i] + px[i + 1])                         # MaxPool2d(2)
+        tot += w[i + 1] * px[i + 1] + w[i] * px[i]                    # up[i] ConvTranspose: level i+1 -> level i
+        tot += px[i] * ((2 * w[i] + w[i]) + (w[i] + w[i]))            # up[i].contract DoubleConv on the concat
+    tot += px[0] * (w[0] + 1) + px[0] * 2                              # head, loss (pred + target)
+    return tot
+
+
+# ABI argument names the byte model reads, per kernel family (tests/test_abi.py checks them against include/ocrs_hip.h so that an
 # ABI change cannot silently corrupt the roofline figure)
 ALG_BYTES_ARGS = {
     "dwpw_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
-    "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout", "pooled", "g2"),
+    "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "blk_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
-    "bn_bwd_reduce": ("N", "H", "W", "C", "pooled", "g2"),
+    "bn_bwd_reduce": ("N", "H", "W", "C"),
     "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
     "convt_bwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
     "maxpool_fwd": ("N", "H", "W", "C"),
 }
+FAMILIES = list(ALG_BYTES_ARGS)
+# pass -> the C-ABI families whose launches belong to it.  The BYTES of a block backward are booked once per block, on the launch that
+# every block backward has exactly once (pw_bwd, or blk_bwd when the fused kernel runs); dw_bwd / bn_bwd_reduce launches of the same
+# block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
+PASSES = {
+    "block_bwd": ("pw_bwd", "blk_bwd", "dw_bwd", "bn_bwd_reduce"),
+    "block_fwd": ("dwpw_fwd",),
+    "convt_fwd": ("convt_fwd",),
+    "convt_bwd": ("convt_bwd",),
+    "maxpool_fwd": ("maxpool_fwd",),
+}
+PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
+    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_blk_bwd<", "k_blk2_bwd<"),
+    "block_fwd": ("k_dwpw_fwd<",),
+    "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
+    "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<"),
+    "maxpool_fwd": ("k_maxpool_fwd<",),
+}
 
 
 def alg_bytes(name, a, sz):
-    """Algorithmic HBM bytes of one launch of a kernel family, from its C-ABI arguments (looked up BY NAME in include/ocrs_hip.h).
-
-    SURVEY.md 8(d) model: a fused pass reads its inputs once and writes its outputs once.
-    """
+    """Algorithmic HBM bytes booked on one launch of a kernel family, from its C-ABI arguments (looked up BY NAME in include/ocrs_hip.h)."""
     from ocrs_models_amd._lib import ARG_NAMES
 
     v = dict(zip(ARG_NAMES["ocrs_" + name], a))
     if name == "dwpw_fwd":  # x (Ca+Cb) in, z (Cout) out
         return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
-    if name == "pw_bwd":  # g (+g2, or a quarter-size pooled g) + z + x in, du out
-        P, cin, cout = v["N"] * v["H"] * v["W"], v["Ca"] + v["Cb"], v["Cout"]
-        g = cout / 4 if v["pooled"] else cout * (2 if v["g2"] else 1)
-        return P * (g + cout + 2 * cin) * sz
-    if name == "dw_bwd":  # du + x in, dL/dx out
-        return v["N"] * v["H"] * v["W"] * 3 * (v["Ca"] + v["Cb"]) * sz
-    if name == "bn_bwd_reduce":
-        P, c = v["N"] * v["H"] * v["W"], v["C"]
-        g = c / 4 if v["pooled"] else c * (2 if v["g2"] else 1)
-        return P * (g + c) * sz
+    if name in ("pw_bwd", "blk_bwd"):  # the whole block backward: x, z, g in; dL/dx out
+        return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
+    if name in ("dw_bwd", "bn_bwd_reduce"):
+        return 0.0
     if name == "convt_fwd":  # x in, out out
         return v["N"] * (v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
-    if name == "convt_bwd":  # x + g in, dx out
-        return v["N"] * (2 * v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
+    if name == "convt_bwd":  # x + g in, dx out (+ nothing else under the model: 2 x (in + out))
+        return 2 * v["N"] * (v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
     if name == "maxpool_fwd":
         return v["N"] * v["H"] * v["W"] * v["C"] * 1.25 * sz
-    return 0.0
+    raise KeyError(name)
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed PMC passes (profiles/*_pmc_hbm.csv: rocprofv3 --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE of this same bench command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from
-    inside the timed run, so this is the profile's figure, not this run's; null when the file is missing."""
+def pmc_profile():
+    """Per-kernel HBM bytes per step from the committed PMC passes (profiles/*_pmc_hbm.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of
+    this same bench command in two separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the
+    timed run, so these are the profile's figures, not this run's; None when the file is missing."""
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")), key=os.path.getmtime)
     if not files:
-        return {"traffic": None}
-    tot, n = 0.0, 0.0
+        return None, None
+    rows = {}
     for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith(FAMILY_KERNELS.get(family, ("k_" + family + "<",))) or r["kernel"] == "k_" + family:
-            tot += (float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9
-            n += float(r["launches_per_step"])
-    return {"traffic": round(tot / n) if n else None, "traffic_source": os.path.basename(files[-1])}
+        if r["kernel"] != "TOTAL":
+            rows[r["kernel"]] = ((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9, float(r["launches_per_step"]))
+    return rows, os.path.basename(files[-1])
 
 
-FAMILIES = ["dwpw_fwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce", "convt_fwd", "convt_bwd", "maxpool_fwd"]
-# kernels launched by one C-ABI call of a family (for the PMC traffic lookup)
-FAMILY_KERNELS = {"pw_bwd": ("k_pw_bwd<", "k_pw_bwd2<"), "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
-                  "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<")}
+def pass_traffic(rows, pname):
+    if not rows:
+        return None
+    return sum(b for k, (b, _) in rows.items() if k.startswith(PASS_KERNELS[pname])) or None
 
 
-def cpu_baseline(steps=3, B=2, H=1024, W=1024):
-    """oracle/ detection train step (fp32, as the reference trains) on the host cores: images/s."""
+# ------------------------------------------------------------------------------------------------ host (CPU) baseline
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    try:
+        ids = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    ids.add((phys, core))
+                phys = core = None
+        return len(ids) or None
+    except OSError:
+        return None
+
+
+def _median_steps(fn, warm, timed):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
+
+
+def cpu_baseline():
+    """oracle/ train steps (stock ATen CPU operators, what the reference dispatches to) on the host cores, SURVEY 8(d) protocol: same
+    synthetic distributions and seeds as the GPU run, reduced batches, median of >= 5 timed steps after 2 warm-ups (the 1024^2 detection
+    case: 3 after 1 -- one step is ~8 s and the default bench must stay within minutes)."""
     import numpy as np
 
-    # the small convolutions of this net do not scale to a 128+-core host (0.18 img/s at 128 threads): use <= 32 threads
-    torch.set_num_threads(min(32, max(1, (os.cpu_count() or 2) // 2)))
-
-    from oracle import detection as odet
-    from oracle import losses as olosses
+    from oracle import aten_step as A
     from oracle import optim as ooptim
-    from oracle.params import detection_specs, make_state
+    from oracle.params import detection_specs, make_state, recognition_specs
 
-    P, Bf = make_state(detection_specs(), 1234)
-    r = np.random.RandomState(0)
-    x = torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, H, W)).astype(np.float32))
-    m = torch.from_numpy((r.uniform(0, 1, (B, 1, H, W)) > 0.9).astype(np.float32))
-    opt = ooptim.Adam(P.values())
+    # the small convolutions of these nets do not scale to a 128+-core host (measured 0.18 img/s at 128 threads vs 0.47 at 32)
+    nthreads = min(32, max(1, _physical_cores() or (os.cpu_count() or 2) // 2))
+    torch.set_num_threads(nthreads)
+    info = {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "physical_cores": _physical_cores(), "torch_threads": torch.get_num_threads()}
 
-    def step():
-        pred = odet.forward(P, Bf, x, True)
-        loss = olosses.balanced_bce(pred, m)
-        grads = torch.autograd.grad(loss, list(P.values()))
-        opt.step(grads)
-        return loss.item()
+    def det(B, S, warm, timed):
+        P, Bf = make_state(detection_specs(), 1234)
+        r = np.random.RandomState(0)
+        x = torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, S, S)).astype(np.float32))
+        m = torch.from_numpy((r.uniform(0, 1, (B, 1, S, S)) > 0.9).astype(np.float32))
+        opt = ooptim.Adam(P.values())
+        dt = _median_steps(lambda: A.det_train_step(P, Bf, opt, x, m), warm, timed)
+        return {"images_per_s": round(B / dt, 3), "step_s": round(dt, 3), "sample": f"median of {timed} steps after {warm} warm-up, B={B} 1x{S}x{S} fp32"}
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(B / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of B={B} 1x{H}x{W} fp32 (oracle/: stock ATen CPU ops, {os.cpu_count()} logical cpus)"}
+    def rec(B, W, autocast, warm, timed):
+        P, Bf = make_state(recognition_specs(), 1234)
+        b = synth_rec_batch(B, W, 2000, "cpu")
+        il = b["image_width"].div(4, rounding_mode="floor")
+        opt = ooptim.Adam(P.values())
+        dt = _median_steps(lambda: A.rec_train_step(P, Bf, opt, b["image"], b["text_seq"], il, b["text_len"], autocast), warm, timed)
+        return {"crops_per_s": round(B / dt, 2), "step_s": round(dt, 3),
+                "sample": f"median of {timed} steps after {warm} warm-up, B={B} 1x64x{W}, {'bf16 autocast (train_rec.py:118)' if autocast else 'fp32'}"}
+
+    d512 = det(2, 512, 2, 5)
+    d1024 = det(4, 1024, 1, 3)
+    r32 = rec(64, 400, False, 2, 5)
+    rbf = rec(64, 400, True, 2, 5)
+    return {"value": d1024["images_per_s"], "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": d1024["sample"] + " (oracle/aten_step.py: stock ATen CPU ops, the operators the reference dispatches to)",
+            "det_config1_B2_512": d512, "det_B4_1024": d1024, "rec_B64_fp32": r32, "rec_B64_bf16_autocast": rbf, **info}
 
 
+# ------------------------------------------------------------------------------------------------ CRNN
 def synth_rec_batch(B, W, gen_seed, dev):
     """BASELINE configs[2]: B line crops 1x64xW, targets L ~ U[5,40] resampled until CTC-feasible for W//4 steps (SURVEY 8d)."""
     import numpy as np
@@ -151,10 +241,41 @@ def synth_rec_batch(B, W, gen_seed, dev):
     return {"image": img.to(dev), "text_seq": text.to(dev), "text_len": tl, "image_width": torch.full((B,), W, dtype=torch.int64)}
 
 
+def config5_batches(B, rank, world, nsteps, dev, seed=5):
+    """BASELINE configs[4] / SURVEY 8(d) "Config 5": variable-width crops w = clip(round(exp(N(5.3,0.6))),10,800), batches formed per
+    width bucket {256,512,768,1024} by the width-bucketed distributed sampler (every rank runs the same T in a step), images padded
+    with 0.0 beyond each crop's width, L = clip(round(w/16), 1, w//8).  Batches are built on the device (synthetic pixels)."""
+    import numpy as np
+
+    from ocrs_models_amd.sampler import WidthBucketedDistributedSampler, config5_population
+    from ocrs_models_amd.text import ctc_input_and_target_compatible, round_up
+
+    w, L = config5_population(B * world * (nsteps + 8) * 2, seed)
+    sampler = WidthBucketedDistributedSampler(w, B, rank, world, seed=seed)
+    out = []
+    g = torch.Generator(device=dev).manual_seed(seed * 100 + rank)
+    r = np.random.RandomState(seed * 100 + rank)
+    for bucket, idx in sampler.schedule()[:nsteps]:
+        widths = torch.tensor([int(w[i]) for i in idx])
+        img = torch.rand(len(idx), 1, 64, bucket, generator=g, device=dev) - 0.5
+        img = img * (torch.arange(bucket, device=dev)[None, None, None, :] < widths.to(dev)[:, None, None, None])
+        lmax = round_up(int(max(L[i] for i in idx)), 64)
+        text = torch.zeros(len(idx), lmax, dtype=torch.int32)
+        for j, i in enumerate(idx):
+            while True:
+                y = r.randint(1, 97, size=int(L[i]))
+                if ctc_input_and_target_compatible(int(w[i]) // 4, y.tolist()):
+                    break
+            text[j, : len(y)] = torch.from_numpy(y.astype(np.int32))
+        out.append({"image": img, "text_seq": text.to(dev), "text_len": torch.tensor([int(L[i]) for i in idx]), "image_width": widths})
+    return out
+
+
 def bench_crnn(args, world, rank, dev, dist, distributed=False):
     """CRNN recognition train step (bf16-autocast conv backbone, fp32 BiGRU, CTC, clip 4.0, Adam): line-crops/s."""
     import ocrs_models_amd as oa
     from ocrs_models_amd import train_rec
+    from ocrs_models_amd._lib import ARG_NAMES, lib
     from ocrs_models_amd.ddp import DistributedDataParallel
 
     B, W = args.rec_batch, args.rec_width
@@ -163,47 +284,106 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
     model.train()
     net = DistributedDataParallel(model) if distributed else model
     opt = train_rec.make_optimizer(model)
-    batch = synth_rec_batch(B, W, 2000 + rank, dev)
     loss_fn = oa.CTCLoss()
-    il = batch["image_width"].div(4, rounding_mode="floor").tolist()
-
-    def step():
-        loss, gn = train_rec.train_step(net, opt, batch, dev, None, loss_fn, check_nan=False)
-        oa.text.greedy_decode_batch(net_last_pred[0], il) if net_last_pred[0] is not None else None
-        return loss
-
     # keep the stats work of train_rec.py:123 (arg-max + CTC collapse + D2H of the collapsed labels) inside the step
-    net_last_pred = [None]
+    last_pred = [None]
     orig_forward = model.forward
 
     def fwd_hook(x):
         out = orig_forward(x)
-        net_last_pred[0] = out.detach()
+        last_pred[0] = out.detach()
         return out
 
     model.forward = fwd_hook
-    for _ in range(max(2, args.warmup)):
-        loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return {"metric": "CRNN train-step line-crops/sec", "value": round(B * world * args.steps / dt, 1), "unit": "crops/s",
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16 conv (autocast) / fp32 GRU+Linear+CTC",
-            "config": {"workload": f"CRNN train step (fwd+CTC+bwd+clip+Adam, greedy decode for stats), {B}x1x64x{W} crops per GPU, T={W // 4 + 1}",
-                       "global_batch": B * world, "final_loss": round(float(loss.item()), 4)}}
+
+    def step(batch):
+        loss, gn = train_rec.train_step(net, opt, batch, dev, None, loss_fn, check_nan=False)
+        oa.text.greedy_decode_batch(last_pred[0], batch["image_width"].div(4, rounding_mode="floor").tolist())
+        return loss
+
+    def timed(batches, warm, steps):
+        for i in range(warm):
+            loss = step(batches[i % len(batches)])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for i in range(steps):
+            b = batches[i % len(batches)]
+            loss = step(b)
+            n += b["image"].shape[0]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt, float(n)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+            dt, n = float(t[0].item()), float(t[1].item())
+        return dt, n, loss
+
+    batch = synth_rec_batch(B, W, 2000 + rank, dev)
+    x3 = os.environ.get("OCRS_GRU_X3", "1") != "0"
+    dt, n, loss = timed([batch], max(2, args.warmup), args.steps)
+    out = {"metric": "CRNN train-step line-crops/sec", "value": round(n / dt, 1), "unit": "crops/s",
+           "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16 conv (autocast) / fp32-class GRU+Linear+CTC",
+           "gru_projection_gemms": "split-bf16 x3 (fp32-class, OCRS_GRU_X3=1)" if x3 else "exact fp32 MFMA (OCRS_GRU_X3=0)",
+           "config": {"workload": f"CRNN train step (fwd+CTC+bwd+clip+Adam, greedy decode for stats), {B}x1x64x{W} crops per GPU, T={W // 4 + 1}",
+                      "global_batch": B * world, "final_loss": round(float(loss.item()), 4)}}
+    if rank == 0 and not args.no_roofline:
+        # one extra step with every conv / GRU launch bracketed by HIP events on the launch stream
+        L = lib()
+        fams = ["conv_igemm", "conv3x3_wgrad", "gru_layer_fwd", "gru_layer_bwd"]
+        L.timing = {k: [] for k in fams}
+        step(batch)
+        torch.cuda.synchronize()
+        tm, L.timing = L.timing, None
+        conv_ms = conv_fl = 0.0
+        for e0, e1, a in tm["conv_igemm"]:
+            v = dict(zip(ARG_NAMES["ocrs_conv_igemm"], a))
+            if v["dtype"] == 1 and v["KH"] * v["KW"] > 1:  # the bf16 conv layers (forward and dgrad); the fp32 GEMM uses are not MFMA-bf16 work
+                conv_ms += e0.elapsed_time(e1)
+                conv_fl += 2.0 * v["N"] * v["Ho"] * v["Wo"] * v["M"] * v["Cin"] * v["KH"] * v["KW"]
+        wg_ms = wg_fl = 0.0
+        for e0, e1, a in tm["conv3x3_wgrad"]:
+            v = dict(zip(ARG_NAMES["ocrs_conv3x3_wgrad"], a))
+            wg_ms += e0.elapsed_time(e1)
+            wg_fl += 2.0 * v["N"] * v["H"] * v["W"] * v["Cout"] * v["Cin"] * 9
+        T = W // 4 + 1
+        gf = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_fwd"])
+        gb = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_bwd"])
+        tf = (conv_fl + wg_fl) / ((conv_ms + wg_ms) * 1e-3) / 1e12 if conv_ms + wg_ms > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "k_conv_igemm (fwd+dgrad) + k_conv3x3_wgrad_tr", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+            "conv_fwd_dgrad": {"ms": round(conv_ms, 3), "gflop": round(conv_fl / 1e9, 1), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else None},
+            "conv_wgrad": {"ms": round(wg_ms, 3), "gflop": round(wg_fl / 1e9, 1), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms else None},
+            "gru": {"bound": "latency", "steps_per_train_step": 4 * T, "fwd_us_per_step": round(gf * 1e3 / (2 * T), 2),
+                    "bwd_us_per_step": round(gb * 1e3 / (2 * T), 2), "floor_us_per_step": KERNEL_BOUNDARY_US,
+                    "ms": round(gf + gb, 3), "floor_ms": round(4 * T * KERNEL_BOUNDARY_US * 1e-3, 3)},
+        }
+    if not args.no_gru_exact:
+        os.environ["OCRS_GRU_X3"] = "0" if x3 else "1"
+        dt2, n2, _ = timed([batch], 2, max(3, args.steps // 2))
+        os.environ["OCRS_GRU_X3"] = "1" if x3 else "0"
+        out["other_gru_mode"] = {"gru_projection_gemms": "exact fp32 MFMA (OCRS_GRU_X3=0)" if x3 else "split-bf16 x3", "value": round(n2 / dt2, 1),
+                                 "ms_per_step": round(dt2 / max(3, args.steps // 2) * 1e3, 3)}
+    if args.rec_config5 or world > 1:
+        nb = max(8, args.steps)
+        batches = config5_batches(B, rank, world, nb, dev)
+        dt5, n5, _ = timed(batches, min(4, len(batches)), len(batches))
+        widths = [b["image"].shape[-1] for b in batches]
+        out["config5"] = {"metric": "CRNN train-step line-crops/sec, width-bucketed variable-width crops", "value": round(n5 / dt5, 1),
+                          "unit": "crops/s", "ms_per_step": round(dt5 / len(batches) * 1e3, 3), "steps": len(batches),
+                          "bucket_widths": {str(k): widths.count(k) for k in sorted(set(widths))}, "crops_per_gpu_per_step": B, "n_gpus": world,
+                          "ctc_alpha_beta": "fp32 in LDS"}
+    model.forward = orig_forward
+    return out
 
 
+# ------------------------------------------------------------------------------------------------ detection
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,8 +395,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-crnn", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing")
+    ap.add_argument("--no-gru-exact", action="store_true", help="skip the second CRNN timing with the other GRU GEMM mode")
     ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
     ap.add_argument("--rec-width", type=int, default=400)
+    ap.add_argument("--rec-config5", action="store_true", help="also time the width-bucketed variable-width CRNN workload (default at N > 1)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -238,88 +421,121 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    act = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    torch.manual_seed(1234)
-    model = oa.DetectionModel(act_dtype=act).to(dev)
-    model.train()
-    net = DistributedDataParallel(model) if distributed else model
-    opt = oa.optim.Adam(model.parameters())
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)
     B, S = args.batch, args.size
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
     img = torch.rand(B, 1, S, S, generator=g, device=dev) - 0.5
     mask = (torch.rand(B, 1, S, S, generator=g, device=dev) > 0.9).float()
-
-    def step():
-        pred = net(img)
-        loss = oa.balanced_cross_entropy_loss(pred, mask)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
-
     L = lib()
-    for i in range(args.warmup):
-        # the last warm-up step times EVERY big kernel family to find the dominant one; the timed region then brackets only
-        # that family's launches with HIP events (bracketing all ~150 launches/step costs ~10 ms/step of pipeline bubbles)
-        if not args.no_roofline and i == args.warmup - 1:
-            L.timing = {k: [] for k in FAMILIES}
-        loss = step()
-    dominant = None
-    if L.timing is not None:
+
+    def run_det(dtype_name, warmup, steps, roofline):
+        act = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+        torch.manual_seed(1234)
+        model = oa.DetectionModel(act_dtype=act).to(dev)
+        model.train()
+        net = DistributedDataParallel(model) if distributed else model
+        opt = oa.optim.Adam(model.parameters())
+
+        def step():
+            pred = net(img)
+            loss = oa.balanced_cross_entropy_loss(pred, mask)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
+        warm = None
+        for i in range(warmup):
+            # the last warm-up step brackets EVERY launch of the big families with events (per-pass breakdown); the timed region then
+            # brackets only the dominant pass (bracketing every launch costs pipeline bubbles that would show up in `value`)
+            if roofline and i == warmup - 1:
+                L.timing = {k: [] for k in FAMILIES}
+            loss = step()
+        if L.timing is not None:
+            torch.cuda.synchronize()
+            warm, L.timing = L.timing, None
+            ptime = {p: sum(e0.elapsed_time(e1) for f in fams for e0, e1, _ in warm.get(f, [])) for p, fams in PASSES.items()}
+            dom = max(ptime, key=ptime.get)
+            L.timing = {f: [] for f in PASSES[dom]}
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        tot = {k: sum(e0.elapsed_time(e1) for e0, e1, _ in v) for k, v in L.timing.items() if v}
-        warm_fam_ms = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-        dominant = max(tot, key=tot.get) if tot else None
-        L.timing = {dominant: []} if dominant else None
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    timing, L.timing = L.timing, None
-    final_loss = float(loss.item())
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        timing, L.timing = L.timing, None
+        final_loss = float(loss.item())
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        del model, net, opt
+        torch.cuda.empty_cache()
+        return dt, final_loss, warm, timing
+
+    dt, final_loss, warm, timing = run_det(args.dtype, args.warmup, args.steps, not args.no_roofline)
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
-
+    sz = 2 if args.dtype == "bf16" else 4
     out = {
         "metric": "detection train-step images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic", "h2d_in_step": False,
         "config": {"workload": f"detection U-Net train step (fwd+balanced BCE+bwd+Adam), {B}x1x{S}x{S} greyscale tiles per GPU",
                    "global_batch": B * world, "tile": S, "parallelism": f"dp{world}", "final_loss": round(final_loss, 5)},
     }
     if rank == 0 and timing is not None:
-        sz = 2 if args.dtype == "bf16" else 4
-        fam = {}
-        for k, recs in timing.items():
-            if not recs:
-                continue
-            tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-            tot_b = sum(alg_bytes(k, a, sz) for _, _, a in recs)
-            fam[k] = (tot_ms, tot_b, len(recs))
-        if fam:
-            dom = max(fam, key=lambda k: fam[k][0])
-            tot_ms, tot_b, n = fam[dom]
-            ach = tot_b / (tot_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": n,
-                               "avg_launch_ms": round(tot_ms / n, 4), "alg_bytes_per_launch": round(tot_b / n)}
-            out["kernel_families_ms_warmup_step"] = warm_fam_ms
-            out["roofline"].update(pmc_traffic(dom))
-    del model, net, opt, img, mask, loss
+        def pass_stats(recs_by_family, pname, nsteps):
+            ms_tot = b_tot = 0.0
+            nlaunch = nblocks = 0
+            for f in PASSES[pname]:
+                for e0, e1, a in recs_by_family.get(f, []):
+                    ms_tot += e0.elapsed_time(e1)
+                    by = alg_bytes(f, a, sz)
+                    b_tot += by
+                    nlaunch += 1
+                    nblocks += 1 if by > 0 else 0
+            if ms_tot <= 0:
+                return None
+            ach = b_tot / (ms_tot * 1e-3) / 1e9
+            return {"ms_per_step": round(ms_tot / nsteps, 3), "alg_GB_per_step": round(b_tot / nsteps / 1e9, 3), "achieved_GBps": round(ach, 1),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_step": nlaunch // nsteps, "units_per_step": nblocks // nsteps}
+
+        rows, src = pmc_profile()
+        dom = next(p for p, fams in PASSES.items() if set(fams) == set(timing))
+        st = pass_stats(timing, dom, args.steps)
+        if st:
+            tr = pass_traffic(rows, dom)
+            n_units = max(1, st["units_per_step"])
+            out["roofline"] = {
+                "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_blk*_bwd, or k_pw_bwd*+k_dw_bwd[+k_bn_bwd_reduce])",
+                           "block_fwd": "DepthwiseConv block forward (k_dwpw_fwd)"}.get(dom, dom),
+                "bound": "hbm", "achieved": st["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["frac"],
+                "traffic": round(tr / n_units) if tr else None, "traffic_source": src,
+                "byte_model": "SURVEY 8(d): per block backward 2*(Cin+Cout) elements/pixel (x, z, g read once; dL/dx written once)",
+                "passes_per_step": n_units, "launches_per_step": st["launches_per_step"], "avg_pass_ms": round(st["ms_per_step"] / n_units, 4),
+                "alg_bytes_per_pass": round(st["alg_GB_per_step"] * 1e9 / n_units), "ms_per_step": st["ms_per_step"],
+            }
+            alg_step = 3 * sz * det_alg_elems_per_image(S, S) * B
+            out["roofline"]["whole_step_alg_GB"] = round(alg_step / 1e9, 2)
+            out["roofline"]["whole_step_frac"] = round(alg_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if rows:
+                tot = sum(b for b, _ in rows.values())
+                out["roofline"]["whole_step_traffic_GB"] = round(tot / 1e9, 2)
+                out["roofline"]["traffic_ratio"] = round(tot / (3 * 2 * det_alg_elems_per_image(1024, 1024) * 32), 3)  # the PMC passes ran the default config
+            out["roofline"]["passes"] = {p: pass_stats(warm, p, 1) for p in PASSES if pass_stats(warm, p, 1)}
+    if rank == 0 and world == 1 and not args.no_fp32 and args.dtype == "bf16":
+        k = max(3, args.steps // 3)
+        dt32, _, _, _ = run_det("fp32", 2, k, False)
+        out["fp32_exact"] = {"value": round(B * k / dt32, 2), "unit": "images/s", "ms_per_step": round(dt32 / k * 1e3, 3), "steps": k,
+                             "note": "parity mode: fp32 storage, exact-fp32 MFMA"}
+    del img, mask
     torch.cuda.empty_cache()
     if not args.no_crnn:
-        crnn = bench_crnn(args, world, rank, dev, dist, distributed)
-        out["crnn"] = crnn
+        out["crnn"] = bench_crnn(args, world, rank, dev, dist, distributed)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -185,3 +185,37 @@ def test_line_output_width_rule():
 
     assert oip.line_output_width(64, 400) == 400 and oip.line_output_width(32, 3) == 10 and oip.line_output_width(10, 1000) == 800
     assert oip.line_output_width(37, 211) == int(64 * (211 / 37))
+
+
+def test_aten_step_forms_agree_with_explicit_oracle():
+    """oracle/aten_step.py (aten::gru + aten::_ctc_loss: what bench.py's cpu_baseline times) == oracle/recognition.py + oracle/ctc.py
+    (explicit recurrence / lattice: what the parity tests use), forward and one full train step."""
+    import numpy as np
+    import torch
+
+    from oracle import aten_step as A
+    from oracle import ctc as octc
+    from oracle import optim as ooptim
+    from oracle import recognition as orec
+    from oracle.params import make_state, recognition_specs
+
+    r = np.random.RandomState(0)
+    x = torch.from_numpy(r.uniform(-0.5, 0.5, (4, 1, 64, 128)).astype(np.float32))
+    tg = torch.from_numpy(r.randint(1, 97, size=(4, 64)).astype(np.int32))
+    il, tl = torch.full((4,), 32), torch.tensor([5, 9, 3, 12])
+    P1, B1 = make_state(recognition_specs(), 3)
+    P2, B2 = make_state(recognition_specs(), 3)
+    lp1 = A.rec_forward_aten(P1, B1, x, True)
+    lp2 = orec.forward(P2, B2, x, True)
+    assert float((lp1 - lp2).abs().max()) < 1e-5
+    l1 = torch.nn.functional.ctc_loss(lp1, tg, il, tl)
+    l2 = octc.ctc_loss_torch(lp2, tg, il.tolist(), tl.tolist())
+    assert abs(float(l1) - float(l2)) < 1e-5 * abs(float(l2))
+    g1 = torch.autograd.grad(l1, list(P1.values()))
+    g2 = torch.autograd.grad(l2, list(P2.values()))
+    for k, a, b in zip(P1, g1, g2):
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-4, k
+    P3, B3 = make_state(recognition_specs(), 3)
+    loss = A.rec_train_step(P3, B3, ooptim.Adam(P3.values()), x, tg, il, tl, False)
+    assert abs(loss - float(l2)) < 1e-5 * abs(float(l2))
+    assert all(float((P3[k] - P2[k]).abs().max()) > 0 for k in ("conv.0.weight", "gru.weight_hh_l1", "output.0.bias"))  # it stepped
