@@ -68,7 +68,7 @@ def det_alg_elems_per_image(H: int, W: int) -> int:
 ALG_BYTES_ARGS = {
     "dwpw_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
-    "blk_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "mm_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
     "bn_bwd_reduce": ("N", "H", "W", "C"),
     "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
@@ -77,17 +77,17 @@ ALG_BYTES_ARGS = {
 }
 FAMILIES = list(ALG_BYTES_ARGS)
 # pass -> the C-ABI families whose launches belong to it.  The BYTES of a block backward are booked once per block, on the launch that
-# every block backward has exactly once (pw_bwd, or blk_bwd when the fused kernel runs); dw_bwd / bn_bwd_reduce launches of the same
+# every block backward has exactly once (mm_bwd on the matrix-core path, else pw_bwd); dw_bwd / bn_bwd_reduce launches of the same
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
 PASSES = {
-    "block_bwd": ("pw_bwd", "blk_bwd", "dw_bwd", "bn_bwd_reduce"),
+    "block_bwd": ("mm_bwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce"),
     "block_fwd": ("dwpw_fwd",),
     "convt_fwd": ("convt_fwd",),
     "convt_bwd": ("convt_bwd",),
     "maxpool_fwd": ("maxpool_fwd",),
 }
 PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
-    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_blk_bwd<", "k_blk2_bwd<"),
+    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<"),
     "block_fwd": ("k_dwpw_fwd<",),
     "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
     "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<"),
@@ -102,7 +102,7 @@ def alg_bytes(name, a, sz):
     v = dict(zip(ARG_NAMES["ocrs_" + name], a))
     if name == "dwpw_fwd":  # x (Ca+Cb) in, z (Cout) out
         return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
-    if name in ("pw_bwd", "blk_bwd"):  # the whole block backward: x, z, g in; dL/dx out
+    if name in ("pw_bwd", "mm_bwd"):  # the whole block backward: x, z, g in; dL/dx out
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
     if name in ("dw_bwd", "bn_bwd_reduce"):
         return 0.0
@@ -511,7 +511,7 @@ def main():
             tr = pass_traffic(rows, dom)
             n_units = max(1, st["units_per_step"])
             out["roofline"] = {
-                "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_blk*_bwd, or k_pw_bwd*+k_dw_bwd[+k_bn_bwd_reduce])",
+                "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_mm_bwd at levels 0-2, k_pw_bwd*+k_dw_bwd[+k_bn_bwd_reduce] below)",
                            "block_fwd": "DepthwiseConv block forward (k_dwpw_fwd)"}.get(dom, dom),
                 "bound": "hbm", "achieved": st["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["frac"],
                 "traffic": round(tr / n_units) if tr else None, "traffic_source": src,

@@ -82,14 +82,18 @@ long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W);
 int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* du,
                 void* gxa, void* gxb, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
                 int N, int H, int W, int dtype, hipStream_t st);
-/* Fused ocrs_pw_bwd + ocrs_dw_bwd of one block (bf16, no max-pool routing, Cin and Cout in {8, 16}): the pointwise input gradient du
- * stays in LDS.  Arguments as in the two separate calls; ws = ocrs_blk_bwd_ws_floats() floats. */
-long ocrs_blk_bwd_supported(int Cin, int Cout, int pooled, int dtype); /* 1 / 0 */
-long ocrs_blk_bwd_ws_floats(int Cin, int Cout, int N, int H, int W);
-int ocrs_blk_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1,
-                 const void* g2, const void* z, const float* bn, const float* coef, const void* wpk_d, void* gxa, void* gxb, float* dwpw,
-                 float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H,
-                 int W, int dtype, hipStream_t st);
+/* The same block backward on the matrix cores (csrc/det_mm.hip; bf16, Cin and Cout in {8, 16, 32}, a 32 | 32 concat as two launches):
+ * depthwise and pointwise conv composed into one 3x3 implicit GEMM with the effective weight Wpw[o][c] * Wdw[c][tap]; replaces
+ * ocrs_pw_bwd + ocrs_dw_bwd (autograd of models.py:12-22 through BatchNorm2d + ReLU [+ MaxPool2d(2) when pooled], models.py:23-24, 54) -- the
+ * pointwise input gradient du is never formed.  wdw [Cin][9] / wpw [Cout][Cin]: fp32 master weights; g1 (+ g2) at half resolution when
+ * pooled = 1; dwpw / dwdw are ACCUMULATED by a single writer per element (deterministic, no atomics); ws = ocrs_mm_bwd_ws_floats() floats;
+ * saved_a / gsum_a, saved_b / gsum_b: as ocrs_dw_bwd (nullable). */
+long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype); /* 1 / 0 */
+long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W);
+int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw,
+                const void* g1, const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw,
+                float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H,
+                int W, int dtype, hipStream_t st);
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
                      const float* bn, const float* coef, float* dwpw, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of ConvTranspose2d + crop. */

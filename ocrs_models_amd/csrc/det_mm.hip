@@ -1,0 +1,681 @@
+// "Everything on the matrix cores" forms of the DepthwiseConv block (reference ocrs_models/models.py:7-28) for the top U-Net levels
+// (gfx950, bf16 storage, Cin, Cout in {8, 16, 32}): the depthwise 3x3 and the pointwise 1x1 are composed into ONE 3x3 implicit GEMM
+// with the effective weight  Weff[o][(tap, c)] = Wpw[o][c] * Wdw[c][tap]  (rank-one per channel, built per launch from the fp32
+// masters), so the 9-tap VALU loops, the depthwise-output tile and -- in the backward -- the du tensor of the separate kernels
+// (k_dwpw_fwd; k_pw_bwd2 + k_dw_bwd) disappear.  The detection net is HBM-bound with the MFMA pipe ~4 % busy: spending
+// 9x the pointwise FLOPs there is free, the VALU / LDS-issue time it removes was what kept those kernels at 3-3.5 TB/s.
+//
+// Backward of one block, per 16x32 (or 8x32) pixel tile, everything from ONE staged copy of (g, z) on the tile + 1-pixel ring and of x
+// on the tile:
+//     dz   = A * ghat + B * z + C                                  BatchNorm/ReLU backward (ghat optionally routed through MaxPool2d(2))
+//     dx~[c][q]   = sum_{tap,o} Weff[o][(tap,c)] dz[q - off(tap)][o]          MFMA, K = 9 * Cout      (dgrad of both convs at once)
+//     G_tap[c][o] = sum_q x~[q][c] dz[q - off(tap)][o]                        MFMA, K = pixels (LDS transpose reads)
+//     dWpw[o][c]  = sum_tap Wdw[c][tap] G_tap[c][o],   dWdw[c][tap] = sum_o Wpw[o][c] G_tap[c][o]      (once per block, from G)
+//     [+ the BatchNorm-backward sums of the block(s) that produced x:  sum ghat', sum ghat' x~  with ghat' = dx~ [x~ > 0]]
+// HBM bytes per pixel: x (Cin) + z, g (Cout, 1.1-1.3x with the ring, mostly L2 hits) in, dx~ (Cin) out -- the 2 (Cin + Cout) of
+// SURVEY.md 8(d); du is never formed.  All flushes are per-block partials reduced by ONE deterministic kernel (no atomics).
+#include "det_common.h"
+
+namespace {
+
+template <int C>
+struct MmPitch {  // bf16 elements per pixel of an LDS tile: 16 / 32-byte rows are conflict-free as they are, 64-byte rows need the 16-byte pad
+    static constexpr int V = (C == 32) ? 40 : C;
+};
+
+template <int CIN, int COUT>
+struct MmCfg {
+    static constexpr int NT = 512, NW = NT / 64;                       // 8 waves
+#ifndef OCRS_MM_TH
+#define OCRS_MM_TH 8  // tile rows for the configurations without a 32-channel side (those always use 8): 16 halves the ring re-reads, needs ~12 more VGPRs
+#endif
+    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? 8 : OCRS_MM_TH, TP = TW * TH;
+    static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
+    static constexpr int CGI = CIN / 8, CGO = COUT / 8;
+    static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
+    static constexpr int MT = (CIN + 15) / 16, NTO = (COUT + 15) / 16;
+    static constexpr int KC = (9 * COUT + 31) / 32;                    // K chunks of the dgrad GEMM
+    static constexpr int NPW = TP / 16 / NW;                           // dgrad N tiles (16 pixels) per wave
+    static constexpr int KS = TP / 32;                                 // 32-pixel k-steps of the weight-gradient GEMM (one tile row each)
+    static constexpr int TAPU = (COUT == 8) ? 5 : 9;                   // B-operand units: a tap, or a PAIR of taps when Cout = 8 (16 columns)
+    static constexpr int NGI = (DP * CGO + NT - 1) / NT;               // (z, g) items per thread
+    static constexpr int NXI = (TP * CGI + NT - 1) / NT;               // x items per thread
+    static constexpr int NWIN = (DH_ / 2) * (DW_ / 2);                 // 2x2 windows of the (window-aligned) domain
+    static constexpr int NWI = (NWIN * CGO + NT - 1) / NT;
+    // LDS (bytes)
+    static constexpr int OFF_D = 0;
+    static constexpr int OFF_X = (OFF_D + DP * PD * 2 + 63) & ~63;
+    static constexpr int OFF_WF = (OFF_X + TP * PX * 2 + 64 + 63) & ~63;  // +64: the Cin = 8 transpose reads run 16 bytes past the last pixel
+    static constexpr int OFF_PAR = OFF_WF + MT * KC * 64 * 16;
+    static constexpr int PAR_FLOATS = 3 * CIN + 6 * COUT + 9 * CIN + COUT * CIN + 4 * CIN;  // trx | bn | coef | wdw [c][9] | wpw [o][c] | stats params
+    static constexpr int TILE_BYTES = OFF_PAR + PAR_FLOATS * 4;
+    static constexpr int SLOT_FLOATS = NW * 2 * MT * NTO * 256 + NW * 2 * MT * 16;  // flush: G slots (own | shared unit) + stats slots
+    static constexpr int SMEM = TILE_BYTES > SLOT_FLOATS * 4 ? TILE_BYTES : SLOT_FLOATS * 4;
+    static constexpr int PART = COUT * CIN + 9 * CIN + 2 * CIN;        // floats per block partial: dWpw [COUT][CIN] | dWdw [CIN][9] | sums [2][CIN]
+};
+
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// half hf (channels 4*hf .. 4*hf+3) of a raw 8-channel bf16 vector
+__device__ __forceinline__ void half4(const Raw8<bf16>& r, int hf, float (&v)[4]) {
+    const unsigned a = hf ? r.a.z : r.a.x, b = hf ? r.a.w : r.a.y;
+    v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
+    v[2] = __uint_as_float(b << 16); v[3] = __uint_as_float(b & 0xffff0000u);
+}
+// 4 bf16 to LDS with the packing hidden from the optimiser (see store8_opaque)
+__device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
+    unsigned lo, hi;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+    *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------------------------------
+// backward
+// ----------------------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
+__global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+                                                   const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
+                                                   const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
+                                                   const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
+                                                   const float* __restrict__ bn, const float* __restrict__ coef, bf16* __restrict__ gxa,
+                                                   bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg) {
+    using C = MmCfg<CIN, COUT>;
+    constexpr int NT = C::NT, TW = C::TW, TH = C::TH, TP = C::TP, DW_ = C::DW_, DP = C::DP, CGI = C::CGI, CGO = C::CGO, PD = C::PD, PX = C::PX;
+    constexpr int MT = C::MT, NTO = C::NTO, KC = C::KC, NPW = C::NPW, KS = C::KS;
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    bf16* tileD = reinterpret_cast<bf16*>(smem + C::OFF_D);   // [DP][PD]  dz on the domain (0 outside the image)
+    bf16* tileX = reinterpret_cast<bf16*>(smem + C::OFF_X);   // [TP][PX]  x~ on the tile (0 outside the image)
+    uint4* s_wf = reinterpret_cast<uint4*>(smem + C::OFF_WF); // [MT][KC][64] effective-weight A fragments
+    float* s_trx = reinterpret_cast<float*>(smem + C::OFF_PAR);  // [CIN/8][3][8]
+    float* s_bn = s_trx + 3 * CIN;                              // [3][COUT]
+    float* s_cf = s_bn + 3 * COUT;                              // [3][COUT]
+    float* s_w9 = s_cf + 3 * COUT;                              // [CIN][9]
+    float* s_wp = s_w9 + 9 * CIN;                               // [COUT][CIN]
+    const int H = tg.H, W = tg.W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- prologue: parameters, effective-weight fragments
+    fill_tr8(s_trx, x, tra, trb, CIN, tid);
+    for (int i = tid; i < 3 * COUT; i += NT) {
+        s_bn[i] = bn[i];
+        s_cf[i] = coef[i];
+    }
+    for (int i = tid; i < 9 * CIN; i += NT) s_w9[i] = wdw[i];
+    for (int i = tid; i < COUT * CIN; i += NT) s_wp[i] = wpw[(i / CIN) * ldw + (i % CIN)];
+    {   // zero both tiles once (pad columns / the slack behind tileX stay zero)
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < C::OFF_WF / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = z4;
+    }
+    __syncthreads();
+    for (int f = tid; f < MT * KC * 64; f += NT) {
+        const int l = f & 63, kc = (f >> 6) % KC, mt = (f >> 6) / KC;
+        const int m = mt * 16 + (l & 15);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc * 32 + (l >> 4) * 8 + j, tap = k / COUT, o = k % COUT;
+            v[j] = (m < CIN && tap < 9) ? s_w9[m * 9 + tap] * s_wp[o * CIN + m] : 0.f;
+        }
+        s_wf[f] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+    __syncthreads();
+
+    // ---- tile-invariant item descriptors
+    // (z, g) items.  Direct gradient: one (domain pixel, 8-channel group) each.  Pooled gradient: one (2x2 window, group) each -- the domain
+    // of a pooled launch is window-aligned (tile origins sit at odd coordinates: org = tile * T - 1), so routing needs no neighbours.
+    const int cgo = tid % CGO;
+    int gi_dyx[PPOOL ? C::NWI : C::NGI];  // dy | dx << 16 (domain coordinates; window top-left when pooled)
+    if constexpr (!PPOOL) {
+#pragma unroll
+        for (int j = 0; j < C::NGI; ++j) {
+            const int d = (tid + j * NT) / CGO, dy = d / DW_, dx = d - dy * DW_;
+            gi_dyx[j] = dy | (dx << 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < C::NWI; ++j) {
+            const int wd = (tid + j * NT) / CGO, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
+            gi_dyx[j] = (2 * wy) | ((2 * wx) << 16);
+        }
+    }
+    // x items: (tile pixel, 8-channel group)
+    const int cgi = tid % CGI;
+    const bool xi_a = cgi * 8 < x.Ca;
+    const bf16* xi_base = xi_a ? x.a + cgi * 8 : x.b + (cgi * 8 - x.Ca);
+    const int xi_pitch = xi_a ? x.Ca : x.Cb;
+    constexpr int ORG = PPOOL ? -1 : 0;  // tile origin shift
+
+    // ---- software pipeline state: raw vectors of the NEXT tile
+    constexpr int NZ = PPOOL ? 4 * C::NWI : C::NGI, NG = PPOOL ? C::NWI : C::NGI;
+    Raw8<bf16> zr[NZ], g1r[NG], g2r[G2 ? NG : 1], xr[C::NXI];
+    unsigned okg = 0, okx = 0;  // validity bits
+    auto issue = [&](const TileOrg& o) {
+        const int h00 = o.h0 + ORG - 1, w00 = o.w0 + ORG - 1;  // image coordinates of the domain's corner pixel (may lie outside)
+        const long corner = ((long)o.n * H + h00) * W + w00;
+        const bf16* zb = z + corner * COUT;
+        okg = okx = 0;
+        if constexpr (!PPOOL) {
+            const bf16* g1b = g1 + corner * COUT;
+            const bf16* g2b = (G2 ? g2 : g1) + corner * COUT;
+#pragma unroll
+            for (int j = 0; j < C::NGI; ++j) {
+                const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;
+                const bool ok = (DP * CGO % NT == 0 || tid + j * NT < DP * CGO) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+                const int goff = (dy * W + dx) * COUT + cgo * 8;
+                zr[j] = load8_raw(ok ? zb + goff : z);
+                g1r[j] = load8_raw(ok ? g1b + goff : g1);
+                if constexpr (G2) g2r[j] = load8_raw(ok ? g2b + goff : g2);
+                okg |= ok ? 1u << j : 0u;
+            }
+        } else {
+            const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+            for (int j = 0; j < C::NWI; ++j) {
+                const bool it_ok = C::NWIN * CGO % NT == 0 || tid + j * NT < C::NWIN * CGO;
+                const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;  // top-left pixel of the window (even coordinates)
+                const int goff = (dy * W + dx) * COUT + cgo * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = it_ok && (unsigned)(h + (k >> 1)) < (unsigned)H && (unsigned)(w + (k & 1)) < (unsigned)W;
+                    zr[4 * j + k] = load8_raw(ok ? zb + goff + ((k >> 1) * W + (k & 1)) * COUT : z);
+                    okg |= ok ? 1u << (4 * j + k) : 0u;
+                }
+                const int ph = h >> 1, pw = w >> 1;
+                const bool gv = it_ok && h >= 0 && w >= 0 && ph < Hp && pw < Wp;  // floor mode: the last odd row / column is in no window
+                const long pp = ((long)o.n * Hp + ph) * Wp + pw;
+                g1r[j] = load8_raw(gv ? g1 + pp * COUT + cgo * 8 : g1);
+                if constexpr (G2) g2r[j] = load8_raw(gv ? g2 + pp * COUT + cgo * 8 : g2);
+                okg |= gv ? 1u << (16 + j) : 0u;
+            }
+        }
+        const long tb = ((long)o.n * H + (o.h0 + ORG)) * W + (o.w0 + ORG);
+#pragma unroll
+        for (int j = 0; j < C::NXI; ++j) {
+            const int p = (tid + j * NT) / CGI, ty = p / TW, tx = p % TW;
+            const int h = o.h0 + ORG + ty, w = o.w0 + ORG + tx;
+            const bool ok = (TP * CGI % NT == 0 || tid + j * NT < TP * CGI) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            xr[j] = load8_raw(ok ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
+            okx |= ok ? 1u << j : 0u;
+        }
+    };
+
+    // ---- dgrad (dx~) MFMA bookkeeping: B-fragment offset of chunk kc for this lane.  k = kc*32 + (lane>>4)*8 .. +7 lies inside ONE tap;
+    // the tap is a compile-time function of kc and a 1- or 2-bit selector from the lane id (selects between literal offsets).
+    const int kg = lane >> 4;
+    auto tap_off = [](int tap) constexpr -> int { return tap < 9 ? ((2 - tap / 3) * DW_ + (2 - tap % 3)) * PD : 0; };
+    auto boff_of = [&](int kc, bool& valid) -> int {
+        if constexpr (COUT == 32) {
+            valid = true;
+            return tap_off(kc) + kg * 8;
+        } else if constexpr (COUT == 16) {
+            const int t0 = 2 * kc, t1 = 2 * kc + 1;
+            valid = (kg < 2) ? t0 < 9 : t1 < 9;
+            return ((kg < 2) ? tap_off(t0) : tap_off(t1)) + (kg & 1) * 8;
+        } else {
+            const int t0 = 4 * kc;
+            valid = t0 + kg < 9;
+            const int a = (kg & 1) ? tap_off(t0 + 1) : tap_off(t0), b = (kg & 1) ? tap_off(t0 + 3) : tap_off(t0 + 2);
+            return (kg & 2) ? b : a;
+        }
+    };
+    // ---- weight-gradient (G) bookkeeping.  Transpose-read lane geometry: pixel row prow (+16 for the second half), 4 channels at pcol.
+    const int prow = 4 * (lane >> 4) + ((lane & 15) >> 2), pcol = (lane & 3) * 4;
+    // unit -> per-lane B offset relative to pixel (ks, 0) of the tile, i.e. element offset of tileD[((ks + 2 - ky) * DW_ + prow + 2 - kx)][...]
+    auto unit_off = [&](int u) -> int {
+        if constexpr (COUT == 8) {
+            const int sel = (lane & 3) >> 1;
+            int tap = 2 * u + sel;
+            tap = tap > 8 ? 8 : tap;  // unit 4 = tap 8 twice (columns 8..15 are ignored at the flush)
+            const int ky = tap / 3, kx = tap - ky * 3;
+            return ((2 - ky) * DW_ + prow + 2 - kx) * PD + (lane & 1) * 4;
+        } else {
+            const int ky = u / 3, kx = u - ky * 3;
+            return ((2 - ky) * DW_ + prow + 2 - kx) * PD + pcol;
+        }
+    };
+    // own unit / k-step range of this wave, and its share of the last unit
+    constexpr int KSH = KS / C::NW;  // k-steps of the shared unit per wave (2 or 1)
+    const int u_own = (C::TAPU == 9) ? wave : (wave & 3);
+    const int ks_own0 = (C::TAPU == 9) ? 0 : (wave >> 2) * (KS / 2), ks_own1 = (C::TAPU == 9) ? KS : ks_own0 + KS / 2;
+    const int off_own = unit_off(u_own), off_sh = unit_off(C::TAPU - 1);
+    f32x4 accO[MT][NTO], accS[MT][NTO];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTO; ++b) accO[a][b] = accS[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float st1[STATS ? MT : 1][4], st2[STATS ? MT : 1][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st1[a][i] = st2[a][i] = 0.f;
+    }
+
+    TileSched ts(tg.ntiles);
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);
+    TileOrg org_next = tit.org();
+    if (ts.first < ts.end) issue(org_next);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = org_next;
+        // ================= phase 1: commit the prefetched tile: dz -> tileD, x~ -> tileX =================
+        // Four channels at a time (the five per-channel coefficient vectors of a half are 20 registers instead of 40; 8-byte LDS stores).
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int c4 = cgo * 8 + hf * 4;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bn + c4), bt = *reinterpret_cast<const f32x4*>(s_bn + COUT + c4);
+            const f32x4 ca = *reinterpret_cast<const f32x4*>(s_cf + c4), cb = *reinterpret_cast<const f32x4*>(s_cf + COUT + c4),
+                        cc = *reinterpret_cast<const f32x4*>(s_cf + 2 * COUT + c4);
+            if constexpr (!PPOOL) {
+#pragma unroll
+                for (int j = 0; j < C::NGI; ++j) {
+                    const int it = tid + j * NT;
+                    if (DP * CGO % NT == 0 || it < DP * CGO) {
+                        float dz[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (okg & (1u << j)) {
+                            float zv[4], ga[4];
+                            half4(zr[j], hf, zv);
+                            half4(g1r[j], hf, ga);
+                            if constexpr (G2) {
+                                float gb[4];
+                                half4(g2r[j], hf, gb);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) ga[i] += gb[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float gh = fmaf(zv[i], bs[i], bt[i]) > 0.f ? ga[i] : 0.f;
+                                dz[i] = fmaf(ca[i], gh, fmaf(cb[i], zv[i], cc[i]));
+                            }
+                        }
+                        st4bf(tileD + (it / CGO) * PD + c4, dz);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < C::NWI; ++j) {
+                    const int it = tid + j * NT;
+                    if (C::NWIN * CGO % NT == 0 || it < C::NWIN * CGO) {
+                        float zv[4][4], gs[4], m[4][4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) half4(zr[4 * j + k], hf, zv[k]);
+                        half4(g1r[j], hf, gs);
+                        if constexpr (G2) {
+                            float gb[4];
+                            half4(g2r[j], hf, gb);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) gs[i] += gb[i];
+                        }
+                        const bool gv = (okg >> (16 + j)) & 1u;
+                        // first maximum of the window in post-ReLU space, row-major order, must be > 0 (the pooled value passes the ReLU)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) m[k][i] = max_lo(fmaf(zv[k][i], bs[i], bt[i]), 0.f);
+                        const int wd = it / CGO, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float dz[4];
+                            const bool ok = (okg >> (4 * j + k)) & 1u;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                bool win = gv && m[k][i] > 0.f;
+#pragma unroll
+                                for (int k2 = 0; k2 < 4; ++k2)
+                                    if (k2 != k) win = win && (k2 < k ? m[k][i] > m[k2][i] : m[k][i] >= m[k2][i]);
+                                const float gh = win ? gs[i] : 0.f;
+                                dz[i] = ok ? fmaf(ca[i], gh, fmaf(cb[i], zv[k][i], cc[i])) : 0.f;
+                            }
+                            st4bf(tileD + ((2 * wy + (k >> 1)) * DW_ + 2 * wx + (k & 1)) * PD + c4, dz);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float* tp = s_trx + cgi * 24 + hf * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(tp), sh = *reinterpret_cast<const f32x4*>(tp + 8), lo = *reinterpret_cast<const f32x4*>(tp + 16);
+#pragma unroll
+            for (int j = 0; j < C::NXI; ++j) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (okx & (1u << j)) {
+                    half4(xr[j], hf, v);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                }
+                if (TP * CGI % NT == 0 || tid + j * NT < TP * CGI) st4bf(tileX + ((tid + j * NT) / CGI) * PX + cgi * 8 + hf * 4, v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + ts.step < ts.end) {
+            tit.next();
+            org_next = tit.org();
+            issue(org_next);
+        }
+        lds_barrier();
+        // ================= phase 2a: dx~ = Weff * dz (shifted), MFMA; epilogue: store + the producers' BatchNorm-backward sums =================
+        {
+            f32x4 acc[NPW][MT];
+            int pbase[NPW];
+#pragma unroll
+            for (int a = 0; a < NPW; ++a) {
+                const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
+                pbase[a] = (ty * DW_ + tx) * PD;
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            uint4 bcur[NPW], bnxt[NPW];
+            auto load_b = [&](uint4 (&dst)[NPW], int kc) {
+                bool bv;
+                const int bo = boff_of(kc, bv);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) {
+                    dst[a] = *reinterpret_cast<const uint4*>(tileD + pbase[a] + bo);
+                    if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
+                }
+            };
+            load_b(bcur, 0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                uint4 wf[MT];
+#pragma unroll
+                for (int b = 0; b < MT; ++b) wf[b] = s_wf[(b * KC + kc) * 64 + lane];
+                if (kc + 1 < KC) load_b(bnxt, kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a)
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] = mfma16(wf[b], bcur[a], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
+            }
+            const long tb = ((long)org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
+#pragma unroll
+            for (int a = 0; a < NPW; ++a) {
+                const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
+                const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx) < (unsigned)W;
+                const long pix = tb + (long)ty * W + tx;
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const int m0 = b * 16 + (lane >> 4) * 4;
+                    if (m0 < CIN) {
+                        const f32x4 v = acc[a][b];
+                        if (pv) {
+                            if (m0 < x.Ca)
+                                store4(gxa + pix * x.Ca + m0, v[0], v[1], v[2], v[3]);
+                            else
+                                store4(gxb + pix * x.Cb + (m0 - x.Ca), v[0], v[1], v[2], v[3]);
+                        }
+                        if constexpr (STATS) {
+                            float xq[4];
+                            load4(tileX + p * PX + m0, xq);  // 0 outside the image: contributes nothing
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                // the producer's backward reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask
+                                const float gh = xq[i] > 0.f ? Elem<bf16>::round(v[i]) : 0.f;
+                                st1[b][i] += gh;
+                                st2[b][i] = fmaf(gh, xq[i], st2[b][i]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ================= phase 2b: G_tap += x~^T dz(shifted), K = the tile's pixels, operands by LDS transpose reads =================
+        {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= wave * KSH && ks < (wave + 1) * KSH;
+                if (!own && !shr) continue;  // (wave-uniform)
+                bf16x8 af[MT];
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const bf16* xa = tileX + (ks * 32 + prow) * PX + a * 16 + pcol;
+                    af[a] = lds_tr8(xa, xa + 16 * PX);
+                }
+                const bf16* dks = tileD + ks * DW_ * PD;
+                if (own) {
+#pragma unroll
+                    for (int b = 0; b < NTO; ++b) {
+                        const bf16* da = dks + off_own + b * 16;
+                        const bf16x8 bfr = lds_tr8(da, da + 16 * PD);
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) accO[a][b] = mfma16(af[a], bfr, accO[a][b]);
+                    }
+                }
+                if (shr) {
+#pragma unroll
+                    for (int b = 0; b < NTO; ++b) {
+                        const bf16* da = dks + off_sh + b * 16;
+                        const bf16x8 bfr = lds_tr8(da, da + 16 * PD);
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) accS[a][b] = mfma16(af[a], bfr, accS[a][b]);
+                    }
+                }
+            }
+        }
+        lds_barrier();  // all readers of the tiles are done before the next commit
+    }
+
+    // ================= flush: G slots -> dWpw / dWdw partials of this block (workspace); stats partials =================
+    __syncthreads();
+    float* slots = reinterpret_cast<float*>(smem);  // [wave][own | shared][MT][NTO][4][64]
+    float* sstat = slots + C::NW * 2 * MT * NTO * 256;  // [wave][2][MT*16]
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTO; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                slots[(((wave * 2 + 0) * MT + a) * NTO + b) * 256 + r * 64 + lane] = accO[a][b][r];
+                slots[(((wave * 2 + 1) * MT + a) * NTO + b) * 256 + r * 64 + lane] = accS[a][b][r];
+            }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v1 = quad16_sum(st1[a][i]), v2 = quad16_sum(st2[a][i]);
+                if ((lane & 15) == 0) {
+                    sstat[(wave * 2 + 0) * MT * 16 + a * 16 + (lane >> 4) * 4 + i] = v1;
+                    sstat[(wave * 2 + 1) * MT * 16 + a * 16 + (lane >> 4) * 4 + i] = v2;
+                }
+            }
+    }
+    __syncthreads();
+    // G[tap][c][o] from the slots (fixed summation order -> deterministic)
+    auto Gval = [&](int tap, int c, int o) -> float {
+        const int a = c >> 4, r = c & 3, lrow = (c & 15) >> 2;
+        if constexpr (COUT == 8) {
+            const int u = tap >> 1, n = (tap < 8 ? (tap & 1) * 8 : 0) + o, ln = lrow * 16 + n;
+            if (tap < 8) return slots[((u * 2 + 0) * MT + a) * NTO * 256 + r * 64 + ln] + slots[(((u + 4) * 2 + 0) * MT + a) * NTO * 256 + r * 64 + ln];
+            float s = 0.f;
+            for (int w = 0; w < C::NW; ++w) s += slots[((w * 2 + 1) * MT + a) * NTO * 256 + r * 64 + ln];
+            return s;
+        } else {
+            const int b = o >> 4, ln = lrow * 16 + (o & 15);
+            if (tap < 8) return slots[(((tap * 2 + 0) * MT + a) * NTO + b) * 256 + r * 64 + ln];
+            float s = 0.f;
+            for (int w = 0; w < C::NW; ++w) s += slots[(((w * 2 + 1) * MT + a) * NTO + b) * 256 + r * 64 + ln];
+            return s;
+        }
+    };
+    float* part = ws + (long)blockIdx.x * C::PART;
+    // (s_w9 / s_wp were overwritten by the slots: re-read the masters -- once per block)
+    for (int e = tid; e < COUT * CIN; e += NT) {
+        const int o = e / CIN, c = e - o * CIN;
+        float s = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) s = fmaf(wdw[c * 9 + tap], Gval(tap, c, o), s);
+        part[e] = s;
+    }
+    for (int e = tid; e < 9 * CIN; e += NT) {
+        const int c = e / 9, tap = e - c * 9;
+        float s = 0.f;
+        for (int o = 0; o < COUT; ++o) s = fmaf(wpw[o * ldw + c], Gval(tap, c, o), s);
+        part[COUT * CIN + e] = s;
+    }
+    for (int e = tid; e < 2 * CIN; e += NT) {  // stats partials interleaved per channel: [CIN][S1 | S2]
+        float s = 0.f;
+        if constexpr (STATS) {
+            const int c = e >> 1, which = e & 1;
+            for (int w = 0; w < C::NW; ++w) s += sstat[(w * 2 + which) * MT * 16 + c];
+        }
+        part[COUT * CIN + 9 * CIN + e] = s;
+    }
+}
+
+// Deterministic second stage of every flush of k_mm_bwd: one thread-column per output element, the nb block partials are summed in a fixed
+// order (8 interleaved chains per element, combined through LDS in a fixed tree), a single writer per element, no atomics.
+//   dwpw [COUT][ldw] (+c_off) += ,  dwdw [(c_off + c)][9] += ,  and for the producers of the input (if asked):
+//   gsum [2][Cs] (fp64) += { S1, rstd * ((S2 - shift*S1)/scale - mean*S1) }   (S1 = sum ghat', S2 = sum ghat' x~,  x~ = z*scale + shift where ghat' != 0)
+__global__ __launch_bounds__(256) void k_mm_bwd_reduce(const float* __restrict__ ws, int nb, int CIN, int COUT, int Ca, float* __restrict__ dwpw, int ldw,
+                                                       float* __restrict__ dwdw, double* __restrict__ gsum_a, double* __restrict__ gsum_b,
+                                                       const float* __restrict__ saved_a, const float* __restrict__ saved_b,
+                                                       const float* __restrict__ tra, const float* __restrict__ trb) {
+    __shared__ float red[8][32];
+    const int nelem = COUT * CIN + 11 * CIN;
+    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + col;
+    float s = 0.f;
+    if (e < nelem)
+        for (int b = chain; b < nb; b += 8) s += ws[(long)b * nelem + e];
+    red[chain][col] = s;
+    __syncthreads();
+    __shared__ float fin[32];
+    const float v = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    if (chain == 0) fin[col] = v;
+    __syncthreads();
+    if (chain != 0 || e >= nelem) return;
+    if (e >= COUT * CIN + 9 * CIN) {
+        const int r2 = e - (COUT * CIN + 9 * CIN);
+        if (r2 & 1) return;  // S2 is consumed by its channel's S1 thread
+        const int c = r2 >> 1, Cb = CIN - Ca;
+        const bool in_a = c < Ca;
+        double* gs = in_a ? gsum_a : gsum_b;
+        if (!gs) return;
+        const int cc = in_a ? c : c - Ca, Cs = in_a ? Ca : Cb;
+        const float* sv = in_a ? saved_a : saved_b;
+        const float* tr = in_a ? tra : trb;
+        const double S1 = v, S2 = fin[col + 1], sc = tr[cc], sh = tr[Cs + cc], mean = sv[cc], rstd = sv[Cs + cc];
+        gs[cc] += S1;
+        if (sc != 0.0) gs[Cs + cc] += rstd * ((S2 - sh * S1) / sc - mean * S1);
+        return;
+    }
+    if (e < COUT * CIN) {
+        const int o = e / CIN, c = e - o * CIN;
+        dwpw[o * ldw + c] += v;
+        return;
+    }
+    const int r = e - COUT * CIN;
+    if (r < 9 * CIN) {
+        dwdw[r] += v;
+        return;
+    }
+    // stats: [CIN][S1 | S2] pairs; the pair of a channel sits in two adjacent columns of the same 32-wide window (the stats base is even)
+    return;
+}
+static int mm_grid(int th, int N, int H, int W, int pooled) {
+    const long ntiles = (long)N * ((W + pooled + 31) / 32) * ((H + pooled + th - 1) / th);
+    return persistent_grid(ntiles, 2);
+}
+static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : OCRS_MM_TH; }
+
+template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
+static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
+                           const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, int N, int H, int W, int nb, hipStream_t st) {
+    using CC = MmCfg<CIN, COUT>;
+    Tiling2 tg = make_tiling2(N, H + (PPOOL ? 1 : 0), W + (PPOOL ? 1 : 0), CC::TW, CC::TH);  // pooled: origins shifted by -1 -> one more row / column of tiles may be needed
+    tg.H = H;
+    tg.W = W;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
+                       ws, tg);
+}
+
+template <int CIN, int COUT>
+static void mm_bwd_dispatch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
+                            int pooled, const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int N, int H, int W,
+                            int nb, hipStream_t st) {
+#define MMB(PP, GG, SS) mm_bwd_launch1<CIN, COUT, PP, GG, SS>(x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb, ws, N, H, W, nb, st)
+    if (pooled) {
+        if (g2) { if (stats) MMB(true, true, true); else MMB(true, true, false); }
+        else    { if (stats) MMB(true, false, true); else MMB(true, false, false); }
+    } else {
+        if (g2) { if (stats) MMB(false, true, true); else MMB(false, true, false); }
+        else    { if (stats) MMB(false, false, true); else MMB(false, false, false); }
+    }
+#undef MMB
+}
+
+extern "C" {
+
+// 1 if the matrix-core block backward covers this shape (bf16; Cin, Cout in {8,16,32}; a 32|32 concat input runs as two launches)
+long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
+    if (dtype != 1 || !(Cout == 8 || Cout == 16 || Cout == 32)) return 0;
+    const int Cin = Ca + Cb;
+    if (Ca == 32 && Cb == 32) return 1;
+    if ((Cin == 8 && Cout == 32) || (Cin == 32 && Cout == 8)) return 0;  // (not in the net: no instantiation)
+    return (Cin == 8 || Cin == 16 || Cin == 32) && Ca % 8 == 0 && Cb % 8 == 0;
+}
+long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
+    const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
+    return (long)mm_grid(mm_th(Cin, Cout), N, H, W, 1) * (Cout * Cin + 11 * Cin);
+}
+
+// Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
+//   xa | xb (Ca | Cb channels) with load transforms tra | trb: the block input;  wdw [Cin][9], wpw [Cout][Cin]: fp32 master weights;
+//   g1 (+ g2): gradient w.r.t. the block output, at half resolution when pooled (routed through MaxPool2d(2));  z, bn, coef: as ocrs_pw_bwd;
+//   gxa | gxb: dL/dx~;  dwpw / dwdw: ACCUMULATED (+=, single writer: deterministic);  ws: ocrs_mm_bwd_ws_floats() floats;
+//   saved_a/gsum_a, saved_b/gsum_b (nullable): as ocrs_dw_bwd.
+int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
+                const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
+                const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && wpw && g1 && z && bn && coef && gxa && dwpw && dwdw && ws && (Cb == 0 || (xb && trb && gxb)));
+    OCRS_CHECK_ARG(ocrs_mm_bwd_supported(Ca, Cb, Cout, dtype) && (long)N * (H + 2) * (W + 2) < (1L << 31) && H >= 2 && W >= 2);
+    OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
+    const int CinTot = Ca + Cb;
+    const bool split = Ca == 32 && Cb == 32;
+    const int nlaunch = split ? 2 : 1;
+    for (int part = 0; part < nlaunch; ++part) {
+        // a 32 | 32 concat input: z = Wpw[:, :32] u_a + Wpw[:, 32:] u_b, so dx~, dWpw and dWdw separate by source; dz is the same for both launches
+        const int Cin = split ? 32 : CinTot, c_off = part * 32;
+        Src2<bf16> x{(const bf16*)(part ? xb : xa), (const bf16*)(split ? nullptr : xb), split ? 32 : Ca, split ? 0 : Cb};
+        const float* tA = part ? trb : tra;
+        const float* tB = split ? nullptr : trb;
+        bf16* ga = (bf16*)(part ? gxb : gxa);
+        bf16* gb = split ? nullptr : (bf16*)gxb;
+        const float* svA = part ? saved_b : saved_a;
+        double* gsA = part ? gsum_b : gsum_a;
+        const float* svB = split ? nullptr : saved_b;
+        double* gsB = split ? nullptr : gsum_b;
+        const bool stats = gsA || gsB;
+        const int nb = mm_grid(mm_th(Cin, Cout), N, H, W, pooled ? 1 : 0);
+        const float* wd = wdw + c_off * 9;
+        const float* wp = wpw + c_off;
+#define MM_CASE(CI_, CO_)                                                                                                             \
+    if (Cin == CI_ && Cout == CO_)                                                                                                    \
+        mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, st);
+        MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
+#undef MM_CASE
+        const int ne = Cout * Cin + 11 * Cin;
+        hipLaunchKernelGGL(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA,
+                           svB, tA, tB);
+    }
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

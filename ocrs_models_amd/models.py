@@ -109,9 +109,8 @@ class _DetRun:
         self.recs = {}
         self.fused = {}  # block prefix -> fp64 [2][C] BatchNorm-backward sums accumulated by its consumers' dw_bwd
         self.fuse_bn_bwd = os.environ.get("OCRS_FUSE_BN_BWD", "1") != "0"
-        # fused pointwise+depthwise backward kernel (csrc/det_blk.hip): correct (tests/test_det_ops_gpu.py) but, at 168 VGPRs with spills
-        # and 1.4x dgrad work, still slower than the two pipelined kernels it replaces (level 0: 1.30 vs 1.08 ms) -> opt-in for now
-        self.fuse_blk = os.environ.get("OCRS_FUSE_BLK", "0") == "1"
+        # block backward on the matrix cores (csrc/det_mm.hip): bf16, levels 0-2
+        self.use_mm = os.environ.get("OCRS_MM", "1") != "0"
         # max-pool written by the producing block's forward kernel (levels 0-2) instead of a separate pass over the full-size z
         self.fuse_pool = os.environ.get("OCRS_FUSE_POOL", "1") != "0"
         self.pooled_by_block = None
@@ -298,16 +297,16 @@ class _DetRun:
             if act.src not in self.fused:
                 self.fused[act.src] = self.zeros64(2 * act.C)
             return self.recs[act.src].saved, self.fused[act.src]
-        if self.fuse_blk and L.blk_bwd_supported(r.Cin, C, pooled, self.dt):
-            # top levels: pointwise + depthwise backward in ONE kernel (du never reaches HBM)
-            gxa = self.empty(N, H, W, Ca) if need_gx else None
-            gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
+        if self.use_mm and need_gx and L.mm_bwd_supported(Ca, Cb, C, self.dt) and H >= 2 and W >= 2:
+            # dz, dgrad of both convs, both weight gradients and the producers' BatchNorm-backward sums from ONE staged copy of (g, z, x)
+            gxa = self.empty(N, H, W, Ca)
+            gxb = self.empty(N, H, W, Cb) if b is not None else None
             sva, gsa = stat_target(a)
             svb, gsb = stat_target(b)
-            ws = self.empty(L.blk_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
-            L.blk_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
-                      ptr(g2), ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
-                      ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
+            ws = self.empty(L.mm_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
+            L.mm_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                     ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
+                     ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
             return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
