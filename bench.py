@@ -67,6 +67,7 @@ def det_alg_elems_per_image(H: int, W: int) -> int:
 # ABI change cannot silently corrupt the roofline figure)
 ALG_BYTES_ARGS = {
     "dwpw_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "mm_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
@@ -81,14 +82,14 @@ FAMILIES = list(ALG_BYTES_ARGS)
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
 PASSES = {
     "block_bwd": ("mm_bwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce"),
-    "block_fwd": ("dwpw_fwd",),
+    "block_fwd": ("mm_fwd", "dwpw_fwd"),
     "convt_fwd": ("convt_fwd",),
     "convt_bwd": ("convt_bwd",),
     "maxpool_fwd": ("maxpool_fwd",),
 }
 PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
     "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<"),
-    "block_fwd": ("k_dwpw_fwd<",),
+    "block_fwd": ("k_mm_fwd<", "k_dwpw_fwd<"),
     "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
     "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<"),
     "maxpool_fwd": ("k_maxpool_fwd<",),
@@ -100,7 +101,7 @@ def alg_bytes(name, a, sz):
     from ocrs_models_amd._lib import ARG_NAMES
 
     v = dict(zip(ARG_NAMES["ocrs_" + name], a))
-    if name == "dwpw_fwd":  # x (Ca+Cb) in, z (Cout) out
+    if name in ("dwpw_fwd", "mm_fwd"):  # x (Ca+Cb) in, z (Cout) out
         return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
     if name in ("pw_bwd", "mm_bwd"):  # the whole block backward: x, z, g in; dL/dx out
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
@@ -512,7 +513,7 @@ def main():
             n_units = max(1, st["units_per_step"])
             out["roofline"] = {
                 "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_mm_bwd at levels 0-2, k_pw_bwd*+k_dw_bwd[+k_bn_bwd_reduce] below)",
-                           "block_fwd": "DepthwiseConv block forward (k_dwpw_fwd)"}.get(dom, dom),
+                           "block_fwd": "DepthwiseConv block forward (k_mm_fwd at levels 0-2, k_dwpw_fwd below)"}.get(dom, dom),
                 "bound": "hbm", "achieved": st["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["frac"],
                 "traffic": round(tr / n_units) if tr else None, "traffic_source": src,
                 "byte_model": "SURVEY 8(d): per block backward 2*(Cin+Cout) elements/pixel (x, z, g read once; dL/dx written once)",

@@ -46,6 +46,16 @@ int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, 
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
                   void* z, double* gstat, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout); /* 1 / 0 */
+/* The same block forward on the matrix cores (csrc/det_mm.hip; bf16, Cin and Cout in {8, 16, 32} and the 32 | 32 concat): depthwise and
+ * pointwise conv composed into one 3x3 implicit GEMM (effective weight Wpw[o][c] * Wdw[c][tap] built from the fp32 masters wdw [Cin][9],
+ * wpw [Cout][Cin]).  The batch statistics go to ws as ocrs_mm_fwd_nparts() per-block partials [Cout][sum z | sum z^2] (fp32) that
+ * ocrs_bn_finalize_parts reduces in a fixed order (bit-reproducible; no atomics).  gamma / pooled: as ocrs_dwpw_fwd. */
+long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype); /* 1 / 0 */
+long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W);
+int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z,
+                float* ws, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+int ocrs_bn_finalize_parts(const float* parts, int nparts, long count, int C, const float* gamma, const float* beta, float eps, float momentum,
+                           float* tr, float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st);
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st);

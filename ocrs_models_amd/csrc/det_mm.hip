@@ -29,7 +29,13 @@ struct MmCfg {
 #ifndef OCRS_MM_TH
 #define OCRS_MM_TH 8  // tile rows for the configurations without a 32-channel side (those always use 8): 16 halves the ring re-reads, needs ~12 more VGPRs
 #endif
-    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? 8 : OCRS_MM_TH, TP = TW * TH;
+    // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
+    // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
+#ifndef OCRS_MM_C32_BPC
+#define OCRS_MM_C32_BPC 1
+#endif
+    static constexpr int BPC = (CIN == 32) ? OCRS_MM_C32_BPC : 2;      // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
+    static constexpr int TW = 32, TH = (CIN == 32) ? (OCRS_MM_C32_BPC == 1 ? 16 : 8) : (COUT == 32 ? 8 : OCRS_MM_TH), TP = TW * TH;
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -47,9 +53,9 @@ struct MmCfg {
     static constexpr int OFF_X = (OFF_D + DP * PD * 2 + 63) & ~63;
     static constexpr int OFF_WF = (OFF_X + TP * PX * 2 + 64 + 63) & ~63;  // +64: the Cin = 8 transpose reads run 16 bytes past the last pixel
     static constexpr int OFF_PAR = OFF_WF + MT * KC * 64 * 16;
-    static constexpr int PAR_FLOATS = 3 * CIN + 6 * COUT + 9 * CIN + COUT * CIN + 4 * CIN;  // trx | bn | coef | wdw [c][9] | wpw [o][c] | stats params
+    static constexpr int PAR_FLOATS = 3 * CIN + 6 * COUT + 9 * CIN + COUT * CIN + NW * 2 * MT * 16;  // trx | bn | coef | wdw [c][9] | wpw [o][c] | stats slots
     static constexpr int TILE_BYTES = OFF_PAR + PAR_FLOATS * 4;
-    static constexpr int SLOT_FLOATS = NW * 2 * MT * NTO * 256 + NW * 2 * MT * 16;  // flush: G slots (own | shared unit) + stats slots
+    static constexpr int SLOT_FLOATS = NW * (MT * NTO + 1) * 256 + NW * 2 * MT * 16;  // flush: G slots (own unit | shared sub-tile) + stats slots
     static constexpr int SMEM = TILE_BYTES > SLOT_FLOATS * 4 ? TILE_BYTES : SLOT_FLOATS * 4;
     static constexpr int PART = COUT * CIN + 9 * CIN + 2 * CIN;        // floats per block partial: dWpw [COUT][CIN] | dWdw [CIN][9] | sums [2][CIN]
 };
@@ -73,13 +79,15 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
 }
 
+template <int CIN>
+constexpr int mm_bwd_lb() { return CIN == 32 ? 2 * OCRS_MM_C32_BPC : 4; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
-__global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(512, mm_bwd_lb<CIN>()) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
@@ -239,22 +247,32 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
             return ((2 - ky) * DW_ + prow + 2 - kx) * PD + pcol;
         }
     };
-    // own unit / k-step range of this wave, and its share of the last unit
-    constexpr int KSH = KS / C::NW;  // k-steps of the shared unit per wave (2 or 1)
+    // own unit / k-step range of this wave, and its share of the last unit: ONE (M tile, N tile) sub-tile of it over a range of k-steps
+    // (a whole-unit share would need a second full accumulator set: 16 more registers at 32 x 32 channels)
+    constexpr int NSUB = MT * NTO, NKR = C::NW / NSUB, KSHR = KS / NKR;
+    static_assert(C::NW % NSUB == 0 && KS % NKR == 0, "shared-unit split");
     const int u_own = (C::TAPU == 9) ? wave : (wave & 3);
     const int ks_own0 = (C::TAPU == 9) ? 0 : (wave >> 2) * (KS / 2), ks_own1 = (C::TAPU == 9) ? KS : ks_own0 + KS / 2;
-    const int off_own = unit_off(u_own), off_sh = unit_off(C::TAPU - 1);
-    f32x4 accO[MT][NTO], accS[MT][NTO];
+    const int sh_a = (wave % NSUB) % MT, sh_b = (wave % NSUB) / MT, sh_k0 = (wave / NSUB) * KSHR;
+    const int off_own = unit_off(u_own), off_sh = unit_off(C::TAPU - 1) + sh_b * 16;
+    f32x4 accO[MT][NTO], accS = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NTO; ++b) accO[a][b] = accS[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float st1[STATS ? MT : 1][4], st2[STATS ? MT : 1][4];
-    if constexpr (STATS) {
+        for (int b = 0; b < NTO; ++b) accO[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // producers' BatchNorm-backward sums: per-lane register accumulators (one M tile), or -- with two M tiles, where 16 more live registers
+    // spill -- per-tile sums added to this wave's own LDS slots (single writer, fixed order: deterministic)
+    constexpr bool STL = STATS && MT == 2;
+    float* s_st = s_wp + COUT * CIN;  // [wave][2][MT*16] (STL only)
+    float st1[(STATS && !STL) ? MT : 1][4], st2[(STATS && !STL) ? MT : 1][4];
+    if constexpr (STATS && !STL) {
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) st1[a][i] = st2[a][i] = 0.f;
+    }
+    if constexpr (STL) {
+        for (int i = tid; i < C::NW * 2 * MT * 16; i += NT) s_st[i] = 0.f;  // (ordered before its first use by the tile loop's barriers)
     }
 
     TileSched ts(tg.ntiles);
@@ -301,9 +319,7 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
                 for (int j = 0; j < C::NWI; ++j) {
                     const int it = tid + j * NT;
                     if (C::NWIN * CGO % NT == 0 || it < C::NWIN * CGO) {
-                        float zv[4][4], gs[4], m[4][4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) half4(zr[4 * j + k], hf, zv[k]);
+                        float gs[4], dz[4][4];
                         half4(g1r[j], hf, gs);
                         if constexpr (G2) {
                             float gb[4];
@@ -312,27 +328,36 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
                             for (int i = 0; i < 4; ++i) gs[i] += gb[i];
                         }
                         const bool gv = (okg >> (16 + j)) & 1u;
-                        // first maximum of the window in post-ReLU space, row-major order, must be > 0 (the pooled value passes the ReLU)
+                        // first maximum of the window in post-ReLU space (row-major scan, strict > keeps the first), must be > 0: the pooled
+                        // value passes the ReLU.  When gv holds all four pixels lie inside the image.
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                        for (int i = 0; i < 4; ++i) {
+                            float zk[4], mk[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) m[k][i] = max_lo(fmaf(zv[k][i], bs[i], bt[i]), 0.f);
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned w2 = hf ? ((i < 2) ? zr[4 * j + k].a.z : zr[4 * j + k].a.w) : ((i < 2) ? zr[4 * j + k].a.x : zr[4 * j + k].a.y);
+                                zk[k] = (i & 1) ? __uint_as_float(w2 & 0xffff0000u) : __uint_as_float(w2 << 16);
+                                mk[k] = max_lo(fmaf(zk[k], bs[i], bt[i]), 0.f);
+                            }
+                            float best = mk[0];
+                            int sel = 0;
+#pragma unroll
+                            for (int k = 1; k < 4; ++k) {
+                                const bool gt = mk[k] > best;
+                                best = gt ? mk[k] : best;
+                                sel = gt ? k : sel;
+                            }
+                            const float gsel = (gv && best > 0.f) ? gs[i] : 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const bool ok = (okg >> (4 * j + k)) & 1u;
+                                const float gh = sel == k ? gsel : 0.f;
+                                dz[k][i] = ok ? fmaf(ca[i], gh, fmaf(cb[i], zk[k], cc[i])) : 0.f;
+                            }
+                        }
                         const int wd = it / CGO, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            float dz[4];
-                            const bool ok = (okg >> (4 * j + k)) & 1u;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                bool win = gv && m[k][i] > 0.f;
-#pragma unroll
-                                for (int k2 = 0; k2 < 4; ++k2)
-                                    if (k2 != k) win = win && (k2 < k ? m[k][i] > m[k2][i] : m[k][i] >= m[k2][i]);
-                                const float gh = win ? gs[i] : 0.f;
-                                dz[i] = ok ? fmaf(ca[i], gh, fmaf(cb[i], zv[k][i], cc[i])) : 0.f;
-                            }
-                            st4bf(tileD + ((2 * wy + (k >> 1)) * DW_ + 2 * wx + (k & 1)) * PD + c4, dz);
-                        }
+                        for (int k = 0; k < 4; ++k) st4bf(tileD + ((2 * wy + (k >> 1)) * DW_ + 2 * wx + (k & 1)) * PD + c4, dz[k]);
                     }
                 }
             }
@@ -361,53 +386,51 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
         }
         lds_barrier();
         // ================= phase 2a: dx~ = Weff * dz (shifted), MFMA; epilogue: store + the producers' BatchNorm-backward sums =================
+        // One M tile (16 input channels) at a time: the second pass re-reads the B fragments from LDS instead of holding 2x the accumulators.
         {
-            f32x4 acc[NPW][MT];
             int pbase[NPW];
 #pragma unroll
             for (int a = 0; a < NPW; ++a) {
                 const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
                 pbase[a] = (ty * DW_ + tx) * PD;
-#pragma unroll
-                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            uint4 bcur[NPW], bnxt[NPW];
-            auto load_b = [&](uint4 (&dst)[NPW], int kc) {
-                bool bv;
-                const int bo = boff_of(kc, bv);
-#pragma unroll
-                for (int a = 0; a < NPW; ++a) {
-                    dst[a] = *reinterpret_cast<const uint4*>(tileD + pbase[a] + bo);
-                    if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
-                }
-            };
-            load_b(bcur, 0);
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) {
-                uint4 wf[MT];
-#pragma unroll
-                for (int b = 0; b < MT; ++b) wf[b] = s_wf[(b * KC + kc) * 64 + lane];
-                if (kc + 1 < KC) load_b(bnxt, kc + 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < NPW; ++a)
-#pragma unroll
-                    for (int b = 0; b < MT; ++b) acc[a][b] = mfma16(wf[b], bcur[a], acc[a][b]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
             }
             const long tb = ((long)org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
 #pragma unroll
-            for (int a = 0; a < NPW; ++a) {
-                const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
-                const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx) < (unsigned)W;
-                const long pix = tb + (long)ty * W + tx;
+            for (int b = 0; b < MT; ++b) {
+                f32x4 acc[NPW];
 #pragma unroll
-                for (int b = 0; b < MT; ++b) {
-                    const int m0 = b * 16 + (lane >> 4) * 4;
+                for (int a = 0; a < NPW; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                uint4 bcur[NPW], bnxt[NPW];
+                auto load_b = [&](uint4 (&dst)[NPW], int kc) {
+                    bool bv;
+                    const int bo = boff_of(kc, bv);
+#pragma unroll
+                    for (int a = 0; a < NPW; ++a) {
+                        dst[a] = *reinterpret_cast<const uint4*>(tileD + pbase[a] + bo);
+                        if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
+                    }
+                };
+                load_b(bcur, 0);
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
+                    if (kc + 1 < KC) load_b(bnxt, kc + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
+                }
+                const int m0 = b * 16 + (lane >> 4) * 4;
+                float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) {
+                    const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
+                    const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx) < (unsigned)W;
+                    const long pix = tb + (long)ty * W + tx;
                     if (m0 < CIN) {
-                        const f32x4 v = acc[a][b];
+                        const f32x4 v = acc[a];
                         if (pv) {
                             if (m0 < x.Ca)
                                 store4(gxa + pix * x.Ca + m0, v[0], v[1], v[2], v[3]);
@@ -421,10 +444,37 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
                             for (int i = 0; i < 4; ++i) {
                                 // the producer's backward reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask
                                 const float gh = xq[i] > 0.f ? Elem<bf16>::round(v[i]) : 0.f;
-                                st1[b][i] += gh;
-                                st2[b][i] = fmaf(gh, xq[i], st2[b][i]);
+                                t1[i] += gh;
+                                t2[i] = fmaf(gh, xq[i], t2[i]);
                             }
                         }
+                    }
+                }
+                if constexpr (STATS && !STL) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        st1[b][i] += t1[i];
+                        st2[b][i] += t2[i];
+                    }
+                }
+                if constexpr (STL) {
+                    float r1[4], r2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        r1[i] = quad16_sum(t1[i]);
+                        r2[i] = quad16_sum(t2[i]);
+                    }
+                    if ((lane & 15) == 0) {
+                        float* q1 = s_st + (wave * 2 + 0) * MT * 16 + m0;
+                        float* q2 = s_st + (wave * 2 + 1) * MT * 16 + m0;
+                        f32x4 o1 = *reinterpret_cast<f32x4*>(q1), o2 = *reinterpret_cast<f32x4*>(q2);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            o1[i] += r1[i];
+                            o2[i] += r2[i];
+                        }
+                        *reinterpret_cast<f32x4*>(q1) = o1;
+                        *reinterpret_cast<f32x4*>(q2) = o2;
                     }
                 }
             }
@@ -433,7 +483,7 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
         {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= wave * KSH && ks < (wave + 1) * KSH;
+                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= sh_k0 && ks < sh_k0 + KSHR;
                 if (!own && !shr) continue;  // (wave-uniform)
                 bf16x8 af[MT];
 #pragma unroll
@@ -452,13 +502,11 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
                     }
                 }
                 if (shr) {
-#pragma unroll
-                    for (int b = 0; b < NTO; ++b) {
-                        const bf16* da = dks + off_sh + b * 16;
-                        const bf16x8 bfr = lds_tr8(da, da + 16 * PD);
-#pragma unroll
-                        for (int a = 0; a < MT; ++a) accS[a][b] = mfma16(af[a], bfr, accS[a][b]);
-                    }
+                    // (its A fragment is read again with the wave's own M-tile offset: selecting between af[0] / af[1] at run time makes hipcc
+                    //  put the fragments into a scratch array)
+                    const bf16* da = dks + off_sh;
+                    const bf16* xa = tileX + (ks * 32 + prow) * PX + sh_a * 16 + pcol;
+                    accS = mfma16(lds_tr8(xa, xa + 16 * PX), lds_tr8(da, da + 16 * PD), accS);
                 }
             }
         }
@@ -467,18 +515,18 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
 
     // ================= flush: G slots -> dWpw / dWdw partials of this block (workspace); stats partials =================
     __syncthreads();
-    float* slots = reinterpret_cast<float*>(smem);  // [wave][own | shared][MT][NTO][4][64]
-    float* sstat = slots + C::NW * 2 * MT * NTO * 256;  // [wave][2][MT*16]
+    float* slots = reinterpret_cast<float*>(smem);        // [wave][MT][NTO][4][64] own unit
+    float* slotS = slots + C::NW * MT * NTO * 256;         // [wave][4][64] this wave's sub-tile of the shared unit
+    float* sstat = slotS + C::NW * 256;                    // [wave][2][MT*16] (register-accumulated stats)
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NTO; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                slots[(((wave * 2 + 0) * MT + a) * NTO + b) * 256 + r * 64 + lane] = accO[a][b][r];
-                slots[(((wave * 2 + 1) * MT + a) * NTO + b) * 256 + r * 64 + lane] = accS[a][b][r];
-            }
-    if constexpr (STATS) {
+            for (int r = 0; r < 4; ++r) slots[((wave * MT + a) * NTO + b) * 256 + r * 64 + lane] = accO[a][b][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slotS[wave * 256 + r * 64 + lane] = accS[r];
+    if constexpr (STATS && !STL) {
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -490,23 +538,28 @@ __global__ __launch_bounds__(512, 4) void k_mm_bwd(Src2<bf16> x, const float* __
                 }
             }
     }
+    if constexpr (STL) {
+        static_assert(!STL || C::SLOT_FLOATS * 4 <= C::OFF_PAR, "the flush slots must not reach the LDS-resident stats");
+        sstat = s_st;
+    }
     __syncthreads();
     // G[tap][c][o] from the slots (fixed summation order -> deterministic)
     auto Gval = [&](int tap, int c, int o) -> float {
         const int a = c >> 4, r = c & 3, lrow = (c & 15) >> 2;
-        if constexpr (COUT == 8) {
-            const int u = tap >> 1, n = (tap < 8 ? (tap & 1) * 8 : 0) + o, ln = lrow * 16 + n;
-            if (tap < 8) return slots[((u * 2 + 0) * MT + a) * NTO * 256 + r * 64 + ln] + slots[(((u + 4) * 2 + 0) * MT + a) * NTO * 256 + r * 64 + ln];
-            float s = 0.f;
-            for (int w = 0; w < C::NW; ++w) s += slots[((w * 2 + 1) * MT + a) * NTO * 256 + r * 64 + ln];
-            return s;
-        } else {
-            const int b = o >> 4, ln = lrow * 16 + (o & 15);
-            if (tap < 8) return slots[(((tap * 2 + 0) * MT + a) * NTO + b) * 256 + r * 64 + ln];
-            float s = 0.f;
-            for (int w = 0; w < C::NW; ++w) s += slots[(((w * 2 + 1) * MT + a) * NTO + b) * 256 + r * 64 + ln];
-            return s;
+        const int b = (COUT == 8) ? 0 : (o >> 4);
+        const int n = (COUT == 8) ? ((tap < 8 ? (tap & 1) * 8 : 0) + o) : (o & 15);
+        const int ln = lrow * 16 + n;
+        if (tap < 8) {
+            if constexpr (COUT == 8) {
+                const int u = tap >> 1;
+                return slots[((u * MT + a) * NTO + b) * 256 + r * 64 + ln] + slots[(((u + 4) * MT + a) * NTO + b) * 256 + r * 64 + ln];
+            } else
+                return slots[((tap * MT + a) * NTO + b) * 256 + r * 64 + ln];
         }
+        float sum = 0.f;
+        const int sub = b * MT + a;
+        for (int kr = 0; kr < NKR; ++kr) sum += slotS[(sub + NSUB * kr) * 256 + r * 64 + ln];
+        return sum;
     };
     float* part = ws + (long)blockIdx.x * C::PART;
     // (s_w9 / s_wp were overwritten by the slots: re-read the masters -- once per block)
@@ -583,11 +636,13 @@ __global__ __launch_bounds__(256) void k_mm_bwd_reduce(const float* __restrict__
     // stats: [CIN][S1 | S2] pairs; the pair of a channel sits in two adjacent columns of the same 32-wide window (the stats base is even)
     return;
 }
-static int mm_grid(int th, int N, int H, int W, int pooled) {
+static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
     const long ntiles = (long)N * ((W + pooled + 31) / 32) * ((H + pooled + th - 1) / th);
-    return persistent_grid(ntiles, 2);
+    return persistent_grid(ntiles, bpc);
 }
-static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : OCRS_MM_TH; }
+static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : OCRS_MM_TH; }  // forward tiles
+static int mm_bwd_th(int Cin, int Cout) { return Cin == 32 ? (OCRS_MM_C32_BPC == 1 ? 16 : 8) : (Cout == 32 ? 8 : OCRS_MM_TH); }
+static int mm_bwd_bpc(int Cin) { return Cin == 32 ? OCRS_MM_C32_BPC : 2; }
 
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
@@ -632,7 +687,7 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 }
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
-    return (long)mm_grid(mm_th(Cin, Cout), N, H, W, 1) * (Cout * Cin + 11 * Cin);
+    return (long)mm_grid(mm_bwd_th(Cin, Cout), N, H, W, 1, mm_bwd_bpc(Cin)) * (Cout * Cin + 11 * Cin);
 }
 
 // Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
@@ -662,7 +717,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const float* svB = split ? nullptr : saved_b;
         double* gsB = split ? nullptr : gsum_b;
         const bool stats = gsA || gsB;
-        const int nb = mm_grid(mm_th(Cin, Cout), N, H, W, pooled ? 1 : 0);
+        const int nb = mm_grid(mm_bwd_th(Cin, Cout), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
 #define MM_CASE(CI_, CO_)                                                                                                             \
@@ -674,6 +729,380 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         hipLaunchKernelGGL(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA,
                            svB, tA, tB);
     }
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------------------------------------------
+// forward:  z[o][p] = sum_{tap,c} Weff[o][(tap,c)] x~[p + off(tap)][c]   (MFMA, K = 9 * Cin; x~ = the producers' BatchNorm+ReLU applied on load)
+//           + per-channel batch sums of the stored z (BatchNorm statistics, deterministic per-block partials)
+//           + optionally MaxPool2d(2) of the block output in its pre-BatchNorm form (see k_dwpw_fwd).
+// CINB channels per stage (8 / 16 / 32), NST stages (2 for the 32 | 32 concat: one stage per source, same accumulators).
+// ----------------------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int CINB, int NST, int COUT>
+struct MfCfg {
+    static constexpr int NT = 512, NW = 8;
+    static constexpr int TW = 32, TH = (CINB == 32 || COUT == 32) ? 8 : OCRS_MM_TH, TP = TW * TH;
+    static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;
+    static constexpr int CGB = CINB / 8;
+    static constexpr int PX = MmPitch<CINB>::V;
+    static constexpr int MT = (COUT + 15) / 16;
+    static constexpr int KC = (9 * CINB + 31) / 32;
+    static constexpr int UPW = TH / 8, NPW = 2 * UPW;                  // (row pair, column half) units per wave; 16-pixel N tiles per wave
+    static constexpr int NXI = (DP * CGB + NT - 1) / NT;               // x items per thread and stage
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_WF = (DP * PX * 2 + 63) & ~63;
+    static constexpr int OFF_PAR = OFF_WF + NST * MT * KC * 64 * 16;
+    static constexpr int PAR_FLOATS = 3 * CINB * NST + 9 * CINB * NST + COUT * CINB * NST + NW * MT * 16 * 2;
+    static constexpr int SMEM = OFF_PAR + PAR_FLOATS * 4;
+};
+}  // namespace
+
+template <int CINB, int NST, int COUT, bool POOL>
+__global__ __launch_bounds__(512, 4) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+                                                   const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
+                                                   bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
+                                                   const float* __restrict__ gamma, bf16* __restrict__ pooled) {
+    using C = MfCfg<CINB, NST, COUT>;
+    constexpr int NT = C::NT, TW = C::TW, TH = C::TH, DW_ = C::DW_, DP = C::DP, CGB = C::CGB, PX = C::PX, MT = C::MT, KC = C::KC, NPW = C::NPW;
+    constexpr int CIN = CINB * NST;
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    bf16* tileX = reinterpret_cast<bf16*>(smem + C::OFF_X);     // [DP][PX] x~ on the domain of the current stage (0 outside the image)
+    uint4* s_wf = reinterpret_cast<uint4*>(smem + C::OFF_WF);   // [NST][MT][KC][64] effective-weight A fragments
+    float* s_trx = reinterpret_cast<float*>(smem + C::OFF_PAR); // [CIN/8][3][8]
+    float* s_w9 = s_trx + 3 * CIN;                               // [CIN][9]
+    float* s_wp = s_w9 + 9 * CIN;                                // [COUT][CIN]
+    float* s_stat = s_wp + COUT * CIN;                           // [wave][MT*16][2]
+    const int H = tg.H, W = tg.W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    fill_tr8(s_trx, x, tra, trb, CIN, tid);
+    for (int i = tid; i < 9 * CIN; i += NT) s_w9[i] = wdw[i];
+    for (int i = tid; i < COUT * CIN; i += NT) s_wp[i] = wpw[i];
+    {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < C::OFF_WF / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = z4;
+    }
+    __syncthreads();
+    for (int f = tid; f < NST * MT * KC * 64; f += NT) {
+        const int l = f & 63, kc = (f >> 6) % KC, mt = ((f >> 6) / KC) % MT, st = (f >> 6) / (KC * MT);
+        const int m = mt * 16 + (l & 15);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc * 32 + (l >> 4) * 8 + j, tap = k / CINB, c = st * CINB + k % CINB;
+            v[j] = (m < COUT && tap < 9) ? s_w9[c * 9 + tap] * s_wp[m * CIN + c] : 0.f;
+        }
+        s_wf[f] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+    __syncthreads();
+
+    // x items: (domain pixel, 8-channel group) of stage st; with one stage the source (a | b) depends on the channel group, with two stages on the stage
+    const int cgb = tid % CGB;
+    int xi_dyx[C::NXI];
+#pragma unroll
+    for (int j = 0; j < C::NXI; ++j) {
+        const int d = (tid + j * NT) / CGB, dy = d / DW_, dx = d - dy * DW_;
+        xi_dyx[j] = dy | (dx << 16);
+    }
+    Raw8<bf16> xr[NST][C::NXI];
+    unsigned okx = 0;
+    auto issue = [&](const TileOrg& o) {
+        okx = 0;
+        const long corner = ((long)o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int c0 = st * CINB + cgb * 8;
+            const bool in_a = c0 < x.Ca;
+            const bf16* base = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
+            const int pitch = in_a ? x.Ca : x.Cb;
+            const bf16* cb = base + corner * pitch;
+#pragma unroll
+            for (int j = 0; j < C::NXI; ++j) {
+                const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
+                const bool ok = (DP * CGB % NT == 0 || tid + j * NT < DP * CGB) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+                xr[st][j] = load8_raw(ok ? cb + (dy * W + dx) * pitch : base);
+                okx |= ok ? 1u << (st * C::NXI + j) : 0u;
+            }
+        }
+    };
+    const int kg = lane >> 4;
+    auto tap_off = [](int tap) constexpr -> int { return tap < 9 ? ((tap / 3) * DW_ + tap % 3) * PX : 0; };
+    auto boff_of = [&](int kc, bool& valid) -> int {
+        if constexpr (CINB == 32) {
+            valid = true;
+            return tap_off(kc) + kg * 8;
+        } else if constexpr (CINB == 16) {
+            const int t0 = 2 * kc, t1 = 2 * kc + 1;
+            valid = (kg < 2) ? t0 < 9 : t1 < 9;
+            return ((kg < 2) ? tap_off(t0) : tap_off(t1)) + (kg & 1) * 8;
+        } else {
+            const int t0 = 4 * kc;
+            valid = t0 + kg < 9;
+            const int a = (kg & 1) ? tap_off(t0 + 1) : tap_off(t0), b = (kg & 1) ? tap_off(t0 + 3) : tap_off(t0 + 2);
+            return (kg & 2) ? b : a;
+        }
+    };
+    // N tiles of this wave: unit u = wave * UPW + i -> row pair u >> 1, column half u & 1; tile a = 2 * i + (row within the pair)
+    int pty[NPW], ptx[NPW];
+#pragma unroll
+    for (int a = 0; a < NPW; ++a) {
+        const int u = wave * C::UPW + (a >> 1);
+        pty[a] = 2 * (u >> 1) + (a & 1);
+        ptx[a] = (u & 1) * 16 + (lane & 15);
+    }
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1[b][i] = s2[b][i] = 0.f;
+    float sg[POOL ? MT : 1][4];
+    if constexpr (POOL) {
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = b * 16 + (lane >> 4) * 4 + i;
+                sg[b][i] = (m < COUT && gamma[m] < 0.f) ? -1.f : 1.f;
+            }
+    }
+
+    TileSched ts(tg.ntiles);
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);
+    TileOrg org_next = tit.org();
+    if (ts.first < ts.end) issue(org_next);
+    for (long t = ts.first; t < ts.end; t += ts.step) {
+        const TileOrg org = org_next;
+        f32x4 acc[NPW][MT];
+#pragma unroll
+        for (int a = 0; a < NPW; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            if (st) lds_barrier();  // the previous stage's readers are done
+            // ---- commit stage st: x~ -> tileX (four channels at a time)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float* tp = s_trx + (st * CGB + cgb) * 24 + hf * 4;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(tp), sh = *reinterpret_cast<const f32x4*>(tp + 8), lo = *reinterpret_cast<const f32x4*>(tp + 16);
+#pragma unroll
+                for (int j = 0; j < C::NXI; ++j) {
+                    const int it = tid + j * NT;
+                    if (DP * CGB % NT == 0 || it < DP * CGB) {
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (okx & (1u << (st * C::NXI + j))) {
+                            half4(xr[st][j], hf, v);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                        }
+                        st4bf(tileX + (it / CGB) * PX + cgb * 8 + hf * 4, v);
+                    }
+                }
+            }
+            if (st == NST - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + ts.step < ts.end) {
+                    tit.next();
+                    org_next = tit.org();
+                    issue(org_next);
+                }
+            }
+            lds_barrier();
+            // ---- MFMA: all K chunks of this stage
+            int pbase[NPW];
+#pragma unroll
+            for (int a = 0; a < NPW; ++a) pbase[a] = (pty[a] * DW_ + ptx[a]) * PX;
+            uint4 bcur[NPW], bnxt[NPW];
+            auto load_b = [&](uint4 (&dst)[NPW], int kc) {
+                bool bv;
+                const int bo = boff_of(kc, bv);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) {
+                    dst[a] = *reinterpret_cast<const uint4*>(tileX + pbase[a] + bo);
+                    if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
+                }
+            };
+            load_b(bcur, 0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                uint4 wf[MT];
+#pragma unroll
+                for (int b = 0; b < MT; ++b) wf[b] = s_wf[((st * MT + b) * KC + kc) * 64 + lane];
+                if (kc + 1 < KC) load_b(bnxt, kc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a)
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] = mfma16(wf[b], bcur[a], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
+            }
+        }
+        // ---- epilogue: store z (4 consecutive channels per lane), statistics of the STORED values, optional 2x2 max-pool
+        const long tb = ((long)org.n * H + org.h0) * W + org.w0;
+#pragma unroll
+        for (int a = 0; a < NPW; ++a) {
+            const bool pv = org.h0 + pty[a] < H && org.w0 + ptx[a] < W;
+            const long pix = tb + (long)pty[a] * W + ptx[a];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int m0 = b * 16 + (lane >> 4) * 4;
+                if (pv && m0 < COUT) {
+                    const f32x4 v = acc[a][b];
+                    store4(z + pix * COUT + m0, v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float q = Elem<bf16>::round(v[i]);
+                        s1[b][i] += q;
+                        s2[b][i] = fmaf(q, q, s2[b][i]);
+                    }
+                }
+            }
+        }
+        if constexpr (POOL) {
+            // relu(bn(z)) is monotone in z with the sign of gamma: the window's selected element is max z (gamma >= 0) or min z (gamma < 0); a window =
+            // this lane's pixel and lane ^ 1 (same row) of N tiles a (even row) and a + 1 (the row below); see k_dwpw_fwd
+            const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+            for (int a = 0; a < NPW; a += 2) {
+                const int ph = (org.h0 + pty[a]) >> 1, pw = (org.w0 + ptx[a]) >> 1;
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    const int m0 = b * 16 + (lane >> 4) * 4;
+                    float m4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v0 = sg[b][i] * Elem<bf16>::round(acc[a][b][i]), v1 = sg[b][i] * Elem<bf16>::round(acc[a + 1][b][i]);
+                        const float vv = fmaxf(v0, v1);
+                        m4[i] = sg[b][i] * fmaxf(vv, dpp_f<0xB1>(vv));  // quad_perm [1,0,3,2]: the horizontally adjacent pixel
+                    }
+                    if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
+                        store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
+                }
+            }
+        }
+        lds_barrier();  // all readers of tileX are done before the next commit
+    }
+    // ---- statistics: lanes -> wave slots -> block partial [COUT][sum | sum of squares] (fixed order: deterministic)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a1 = quad16_sum(s1[b][i]), a2 = quad16_sum(s2[b][i]);
+            if ((lane & 15) == 0) {
+                const int m = b * 16 + (lane >> 4) * 4 + i;
+                s_stat[(wave * MT * 16 + m) * 2 + 0] = a1;
+                s_stat[(wave * MT * 16 + m) * 2 + 1] = a2;
+            }
+        }
+    __syncthreads();
+    for (int e = tid; e < 2 * COUT; e += NT) {
+        float s = 0.f;
+        for (int w = 0; w < C::NW; ++w) s += s_stat[w * MT * 32 + e];
+        ws[(long)blockIdx.x * (2 * COUT) + e] = s;
+    }
+}
+
+// BatchNorm2d training statistics from per-block partials [nparts][C][sum | sum of squares] (fp32 partials, fp64 total, fixed summation order:
+// bit-reproducible) -> load transform, saved mean | rstd, running statistics.  Same arithmetic as k_bn_finalize (det_fwd.hip).
+__global__ __launch_bounds__(256) void k_bn_finalize_parts(const float* __restrict__ parts, int nparts, long count, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum, float* __restrict__ tr,
+                                                           float* __restrict__ saved, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                           long long* __restrict__ nbt, float lo) {
+    __shared__ double red[8][32];
+    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + col;  // element of [C][2]
+    double s = 0.0;
+    if (e < 2 * C)
+        for (int b = chain; b < nparts; b += 8) s += (double)parts[(long)b * 2 * C + e];
+    red[chain][col] = s;
+    __syncthreads();
+    if (chain != 0) return;
+    const double tot = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    red[0][col] = tot;
+    __syncthreads();  // (only chain 0 = one wave half reaches here: 32 lanes of the first wave)
+    if (e == 0 && nbt) *nbt += 1;
+    if (e >= 2 * C || (e & 1)) return;
+    const int c = e >> 1;
+    const double mean = tot / (double)count;
+    double var = red[0][col + 1] / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    tr[c] = sc;
+    tr[C + c] = beta[c] - (float)mean * sc;
+    tr[2 * C + c] = lo;
+    saved[c] = (float)mean;
+    saved[C + c] = rstd;
+    if (run_mean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+template <int CINB, int NST, int COUT>
+static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, bf16* z, float* ws, const float* gamma,
+                          bf16* pooled, int N, int H, int W, int nb, hipStream_t st) {
+    using CC = MfCfg<CINB, NST, COUT>;
+    const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+        attr_set = true;
+    }
+    if (pooled)
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled);
+    else
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, false>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled);
+}
+
+extern "C" {
+
+long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
+    if (dtype != 1 || !(Cout == 8 || Cout == 16 || Cout == 32)) return 0;
+    const int Cin = Ca + Cb;
+    if (Ca == 32 && Cb == 32) return Cout == 32;
+    if ((Cin == 8 && Cout == 32) || (Cin == 32 && Cout == 8)) return 0;
+    return (Cin == 8 || Cin == 16 || Cin == 32) && Ca % 8 == 0 && Cb % 8 == 0;
+}
+// number of per-block statistics partials ocrs_mm_fwd writes (ws = that many x 2 * Cout floats)
+long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
+    const int cinb = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
+    const int th = mm_th(cinb, Cout);
+    return mm_grid(th, N, H, W, 0);
+}
+
+// DepthwiseConv block forward on the matrix cores up to the pre-BatchNorm output (replaces ocrs_dwpw_fwd for bf16, Cin / Cout in {8, 16, 32}
+// and the 32 | 32 concat): wdw [Cin][9] / wpw [Cout][Cin] fp32 masters; z [P][Cout]; ws: ocrs_mm_fwd_nparts() x [Cout][sum | sum^2] fp32
+// per-block partials of the batch statistics (-> ocrs_bn_finalize_parts); gamma / pooled (nullable): as ocrs_dwpw_fwd.
+int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
+                const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && wpw && z && ws && (Cb == 0 || (xb && trb)) && (!pooled || gamma));
+    OCRS_CHECK_ARG(ocrs_mm_fwd_supported(Ca, Cb, Cout, dtype) && (long)N * (H + 2) * (W + 2) < (1L << 31));
+    const int Cin = Ca + Cb;
+    Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
+    const int nb = (int)ocrs_mm_fwd_nparts(Ca, Cb, Cout, N, H, W);
+#define MF_CASE(CB_, NS_, CO_) \
+    if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, st);
+    MF_CASE(8, 1, 8) MF_CASE(8, 1, 16) MF_CASE(16, 1, 8) MF_CASE(16, 1, 16) MF_CASE(16, 1, 32) MF_CASE(32, 1, 16) MF_CASE(32, 1, 32) MF_CASE(32, 2, 32)
+#undef MF_CASE
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// nn.BatchNorm2d training statistics from ocrs_mm_fwd's per-block partials (models.py:23): see ocrs_bn_finalize.
+int ocrs_bn_finalize_parts(const float* parts, int nparts, long count, int C, const float* gamma, const float* beta, float eps, float momentum, float* tr,
+                           float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st) {
+    OCRS_CHECK_ARG(parts && nparts > 0 && gamma && beta && tr && saved && C > 0 && count > 0);
+    hipLaunchKernelGGL(k_bn_finalize_parts, dim3((2 * C + 31) / 32), dim3(256), 0, st, parts, nparts, count, C, gamma, beta, eps, momentum, tr, saved, run_mean,
+                       run_var, nbt, lo);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

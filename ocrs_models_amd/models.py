@@ -173,11 +173,15 @@ class _DetRun:
         self.L.pack_frags_multi(ptr(table), n, maxthr, self.dt)
         self.packs = views
 
-    def bn_tr(self, prefix, gstat, count, C):
+    def bn_tr(self, prefix, gstat, count, C, nparts=0):
+        """gstat: fp64 [2][C] accumulated sums, or (nparts > 0) fp32 per-block partials [nparts][C][2] of the matrix-core forward"""
         P, Bf = self.P, self.Bf
         tr = self.empty(3, C, dtype=torch.float32)
         saved = self.empty(2, C, dtype=torch.float32)
-        if self.train:
+        if self.train and nparts:
+            self.L.bn_finalize_parts(ptr(gstat), nparts, count, C, ptr(P[f"{prefix}.weight"]), ptr(P[f"{prefix}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved),
+                                     ptr(Bf[f"{prefix}.running_mean"]), ptr(Bf[f"{prefix}.running_var"]), ptr(Bf[f"{prefix}.num_batches_tracked"]), 0.0)
+        elif self.train:
             self.L.bn_finalize(ptr(gstat), count, C, ptr(P[f"{prefix}.weight"]), ptr(P[f"{prefix}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved),
                                ptr(Bf[f"{prefix}.running_mean"]), ptr(Bf[f"{prefix}.running_var"]), ptr(Bf[f"{prefix}.num_batches_tracked"]), 0.0)
         else:
@@ -195,8 +199,24 @@ class _DetRun:
         H, W = a.H, a.W
         Cin = a.C + (b.C if b is not None else 0)
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
-        wpk = self.pack(wpw, 0, Cin, Cout, Cin, 0, 1, Cin)
         z = self.empty(N, H, W, Cout)
+        Cb = b.C if b is not None else 0
+        if self.use_mm and L.mm_fwd_supported(a.C, Cb, Cout, self.dt):
+            # depthwise + pointwise as ONE implicit GEMM on the matrix cores; batch statistics as deterministic per-block partials
+            pooled = gamma = None
+            if pool and self.fuse_pool:
+                pooled, gamma = self.empty(N, H // 2, W // 2, Cout), P[f"{prefix}.seq.2.weight"]
+            self.pooled_by_block = pooled
+            nparts = L.mm_fwd_nparts(a.C, Cb, Cout, N, H, W)
+            parts = self.empty(nparts * 2 * Cout, dtype=torch.float32)
+            L.mm_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                     ptr(z), ptr(parts), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
+            tr, saved = self.bn_tr(f"{prefix}.seq.2", parts, N * H * W, Cout, nparts=nparts)
+            r = _BlockRec()
+            r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
+            self.recs[prefix] = r
+            return _Act(z, tr, Cout, H, W, src=prefix)
+        wpk = self.pack(wpw, 0, Cin, Cout, Cin, 0, 1, Cin)
         gstat = self.zeros64(2 * Cout)
         pooled = gamma = None
         if pool and self.fuse_pool and L.dwpw_fwd_pool_supported(Cin, Cout):
@@ -391,6 +411,9 @@ class _DetRun:
 def _check_versions(ctx):
     """Backward reads the LIVE parameters (run.P aliases them): refuse, like stock autograd's version-counter check, when one was
     modified in place (e.g. optimizer.step()) between this forward and its backward."""
+    if ctx.run is None:
+        raise RuntimeError("Trying to backward through the graph a second time: the saved activations of this network were freed by the first "
+                           "backward (retain_graph is not supported by the fused whole-network autograd node)")
     for p, v in zip(ctx.params, ctx.versions):
         if p._version != v:
             raise RuntimeError("one of the parameters needed for gradient computation has been modified by an inplace operation "
@@ -411,6 +434,9 @@ class _DetFn(torch.autograd.Function):
     def backward(ctx, gpred):
         _check_versions(ctx)
         grads = ctx.run.backward(gpred)
+        # free the saved activations now (like autograd without retain_graph) -- this also breaks the reference cycle
+        # pred -> grad_fn -> ctx -> run -> pred, which would otherwise keep ~15 GB per step alive until the cyclic GC runs
+        ctx.run = None
         return (None, None, None, *grads)
 
 

@@ -334,6 +334,7 @@ class _RecFn(torch.autograd.Function):
     def backward(ctx, g):
         _check_versions(ctx)
         grads = ctx.run.backward(g)
+        ctx.run = None  # free the saved activations (and break the output -> grad_fn -> ctx -> run cycle)
         return (None, None, None, None, *grads)
 
 
