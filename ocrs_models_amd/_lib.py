@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocrs_hip.so")
+LIB_PATH = os.environ.get("OCRS_LIB_PATH") or os.path.join(_HERE, "libocrs_hip.so")  # (OCRS_LIB_PATH: measurement builds, tools/build_variant.sh)
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
 

@@ -16,6 +16,24 @@
 // SURVEY.md 8(d); du is never formed.  All flushes are per-block partials reduced by ONE deterministic kernel (no atomics).
 #include "det_common.h"
 
+// ---- tile-shape / residency knobs (measurement builds: tools/build_variant.sh; the defaults are the measured optimum, profiles/README.md)
+#ifndef OCRS_MM_TH
+#define OCRS_MM_TH 8       // backward tile rows, Cin and Cout <= 16 (16 halves the ring re-reads but spills at 128 registers)
+#endif
+#ifndef OCRS_MM_C32_BPC
+#define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
+                           // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
+#endif
+#ifndef OCRS_MF_TH8
+#define OCRS_MF_TH8 16     // forward tile rows, Cin = 8 (measured: 16 rows x 2 blocks/CU 300 us, 8 rows x 3 blocks/CU 329 us, 8 x 2: 356 us at level 0)
+#endif
+#ifndef OCRS_MF_TH16
+#define OCRS_MF_TH16 8     // forward tile rows, Cin = 16 (16 spills)
+#endif
+#ifndef OCRS_MF_BPC8
+#define OCRS_MF_BPC8 2     // forward blocks per CU, Cin = 8
+#endif
+
 namespace {
 
 template <int C>
@@ -26,16 +44,10 @@ struct MmPitch {  // bf16 elements per pixel of an LDS tile: 16 / 32-byte rows a
 template <int CIN, int COUT>
 struct MmCfg {
     static constexpr int NT = 512, NW = NT / 64;                       // 8 waves
-#ifndef OCRS_MM_TH
-#define OCRS_MM_TH 8  // tile rows for the configurations without a 32-channel side (those always use 8): 16 halves the ring re-reads, needs ~12 more VGPRs
-#endif
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
-#ifndef OCRS_MM_C32_BPC
-#define OCRS_MM_C32_BPC 1
-#endif
-    static constexpr int BPC = (CIN == 32) ? OCRS_MM_C32_BPC : 2;      // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
-    static constexpr int TW = 32, TH = (CIN == 32) ? (OCRS_MM_C32_BPC == 1 ? 16 : 8) : (COUT == 32 ? 8 : OCRS_MM_TH), TP = TW * TH;
+    static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : 2;  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
+    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : OCRS_MM_TH, TP = TW * TH;
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -79,15 +91,18 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
 }
 
-template <int CIN>
-constexpr int mm_bwd_lb() { return CIN == 32 ? 2 * OCRS_MM_C32_BPC : 4; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
+// forward: Cin = 8 needs < 80 registers and ~10 KB of LDS: three blocks per CU (more bytes in flight: these launches are latency-bound)
+template <int CINB>
+constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : 4; }
+template <int CIN, int COUT>
+constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT>::BPC; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
-__global__ __launch_bounds__(512, mm_bwd_lb<CIN>()) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
@@ -249,11 +264,11 @@ __global__ __launch_bounds__(512, mm_bwd_lb<CIN>()) void k_mm_bwd(Src2<bf16> x, 
     };
     // own unit / k-step range of this wave, and its share of the last unit: ONE (M tile, N tile) sub-tile of it over a range of k-steps
     // (a whole-unit share would need a second full accumulator set: 16 more registers at 32 x 32 channels)
-    constexpr int NSUB = MT * NTO, NKR = C::NW / NSUB, KSHR = KS / NKR;
-    static_assert(C::NW % NSUB == 0 && KS % NKR == 0, "shared-unit split");
+    constexpr int NSUB = MT * NTO, NKR = C::NW / NSUB;
+    static_assert(C::NW % NSUB == 0 && KS >= NKR, "shared-unit split");
     const int u_own = (C::TAPU == 9) ? wave : (wave & 3);
     const int ks_own0 = (C::TAPU == 9) ? 0 : (wave >> 2) * (KS / 2), ks_own1 = (C::TAPU == 9) ? KS : ks_own0 + KS / 2;
-    const int sh_a = (wave % NSUB) % MT, sh_b = (wave % NSUB) / MT, sh_k0 = (wave / NSUB) * KSHR;
+    const int sh_a = (wave % NSUB) % MT, sh_b = (wave % NSUB) / MT, sh_k0 = (wave / NSUB) * KS / NKR, sh_k1 = (wave / NSUB + 1) * KS / NKR;
     const int off_own = unit_off(u_own), off_sh = unit_off(C::TAPU - 1) + sh_b * 16;
     f32x4 accO[MT][NTO], accS = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(512, mm_bwd_lb<CIN>()) void k_mm_bwd(Src2<bf16> x, 
         {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= sh_k0 && ks < sh_k0 + KSHR;
+                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= sh_k0 && ks < sh_k1;
                 if (!own && !shr) continue;  // (wave-uniform)
                 bf16x8 af[MT];
 #pragma unroll
@@ -598,9 +613,19 @@ __global__ __launch_bounds__(256) void k_mm_bwd_reduce(const float* __restrict__
     const int nelem = COUT * CIN + 11 * CIN;
     const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + col;
+    // chain c sums partials c, c+8, c+16, ...: eight independent accumulators keep eight loads in flight (the loop is pure L2 latency); the
+    // association order is fixed, so the result is bit-reproducible
     float s = 0.f;
-    if (e < nelem)
-        for (int b = chain; b < nb; b += 8) s += ws[(long)b * nelem + e];
+    if (e < nelem) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = chain;
+        for (; b + 56 < nb; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ws[(long)(b + 8 * u) * nelem + e];
+        }
+        for (int u = 0; b < nb; b += 8, ++u) a[u & 7] += ws[(long)b * nelem + e];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[chain][col] = s;
     __syncthreads();
     __shared__ float fin[32];
@@ -640,9 +665,9 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
     const long ntiles = (long)N * ((W + pooled + 31) / 32) * ((H + pooled + th - 1) / th);
     return persistent_grid(ntiles, bpc);
 }
-static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : OCRS_MM_TH; }  // forward tiles
-static int mm_bwd_th(int Cin, int Cout) { return Cin == 32 ? (OCRS_MM_C32_BPC == 1 ? 16 : 8) : (Cout == 32 ? 8 : OCRS_MM_TH); }
-static int mm_bwd_bpc(int Cin) { return Cin == 32 ? OCRS_MM_C32_BPC : 2; }
+static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : (Cin == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16); }  // forward tiles
+static int mm_bwd_bpc(int Cin, int Cout) { return (Cin == 32 && Cout == 32) ? OCRS_MM_C32_BPC : 2; }
+static int mm_bwd_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? (mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8) : OCRS_MM_TH; }
 
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
@@ -687,7 +712,7 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 }
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
-    return (long)mm_grid(mm_bwd_th(Cin, Cout), N, H, W, 1, mm_bwd_bpc(Cin)) * (Cout * Cin + 11 * Cin);
+    return (long)mm_grid(mm_bwd_th(Cin, Cout), N, H, W, 1, mm_bwd_bpc(Cin, Cout)) * (Cout * Cin + 11 * Cin);
 }
 
 // Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
@@ -717,7 +742,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const float* svB = split ? nullptr : saved_b;
         double* gsB = split ? nullptr : gsum_b;
         const bool stats = gsA || gsB;
-        const int nb = mm_grid(mm_bwd_th(Cin, Cout), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin));
+        const int nb = mm_grid(mm_bwd_th(Cin, Cout), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
 #define MM_CASE(CI_, CO_)                                                                                                             \
@@ -745,7 +770,7 @@ namespace {
 template <int CINB, int NST, int COUT>
 struct MfCfg {
     static constexpr int NT = 512, NW = 8;
-    static constexpr int TW = 32, TH = (CINB == 32 || COUT == 32) ? 8 : OCRS_MM_TH, TP = TW * TH;
+    static constexpr int TW = 32, TH = (CINB == 32 || COUT == 32) ? 8 : (CINB == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16), TP = TW * TH;
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;
     static constexpr int CGB = CINB / 8;
     static constexpr int PX = MmPitch<CINB>::V;
@@ -762,7 +787,7 @@ struct MfCfg {
 }  // namespace
 
 template <int CINB, int NST, int COUT, bool POOL>
-__global__ __launch_bounds__(512, 4) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
                                                    bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
                                                    const float* __restrict__ gamma, bf16* __restrict__ pooled) {
@@ -1018,8 +1043,16 @@ __global__ __launch_bounds__(256) void k_bn_finalize_parts(const float* __restri
     const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + col;  // element of [C][2]
     double s = 0.0;
-    if (e < 2 * C)
-        for (int b = chain; b < nparts; b += 8) s += (double)parts[(long)b * 2 * C + e];
+    if (e < 2 * C) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight loads in flight per chain, fixed association order
+        int b = chain;
+        for (; b + 56 < nparts; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += (double)parts[(long)(b + 8 * u) * 2 * C + e];
+        }
+        for (int u = 0; b < nparts; b += 8, ++u) a[u & 7] += (double)parts[(long)b * 2 * C + e];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[chain][col] = s;
     __syncthreads();
     if (chain != 0) return;
@@ -1076,7 +1109,7 @@ long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
 long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int cinb = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int th = mm_th(cinb, Cout);
-    return mm_grid(th, N, H, W, 0);
+    return mm_grid(th, N, H, W, 0, cinb == 8 ? OCRS_MF_BPC8 : 2);
 }
 
 // DepthwiseConv block forward on the matrix cores up to the pre-BatchNorm output (replaces ocrs_dwpw_fwd for bf16, Cin / Cout in {8, 16, 32}
