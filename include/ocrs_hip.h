@@ -172,6 +172,13 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
                  int T, int N, int C, int Lpad, int Smax, hipStream_t st);
 int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
                  const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+/* The same with the alpha lattice kept for the backward in fp16 (BASELINE configs[4] "fp16 CTC alpha/beta"; SURVEY D5: a separately-toleranced
+ * variant): alpha16 [N][T][Smax] fp16 = alpha - rowmax, rowmax [N][T] fp32 (row maximum per time step).  The recursion and the loss stay fp32
+ * (identical loss bits); the gradient sees the fp16 rounding of the lattice (~1e-3 relative). */
+int ocrs_ctc_fwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, void* alpha16, float* rowmax, float* nll,
+                     float* loss, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+int ocrs_ctc_bwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const void* alpha16, const float* rowmax,
+                     const float* nll, const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
 /* preds.argmax(-1) + ctc_greedy_decode_text's collapse (train_rec.py:52; datasets/util.py:147-177). */
 int ocrs_ctc_greedy_decode(const float* lp, const long long* in_len, int* amax, int* labels, int* lens, int T, int N, int C, hipStream_t st);
 

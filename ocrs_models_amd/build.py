@@ -64,5 +64,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+TORCH_OPS_SRC = os.path.join(CSRC, "torch_ops.cpp")
+TORCH_OPS_LIB = os.path.join(HERE, "libocrs_torch_ops.so")
+
+
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """libocrs_torch_ops.so: TORCH_LIBRARY(ocrs, ...) registration of C-ABI entry points as torch.ops.ocrs.* (host-only C++, links
+    libocrs_hip.so through an $ORIGIN rpath and the libtorch of the running interpreter)."""
+    import torch
+
+    header = os.path.join(os.path.dirname(HERE), "include", "ocrs_hip.h")
+    if not (force or _newer(TORCH_OPS_SRC, TORCH_OPS_LIB) or _newer(header, TORCH_OPS_LIB) or _newer(LIB, TORCH_OPS_LIB)):
+        return TORCH_OPS_LIB
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include",
+           "-I/opt/rocm/include", "-x", "c++", TORCH_OPS_SRC, "-o", TORCH_OPS_LIB, f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10",
+           "-lc10_hip", f"-L{HERE}", "-locrs_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"torch ops build failed:\n{r.stdout}\n{r.stderr}")
+    return TORCH_OPS_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_torch_ops(force="--force" in sys.argv))

@@ -60,10 +60,26 @@ __global__ __launch_bounds__(256) void k_log_softmax_bwd(const float* __restrict
 //   alpha   [N][T][Smax] fp32 workspace;  nll [N] fp32
 static constexpr int CTC_SPT = 3;  // states per thread: supports S <= 768 (L <= 383)
 
+// H16 (the separately-toleranced "fp16 alpha/beta" variant of BASELINE configs[4]): the alpha lattice kept for the backward is stored as
+// fp16 of (alpha[t][s] - max_s alpha[t][s]) plus one fp32 row maximum per time step -- half the lattice bytes; the states that carry
+// probability mass sit within a few units of the row maximum, where fp16 resolves <= 2^-8.  The recursion itself (LDS rolling rows) and the
+// loss stay fp32, so the loss is IDENTICAL to the fp32 variant; only the gradient sees the rounding (measured ~1e-3 relative).
+__device__ __forceinline__ float block_max256(float v, float* s_red /*[4]*/) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    return m;
+}
+template <bool H16>
 __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
-                                                   const long long* __restrict__ tg_len, float* __restrict__ alpha, float* __restrict__ nll,
-                                                   int T, int N, int C, int Lpad, int Smax) {
+                                                   const long long* __restrict__ tg_len, void* __restrict__ alpha_v, float* __restrict__ rowmax,
+                                                   float* __restrict__ nll, int T, int N, int C, int Lpad, int Smax) {
     __shared__ float row[2][256 * CTC_SPT + 2];
+    __shared__ float s_red[4];
+    float* alpha = reinterpret_cast<float*>(alpha_v);
+    _Float16* alpha16 = reinterpret_cast<_Float16*>(alpha_v);
     const int n = blockIdx.x;
     // device-side lengths are clamped to the tensor extents (torch raises for input_lengths > T / target_lengths > Lpad on host lengths --
     // losses.py does the same check there; lengths that only exist on the device cannot raise without a sync, so they must not go out of bounds)
@@ -74,6 +90,7 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
     const int S = 2 * L + 1;
     const int* tg = targets + (long)n * Lpad;
     float* al = alpha + (long)n * T * Smax;
+    _Float16* al16 = alpha16 + (long)n * T * Smax;
     int ext[CTC_SPT];
     bool skip[CTC_SPT];
 #pragma unroll
@@ -82,35 +99,63 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
         ext[j] = (s < S && (s & 1)) ? tg[s >> 1] : 0;
         skip[j] = s < S && (s & 1) && s >= 2 && tg[s >> 1] != tg[(s >> 1) - 1];
     }
+    // store one lattice row: fp32 as is, or fp16 relative to the row maximum (a block reduction per time step)
+    auto store_row = [&](int t, const float (&a)[CTC_SPT]) {
+        if constexpr (!H16) {
+#pragma unroll
+            for (int j = 0; j < CTC_SPT; ++j) {
+                const int s = threadIdx.x + j * 256;
+                if (s < S) al[(long)t * Smax + s] = a[j];
+            }
+        } else {
+            float m = NEG_INF;
+#pragma unroll
+            for (int j = 0; j < CTC_SPT; ++j) m = fmaxf(m, a[j]);
+            m = block_max256(m, s_red);
+            if (threadIdx.x == 0) rowmax[(long)n * T + t] = m;
+#pragma unroll
+            for (int j = 0; j < CTC_SPT; ++j) {
+                const int s = threadIdx.x + j * 256;
+                if (s < S) al16[(long)t * Smax + s] = (_Float16)((a[j] == NEG_INF || m == NEG_INF) ? -65504.f : fmaxf(a[j] - m, -65504.f));
+            }
+        }
+    };
     if (Ti <= 0) {
         if (threadIdx.x == 0) nll[n] = (L == 0) ? 0.f : -NEG_INF;
         return;
     }
     // t = 0
     // rolling rows: state s lives at index s + 2; indices 0,1 are -inf pad slots (written below)
+    {
+        float a0v[CTC_SPT];
 #pragma unroll
-    for (int j = 0; j < CTC_SPT; ++j) {
-        const int s = threadIdx.x + j * 256;
-        float a = NEG_INF;
-        if (s < S && s < 2) a = lp[(long)n * C + ext[j]];
-        row[0][s + 2] = a;
-        if (s < S) al[s] = a;
+        for (int j = 0; j < CTC_SPT; ++j) {
+            const int s = threadIdx.x + j * 256;
+            float a = NEG_INF;
+            if (s < S && s < 2) a = lp[(long)n * C + ext[j]];
+            row[0][s + 2] = a;
+            a0v[j] = s < S ? a : NEG_INF;
+        }
+        store_row(0, a0v);
     }
     if (threadIdx.x < 2) row[0][threadIdx.x] = row[1][threadIdx.x] = NEG_INF;
     __syncthreads();
     int cur = 0;
     for (int t = 1; t < Ti; ++t) {
         const float* lpt = lp + ((long)t * N + n) * C;
+        float av[CTC_SPT];
 #pragma unroll
         for (int j = 0; j < CTC_SPT; ++j) {
             const int s = threadIdx.x + j * 256;
+            av[j] = NEG_INF;
             if (s < S) {
                 const float a0 = row[cur][s + 2], a1 = row[cur][s + 1], a2 = skip[j] ? row[cur][s] : NEG_INF;
                 const float a = lse3(a0, a1, a2) + lpt[ext[j]];
                 row[cur ^ 1][s + 2] = a;
-                al[(long)t * Smax + s] = a;
+                av[j] = a;
             }
         }
+        store_row(t, av);
         cur ^= 1;
         __syncthreads();
     }
@@ -137,12 +182,13 @@ __global__ __launch_bounds__(256) void k_ctc_reduce(const float* __restrict__ nl
 }
 
 // CTC backward: beta recursion + gradient, one block per sample.  grad [T][N][C] is fully written (zeros for t >= T_n).
+template <bool H16>
 __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
-                                                       const long long* __restrict__ tg_len, const float* __restrict__ alpha,
-                                                       const float* __restrict__ nll, const float* __restrict__ gout, float* __restrict__ grad,
-                                                       int T, int N, int C, int Lpad, int Smax) {
+                                                       const long long* __restrict__ tg_len, const void* __restrict__ alpha_v,
+                                                       const float* __restrict__ rowmax, const float* __restrict__ nll,
+                                                       const float* __restrict__ gout, float* __restrict__ grad, int T, int N, int C, int Lpad, int Smax) {
     __shared__ float row[2][256 * CTC_SPT + 2];
-    extern __shared__ float s_occ[];  // [C]
+    extern __shared__ unsigned s_occ[];  // [C] state-occupancy sums per class in 2^-30 fixed point (see below)
     const int n = blockIdx.x;
     // device-side lengths are clamped to the tensor extents (torch raises for input_lengths > T / target_lengths > Lpad on host lengths --
     // losses.py does the same check there; lengths that only exist on the device cannot raise without a sync, so they must not go out of bounds)
@@ -152,7 +198,8 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
     L = 2 * L + 1 > Smax ? (Smax - 1) / 2 : L;
     const int S = 2 * L + 1;
     const int* tg = targets + (long)n * Lpad;
-    const float* al = alpha + (long)n * T * Smax;
+    const float* al = reinterpret_cast<const float*>(alpha_v) + (long)n * T * Smax;
+    const _Float16* al16 = reinterpret_cast<const _Float16*>(alpha_v) + (long)n * T * Smax;
     const float nl = nll[n];
     const float scale = gout[0] / ((float)N * (float)(L > 1 ? L : 1));
     int ext[CTC_SPT];
@@ -173,7 +220,9 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
     int cur = 0;
     for (int t = Ti - 1; t >= 0; --t) {
         const float* lpt = lp + ((long)t * N + n) * C;
-        for (int c = threadIdx.x; c < C; c += 256) s_occ[c] = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s_occ[c] = 0u;
+        float rm = 0.f;
+        if constexpr (H16) rm = rowmax[(long)n * T + t];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < CTC_SPT; ++j) {
@@ -187,13 +236,25 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
                     b = lse3(b0, b1, b2) + lpt[ext[j]];
                 }
                 row[cur ^ 1][s] = b;
-                const float ab = al[(long)t * Smax + s] + b;
-                if (ab != NEG_INF) atomicAdd(&s_occ[ext[j]], expf(ab + nl - lpt[ext[j]]));
+                float a;
+                if constexpr (H16) {
+                    const float d = (float)al16[(long)t * Smax + s];
+                    a = d <= -65504.f ? NEG_INF : d + rm;
+                } else
+                    a = al[(long)t * Smax + s];
+                const float ab = a + b;
+                // occupancy gamma_t(s) = exp(alpha + beta - lp + nll) in [0, 1], summed per class.  Accumulated as 2^-30 fixed point with INTEGER
+                // LDS atomics: integer addition is associative, so the sum does not depend on the order the waves arrive in (float LDS atomics
+                // made this gradient differ in the last bits from run to run); resolution 9e-10 absolute, the class total is <= 1 (+ rounding)
+                if (ab != NEG_INF) {
+                    const float g = fminf(expf(ab + nl - lpt[ext[j]]), 2.f);
+                    atomicAdd(&s_occ[ext[j]], (unsigned)(g * 1073741824.f + 0.5f));
+                }
             }
         }
         cur ^= 1;
         __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) grad[((long)t * N + n) * C + c] = (expf(lpt[c]) - s_occ[c]) * scale;
+        for (int c = threadIdx.x; c < C; c += 256) grad[((long)t * N + n) * C + c] = (expf(lpt[c]) - (float)s_occ[c] * (1.f / 1073741824.f)) * scale;
         __syncthreads();
     }
 }
@@ -277,7 +338,18 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
                  int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && nll && loss && T > 0 && N > 0 && C > 0);
     OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT && Smax >= 1);
-    hipLaunchKernelGGL(k_ctc_alpha, dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha, nll, T, N, C, Lpad, Smax);
+    hipLaunchKernelGGL(k_ctc_alpha<false>, dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
+    hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+// The "fp16 alpha/beta" variant (BASELINE configs[4]; SURVEY D5: offered as a separately-toleranced variant): the lattice kept for the
+// backward is alpha16 [N][T][Smax] fp16 = alpha - rowmax with rowmax [N][T] fp32.  Same loss bits as ocrs_ctc_fwd.
+int ocrs_ctc_fwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, void* alpha16, float* rowmax, float* nll,
+                     float* loss, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
+    OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha16 && rowmax && nll && loss && T > 0 && N > 0 && C > 0);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT && Smax >= 1);
+    hipLaunchKernelGGL(k_ctc_alpha<true>, dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, T, N, C, Lpad, Smax);
     hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -287,8 +359,16 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
 int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
                  const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && nll && gout && grad);
-    hipLaunchKernelGGL(k_ctc_beta_grad, dim3(N), dim3(256), C * sizeof(float), st, lp, targets, in_len, tg_len, alpha, nll, gout, grad, T, N, C,
-                       Lpad, Smax);
+    hipLaunchKernelGGL(k_ctc_beta_grad<false>, dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, (const void*)alpha,
+                       (const float*)nullptr, nll, gout, grad, T, N, C, Lpad, Smax);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int ocrs_ctc_bwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const void* alpha16, const float* rowmax,
+                     const float* nll, const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
+    OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha16 && rowmax && nll && gout && grad);
+    hipLaunchKernelGGL(k_ctc_beta_grad<true>, dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, gout, grad, T,
+                       N, C, Lpad, Smax);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -54,7 +54,7 @@ MAX_CTC_STATES = 768  # csrc/rec_seq.hip: CTC_SPT (3) states per thread x 256 th
 
 class _CTC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_probs, targets, in_len, tg_len, smax=None):
+    def forward(ctx, log_probs, targets, in_len, tg_len, smax=None, h16=False):
         L = lib()
         lp = log_probs.contiguous().float()
         T, N, C = lp.shape
@@ -62,22 +62,31 @@ class _CTC(torch.autograd.Function):
         Lpad = tg.shape[1]
         Smax = smax or 2 * Lpad + 1
         dev = lp.device
-        alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
         nll = torch.empty(N, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
-        ctx.save_for_backward(lp, tg, in_len, tg_len, alpha, nll)
-        ctx.smax = Smax
+        if h16:
+            alpha = torch.empty(N, T, Smax, dtype=torch.float16, device=dev)
+            rowmax = torch.empty(N, T, dtype=torch.float32, device=dev)
+            L.ctc_fwd_h16(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(rowmax), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
+        else:
+            alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
+            rowmax = nll  # (unused)
+            L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
+        ctx.save_for_backward(lp, tg, in_len, tg_len, alpha, nll, rowmax)
+        ctx.smax, ctx.h16 = Smax, h16
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        lp, tg, in_len, tg_len, alpha, nll = ctx.saved_tensors
+        lp, tg, in_len, tg_len, alpha, nll, rowmax = ctx.saved_tensors
         T, N, C = lp.shape
         grad = torch.empty_like(lp)
         g = gout.contiguous().float().reshape(1)
-        lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
-        return grad, None, None, None, None
+        if ctx.h16:
+            lib().ctc_bwd_h16(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(rowmax), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
+        else:
+            lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
+        return grad, None, None, None, None, None
 
 
 class CTCLoss(torch.nn.Module):
@@ -87,10 +96,16 @@ class CTCLoss(torch.nn.Module):
     ``forward(log_probs (T,N,C), targets (N,Lpad) int, input_lengths (N,), target_lengths (N,))`` -> scalar loss.
     Lengths may be CPU tensors / lists as in the reference; they are moved to the device (no host sync)."""
 
-    def __init__(self, blank: int = 0, reduction: str = "mean", zero_infinity: bool = False):
+    def __init__(self, blank: int = 0, reduction: str = "mean", zero_infinity: bool = False, lattice_dtype: torch.dtype = torch.float32):
+        """``lattice_dtype=torch.float16``: keep the alpha lattice saved for the backward in fp16 relative to a per-time-step maximum (the
+        "fp16 CTC alpha/beta" variant of BASELINE configs[4]; half the lattice bytes, same loss bits, gradient within ~1e-3; the default and
+        parity mode is fp32)."""
         super().__init__()
         if blank != 0 or reduction != "mean" or zero_infinity:
             raise NotImplementedError("only torch.nn.CTCLoss() defaults are implemented (the reference's configuration)")
+        if lattice_dtype not in (torch.float32, torch.float16):
+            raise ValueError("lattice_dtype must be torch.float32 or torch.float16")
+        self.h16 = lattice_dtype == torch.float16
 
     def forward(self, log_probs, targets, input_lengths, target_lengths):
         if not log_probs.is_cuda:
@@ -115,4 +130,4 @@ class CTCLoss(torch.nn.Module):
         if (smax or 2 * targets.shape[1] + 1) > MAX_CTC_STATES:
             raise RuntimeError(f"CTC lattices wider than {MAX_CTC_STATES} states (targets longer than {(MAX_CTC_STATES - 1) // 2} labels) are not "
                                "supported by the LDS-resident alpha/beta kernels; pass host-side target_lengths so that the padding does not count")
-        return _CTC.apply(log_probs, targets.to(dev), il.to(dev, non_blocking=True), tl.to(dev, non_blocking=True), smax)
+        return _CTC.apply(log_probs, targets.to(dev), il.to(dev, non_blocking=True), tl.to(dev, non_blocking=True), smax, self.h16)

@@ -81,3 +81,17 @@ def test_recognition_state_dict_contract_matches_reference_keys():
 
     sd = oa.RecognitionModel(oa.text.DEFAULT_ALPHABET).state_dict()
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(n, s) for n, s, _ in recognition_specs()]
+
+
+def test_torch_library_ops_are_registered():
+    """TORCH_LIBRARY(ocrs, ...) registration over the C ABI builds, loads (no GPU needed) and exposes the schemas."""
+    from ocrs_models_amd import build as b
+    from ocrs_models_amd import torch_ops
+
+    b.build(verbose=False)
+    b.build_torch_ops(verbose=False)
+    torch_ops.load()
+    assert str(torch.ops.ocrs.head_fwd.default._schema) == "ocrs::head_fwd(Tensor z, Tensor tr, Tensor w, Tensor b) -> Tensor"
+    assert "ocrs::ctc_greedy_decode" in str(torch.ops.ocrs.ctc_greedy_decode.default._schema)
+    with pytest.raises((RuntimeError, NotImplementedError)):  # registered for the device backend only: no CPU kernel
+        torch.ops.ocrs.head_fwd(torch.zeros(1, 2, 2, 8), torch.zeros(3, 8), torch.zeros(8), torch.zeros(1))

@@ -183,6 +183,38 @@ def test_c_abi_error_codes(dev):
         L.dwpw_fwd(t.data_ptr(), None, 12, 0, t.data_ptr(), None, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, None, 12, 1, 1, 1, 0)
 
 
+def test_torch_library_ops_match_ctypes_binding(dev):
+    """torch.ops.ocrs.* (dispatcher-registered, csrc/torch_ops.cpp) and the ctypes binding launch the same kernels: bit-identical results."""
+    import ocrs_models_amd as oa
+    from ocrs_models_amd import torch_ops
+    from ocrs_models_amd._lib import lib, ptr
+
+    torch_ops.load()
+    L = lib()
+    g = torch.Generator().manual_seed(4)
+    for dtype in (torch.float32, torch.bfloat16):
+        z = torch.randn(2, 13, 21, 8, generator=g).to(dev).to(dtype)
+        tr = torch.stack([1 + 0.1 * torch.randn(8, generator=g), 0.1 * torch.randn(8, generator=g), torch.zeros(8)]).to(dev)
+        w, b = torch.randn(8, generator=g).to(dev), torch.randn(1, generator=g).to(dev)
+        p1 = torch.ops.ocrs.head_fwd(z, tr, w, b)
+        p2 = torch.empty(2, 1, 13, 21, device=dev)
+        L.head_fwd(ptr(z), ptr(tr), ptr(w), ptr(b), ptr(p2), 2 * 13 * 21, 0 if dtype == torch.float32 else 1)
+        assert p1.shape == p2.shape and torch.equal(p1, p2)
+        want = torch.sigmoid((torch.clamp_min(z.float() * tr[0] + tr[1], 0.0) * w).sum(-1) + b).unsqueeze(1)
+        assert rel(p1, want) < 1e-5
+        zp = torch.ops.ocrs.maxpool_fwd(z, tr, False)
+        want_p = torch.nn.functional.max_pool2d(torch.clamp_min(z.float() * tr[0] + tr[1], 0.0).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert rel(zp.float(), want_p) < (1e-6 if dtype == torch.float32 else 5e-3)
+    lp = torch.log_softmax(torch.randn(19, 5, 97, generator=g), -1).to(dev)
+    il = torch.tensor([19, 7, 12, 1, 15])
+    amax, labels, lens = torch.ops.ocrs.ctc_greedy_decode(lp, il.to(dev))
+    dec, amax2 = oa.text.greedy_decode_batch(lp, il.tolist())
+    assert torch.equal(amax, amax2)
+    assert [row[:n] for row, n in zip(labels.cpu().tolist(), lens.cpu().tolist())] == dec
+    with pytest.raises(RuntimeError):
+        torch.ops.ocrs.head_fwd(z[..., :4].contiguous(), tr, w, b)  # TORCH_CHECK -> RuntimeError, the reference's error convention
+
+
 # ------------------------------------------------------------------------------------------------ data parallel on RCCL
 def _free_port():
     with socket.socket() as s:
