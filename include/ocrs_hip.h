@@ -104,17 +104,21 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
                 const void* g1, const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw,
                 float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H,
                 int W, int dtype, hipStream_t st);
+/* acc64 [17] fp64 = dWpw [8] | dWdw [9], ACCUMULATED (caller-zeroed; the caller adds it to the fp32 gradients): fp64 sums of the per-block
+ * fp32 partials are exact, hence independent of the order the blocks finish in (float atomics into the fp32 gradients were not). */
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
-                     const float* bn, const float* coef, float* dwpw, float* dwdw, int N, int H, int W, int dtype, hipStream_t st);
+                     const float* bn, const float* coef, double* acc64, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of ConvTranspose2d + crop. */
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype);
 /* saved / gsum (nullable; need ocrs_convt_bwd_stats_supported): x is the raw output of a block consumed ONLY by this ConvTranspose -> its
  * BatchNorm-backward sums [2][Cup] (fp64, ACCUMULATED; saved = the block's [mean | rstd]) come from this pass instead of ocrs_bn_bwd_reduce. */
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws,
+/* dbias64 [Cout] fp64 (caller-zeroed): where the generic (deep-level) path accumulates the bias gradient; the caller adds it to dbias. */
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                    const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
 long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
 /* autograd of out_conv + sigmoid. */
-int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
+/* acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients; see ocrs_dwpw_c1_bwd). */
+int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,
                   const float* saved, double* gsum, long P, int dtype, hipStream_t st);
 
 /* ------------------------------------------------------------------ detection loss ---------- */

@@ -176,6 +176,26 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Deterministic block-level sum of N per-thread values (all threads of a 256-thread block contribute to the same N outputs): fixed wave
+// shuffle tree -> one LDS slot per (wave, value) -> thread i < N adds the four waves in order.  No atomics: float LDS atomics from several
+// waves onto one address complete in arrival order, which made every statistic that went through them differ in the last bits from run to
+// run.  s_slots: [4][N] floats.  Returns the block total to thread i (i < N); other threads get 0.
+template <int N>
+__device__ __forceinline__ float block_sum_det(const float (&v)[N], float* s_slots) {
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // s_slots may still be read from an earlier use
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float a = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if ((threadIdx.x & 63) == 0) s_slots[wave * N + i] = a;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    return i < N ? (s_slots[i] + s_slots[N + i]) + (s_slots[2 * N + i] + s_slots[3 * N + i]) : 0.f;
+}
+
 // sum over the 16 lanes sharing (lane >> 4) = one DPP row; every lane of the row gets the sum (4 DPP adds, no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

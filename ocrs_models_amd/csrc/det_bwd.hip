@@ -14,9 +14,7 @@ template <class T>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn /*[3][C]*/,
                                                        const float* __restrict__ saved /*[2][C]*/, double* __restrict__ gsum /*[2][C]*/,
                                                        int C, int H, int W, long P) {
-    extern __shared__ float s_acc[];  // [2][C]
-    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float s_acc[];  // [2][C] (unused) | [256][16] per-thread partials
     const int CG = C / 8;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long nthr = (long)gridDim.x * 256;
@@ -85,13 +83,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(GradSrc<T> gs, const T* _
             }
         }
     }
+    // deterministic block sum: every thread parks its 16 partials in LDS, thread j adds the 256 / CG threads of its channel group in order
+    // (float LDS atomics complete in arrival order: the sums differed in the last bits from run to run); across blocks: fp64 atomics, exact
+    // for fp32 partials of comparable magnitude ("Reproducibility")
+    float* s_all = s_acc + 2 * C;  // [256][16]
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        atomicAdd(&s_acc[c0 + i], s1[i]);
-        atomicAdd(&s_acc[C + c0 + i], s2[i]);
+        s_all[threadIdx.x * 16 + i] = s1[i];
+        s_all[threadIdx.x * 16 + 8 + i] = s2[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+    for (int j = threadIdx.x; j < 2 * C; j += 256) {
+        const int which = j / C, c = j - which * C, cg = c >> 3, i = (c & 7) + which * 8;
+        float v = 0.f;
+        for (int t = cg; t < 256; t += CG) v += s_all[t * 16 + i];
+        atomicAdd(&gsum[j], (double)v);
+    }
 }
 
 __global__ void k_bn_bwd_finalize(const double* __restrict__ gsum, long count, int C, const float* __restrict__ gamma,
@@ -125,30 +132,36 @@ __device__ __forceinline__ void flush_w(float* __restrict__ dw, float* __restric
     else
         atomicAdd(&dw[idx], v);
 }
-// dw[(e / cin) * ldw + e % cin] += sum_b ws[b][e]  (ldw = cin: plain dw[e]);  grid (ceil(nelem/256), chunks of partials)
+// Deterministic column sum of per-block partials ws[nb][nelem] for element e: 256-thread blocks = 32 columns x 8 interleaved chains, eight
+// loads in flight per chain, fixed association order, ONE writer per element (no atomics).  Returns true (with the total) in the writer.
+__device__ __forceinline__ bool det_column_sum(const float* __restrict__ ws, int nb, long nelem, long e, float& total) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
+    float s = 0.f;
+    if (e < nelem) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = chain;
+        for (; b + 56 < nb; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ws[(long)(b + 8 * u) * nelem + e];
+        }
+        for (int u = 0; b < nb; b += 8, ++u) a[u & 7] += ws[(long)b * nelem + e];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[chain][col] = s;
+    __syncthreads();
+    total = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    return chain == 0 && e < nelem;
+}
+// dw[(e / cin) * ldw + e % cin] += sum_b ws[b][e]  (ldw = cin: plain dw[e]);  grid ceil(nelem / 32)
 __global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __restrict__ ws, int nb, int nelem, float* __restrict__ dw, int cin,
                                                                int ldw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nelem) return;
-    const int eo = ldw == cin ? e : (e / cin) * ldw + e % cin;
-    const int per = (nb + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 3 < b1; b += 4) {  // four independent loads in flight
-        s0 += ws[(long)b * nelem + e];
-        s1 += ws[(long)(b + 1) * nelem + e];
-        s2 += ws[(long)(b + 2) * nelem + e];
-        s3 += ws[(long)(b + 3) * nelem + e];
-    }
-    for (; b < b1; ++b) s0 += ws[(long)b * nelem + e];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (gridDim.y == 1)
-        dw[eo] += s;
-    else
-        atomicAdd(&dw[eo], s);
+    const long e = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+    float s;
+    if (!det_column_sum(ws, nb, nelem, e, s)) return;
+    const long eo = ldw == cin ? e : (e / cin) * ldw + e % cin;
+    dw[eo] += s;
 }
-static inline int partial_chunks(int nb) { return nb >= 512 ? 64 : (nb >= 128 ? 32 : (nb >= 16 ? 8 : 1)); }
 
 template <int CIN, int COUT>
 struct PwBwdCfg {
@@ -682,29 +695,19 @@ __global__ __launch_bounds__(256, (Elem<T>::is_bf16 && STATS) ? OCRS_DW_BLOCKS :
 __global__ __launch_bounds__(256) void k_dw_partials_reduce(const float* __restrict__ ws, int nb, int C, int Ca, int nrow, float* __restrict__ dwdw,
                                                             double* __restrict__ gsum_a, double* __restrict__ gsum_b,
                                                             const float* __restrict__ saved_a, const float* __restrict__ saved_b) {
-    const int e = blockIdx.x * 256 + threadIdx.x, nelem = C * nrow;
-    if (e >= nelem) return;
-    const int per = (nb + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = b0 + per < nb ? b0 + per : nb;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 3 < b1; b += 4) {
-        s0 += ws[(long)b * nelem + e];
-        s1 += ws[(long)(b + 1) * nelem + e];
-        s2 += ws[(long)(b + 2) * nelem + e];
-        s3 += ws[(long)(b + 3) * nelem + e];
-    }
-    for (; b < b1; ++b) s0 += ws[(long)b * nelem + e];
-    const float v = (s0 + s1) + (s2 + s3);
+    const int nelem = C * nrow;
+    const long e = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+    float v;
+    if (!det_column_sum(ws, nb, nelem, e, v)) return;  // single writer per element: deterministic
     if (e < 9 * C) {
-        atomicAdd(&dwdw[e], v);
+        dwdw[e] += v;
         return;
     }
-    const int which = (e - 9 * C) / C, c = (e - 9 * C) % C, Cb = C - Ca;
+    const int which = (int)(e - 9 * C) / C, c = (int)(e - 9 * C) % C, Cb = C - Ca;
     if (c < Ca) {
-        if (gsum_a) atomicAdd(&gsum_a[which * Ca + c], (double)(which ? v * saved_a[Ca + c] : v));
+        if (gsum_a) gsum_a[which * Ca + c] += (double)(which ? v * saved_a[Ca + c] : v);
     } else if (gsum_b)
-        atomicAdd(&gsum_b[which * Cb + (c - Ca)], (double)(which ? v * saved_b[Cb + (c - Ca)] : v));
+        gsum_b[which * Cb + (c - Ca)] += (double)(which ? v * saved_b[Cb + (c - Ca)] : v);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -714,14 +717,13 @@ __global__ __launch_bounds__(256) void k_dw_partials_reduce(const float* __restr
 template <class T>
 __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                 GradSrc<T> gs, const T* __restrict__ z, const float* __restrict__ bn,
-                                                const float* __restrict__ coef, float* __restrict__ dwpw, float* __restrict__ dwdw, int H, int W,
+                                                const float* __restrict__ coef, double* __restrict__ acc64 /*[17]: dWpw[8] | dWdw[9]*/, int H, int W,
                                                 long P) {
-    __shared__ float s_bn[24], s_cf[24], s_acc[17];
+    __shared__ float s_bn[24], s_cf[24], s_slots[4 * 17];
     if (threadIdx.x < 24) {
         s_bn[threadIdx.x] = bn[threadIdx.x];
         s_cf[threadIdx.x] = coef[threadIdx.x];
     }
-    if (threadIdx.x < 17) s_acc[threadIdx.x] = 0.f;
     __syncthreads();
     float wd[9], wp[8], acc[17];  // acc: dWpw[0..8) | dWdw[8..17)
 #pragma unroll
@@ -778,14 +780,10 @@ __global__ __launch_bounds__(256) void k_c1_bwd(const float* __restrict__ img, c
         compute(bufB);
         p += stride;
     }
-#pragma unroll
-    for (int i = 0; i < 17; ++i) {
-        const float a = wave_sum(acc[i]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) atomicAdd(&dwpw[threadIdx.x], s_acc[threadIdx.x]);
-    else if (threadIdx.x < 17) atomicAdd(&dwdw[threadIdx.x - 8], s_acc[threadIdx.x]);
+    // deterministic block sum, then fp64 accumulation across blocks (exact for fp32 partials of comparable magnitude -> order-independent;
+    // float atomics straight into the fp32 gradients were not)
+    const float tot = block_sum_det<17>(acc, s_slots);
+    if (threadIdx.x < 17) atomicAdd(&acc64[threadIdx.x], (double)tot);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -809,7 +807,7 @@ struct CtwCfg {
     static constexpr int DKC = (9 * COUT + 31) / 32, DNT = TPOS / 16 / 4;  // K chunks, N tiles (of 16 positions) per wave
     static constexpr int WD_EL = DKC * MT * 64 * 8;                          // cached packed dgrad weight fragments (bf16 elements)
     static constexpr int STAGE_BYTES = (XS_EL + GS_EL + 8 + WD_EL) * 2 + 3 * CUP * 4 + XS_EL * 2 + CUP * 4;  // + raw x tile and means (STATS)
-    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4 + 256 * 8 * 4 + 2 * CUP * 4;
+    static constexpr int RED_BYTES = (KW - 1) * MT * NTW * NW * 256 * 4 + 256 * 8 * 4 + 4 * 2 * CUP * 4;  // ... | dbias [256][8] | stats [wave][2][CUP]
     static constexpr int SMEM = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
     static constexpr int PART = CUP * NT * 16 + COUT + 2 * CUP;  // floats per block partial: dW [CUP][NT*16] | dbias [COUT] | BN sums [2][CUP]
 };
@@ -1003,7 +1001,6 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     // ---- block reduction over the KW k-waves (same N half), then the block partial -> ws[block][CUP][NT*16]
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [(KW-1)][NW][MT*NTW][256]
-    if (STATS && tid < 2 * CUP) red[(KW - 1) * MT * NTW * C::NW * 256 + 256 * 8 + tid] = 0.f;  // sst (see below), zeroed before the barrier that follows
     if (ks > 0) {
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -1015,20 +1012,20 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
     __syncthreads();
     {   // dbias: threads with the same channel group (tid % (COUT/8)) are summed through LDS (behind the wgrad reduction area)
         float* bred = red + (KW - 1) * MT * NTW * C::NW * 256;  // [256][8]
-        float* sst = bred + 256 * 8;                            // [2][CUP] BatchNorm-backward sums of the block (STATS)
+        float* sst = bred + 256 * 8;                            // [wave][2][CUP] BatchNorm-backward sums (STATS): one slot per wave, no atomics
 #pragma unroll
         for (int i = 0; i < 8; ++i) bred[tid * 8 + i] = bsum[i];
         if constexpr (STATS) {
-            // channel c = b*16 + kg*4 + r is shared by the 16 lanes of a kg group in every wave: sum over those lanes, then 16 LDS atomics
-            // per wave onto 2*CUP addresses (once per block)
+            // channel c = b*16 + kg*4 + r is shared by the 16 lanes of a kg group in every wave: sum over those lanes, one plain store per
+            // (wave, channel); the four waves are added in order below (float LDS atomics would complete in arrival order)
 #pragma unroll
             for (int b = 0; b < MT; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a1 = quad16_sum(st1[b][r]), a2 = quad16_sum(st2[b][r]);
                     if (i16 == 0) {
-                        atomicAdd(&sst[b * 16 + kg * 4 + r], a1);
-                        atomicAdd(&sst[CUP + b * 16 + kg * 4 + r], a2);
+                        sst[(tid >> 6) * 2 * CUP + b * 16 + kg * 4 + r] = a1;
+                        sst[(tid >> 6) * 2 * CUP + CUP + b * 16 + kg * 4 + r] = a2;
                     }
                 }
         }
@@ -1039,7 +1036,8 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
             for (int t2 = cg8; t2 < 256; t2 += COUT / 8) v += bred[t2 * 8 + i];
             ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + tid] = v;
         }
-        if (STATS && tid < 2 * CUP) ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + COUT + tid] = sst[tid];
+        if (STATS && tid < 2 * CUP)
+            ws[(long)blockIdx.x * C::PART + CUP * C::NT * 16 + COUT + tid] = (sst[tid] + sst[2 * CUP + tid]) + (sst[4 * CUP + tid] + sst[6 * CUP + tid]);
     }
     if (ks == 0) {
         float* part = ws + (long)blockIdx.x * C::PART;
@@ -1060,38 +1058,33 @@ __global__ __launch_bounds__(256) void k_convt_wgrad_tr(const bf16* __restrict__
 // With gsum (nullable): the per-block BatchNorm-backward sums [2][CUP] are added to gsum (fp64; row 1 scaled by rstd = saved[CUP + c]).
 __global__ __launch_bounds__(256) void k_convt_wgrad_reduce(const float* __restrict__ ws, int nblocks, int CUP, int COUT, int NT16, float* __restrict__ dW,
                                                             float* __restrict__ dbias, const float* __restrict__ saved, double* __restrict__ gsum) {
-    const int e = blockIdx.x * 256 + threadIdx.x, part = CUP * NT16 + COUT + 2 * CUP, ne = CUP * 9 * COUT + COUT;
-    if (e >= ne + (gsum ? 2 * CUP : 0)) return;
-    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-    if (e >= ne) {  // BatchNorm-backward sums
-        const int idx = e - ne, which = idx / CUP, c = idx - which * CUP;
-        float sb = 0.f;
-        for (int b = b0; b < b1; ++b) sb += ws[(long)b * part + CUP * NT16 + COUT + idx];
-        atomicAdd(&gsum[idx], (double)(which ? sb * saved[CUP + c] : sb));
+    // one writer per output element over ALL block partials (fixed order: deterministic); element e of the logical output list
+    //   [CUP*9*COUT dW | COUT dbias | 2*CUP BatchNorm-backward sums]  lives at column col(e) of a partial row
+    const int part = CUP * NT16 + COUT + 2 * CUP, ne = CUP * 9 * COUT + COUT;
+    const long e = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+    const long ntot = ne + (gsum ? 2 * CUP : 0);
+    long col = 0;
+    if (e < (long)CUP * 9 * COUT) {
+        const int c = (int)(e / (9 * COUT)), n = (int)(e - (long)c * 9 * COUT);
+        col = (long)c * NT16 + n;
+    } else if (e < ntot)
+        col = (long)CUP * NT16 + (e - (long)CUP * 9 * COUT);
+    // (det_column_sum indexes ws[b * nelem + e]: pass the row pitch as nelem and the column as e; out-of-range threads read column 0, unused)
+    float s;
+    const bool writer = det_column_sum(ws, nblocks, part, e < ntot ? col : 0, s);
+    if (!writer || e >= ntot) return;
+    if (e >= ne) {  // BatchNorm-backward sums (fp64 accumulators of the producing block)
+        const int idx = (int)(e - ne), which = idx / CUP, c = idx - which * CUP;
+        gsum[idx] += (double)(which ? s * saved[CUP + c] : s);
         return;
     }
-    if (e >= CUP * 9 * COUT) {  // dbias [COUT]
-        const int o = e - CUP * 9 * COUT;
-        float sb = 0.f;
-        for (int b = b0; b < b1; ++b) sb += ws[(long)b * part + CUP * NT16 + o];
-        atomicAdd(&dbias[o], sb);
+    if (e >= (long)CUP * 9 * COUT) {  // dbias [COUT]
+        dbias[e - (long)CUP * 9 * COUT] += s;
         return;
     }
-    const int c = e / (9 * COUT), n = e - c * 9 * COUT;
-    const float* src = ws + c * NT16 + n;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = b0;
-    for (; b + 3 < b1; b += 4) {  // four independent loads in flight (the partials of one element are a block apart)
-        s0 += src[(long)b * part];
-        s1 += src[(long)(b + 1) * part];
-        s2 += src[(long)(b + 2) * part];
-        s3 += src[(long)(b + 3) * part];
-    }
-    for (; b < b1; ++b) s0 += src[(long)b * part];
-    const float s = (s0 + s1) + (s2 + s3);
+    const int c = (int)(e / (9 * COUT)), n = (int)(e - (long)c * 9 * COUT);
     const int tap = n / COUT, o = n - tap * COUT;
-    atomicAdd(&dW[((long)c * COUT + o) * 9 + tap], s);
+    dW[((long)c * COUT + o) * 9 + tap] += s;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1152,10 +1145,8 @@ __global__ __launch_bounds__(256) void k_convt_dgrad(const T* __restrict__ g, co
 
 // per-channel sum over pixels (ConvTranspose2d bias gradient)
 template <class T>
-__global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, float* __restrict__ out, int C, long P) {
+__global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, double* __restrict__ out, int C, long P) {
     extern __shared__ float s_acc[];
-    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
     const int CG = C / 8;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x;
     const long nthr = (long)gridDim.x * 256;
@@ -1176,23 +1167,27 @@ __global__ __launch_bounds__(256) void k_channel_sum(const T* __restrict__ g, fl
 #pragma unroll
         for (int i = 0; i < 8; ++i) s[i] += v[i];
     }
+    // deterministic block sum (every thread parks its 8 partials, thread j adds its channel's 256 / CG threads in order), fp64 across blocks
+    float* s_all = s_acc + C;  // [256][8]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&s_acc[c0 + i], s[i]);
+    for (int i = 0; i < 8; ++i) s_all[threadIdx.x * 8 + i] = s[i];
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+    for (int j = threadIdx.x; j < C; j += 256) {
+        float v = 0.f;
+        for (int t = j >> 3; t < 256; t += CG) v += s_all[t * 8 + (j & 7)];
+        atomicAdd(&out[j], (double)v);
+    }
 }
 
 // head backward: pred = sigmoid(w . x~ + b);  gl = gpred * pred * (1 - pred);  gy[p][c] = gl * w[c];  dw, db.
 template <class T>
 __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
                                                   const float* __restrict__ pred, const float* __restrict__ gpred, T* __restrict__ gy,
-                                                  float* __restrict__ dw, float* __restrict__ db, const float* __restrict__ saved /*[2][8] or null*/,
+                                                  double* __restrict__ acc64 /*[9]: dw[8] | db*/, const float* __restrict__ saved /*[2][8] or null*/,
                                                   double* __restrict__ gsum /*[2][8] or null*/, long P) {
     // gsum != null: also the BatchNorm-backward sums (sum ghat, sum ghat*zhat) of the block that produced z -- this kernel is that
     // block's only consumer and already reads z, so its k_bn_bwd_reduce pass (0.24 ms at 32x1024^2) is not needed
-    __shared__ float s_acc[25];
-    if (threadIdx.x < 25) s_acc[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float s_slots[4 * 25];
     float wv[8], sc[8], sh[8], lo[8], mu[8], acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st1[8], st2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1221,27 +1216,20 @@ __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const
         acc[8] += gl;
         store8(gy + p * 8, o);
     }
+    // deterministic block sums (no LDS float atomics), fp64 accumulation across blocks
+    float all[25];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const float a = wave_sum(acc[i]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc[i], a);
-    }
-    if (gsum) {
+    for (int i = 0; i < 9; ++i) all[i] = acc[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float a = wave_sum(st1[i]), b = wave_sum(st2[i]);
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&s_acc[9 + i], a);
-                atomicAdd(&s_acc[17 + i], b);
-            }
-        }
+    for (int i = 0; i < 8; ++i) {
+        all[9 + i] = st1[i];
+        all[17 + i] = st2[i];
     }
-    __syncthreads();
-    if (threadIdx.x < 8) atomicAdd(&dw[threadIdx.x], s_acc[threadIdx.x]);
-    if (threadIdx.x == 8) atomicAdd(db, s_acc[8]);
+    const float tot = block_sum_det<25>(all, s_slots);
+    if (threadIdx.x < 9) atomicAdd(&acc64[threadIdx.x], (double)tot);
     if (gsum && threadIdx.x >= 9 && threadIdx.x < 25) {
         const int i = threadIdx.x - 9;  // 0..7: sum ghat, 8..15: sum ghat*(z - mean) -> * rstd
-        atomicAdd(&gsum[i], (double)(i < 8 ? s_acc[threadIdx.x] : s_acc[threadIdx.x] * saved[8 + (i - 8)]));
+        atomicAdd(&gsum[i], (double)(i < 8 ? tot : tot * saved[8 + (i - 8)]));
     }
 }
 
@@ -1283,7 +1271,7 @@ int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z
     // at least 8 items instead of launching 2048 nearly idle blocks (those launches were 60 us of pure flush)
     long gl = (P * (C / 8) + 256 * 8 - 1) / (256 * 8);
     const int grid = (int)(gl < 8 ? 8 : (gl > kNumCU * 8 ? kNumCU * 8 : gl));
-    const size_t smem = 2 * C * sizeof(float);
+    const size_t smem = (2 * C + 256 * 16) * sizeof(float);
     if (dtype == 1) {
         GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
         hipLaunchKernelGGL(k_bn_bwd_reduce<bf16>, dim3(grid), dim3(256), smem, st, gs, (const bf16*)z, bn, saved, gsum, C, H, W, P);
@@ -1336,7 +1324,7 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
                        wpk_d, (T*)du, dwpw, ws, tg);
     if (ws) {
         const int ne = CIN * COUT;
-        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, ne, dwpw, CIN, CIN);
+        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, gx, ne, dwpw, CIN, CIN);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1355,7 +1343,7 @@ extern "C" {
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
 void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 255) / 256, partial_chunks(nb)), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
+    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 31) / 32), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
 }
 // det_pw2.hip: two-pixel-per-thread pipelined kernel for bf16, Cin, Cout <= 32 (levels 0-2)
 long det_pw2_supported(int Cin, int Cout, int dtype);
@@ -1482,27 +1470,28 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 #undef DWB
     if (ws) {
         const int nrow = stat_mask ? 11 : 9;
-        hipLaunchKernelGGL(k_dw_partials_reduce, dim3((C * nrow + 255) / 256, partial_chunks(gx)), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
+        hipLaunchKernelGGL(k_dw_partials_reduce, dim3((C * nrow + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
                            gsum_b, saved_a, saved_b);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 
-// First block (1->8) backward.  dwpw [8], dwdw [9] accumulated (the input image gets no gradient).
+// First block (1->8) backward.  acc64 [17] fp64 = dWpw [8] | dWdw [9], ACCUMULATED (caller-zeroed; the caller adds it to the fp32 gradients: fp64
+// accumulation of the per-block fp32 partials is exact, hence order-independent -- float atomics were not).  The input image gets no gradient.
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
-                     const float* bn, const float* coef, float* dwpw, float* dwdw, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(img && wdw && wpw && g1 && z && bn && coef && dwpw && dwdw);
+                     const float* bn, const float* coef, double* acc64, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(img && wdw && wpw && g1 && z && bn && coef && acc64);
     const long P = (long)N * H * W;
     int grid = ew_grid(P);
     const int resident = (dtype == 1 ? 3 : 2) * kNumCU;  // persistent grid-stride kernel: exactly the resident blocks (168 / 217 VGPRs)
     if (grid > resident) grid = resident;
     if (dtype == 1) {
         GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
-        hipLaunchKernelGGL(k_c1_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const bf16*)z, bn, coef, dwpw, dwdw, H, W, P);
+        hipLaunchKernelGGL(k_c1_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const bf16*)z, bn, coef, acc64, H, W, P);
     } else {
         GradSrc<float> gs{(const float*)g1, (const float*)g2, pooled};
-        hipLaunchKernelGGL(k_c1_bwd<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const float*)z, bn, coef, dwpw, dwdw, H, W, P);
+        hipLaunchKernelGGL(k_c1_bwd<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, gs, (const float*)z, bn, coef, acc64, H, W, P);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1535,9 +1524,11 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
 
 // saved / gsum (nullable, need ws and ocrs_convt_bwd_stats_supported): x is the raw output of a block consumed ONLY by this ConvTranspose;
 // its BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
-int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, float* ws,
+int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                    const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
+    // dbias64 [Cout] fp64 (caller-zeroed): the generic (deep-level) path accumulates the bias gradient there (order-independent fp64 sums of
+    // per-block fp32 partials) and the caller adds it to dbias; the tiled path (levels 0-2) adds to dbias itself from its single-writer reduce
+    OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && dbias64 && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
     OCRS_CHECK_ARG(!gsum || (saved && ws && ocrs_convt_bwd_stats_supported(Cup, Cout, dtype)));
     if (ws && convt_wgrad_tr_ok(Cup, Cout, dtype)) {
         // levels 0-2 (bf16): ONE tiled kernel produces dx, the weight-gradient partials and the bias-gradient partials; one reduce
@@ -1553,7 +1544,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
             hipLaunchKernelGGL((k_convt_wgrad_tr<CU_, CO_, false>), dim3(nb), dim3(256), CC::SMEM, st, (const bf16*)x, tr, (const bf16*)g, wpk_d,  \
                                (bf16*)dx, ws, saved, h, w, H, W, tg);                                                                        \
         const int ne = CU_ * 9 * CO_ + CO_ + (gsum ? 2 * CU_ : 0);                                                                           \
-        hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 255) / 256, nb >= 64 ? 16 : 1), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW, \
+        hipLaunchKernelGGL(k_convt_wgrad_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, CU_, CO_, CC::NT * 16, dW, \
                            dbias, saved, gsum);                                                                                              \
     }
         CTW_CASE(16, 8) CTW_CASE(32, 16) CTW_CASE(32, 32)
@@ -1596,24 +1587,24 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
     int gs = cg_grid((Pout * (Cout / 8) + 3) / 4);
     if (gs > 2 * kNumCU) gs = 2 * kNumCU;
     if (dtype == 1)
-        hipLaunchKernelGGL(k_channel_sum<bf16>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const bf16*)g, dbias, Cout, Pout);
+        hipLaunchKernelGGL(k_channel_sum<bf16>, dim3(gs), dim3(256), (Cout + 256 * 8) * sizeof(float), st, (const bf16*)g, dbias64, Cout, Pout);
     else
-        hipLaunchKernelGGL(k_channel_sum<float>, dim3(gs), dim3(256), Cout * sizeof(float), st, (const float*)g, dbias, Cout, Pout);
+        hipLaunchKernelGGL(k_channel_sum<float>, dim3(gs), dim3(256), (Cout + 256 * 8) * sizeof(float), st, (const float*)g, dbias64, Cout, Pout);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 
-// Head backward: gy [P][8] written (dtype T); dw [8], db [1] accumulated.  saved / gsum (nullable): also accumulate the BatchNorm-backward
+// Head backward: gy [P][8] written (dtype T); acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients).  saved / gsum (nullable): also accumulate the BatchNorm-backward
 // sums [2][8] (fp64, caller-zeroed) of the block that produced z (saved = its [mean | rstd]) -- replaces that block's ocrs_bn_bwd_reduce.
-int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* dw, float* db,
+int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,
                   const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && dw && db && P > 0 && (!gsum || saved));
+    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && acc64 && P > 0 && (!gsum || saved));
     int grid = ew_grid(P);
     if (grid > 1024) grid = 1024;  // streaming kernel ending in same-address atomics: 4 blocks per CU are plenty
     if (dtype == 1)
-        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, dw, db, saved, gsum, P);
+        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, acc64, saved, gsum, P);
     else
-        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, dw, db, saved, gsum, P);
+        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, acc64, saved, gsum, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
     T* tile = reinterpret_cast<T*>(smem);                                                   // [TP][PITCH]  dw output (MFMA operand)
     float* xs = reinterpret_cast<float*>(smem + ((TP * PITCH * sizeof(T) + 15) & ~15));     // 2 planes [HP*CG][4]: transformed input + halo
     float* s_par = xs + HP * CG * 8;                                                         // [12][CIN]: tr(3, HaloStager layout) | wdw(9, tap-major)
-    float* s_stat = s_par + 12 * CIN;                                                        // [2][MT*16]
+    float* s_stat = s_par + 12 * CIN;                                                        // [wave][2][MT*16]: one slot per wave, no atomics
     const int H = tg.H, W = tg.W;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
         const int t = i / CIN, c = i - t * CIN;
         s_par[3 * CIN + i] = wdw[c * 9 + t];
     }
-    for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+    for (int i = tid; i < 4 * 2 * MT * 16; i += 256) s_stat[i] = 0.f;
     __syncthreads();
     const HaloStager<T, CG, TW, TH> stager(tid, W);
 
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
-                if ((lane & 15) == 0) {
-                    atomicAdd(&s_stat[m0 + r], a1);
-                    atomicAdd(&s_stat[MT * 16 + m0 + r], a2);
+                if ((lane & 15) == 0) {  // the only lane of this wave that owns channel m0 + r: plain read-modify-write of the wave's slot
+                    s_stat[wave * 2 * MT * 16 + m0 + r] += a1;
+                    s_stat[wave * 2 * MT * 16 + MT * 16 + m0 + r] += a2;
                 }
             }
             // ---- fused MaxPool2d(2) (models.py:54) in its pre-BatchNorm form: the consumer sees relu(bn(z)), monotone in z with the sign of
@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256, (ONE && Elem<T>::is_bf16) ? OCRS_PIPE_BLOCKS :
     }
     __syncthreads();
     for (int c = tid; c < COUT; c += 256) {
-        atomicAdd(&gstat[c], (double)s_stat[c]);
-        atomicAdd(&gstat[COUT + c], (double)s_stat[MT * 16 + c]);
+        constexpr int WS = 2 * MT * 16;
+        atomicAdd(&gstat[c], (double)((s_stat[c] + s_stat[WS + c]) + (s_stat[2 * WS + c] + s_stat[3 * WS + c])));
+        atomicAdd(&gstat[COUT + c], (double)((s_stat[MT * 16 + c] + s_stat[WS + MT * 16 + c]) + (s_stat[2 * WS + MT * 16 + c] + s_stat[3 * WS + MT * 16 + c])));
     }
 }
 
@@ -263,9 +264,7 @@ template <class T>
 __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ img, const float* __restrict__ wdw /*[9]*/,
                                                      const float* __restrict__ wpw /*[8]*/, T* __restrict__ z, double* __restrict__ gstat,
                                                      int H, int W, long P) {
-    __shared__ float s_stat[16];
-    if (threadIdx.x < 16) s_stat[threadIdx.x] = 0.f;
-    __syncthreads();
+    __shared__ float s_slots[4 * 16];
     float wd[9], wp[8];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wd[i] = wdw[i];
@@ -307,16 +306,14 @@ __global__ __launch_bounds__(256) void k_dwpw_c1_fwd(const float* __restrict__ i
         compute(bufB, p);
         p += stride;
     }
+    float all[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float a = wave_sum(s1[i]), b = wave_sum(s2[i]);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&s_stat[i], a);
-            atomicAdd(&s_stat[8 + i], b);
-        }
+        all[i] = s1[i];
+        all[8 + i] = s2[i];
     }
-    __syncthreads();
-    if (threadIdx.x < 16) atomicAdd(&gstat[threadIdx.x], (double)s_stat[threadIdx.x]);
+    const float tot = block_sum_det<16>(all, s_slots);  // fixed-order block sum; fp64 across blocks (exact for comparable fp32 partials)
+    if (threadIdx.x < 16) atomicAdd(&gstat[threadIdx.x], (double)tot);
 }
 
 // BatchNorm2d training-mode statistics (biased var for normalisation, unbiased into running_var, eps 1e-5,
@@ -517,7 +514,7 @@ static int launch_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     const Tiling2 tg = make_tiling2(N, H, W, FT::TW, FT::TH);
     const size_t smem = ((TP * FwdPitch<T, CG>::V * sizeof(T) + 15) & ~15) +
-                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 2 * MT * 16) * sizeof(float);
+                        (HaloTile<FT::TW, FT::TH>::HP * CG * 8 + 12 * CIN + 4 * 2 * MT * 16) * sizeof(float);
     // every block ends with 2*COUT same-address fp64 atomics (~15 ns each, serialised): at the middle levels (a few thousand tiles)
     // two tiles per block halve that tail; below that parallelism matters more (measured: OCRS_FWD_TPB sweep, profiles/README.md)
     static const int fwd_tpb = env_int("OCRS_FWD_TPB", 0);

@@ -303,8 +303,10 @@ class _DetRun:
                           ptr(self.G[f"{prefix}.seq.2.weight"]), ptr(self.G[f"{prefix}.seq.2.bias"]))
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
         if r.Cin == 1:
-            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef),
-                          ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), N, H, W, self.dt)
+            acc = self.zeros64(17)  # fp64 accumulators (order-independent), folded into the fp32 gradients below
+            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(acc), N, H, W, self.dt)
+            self.G[f"{prefix}.seq.1.weight"].view(-1).add_(acc[:8])
+            self.G[f"{prefix}.seq.0.weight"].view(-1).add_(acc[8:17])
             return None, None
         a, b = r.a, r.b
         Ca, Cb = a.C, (b.C if b is not None else 0)
@@ -370,8 +372,11 @@ class _DetRun:
         if self.fuse_bn_bwd and up.src is not None:  # the head is this block's only consumer and reads its z anyway
             sv, gs_head = self.recs[up.src].saved, self.zeros64(16)
             self.fused[up.src] = gs_head
-        L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(self.G["out_conv.0.weight"]),
-                   ptr(self.G["out_conv.0.bias"]), ptr(sv), ptr(gs_head), N * H * W, self.dt)
+        acc = self.zeros64(9)
+        L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
+                   N * H * W, self.dt)
+        self.G["out_conv.0.weight"].view(-1).add_(acc[:8])
+        self.G["out_conv.0.bias"].view(-1).add_(acc[8:9])
         stage_done("out_conv")
         skip_g = [[] for _ in range(7)]
         for i in range(6):
@@ -388,8 +393,10 @@ class _DetRun:
                 # the ConvTranspose is this block's only consumer and stages its z anyway: it also produces the block's BatchNorm-backward sums
                 sv, gs_up = self.recs[up_in.src].saved, self.zeros64(2 * Cup)
                 self.fused[up_in.src] = gs_up
+            db64 = self.zeros64(Cout)
             L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
-                        ptr(self.G[f"up.{i}.up.bias"]), ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+                        ptr(self.G[f"up.{i}.up.bias"]), ptr(db64), ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
+            self.G[f"up.{i}.up.bias"].add_(db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
             stage_done(f"up.{i}")
             g = dx
         skip_g[6].append(g)

@@ -456,7 +456,9 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
     dx = run.empty(N, h, w, Cup)
     dW, db = torch.zeros_like(Wt), torch.zeros_like(bias)
     ws = torch.empty(run.L.convt_bwd_ws_floats(Cup, Cout, N, h, w, run.dt), device=dev)
-    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), ptr(ws), None, None, Cup, Cout, N, h, w, H, W, run.dt)
+    db64 = torch.zeros(Cout, dtype=torch.float64, device=dev)
+    run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx), ptr(dW), ptr(db), ptr(db64), ptr(ws), None, None, Cup, Cout, N, h, w, H, W, run.dt)
+    db.add_(db64)
     torch.cuda.synchronize()
     assert rel(nchw(dx), xt.grad) < 10 * tol, "dgrad"
     assert rel(dW, Wr.grad) < 10 * tol, "wgrad"
@@ -468,8 +470,10 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
         gsum = torch.zeros(2 * Cup, dtype=torch.float64, device=dev)
         dx2 = run.empty(N, h, w, Cup)
         dW2, db2 = torch.zeros_like(Wt), torch.zeros_like(bias)
-        run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx2), ptr(dW2), ptr(db2), ptr(ws), ptr(saved), ptr(gsum), Cup, Cout, N, h, w, H, W,
+        db64b = torch.zeros(Cout, dtype=torch.float64, device=dev)
+        run.L.convt_bwd(ptr(xs), ptr(tr), ptr(gy), ptr(wpk_d), ptr(dx2), ptr(dW2), ptr(db2), ptr(db64b), ptr(ws), ptr(saved), ptr(gsum), Cup, Cout, N, h, w, H, W,
                         run.dt)
+        db2.add_(db64b)
         torch.cuda.synchronize()
         assert torch.equal(dx2, dx) and rel(dW2, dW) < 1e-5 and rel(db2, db) < 1e-5
         dxf, xf = nchw(dx2).double(), nchw(xs).double()
@@ -506,7 +510,10 @@ def test_head(dev, dtype):
     # also ask for the BatchNorm-backward sums of the block that produced z (the head is its only consumer)
     saved = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)  # [mean | rstd]
     gsum = torch.zeros(16, dtype=torch.float64, device=dev)
-    run.L.head_bwd(ptr(zs), ptr(tr), ptr(w), ptr(pred), ptr(gp), ptr(gy), ptr(dw), ptr(db), ptr(saved), ptr(gsum), N * H * W, run.dt)
+    acc64 = torch.zeros(9, dtype=torch.float64, device=dev)
+    run.L.head_bwd(ptr(zs), ptr(tr), ptr(w), ptr(pred), ptr(gp), ptr(gy), ptr(acc64), ptr(saved), ptr(gsum), N * H * W, run.dt)
+    dw.view(-1).add_(acc64[:8])
+    db.view(-1).add_(acc64[8:9])
     torch.cuda.synchronize()
     tol = TOL[dtype]
     assert rel(nchw(gy), xt.grad) < 5 * tol
