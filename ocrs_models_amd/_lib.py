@@ -78,8 +78,12 @@ class _Lib:
         short = name[5:]
         owner = self
 
+        trace = bool(os.environ.get("OCRS_TRACE"))  # debugging aid: print every entry point before the launch and synchronise after it
+
         def call(*args):
             rec = None
+            if trace:
+                print("[ocrs]", name, [a if not isinstance(a, int) or a < (1 << 32) else hex(a) for a in args], flush=True)
             if owner.timing is not None and short in owner.timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -91,6 +95,8 @@ class _Lib:
             if rec is not None:
                 rec[1].record()
                 owner.timing[short].append(rec)
+            if trace:
+                torch.cuda.synchronize()
             if res == "i" and sig and r != 0:
                 raise RuntimeError(f"{name} failed: {_ERR.get(r, r)}")
             return r

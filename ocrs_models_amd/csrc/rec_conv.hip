@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
                 const long kc = (long)tap * ncc + cc;
 #pragma unroll
                 for (int b = 0; b < MTW; ++b) {
-                    const typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, kc * MT_total + mt0 + mw0 + b, lane);
+                    // M tiles past the packed weight (M = 97 -> 7 tiles, this block covers 8): read tile 0 instead and use a zero fragment.  The
+                    // unguarded read ran 2 KB past the end of the packed buffer in the last K chunk -- a memory access fault whenever that
+                    // buffer was the last thing in its allocator segment -- and put the next chunk's weights into the pad columns before
+                    const int mtile = mt0 + mw0 + b;
+                    typename Mma<T>::Frag wf = Mma<T>::load_w(wpk, kc * MT_total + (mtile < MT_total ? mtile : 0), lane);
+                    if (mtile >= MT_total) wf = typename Mma<T>::Frag{};
 #pragma unroll
                     for (int a = 0; a < PTW; ++a) acc[a][b] = Mma<T>::template mma<8>(wf, pf[a], acc[a][b]);
                 }

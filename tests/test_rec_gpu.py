@@ -350,3 +350,20 @@ def test_ctc_fp16_lattice_variant_and_determinism(dev):
         e = rel(res["f16"][1], res["f32"][1])
         print(f"fp16-lattice CTC gradient vs fp32 lattice (T={T}): relL2 {e:.2e}")
         assert e < 5e-3
+
+
+def test_gemm_partial_last_m_tile_reads_no_weights_past_the_pack(dev):
+    """Linear(512 -> 97): M = 97 is 7 MFMA tiles but the GEMM blocks cover 8.  The eighth tile must come from a zero fragment, not from whatever
+    follows the packed weight buffer (round 2: that read ran 2 KB past the buffer in the last K chunk and faulted when the buffer ended its
+    allocator segment; before that it silently put the next chunk's weights into the pad columns): pad columns 97..127 are exactly 0."""
+    g = torch.Generator().manual_seed(3)
+    rows, K, M, ldo = 300, 512, 97, 128
+    r = _run(dev, torch.float32, 1)
+    x = torch.randn(rows, K, generator=g).to(dev)
+    w = (torch.randn(M, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(M, generator=g).to(dev)
+    wpk = r.pack(w, K, M, K, 0, 1, K, dt=0)
+    out = r.gemm(x, K, K, wpk, b, M, ldo, rows)
+    torch.cuda.synchronize()
+    assert rel(out[:, :M], x @ w.t() + b) < 1e-5
+    assert float(out[:, M:].abs().max()) == 0.0
