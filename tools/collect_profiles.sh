@@ -1,18 +1,22 @@
-# Collects every profile artefact of a round into gpurun_out/prof_<tag>/ (copy to profiles/ afterwards).  usage: bash tools/collect_profiles.sh r01_final
-TAG=${1:-r01_final}
+# Collects every profile artefact of a round into gpurun_out/prof_<tag>/ (copy to profiles/ afterwards).  usage: bash tools/collect_profiles.sh r02_final
+TAG=${1:-r02_final}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
-# 1. un-profiled default bench line
+# 1. un-profiled default bench line (what the driver runs)
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 # 2. kernel stats of the same command (detection + CRNN), CPU baseline off
-rm -rf gpurun_out/ks; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/ks.err
+rm -rf gpurun_out/ks; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 --no-gru-exact > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/ks.err
 cp $(find gpurun_out/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 # 3. per-launch trace of one detection step
 bash tools/run_trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step.txt $OUT/${TAG}_step_trace.txt
-# 4. HBM traffic (two separate PMC passes)
+# 4. HBM traffic (two separate PMC passes, kernel-trace only)
 bash tools/run_pmc_hbm.sh ${TAG}_pmc_hbm.csv > $OUT/pmc_hbm.log 2>&1; cp gpurun_out/${TAG}_pmc_hbm.csv $OUT/
-# 5. SQ counters of the three big families
-bash tools/run_pmc_sq.sh "k_dwpw_fwd<bf16, [12], 1, true>|k_pw_bwd2<(8|16), (8|16), (false|true)>|k_dw_bwd<bf16, [12], true>" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
-rm -rf gpurun_out/ks gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc_f gpurun_out/pmc_w
-ls -la $OUT; tail -c 600 $OUT/${TAG}_bench.json
+# 5. SQ counters of the matrix-core block kernels at level 0 / 1
+bash tools/run_pmc_sq.sh "k_mm_bwd<8, 8, false, false, true>|k_mm_bwd<16, 16, true, true, true>|k_mm_bwd<8, 16, false, false, true>|k_mm_bwd<32, 32, true, true, true>|k_mm_fwd<8, 1, 8, false>|k_mm_fwd<16, 1, 16, true>|k_mm_fwd<32, 1, 32, true>" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
+# 6. CRNN: per-kernel time, and the MFMA-busy counter of the convolution kernels (separate PMC pass)
+bash tools/run_trace_crnn.sh > /dev/null 2>&1; cp gpurun_out/crnn_stats.txt $OUT/${TAG}_crnn_kernel_stats.txt
+rm -rf gpurun_out/pmc_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/prof_crnn.py --steps 2 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_mfma "k_conv_igemm<bf16|k_conv3x3_wgrad_tr|k_gru_step" > $OUT/${TAG}_crnn_pmc_mfma.txt 2>&1
+rm -rf gpurun_out/ks gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_mfma gpurun_out/trace_crnn
+ls -la $OUT; head -c 700 $OUT/${TAG}_bench.json; echo; tail -3 $OUT/${TAG}_step_trace.txt; tail -2 $OUT/${TAG}_pmc_hbm.csv; head -30 $OUT/${TAG}_crnn_pmc_mfma.txt
