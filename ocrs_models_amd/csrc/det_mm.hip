@@ -18,11 +18,27 @@
 
 // ---- tile-shape / residency knobs (measurement builds: tools/build_variant.sh; the defaults are the measured optimum, profiles/README.md)
 #ifndef OCRS_MM_TH
-#define OCRS_MM_TH 8       // backward tile rows, Cin and Cout <= 16 (16 halves the ring re-reads but spills at 128 registers)
+#define OCRS_MM_TH 8       // backward tile rows, Cin and Cout <= 16 (16 halves the ring re-reads but spills at 128 registers); per-shape overrides:
 #endif
+#ifndef OCRS_MM_TH_8_8
+#define OCRS_MM_TH_8_8 12  // 12 rows: 476 of 512 threads hold a (z, g) item instead of 340 -- more bytes in flight from the same registers (650 -> 621 us)
+#endif
+#ifndef OCRS_MM_TH_16_8
+#define OCRS_MM_TH_16_8 OCRS_MM_TH
+#endif
+#ifndef OCRS_MM_TH_8_16
+#define OCRS_MM_TH_8_16 12  // (946 -> 881 us; needs the single-buffered dgrad to fit 128 registers)
+#endif
+#ifndef OCRS_MM_TH_16_16
+#define OCRS_MM_TH_16_16 OCRS_MM_TH
+#endif
+#define OCRS_MM_TH_OF(ci, co) ((ci) == 8 ? ((co) == 8 ? OCRS_MM_TH_8_8 : OCRS_MM_TH_8_16) : ((co) == 8 ? OCRS_MM_TH_16_8 : OCRS_MM_TH_16_16))
 #ifndef OCRS_MM_C32_BPC
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
+#endif
+#ifndef OCRS_MM_BDB
+#define OCRS_MM_BDB 1      // backward dgrad: double-buffer the B fragments across K chunks
 #endif
 #ifndef OCRS_MF_TH8
 #define OCRS_MF_TH8 16     // forward tile rows, Cin = 8 (measured: 16 rows x 2 blocks/CU 300 us, 8 rows x 3 blocks/CU 329 us, 8 x 2: 356 us at level 0)
@@ -47,7 +63,8 @@ struct MmCfg {
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
     static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : 2;  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
-    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : OCRS_MM_TH, TP = TW * TH;
+    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : OCRS_MM_TH_OF(CIN, COUT), TP = TW * TH;
+    static constexpr bool BDB = OCRS_MM_BDB && !(CIN == 8 && COUT == 16 && TH == 12);  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -425,17 +442,28 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
                         if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
                     }
                 };
-                load_b(bcur, 0);
+                if constexpr (C::BDB) {  // B fragments double-buffered across K chunks
+                    load_b(bcur, 0);
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) {
-                    const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
-                    if (kc + 1 < KC) load_b(bnxt, kc + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int kc = 0; kc < KC; ++kc) {
+                        const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
+                        if (kc + 1 < KC) load_b(bnxt, kc + 1);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
+                        for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
+                    }
+                } else {  // (8 fewer live registers: what lets the 12-row tile of the 8 -> 16 channel shape fit 128)
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) {
+                        const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
+                        load_b(bcur, kc);
+#pragma unroll
+                        for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 const int m0 = b * 16 + (lane >> 4) * 4;
                 float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -667,7 +695,7 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
 }
 static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : (Cin == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16); }  // forward tiles
 static int mm_bwd_bpc(int Cin, int Cout) { return (Cin == 32 && Cout == 32) ? OCRS_MM_C32_BPC : 2; }
-static int mm_bwd_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? (mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8) : OCRS_MM_TH; }
+static int mm_bwd_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? (mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8) : OCRS_MM_TH_OF(Cin, Cout); }
 
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
