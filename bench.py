@@ -123,7 +123,7 @@ def pmc_profile():
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))  # rNN_ prefix: name order == round order (mtime does not survive a checkout)
     if not files:
         return None, None
     rows = {}
