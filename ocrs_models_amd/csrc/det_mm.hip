@@ -32,7 +32,19 @@
 #ifndef OCRS_MM_TH_16_16
 #define OCRS_MM_TH_16_16 OCRS_MM_TH
 #endif
+#ifndef OCRS_MM_TH_16_16_P
+#define OCRS_MM_TH_16_16_P 8   // pooled gradient (the level-0 16 -> 16 block): 8 rows (1112 us) beat 12 (1151 us: 20 B of spills even with the two register diets)
+#endif
 #define OCRS_MM_TH_OF(ci, co) ((ci) == 8 ? ((co) == 8 ? OCRS_MM_TH_8_8 : OCRS_MM_TH_8_16) : ((co) == 8 ? OCRS_MM_TH_16_8 : OCRS_MM_TH_16_16))
+#ifndef OCRS_MM_SW
+#define OCRS_MM_SW 1       // wave index in a scalar register
+#endif
+#ifndef OCRS_MM_EPI
+#define OCRS_MM_EPI 1      // dgrad epilogue store addressing (0: per-lane 64-bit pixel index, 1: scalar row + lane offset, 2: 1 with both row pointers pinned scalar)
+#endif
+#ifndef OCRS_MM_BDB_EXCL
+#define OCRS_MM_BDB_EXCL 1  // single-buffer the dgrad B fragments of the 12-row 8 -> 16 and pooled 16 -> 16 tiles (register diet)
+#endif
 #ifndef OCRS_MM_C32_BPC
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
@@ -57,14 +69,17 @@ struct MmPitch {  // bf16 elements per pixel of an LDS tile: 16 / 32-byte rows a
     static constexpr int V = (C == 32) ? 40 : C;
 };
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool PPOOL = false>
 struct MmCfg {
     static constexpr int NT = 512, NW = NT / 64;                       // 8 waves
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
     static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : 2;  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
-    static constexpr int TW = 32, TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : OCRS_MM_TH_OF(CIN, COUT), TP = TW * TH;
-    static constexpr bool BDB = OCRS_MM_BDB && !(CIN == 8 && COUT == 16 && TH == 12);  // dgrad B fragments double-buffered across K chunks
+    static constexpr int TW = 32;
+    static constexpr int TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : ((PPOOL && CIN == 16 && COUT == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(CIN, COUT));
+    static constexpr int TP = TW * TH;
+    static constexpr bool T12P = PPOOL && CIN == 16 && COUT == 16 && TH == 12;  // 12-row pooled tile: needs the two register diets below to fit 128
+    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P));  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -76,7 +91,8 @@ struct MmCfg {
     static constexpr int NGI = (DP * CGO + NT - 1) / NT;               // (z, g) items per thread
     static constexpr int NXI = (TP * CGI + NT - 1) / NT;               // x items per thread
     static constexpr int NWIN = (DH_ / 2) * (DW_ / 2);                 // 2x2 windows of the (window-aligned) domain
-    static constexpr int NWI = (NWIN * CGO + NT - 1) / NT;
+    static constexpr int NWI = (NWIN * 2 * CGO + NT - 1) / NT;       // pooled launches: (window, 4-channel quad) items per thread
+    static_assert(DH_ % 2 == 0 && NT % (2 * CGO) == 0 && 4 * NWI <= 16, "pooled item layout");
     // LDS (bytes)
     static constexpr int OFF_D = 0;
     static constexpr int OFF_X = (OFF_D + DP * PD * 2 + 63) & ~63;
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
                                                    const float* __restrict__ bn, const float* __restrict__ coef, bf16* __restrict__ gxa,
                                                    bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg) {
-    using C = MmCfg<CIN, COUT>;
+    using C = MmCfg<CIN, COUT, PPOOL>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, TP = C::TP, DW_ = C::DW_, DP = C::DP, CGI = C::CGI, CGO = C::CGO, PD = C::PD, PX = C::PX;
     constexpr int MT = C::MT, NTO = C::NTO, KC = C::KC, NPW = C::NPW, KS = C::KS;
     extern __shared__ __attribute__((aligned(64))) char smem[];
@@ -138,7 +154,12 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
     float* s_w9 = s_cf + 3 * COUT;                              // [CIN][9]
     float* s_wp = s_w9 + 9 * CIN;                               // [COUT][CIN]
     const int H = tg.H, W = tg.W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15;
+#if OCRS_MM_SW
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar register: wave-dependent branches and offsets become scalar code)
+#else
+    const int wave = tid >> 6;
+#endif
 
     // ---- prologue: parameters, effective-weight fragments
     fill_tr8(s_trx, x, tra, trb, CIN, tid);
@@ -167,9 +188,13 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
     __syncthreads();
 
     // ---- tile-invariant item descriptors
-    // (z, g) items.  Direct gradient: one (domain pixel, 8-channel group) each.  Pooled gradient: one (2x2 window, group) each -- the domain
-    // of a pooled launch is window-aligned (tile origins sit at odd coordinates: org = tile * T - 1), so routing needs no neighbours.
+    // (z, g) items.  Direct gradient: one (domain pixel, 8-channel group) each.  Pooled gradient: one (2x2 window, 4-channel quad) each --
+    // the domain of a pooled launch is window-aligned (tile origins sit at odd coordinates: org = tile * T - 1), so routing needs no
+    // neighbours; quads instead of groups because a window item is four pixels of work: with groups only 170 of the 512 threads of a
+    // 16-channel launch held one and the other waves idled at the barrier (the routing is the heaviest VALU phase of these launches).
     const int cgo = tid % CGO;
+    constexpr int NQ = 2 * CGO;        // channel quads per pixel
+    const int cq4 = (tid % NQ) * 4;    // this thread's quad (the same in every round: NT % NQ == 0)
     int gi_dyx[PPOOL ? C::NWI : C::NGI];  // dy | dx << 16 (domain coordinates; window top-left when pooled)
     if constexpr (!PPOOL) {
 #pragma unroll
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
     } else {
 #pragma unroll
         for (int j = 0; j < C::NWI; ++j) {
-            const int wd = (tid + j * NT) / CGO, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
+            const int wd = (tid + j * NT) / NQ, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
             gi_dyx[j] = (2 * wy) | ((2 * wx) << 16);
         }
     }
@@ -192,8 +217,9 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
     constexpr int ORG = PPOOL ? -1 : 0;  // tile origin shift
 
     // ---- software pipeline state: raw vectors of the NEXT tile
-    constexpr int NZ = PPOOL ? 4 * C::NWI : C::NGI, NG = PPOOL ? C::NWI : C::NGI;
-    Raw8<bf16> zr[NZ], g1r[NG], g2r[G2 ? NG : 1], xr[C::NXI];
+    constexpr int NG = PPOOL ? 1 : C::NGI, NP = PPOOL ? C::NWI : 1;
+    Raw8<bf16> zr[NG], g1r[NG], g2r[G2 ? NG : 1], xr[C::NXI];
+    uint2 zp[4 * NP], gp1[NP], gp2[G2 ? NP : 1];  // pooled: raw quads of the window's four z and of the pooled gradient(s)
     unsigned okg = 0, okx = 0;  // validity bits
     auto issue = [&](const TileOrg& o) {
         const int h00 = o.h0 + ORG - 1, w00 = o.w0 + ORG - 1;  // image coordinates of the domain's corner pixel (may lie outside)
@@ -217,20 +243,20 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
             const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
             for (int j = 0; j < C::NWI; ++j) {
-                const bool it_ok = C::NWIN * CGO % NT == 0 || tid + j * NT < C::NWIN * CGO;
+                const bool it_ok = C::NWIN * NQ % NT == 0 || tid + j * NT < C::NWIN * NQ;
                 const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;  // top-left pixel of the window (even coordinates)
-                const int goff = (dy * W + dx) * COUT + cgo * 8;
+                const int goff = (dy * W + dx) * COUT + cq4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool ok = it_ok && (unsigned)(h + (k >> 1)) < (unsigned)H && (unsigned)(w + (k & 1)) < (unsigned)W;
-                    zr[4 * j + k] = load8_raw(ok ? zb + goff + ((k >> 1) * W + (k & 1)) * COUT : z);
+                    zp[4 * j + k] = *reinterpret_cast<const uint2*>(ok ? zb + goff + ((k >> 1) * W + (k & 1)) * COUT : z);
                     okg |= ok ? 1u << (4 * j + k) : 0u;
                 }
                 const int ph = h >> 1, pw = w >> 1;
                 const bool gv = it_ok && h >= 0 && w >= 0 && ph < Hp && pw < Wp;  // floor mode: the last odd row / column is in no window
                 const long pp = ((long)o.n * Hp + ph) * Wp + pw;
-                g1r[j] = load8_raw(gv ? g1 + pp * COUT + cgo * 8 : g1);
-                if constexpr (G2) g2r[j] = load8_raw(gv ? g2 + pp * COUT + cgo * 8 : g2);
+                gp1[j] = *reinterpret_cast<const uint2*>(gv ? g1 + pp * COUT + cq4 : g1);
+                if constexpr (G2) gp2[j] = *reinterpret_cast<const uint2*>(gv ? g2 + pp * COUT + cq4 : g2);
                 okg |= gv ? 1u << (16 + j) : 0u;
             }
         }
@@ -294,7 +320,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
         for (int b = 0; b < NTO; ++b) accO[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // producers' BatchNorm-backward sums: per-lane register accumulators (one M tile), or -- with two M tiles, where 16 more live registers
     // spill -- per-tile sums added to this wave's own LDS slots (single writer, fixed order: deterministic)
-    constexpr bool STL = STATS && MT == 2;
+    constexpr bool STL = STATS && (MT == 2 || C::T12P);
     float* s_st = s_wp + COUT * CIN;  // [wave][2][MT*16] (STL only)
     float st1[(STATS && !STL) ? MT : 1][4], st2[(STATS && !STL) ? MT : 1][4];
     if constexpr (STATS && !STL) {
@@ -315,13 +341,13 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
         const TileOrg org = org_next;
         // ================= phase 1: commit the prefetched tile: dz -> tileD, x~ -> tileX =================
         // Four channels at a time (the five per-channel coefficient vectors of a half are 20 registers instead of 40; 8-byte LDS stores).
+        if constexpr (!PPOOL) {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int c4 = cgo * 8 + hf * 4;
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bn + c4), bt = *reinterpret_cast<const f32x4*>(s_bn + COUT + c4);
-            const f32x4 ca = *reinterpret_cast<const f32x4*>(s_cf + c4), cb = *reinterpret_cast<const f32x4*>(s_cf + COUT + c4),
-                        cc = *reinterpret_cast<const f32x4*>(s_cf + 2 * COUT + c4);
-            if constexpr (!PPOOL) {
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c4 = cgo * 8 + hf * 4;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bn + c4), bt = *reinterpret_cast<const f32x4*>(s_bn + COUT + c4);
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(s_cf + c4), cb = *reinterpret_cast<const f32x4*>(s_cf + COUT + c4),
+                            cc = *reinterpret_cast<const f32x4*>(s_cf + 2 * COUT + c4);
 #pragma unroll
                 for (int j = 0; j < C::NGI; ++j) {
                     const int it = tid + j * NT;
@@ -346,51 +372,54 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
                         st4bf(tileD + (it / CGO) * PD + c4, dz);
                     }
                 }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bn + cq4), bt = *reinterpret_cast<const f32x4*>(s_bn + COUT + cq4);
+            const f32x4 ca = *reinterpret_cast<const f32x4*>(s_cf + cq4), cb = *reinterpret_cast<const f32x4*>(s_cf + COUT + cq4),
+                        cc = *reinterpret_cast<const f32x4*>(s_cf + 2 * COUT + cq4);
 #pragma unroll
-                for (int j = 0; j < C::NWI; ++j) {
-                    const int it = tid + j * NT;
-                    if (C::NWIN * CGO % NT == 0 || it < C::NWIN * CGO) {
-                        float gs[4], dz[4][4];
-                        half4(g1r[j], hf, gs);
-                        if constexpr (G2) {
-                            float gb[4];
-                            half4(g2r[j], hf, gb);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) gs[i] += gb[i];
-                        }
-                        const bool gv = (okg >> (16 + j)) & 1u;
-                        // first maximum of the window in post-ReLU space (row-major scan, strict > keeps the first), must be > 0: the pooled
-                        // value passes the ReLU.  When gv holds all four pixels lie inside the image.
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float zk[4], mk[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const unsigned w2 = hf ? ((i < 2) ? zr[4 * j + k].a.z : zr[4 * j + k].a.w) : ((i < 2) ? zr[4 * j + k].a.x : zr[4 * j + k].a.y);
-                                zk[k] = (i & 1) ? __uint_as_float(w2 & 0xffff0000u) : __uint_as_float(w2 << 16);
-                                mk[k] = max_lo(fmaf(zk[k], bs[i], bt[i]), 0.f);
-                            }
-                            float best = mk[0];
-                            int sel = 0;
-#pragma unroll
-                            for (int k = 1; k < 4; ++k) {
-                                const bool gt = mk[k] > best;
-                                best = gt ? mk[k] : best;
-                                sel = gt ? k : sel;
-                            }
-                            const float gsel = (gv && best > 0.f) ? gs[i] : 0.f;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const bool ok = (okg >> (4 * j + k)) & 1u;
-                                const float gh = sel == k ? gsel : 0.f;
-                                dz[k][i] = ok ? fmaf(ca[i], gh, fmaf(cb[i], zk[k], cc[i])) : 0.f;
-                            }
-                        }
-                        const int wd = it / CGO, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) st4bf(tileD + ((2 * wy + (k >> 1)) * DW_ + 2 * wx + (k & 1)) * PD + c4, dz[k]);
+            for (int j = 0; j < C::NWI; ++j) {
+                const int it = tid + j * NT;
+                if (C::NWIN * NQ % NT == 0 || it < C::NWIN * NQ) {
+                    float gs[4], dz[4][4];
+                    gs[0] = __uint_as_float(gp1[j].x << 16); gs[1] = __uint_as_float(gp1[j].x & 0xffff0000u);
+                    gs[2] = __uint_as_float(gp1[j].y << 16); gs[3] = __uint_as_float(gp1[j].y & 0xffff0000u);
+                    if constexpr (G2) {
+                        gs[0] += __uint_as_float(gp2[j].x << 16); gs[1] += __uint_as_float(gp2[j].x & 0xffff0000u);
+                        gs[2] += __uint_as_float(gp2[j].y << 16); gs[3] += __uint_as_float(gp2[j].y & 0xffff0000u);
                     }
+                    const bool gv = (okg >> (16 + j)) & 1u;
+                    // first maximum of the window in post-ReLU space (row-major scan, strict > keeps the first), must be > 0: the pooled
+                    // value passes the ReLU.  When gv holds all four pixels lie inside the image.
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float zk[4], mk[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned w2 = (i < 2) ? zp[4 * j + k].x : zp[4 * j + k].y;
+                            zk[k] = (i & 1) ? __uint_as_float(w2 & 0xffff0000u) : __uint_as_float(w2 << 16);
+                            mk[k] = max_lo(fmaf(zk[k], bs[i], bt[i]), 0.f);
+                        }
+                        float best = mk[0];
+                        int sel = 0;
+#pragma unroll
+                        for (int k = 1; k < 4; ++k) {
+                            const bool gt = mk[k] > best;
+                            best = gt ? mk[k] : best;
+                            sel = gt ? k : sel;
+                        }
+                        const float gsel = (gv && best > 0.f) ? gs[i] : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bool ok = (okg >> (4 * j + k)) & 1u;
+                            const float gh = sel == k ? gsel : 0.f;
+                            dz[k][i] = ok ? fmaf(ca[i], gh, fmaf(cb[i], zk[k], cc[i])) : 0.f;
+                        }
+                    }
+                    const int wd = it / NQ, wy = wd / (DW_ / 2), wx = wd - wy * (DW_ / 2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) st4bf(tileD + ((2 * wy + (k >> 1)) * DW_ + 2 * wx + (k & 1)) * PD + cq4, dz[k]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -420,11 +449,13 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
         // ================= phase 2a: dx~ = Weff * dz (shifted), MFMA; epilogue: store + the producers' BatchNorm-backward sums =================
         // One M tile (16 input channels) at a time: the second pass re-reads the B fragments from LDS instead of holding 2x the accumulators.
         {
+            // N tile a of this wave = 16 consecutive pixels of ONE tile row: row and first column are wave-uniform (scalar registers), the
+            // lane only adds (lane & 15) -- the per-store 64-bit address arithmetic was a quarter of the kernel's vector instructions
             int pbase[NPW];
 #pragma unroll
             for (int a = 0; a < NPW; ++a) {
-                const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
-                pbase[a] = (ty * DW_ + tx) * PD;
+                const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
+                pbase[a] = (ty * DW_ + tx0 + l15) * PD;
             }
             const long tb = ((long)org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
 #pragma unroll
@@ -466,23 +497,36 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
                     }
                 }
                 const int m0 = b * 16 + (lane >> 4) * 4;
+                const bool in_a = m0 < x.Ca;
+                const int voff = l15 * (in_a ? x.Ca : x.Cb) + (in_a ? m0 : m0 - x.Ca);  // element offset of this lane's 4 channels from the N tile's first pixel
                 float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < NPW; ++a) {
-                    const int p = (wave * NPW + a) * 16 + (lane & 15), ty = p / TW, tx = p % TW;
-                    const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx) < (unsigned)W;
-                    const long pix = tb + (long)ty * W + tx;
+                    const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
+                    const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W;
+                    const long srow = tb + (long)ty * W + tx0;  // (scalar)
                     if (m0 < CIN) {
                         const f32x4 v = acc[a];
                         if (pv) {
-                            if (m0 < x.Ca)
+#if OCRS_MM_EPI == 2
+                            bf16* pa = gxa + srow * x.Ca;
+                            bf16* pb = gxb + srow * x.Cb;
+                            asm volatile("" : "+s"(pa), "+s"(pb));  // both row pointers stay scalar (hipcc re-associates the select into a per-lane 64-bit multiply)
+                            store4((in_a ? pa : pb) + voff, v[0], v[1], v[2], v[3]);
+#elif OCRS_MM_EPI == 1
+                            bf16* dst = (in_a ? gxa + srow * x.Ca : gxb + srow * x.Cb) + voff;
+                            store4(dst, v[0], v[1], v[2], v[3]);
+#else
+                            const long pix = srow + l15;
+                            if (in_a)
                                 store4(gxa + pix * x.Ca + m0, v[0], v[1], v[2], v[3]);
                             else
                                 store4(gxb + pix * x.Cb + (m0 - x.Ca), v[0], v[1], v[2], v[3]);
+#endif
                         }
                         if constexpr (STATS) {
                             float xq[4];
-                            load4(tileX + p * PX + m0, xq);  // 0 outside the image: contributes nothing
+                            load4(tileX + (k * 16 + l15) * PX + m0, xq);  // 0 outside the image: contributes nothing
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 // the producer's backward reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask
@@ -695,12 +739,15 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
 }
 static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : (Cin == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16); }  // forward tiles
 static int mm_bwd_bpc(int Cin, int Cout) { return (Cin == 32 && Cout == 32) ? OCRS_MM_C32_BPC : 2; }
-static int mm_bwd_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? (mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8) : OCRS_MM_TH_OF(Cin, Cout); }
+static int mm_bwd_th(int Cin, int Cout, int pooled) {
+    if (Cin == 32 || Cout == 32) return mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8;
+    return (pooled && Cin == 16 && Cout == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(Cin, Cout);
+}
 
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                            const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, int N, int H, int W, int nb, hipStream_t st) {
-    using CC = MmCfg<CIN, COUT>;
+    using CC = MmCfg<CIN, COUT, PPOOL>;
     Tiling2 tg = make_tiling2(N, H + (PPOOL ? 1 : 0), W + (PPOOL ? 1 : 0), CC::TW, CC::TH);  // pooled: origins shifted by -1 -> one more row / column of tiles may be needed
     tg.H = H;
     tg.W = W;
@@ -740,7 +787,8 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 }
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
-    return (long)mm_grid(mm_bwd_th(Cin, Cout), N, H, W, 1, mm_bwd_bpc(Cin, Cout)) * (Cout * Cin + 11 * Cin);
+    const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout));
+    return (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin);
 }
 
 // Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
@@ -770,7 +818,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const float* svB = split ? nullptr : saved_b;
         double* gsB = split ? nullptr : gsum_b;
         const bool stats = gsA || gsB;
-        const int nb = mm_grid(mm_bwd_th(Cin, Cout), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout));
+        const int nb = mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
 #define MM_CASE(CI_, CO_)                                                                                                             \
