@@ -1,0 +1,495 @@
+// Bidirectional GRU recurrence as ONE persistent launch per layer and pass (gfx950) -- same arithmetic contract as rec_gru.hip (PyTorch gate
+// order r, z, n; reference ocrs_models/models.py:245, 264-266), without the T kernel boundaries.
+//
+// rec_gru.hip runs one launch per time step: 404 launches per train step of 6.9 (forward) / 8.6 us (backward) each -- 3.1 ms, 36 % of the
+// CRNN step -- of which the recurrent GEMM itself is ~1.3 us: the rest is the kernel boundary (L2 write-back + invalidate, ~1.5 us), the
+// re-load of W_hh and of the step's operands behind it, and the launch ramp.  Here the T steps run inside one launch:
+//   * the recurrence is independent per batch column, so a GROUP of 16 workgroups owns (direction, 32 batch columns): workgroup jt of the
+//     group computes hidden units 16 jt .. 16 jt + 15 (3 gates = 3 MFMA M tiles, 2 N tiles of 16 columns) for every step;
+//   * its slice of W_hh lives in registers for the whole sequence (K = 256 split over the 8 waves as in rec_gru.hip: 24 registers per wave);
+//   * per step the group exchanges h_t (forward) / dgh_t (backward) through global memory with the hand-off recipe of the CDNA4 guide
+//     (Guideline 16, form "8-byte agent-scope atomics on both sides"): every value is stored once with an 8-byte agent-scope store (write
+//     through), each storing wave drains vmcnt, the workgroup barriers, ONE lane bumps the group's arrival counter; consumers poll that one
+//     word relaxed (one lane), barrier, and read the operands with 8-byte agent-scope loads (L1 bypass).  No fences, no dependence on
+//     dispatch order or workgroup -> XCD placement (the group -> XCD mapping below is for speed only).  Arrival counters are monotonic
+//     (16 * step) and zeroed by a memset node before every launch; a bounded spin raises a caller-owned, sticky error word instead of
+//     hanging the GPU (the host side checks it: ocrs_models_amd/recognition.py).
+//   * SAME-XCD FAST PATH.  Write-through stores, memory-side atomics and loads that miss the L2 make a hand-off ~4 us -- no better than the
+//     kernel boundary it replaces.  The launch places the 16 workgroups of a group on ONE XCD (block b runs on XCD b % 8) and VERIFIES it at
+//     run time: every workgroup publishes its HW_REG_XCC_ID with the agent-scope recipe above and reads its 15 peers'.  Only if all 16 agree
+//     does the group switch to plain stores and an L2-executed (workgroup-scope) arrival counter: the XCD's L2 is the coherence point of its
+//     CUs (L1 is write-through; the consumers' agent-scope loads bypass their L1), so the exchange never leaves the L2.  Any other placement
+//     keeps the agent-scope path: results never depend on where the dispatcher puts a workgroup, only the speed does.
+//   * the step's own operands (gi; dout, saved gates) are prefetched one step ahead, h_{t-1} of the thread's own (unit, column) pair and the
+//     z * dh carry of the backward stay in registers.
+// EXACT = true: v_mfma_f32_16x16x4_f32 (the reference's fp32 arithmetic); false: split-bf16 x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32
+// accumulation: fp32-class, ~2^-17 relative per product, 5x fewer MFMA cycles) -- the same switch as the projection GEMMs (OCRS_GRU_X3).
+#include "common.h"
+
+namespace {
+constexpr int SH = 256, S3 = 768;  // hidden size, 3 gates
+constexpr int SNB = 32;            // batch columns per group
+constexpr int SNW = 8;             // waves per workgroup
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 ld_agent(const void* p) { return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(void* p, float a, float b) {
+    const u64 v = (u64)__float_as_uint(a) | ((u64)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<u64*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 8 consecutive floats by four 8-byte agent-scope loads
+__device__ __forceinline__ void ld8_agent(const float* p, float (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u64 x = ld_agent(p + 2 * q);
+        v[2 * q] = __uint_as_float((unsigned)x);
+        v[2 * q + 1] = __uint_as_float((unsigned)(x >> 32));
+    }
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// hi / lo bf16 split of 8 floats (one 16x16x32 operand each)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+
+constexpr int SYNC_STRIDE = 32;  // 32-bit words per group: [0] arrival counter, [16 .. 31] XCC ids (+1) of its workgroups; one 128-byte line
+
+// workgroup -> (group, jt): group g on XCD g % 8 (block b is observed to run on XCD b % 8; the grid is padded to 8 x ceil(ngroups / 8) groups
+// and workgroups of the padding exit at once).  Speed only: see seq_same_xcd().
+__device__ __forceinline__ bool seq_role(int ngroups, int& group, int& jt) {
+    const int b = blockIdx.x, slot = b >> 3;
+    group = (b & 7) + 8 * (slot >> 4);
+    jt = slot & 15;
+    return group < ngroups;
+}
+
+// one lane, once per launch: publish this workgroup's XCD id, read the 15 peers'; true iff the whole group shares one XCD (= one L2)
+__device__ __forceinline__ bool seq_same_xcd(unsigned* gs, int jt, unsigned* err, bool& ok) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 0xfu) + 1u;  // (0 = not published yet)
+    __hip_atomic_store(gs + 16 + jt, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    ok = true;
+    for (int k = 0; k < 16 && ok; ++k) {
+        unsigned v = 0;
+        for (unsigned spins = 0;; ++spins) {
+            v = __hip_atomic_load(gs + 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0u) break;
+            if ((spins & 1023u) == 1023u) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                if (spins >= SPIN_LIMIT) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        same = same && v == xcc;
+    }
+    return same;
+}
+// the group's exchange stores / arrival signal: agent scope (write-through, memory-side atomic) or, on the verified same-XCD path, L2-local
+__device__ __forceinline__ void st_x(bool fast, float* p, float a, float b) {
+    if (fast)
+        *reinterpret_cast<float2*>(p) = make_float2(a, b);
+    else
+        st_agent(p, a, b);
+}
+__device__ __forceinline__ void seq_signal(bool fast, unsigned* cnt) {
+    if (fast)
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (executes in the XCD's L2)
+    else
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane: wait until the group's arrival counter reaches `need`; false on timeout / error raised elsewhere
+__device__ __forceinline__ bool seq_wait(unsigned* cnt, unsigned need, unsigned* err) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        if ((spins & 1023u) == 1023u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins >= SPIN_LIMIT) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+}  // namespace
+
+// gi [T][N][2*768] (b_ih added), whh [2][768][256] fp32 master, bhh [2][768], out [T][N][512], saved [T][N][2][4][256] (nullable)
+// sync: ngroups arrival counters (zeroed before the launch); err: sticky error word (set when a wait times out).
+template <bool EXACT>
+__global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ whh, const float* __restrict__ bhh,
+                                                        float* out, float* __restrict__ saved, int T, int N, unsigned* sync, unsigned* err, int ngroups,
+                                                        int try_fast) {
+    __shared__ float red[SNW][3][2][16][17];
+    __shared__ int s_ok, s_fast;
+    int group, jt;
+    if (!seq_role(ngroups, group, jt)) return;
+    const int d = group & 1, b0 = (group >> 1) * SNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    unsigned* cnt = sync + group * SYNC_STRIDE;
+    if (tid == 0) {
+        bool ok;
+        const bool same = seq_same_xcd(cnt, jt, err, ok);
+        s_ok = ok ? 1 : 0;
+        s_fast = (same && try_fast) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const bool fast = s_fast != 0;
+
+    // this wave's slice of W_hh: rows (gate g, unit 16 jt + l15), K = 32 wave + 8 kq .. + 7
+    float wf[EXACT ? 3 : 1][8];
+    bf16x8 whi[EXACT ? 1 : 3], wlo[EXACT ? 1 : 3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float* wr = whh + ((long)d * S3 + g * SH + jt * 16 + l15) * SH + wave * 32 + kq * 8;
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf[g][i] = v[i];
+        } else {
+            split8(v, whi[g], wlo[g]);
+        }
+    }
+    // epilogue role: one (unit, column) pair per thread
+    const int jl = tid & 15, bl = tid >> 4;
+    const int b = b0 + bl, j = jt * 16 + jl;
+    const bool bv = b < N;
+    const float bh_r = bhh[d * S3 + j], bh_z = bhh[d * S3 + SH + j], bh_n = bhh[d * S3 + 2 * SH + j];
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f;
+    auto load_gi = [&](int t) {
+        if (bv) {
+            const float* gir = gi + ((long)t * N + b) * (2 * S3) + d * S3 + j;
+            gi_r = gir[0];
+            gi_z = gir[SH];
+            gi_n = gir[2 * SH];
+        }
+    };
+    load_gi(d == 0 ? 0 : T - 1);
+
+#ifdef OCRS_GRU_SEQ_PROF
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
+#define PROF_MARK(i) { const unsigned long long now = __builtin_readcyclecounter(); pt[i] += now - pc; pc = now; }
+#else
+#define PROF_MARK(i)
+#endif
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        float gh[3] = {0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
+            __syncthreads();
+            PROF_MARK(0)
+            if (!s_ok) return;  // (uniform)
+            // recurrent GEMM: gh[gate][unit][column] += W_hh[., K slab] h_{t-1}[column][K slab]
+            f32x4 acc[3][2];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[g][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float hb[2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int row = b0 + nt * 16 + l15;
+                if (row < N) {
+                    ld8_agent(out + ((long)tp * N + row) * 512 + d * SH + wave * 32 + kq * 8, hb[nt]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hb[nt][i] = 0.f;
+                }
+            }
+#ifdef OCRS_GRU_SEQ_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PROF_MARK(1)
+#endif
+            if constexpr (EXACT) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][i], hb[nt][i], acc[g][nt], 0, 0, 0);
+            } else {
+                bf16x8 hhi[2], hlo[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) split8(hb[nt], hhi[nt], hlo[nt]);
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g], hhi[nt], acc[g][nt], 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g], hlo[nt], c, 0, 0, 0);
+                        acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g], hhi[nt], c, 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave][g][nt][kq * 4 + r][l15] = acc[g][nt][r];
+            __syncthreads();
+            PROF_MARK(2)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float* rp = &red[0][g][bl >> 4][jl][bl & 15];
+                constexpr int WS = 3 * 2 * 16 * 17;
+                gh[g] = ((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS])) + ((rp[4 * WS] + rp[5 * WS]) + (rp[6 * WS] + rp[7 * WS]));
+            }
+        }
+        const float rv = sigm(gi_r + gh[0] + bh_r);
+        const float zv = sigm(gi_z + gh[1] + bh_z);
+        const float hn = gh[2] + bh_n;
+        const float nv = tanhf(gi_n + rv * hn);
+        const float hv = (1.f - zv) * nv + zv * hp;
+        hp = hv;
+        const float hv1 = __shfl_down(hv, 1);  // unit j + 1 of the same column (adjacent lane)
+        if (bv) {
+            if ((jl & 1) == 0) st_x(fast, out + ((long)t * N + b) * 512 + d * SH + j, hv, hv1);
+            if (saved) {
+                float* sv = saved + (((long)t * N + b) * 2 + d) * 4 * SH + j;
+                sv[0] = rv;
+                sv[SH] = zv;
+                sv[2 * SH] = nv;
+                sv[3 * SH] = hn;
+            }
+        }
+        PROF_MARK(3)
+        if (s + 1 < T) {
+            // publish h_t: every storing wave drains, the workgroup barriers, one lane signals
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) seq_signal(fast, cnt);
+            load_gi(d == 0 ? s + 1 : T - 2 - s);  // next step's operands: in flight during the wait
+        }
+        PROF_MARK(4)
+    }
+#ifdef OCRS_GRU_SEQ_PROF
+    if (tid == 0 && jt == 0) {
+        cnt[1] = fast ? 1u : 0u;
+        for (int i = 0; i < 5; ++i) cnt[2 + i] = (unsigned)(pt[i] / (unsigned long long)T);
+    }
+#endif
+}
+
+// BPTT.  dout [T][N][512], saved / out from the forward, whh [2][768][256] master; dgi, dgh [T][N][1536] (gradients w.r.t. gi and gh).
+// Step s: direction 0 processes t = T-1-s, direction 1 processes t = s;  dh = dout[t] + z * dh (carry) + W_hh^T dgh[previous step].
+template <bool EXACT>
+__global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
+                                                        const float* __restrict__ whh, float* __restrict__ dgi, float* dgh, int T, int N, unsigned* sync,
+                                                        unsigned* err, int ngroups, int try_fast) {
+    __shared__ float red[SNW][2][16][17];
+    __shared__ int s_ok, s_fast;
+    int group, jt;
+    if (!seq_role(ngroups, group, jt)) return;
+    const int d = group & 1, b0 = (group >> 1) * SNB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    unsigned* cnt = sync + group * SYNC_STRIDE;
+    if (tid == 0) {
+        bool ok;
+        const bool same = seq_same_xcd(cnt, jt, err, ok);
+        s_ok = ok ? 1 : 0;
+        s_fast = (same && try_fast) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    const bool fast = s_fast != 0;
+
+    // this wave's slice of W_hh^T: rows = unit 16 jt + l15, K = gate rows 96 wave + 32 c + 8 kq .. + 7
+    float wf[EXACT ? 3 : 1][8];
+    bf16x8 whi[EXACT ? 1 : 3], wlo[EXACT ? 1 : 3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = whh[((long)d * S3 + wave * 96 + c * 32 + kq * 8 + i) * SH + jt * 16 + l15];
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf[c][i] = v[i];
+        } else {
+            split8(v, whi[c], wlo[c]);
+        }
+    }
+    const int jl = tid & 15, bl = tid >> 4;
+    const int b = b0 + bl, j = jt * 16 + jl;
+    const bool bv = b < N;
+    float e_dout = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_hn = 0.f, e_hp = 0.f, carry = 0.f;
+    auto load_ep = [&](int t) {
+        if (bv) {
+            e_dout = dout[((long)t * N + b) * 512 + d * SH + j];
+            const float* sv = saved + (((long)t * N + b) * 2 + d) * 4 * SH + j;
+            e_r = sv[0];
+            e_z = sv[SH];
+            e_n = sv[2 * SH];
+            e_hn = sv[3 * SH];
+            const int tp = d == 0 ? t - 1 : t + 1;
+            e_hp = (tp >= 0 && tp < T) ? out[((long)tp * N + b) * 512 + d * SH + j] : 0.f;
+        }
+    };
+    load_ep(d == 0 ? T - 1 : 0);
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tq = d == 0 ? t + 1 : t - 1;  // time processed at the previous step
+        float dh = e_dout;
+        if (s > 0) {
+            if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
+            __syncthreads();
+            if (!s_ok) return;
+            f32x4 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float gb[2][8];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int row = b0 + nt * 16 + l15;
+                    if (row < N) {
+                        ld8_agent(dgh + ((long)tq * N + row) * (2 * S3) + d * S3 + wave * 96 + c * 32 + kq * 8, gb[nt]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) gb[nt][i] = 0.f;
+                    }
+                }
+                if constexpr (EXACT) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][i], gb[nt][i], acc[nt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        bf16x8 ghi, glo;
+                        split8(gb[nt], ghi, glo);
+                        f32x4 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[c], ghi, acc[nt], 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[c], glo, cc, 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[c], ghi, cc, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][nt][kq * 4 + r][l15] = acc[nt][r];
+            __syncthreads();
+            const float* rp = &red[0][bl >> 4][jl][bl & 15];
+            constexpr int WS = 2 * 16 * 17;
+            dh += carry + (((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS])) + ((rp[4 * WS] + rp[5 * WS]) + (rp[6 * WS] + rp[7 * WS])));
+        }
+        const float dn_pre = dh * (1.f - e_z) * (1.f - e_n * e_n);
+        const float dz = dh * (e_hp - e_n) * e_z * (1.f - e_z);
+        const float dr = dn_pre * e_hn * e_r * (1.f - e_r);
+        const float dnr = dn_pre * e_r;
+        carry = dh * e_z;
+        const float dr1 = __shfl_down(dr, 1), dz1 = __shfl_down(dz, 1), dnr1 = __shfl_down(dnr, 1);
+        if (bv) {
+            float* gi_ = dgi + ((long)t * N + b) * (2 * S3) + d * S3 + j;
+            gi_[0] = dr;
+            gi_[SH] = dz;
+            gi_[2 * SH] = dn_pre;
+            if ((jl & 1) == 0) {
+                float* gh_ = dgh + ((long)t * N + b) * (2 * S3) + d * S3 + j;
+                st_x(fast, gh_, dr, dr1);
+                st_x(fast, gh_ + SH, dz, dz1);
+                st_x(fast, gh_ + 2 * SH, dnr, dnr1);
+            }
+        }
+        if (s + 1 < T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) seq_signal(fast, cnt);
+            load_ep(d == 0 ? T - 2 - s : s + 1);
+        }
+    }
+}
+
+static int seq_groups(int N) { return 2 * ((N + SNB - 1) / SNB); }
+static int seq_grid(int N) { return 8 * ((seq_groups(N) + 7) / 8) * 16; }  // padded to whole rounds of the 8 XCDs
+static int seq_try_fast() { return env_int("OCRS_GRU_SEQ_FAST", 1); }  // (read per call: the tests compare both paths in one process)
+
+template <class K>
+static bool seq_fits(K kernel, int nblocks) {
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, 0) != hipSuccess) return false;
+    return (long)ncu * per_cu >= nblocks;  // every workgroup must be resident: they wait for each other
+}
+
+extern "C" {
+
+// 1 if the persistent recurrence can run for N batch columns on the current device (all 32 * ceil(N / 32) workgroups co-resident)
+long ocrs_gru_seq_supported(int N) {
+    static const int on = env_int("OCRS_GRU_SEQ", 1);
+    if (!on || N <= 0) return 0;
+    static int cap = -1;  // resident workgroups the device holds of the most demanding of the four kernels
+    if (cap < 0) {
+        cap = 0;
+        for (int nb = 16; nb <= 4096; nb += 16) {
+            if (!(seq_fits(k_gru_seq_fwd<true>, nb) && seq_fits(k_gru_seq_bwd<true>, nb) && seq_fits(k_gru_seq_fwd<false>, nb) && seq_fits(k_gru_seq_bwd<false>, nb))) break;
+            cap = nb;
+        }
+    }
+    return seq_grid(N) <= cap;
+}
+long ocrs_gru_seq_sync_words(int N) { return (long)seq_groups(N) * SYNC_STRIDE; }
+
+// Recurrent part of one bidirectional GRU layer, all T steps in one launch.  whh: the fp32 master [2][768][256] (no fragment packing);
+// sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed here);  err: ONE caller-owned 32-bit word, zeroed by the caller once and sticky: set
+// when a wait inside the launch timed out (outputs incomplete) -- check it with ocrs_gru_seq_status or from the host side at a convenient
+// point;  exact != 0: fp32 MFMA, 0: split-bf16 x3.  Other arguments as ocrs_gru_layer_fwd.  Returns OCRS_ERR_ARG when the grid cannot be
+// co-resident (use the per-step entry point then).
+int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* saved, int T, int N, unsigned* sync, unsigned* err, int exact,
+                     hipStream_t st) {
+    OCRS_CHECK_ARG(gi && whh && bhh && out && sync && err && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
+    const int ng = seq_groups(N);
+    if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (exact)
+        hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, ng, seq_try_fast());
+    else
+        hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, ng, seq_try_fast());
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+int ocrs_gru_seq_bwd(const float* dout, const float* saved, const float* out, const float* whh, float* dgi, float* dgh, int T, int N, unsigned* sync,
+                     unsigned* err, int exact, hipStream_t st) {
+    OCRS_CHECK_ARG(dout && saved && out && whh && dgi && dgh && sync && err && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
+    const int ng = seq_groups(N);
+    if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (exact)
+        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, ng, seq_try_fast());
+    else
+        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, ng, seq_try_fast());
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// the sticky error word (non-zero: a wait timed out in some launch since it was zeroed -- outputs incomplete); synchronises the stream
+int ocrs_gru_seq_status(const unsigned* err, hipStream_t st) {
+    unsigned e = 0;
+    if (hipMemcpyAsync(&e, err, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) return OCRS_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return OCRS_ERR_HIP;
+    return e ? OCRS_ERR_HIP : OCRS_OK;
+}
+
+}  // extern "C"

@@ -44,6 +44,10 @@ class _RecRun:
         self.dtype = dtype
         self.dt = _DT[self.dtype]
         self.x3 = os.environ.get("OCRS_GRU_X3", "1") != "0"  # split-bf16 GEMMs for the fp32 GRU weight gradients in throughput mode
+        # recurrence as one persistent launch per layer and pass (csrc/rec_gru_seq.hip) when all its workgroups can be resident; its matrix
+        # products follow the projection GEMMs' arithmetic: exact fp32 MFMA in parity mode, split-bf16 x3 in throughput mode
+        self.gru_seq = bool(self.L.gru_seq_supported(x.shape[0]))
+        self.gru_exact = 0 if (self.dt == 1 and self.x3 and os.environ.get("OCRS_GRU_REC_X3", "1") != "0") else 1
         self.x = x
         self.N, _, self.H, self.W = x.shape
         self.ncls = self.P["output.0.weight"].shape[0]
@@ -51,6 +55,10 @@ class _RecRun:
     # ---- helpers -------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def seq_sync(self):
+        """arrival counters of one persistent GRU launch (zeroed by the entry point)"""
+        return torch.empty(self.L.gru_seq_sync_words(self.N), dtype=torch.int32, device=self.dev)
 
     def pack(self, src, K, M, K2, s1, s2, sm, dt=None, offset=0):
         dt = self.dt if dt is None else dt
@@ -151,13 +159,17 @@ class _RecRun:
                 gi = self.gemm_x3(xin, I, I, w_ih, I, 0, b_ih, 1536, 1536, rows)  # W_ih [1536][I]
             else:
                 gi = self.gemm(xin, I, I, self.pack(w_ih, I, 1536, I, 0, 1, I, dt=0), b_ih, 1536, 1536, rows)
-            nfl = 8 * 48 * 64 * 8
-            whh_pk = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
-            for d in (0, 1):
-                L.pack_frags(w_hh.data_ptr() + 4 * d * 768 * 256, 0, 256, 768, 256, 0, 1, 256, whh_pk.data_ptr() + 4 * d * nfl, 0)
             out = self.empty(T, N, 512, dtype=torch.float32)
             saved = self.empty(T, N, 2, 4, 256, dtype=torch.float32) if self.train else None
-            L.gru_layer_fwd(ptr(gi), ptr(whh_pk), ptr(b_hh), ptr(out), ptr(saved), T, N)
+            if self.gru_seq:
+                sync = self.seq_sync()  # (kept alive across the call: a temporary would be freed -- and its block re-used -- before the launch)
+                L.gru_seq_fwd(ptr(gi), ptr(w_hh), ptr(b_hh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(_gru_err(self.dev)), self.gru_exact)
+            else:
+                nfl = 8 * 48 * 64 * 8
+                whh_pk = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
+                for d in (0, 1):
+                    L.pack_frags(w_hh.data_ptr() + 4 * d * 768 * 256, 0, 256, 768, 256, 0, 1, 256, whh_pk.data_ptr() + 4 * d * nfl, 0)
+                L.gru_layer_fwd(ptr(gi), ptr(whh_pk), ptr(b_hh), ptr(out), ptr(saved), T, N)
             S.gru.append({"x": xin, "I": I, "w_ih": w_ih, "w_hh": w_hh, "out": out, "saved": saved})
             xin, I = out, 512
         # ---- Linear + LogSoftmax (fp32) ----
@@ -265,13 +277,18 @@ class _RecRun:
         for layer in (1, 0):
             gl = S.gru[layer]
             I = gl["I"]
-            nfl = 24 * 16 * 64 * 8
-            whhT = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
-            for d in (0, 1):
-                L.pack_frags(gl["w_hh"].data_ptr() + 4 * d * 768 * 256, 0, 768, 256, 768, 0, 256, 1, whhT.data_ptr() + 4 * d * nfl, 0)
             dgi = self.empty(rows, 1536, dtype=torch.float32)
             dgh = self.empty(rows, 1536, dtype=torch.float32)
-            L.gru_layer_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(whhT), ptr(dgi), ptr(dgh), ptr(dhz), T, N)
+            if self.gru_seq:
+                sync = self.seq_sync()
+                L.gru_seq_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(gl["w_hh"]), ptr(dgi), ptr(dgh), T, N, ptr(sync),
+                              ptr(_gru_err(self.dev)), self.gru_exact)
+            else:
+                nfl = 24 * 16 * 64 * 8
+                whhT = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
+                for d in (0, 1):
+                    L.pack_frags(gl["w_hh"].data_ptr() + 4 * d * 768 * 256, 0, 768, 256, 768, 0, 256, 1, whhT.data_ptr() + 4 * d * nfl, 0)
+                L.gru_layer_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(whhT), ptr(dgi), ptr(dgh), ptr(dhz), T, N)
             sfx = [f"_l{layer}", f"_l{layer}_reverse"]
             # stacked views: [w_ih, w_ih_reverse] etc. are adjacent in the flat buffer (see `order`)
             gw_ih = G["gru.weight_ih" + sfx[0]]
@@ -321,6 +338,28 @@ class _RecRun:
         return [G[k] for k in self.names]
 
 
+_GRU_ERR = {}  # device -> (sticky device error word of the persistent GRU launches, pinned host copy)
+
+
+def _gru_err(dev):
+    """The error word the persistent GRU launches raise when a wait times out (ocrs_gru_seq_fwd / _bwd: outputs incomplete).  Checked WITHOUT a
+    device synchronisation: every backward queues a copy of the word into pinned host memory, every forward looks at the host copy first -- a
+    failure is reported loudly one step late instead of stalling the pipeline every step."""
+    ent = _GRU_ERR.get(dev)
+    if ent is None:
+        ent = _GRU_ERR[dev] = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory())
+    if int(ent[1][0]) != 0:
+        raise RuntimeError("a persistent GRU launch (ocrs_gru_seq_fwd/_bwd) timed out waiting for its peer workgroups: results since then are "
+                           "incomplete (set OCRS_GRU_SEQ=0 to use the per-step kernels)")
+    return ent[0]
+
+
+def _gru_err_poll(dev):
+    ent = _GRU_ERR.get(dev)
+    if ent is not None:
+        ent[1].copy_(ent[0], non_blocking=True)
+
+
 class _RecFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, names, dtype, *params):
@@ -334,6 +373,7 @@ class _RecFn(torch.autograd.Function):
     def backward(ctx, g):
         _check_versions(ctx)
         grads = ctx.run.backward(g)
+        _gru_err_poll(ctx.run.dev)
         ctx.run = None  # free the saved activations (and break the output -> grad_fn -> ctx -> run cycle)
         return (None, None, None, None, *grads)
 
