@@ -336,7 +336,7 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
     if rank == 0 and not args.no_roofline:
         # one extra step with every conv / GRU launch bracketed by HIP events on the launch stream
         L = lib()
-        fams = ["conv_igemm", "conv3x3_wgrad", "gru_layer_fwd", "gru_layer_bwd"]
+        fams = ["conv_igemm", "conv3x3_wgrad", "gru_layer_fwd", "gru_layer_bwd", "gru_seq_fwd", "gru_seq_bwd"]
         L.timing = {k: [] for k in fams}
         step(batch)
         torch.cuda.synchronize()
@@ -353,15 +353,18 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
             wg_ms += e0.elapsed_time(e1)
             wg_fl += 2.0 * v["N"] * v["H"] * v["W"] * v["Cout"] * v["Cin"] * 9
         T = W // 4 + 1
-        gf = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_fwd"])
-        gb = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_bwd"])
+        persistent = len(tm["gru_seq_fwd"]) > 0  # one launch per layer and pass (csrc/rec_gru_seq.hip) instead of one per time step
+        gf = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_fwd"] + tm["gru_seq_fwd"])
+        gb = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_bwd"] + tm["gru_seq_bwd"])
         tf = (conv_fl + wg_fl) / ((conv_ms + wg_ms) * 1e-3) / 1e12 if conv_ms + wg_ms > 0 else 0.0
         out["roofline"] = {
             "kernel": "k_conv_igemm (fwd+dgrad) + k_conv3x3_wgrad_tr", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
             "conv_fwd_dgrad": {"ms": round(conv_ms, 3), "gflop": round(conv_fl / 1e9, 1), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else None},
             "conv_wgrad": {"ms": round(wg_ms, 3), "gflop": round(wg_fl / 1e9, 1), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms else None},
-            "gru": {"bound": "latency", "steps_per_train_step": 4 * T, "fwd_us_per_step": round(gf * 1e3 / (2 * T), 2),
+            "gru": {"bound": "latency", "form": "persistent: 1 launch per layer and pass, in-kernel group hand-off per step" if persistent else "1 launch per step",
+                    "recurrent_products": ("split-bf16 x3" if x3 else "exact fp32 MFMA") if persistent else "exact fp32 MFMA",
+                    "steps_per_train_step": 4 * T, "fwd_us_per_step": round(gf * 1e3 / (2 * T), 2),
                     "bwd_us_per_step": round(gb * 1e3 / (2 * T), 2), "floor_us_per_step": KERNEL_BOUNDARY_US,
                     "ms": round(gf + gb, 3), "floor_ms": round(4 * T * KERNEL_BOUNDARY_US * 1e-3, 3)},
         }

@@ -127,19 +127,39 @@ __device__ __forceinline__ bool seq_wait(unsigned* cnt, unsigned need, unsigned*
 }
 }  // namespace
 
+// Exchange workspace (xws): the operand each step hands to the next, in MFMA B-fragment order so that every load instruction of a wave covers
+// whole cache lines:  X[group][parity = step & 1][kc = K chunk of 32][nt = 16-column tile][q = 0..3][lane = column (lane & 15) + 16 * kq][2]
+// holds element k = 32 kc + 8 kq + 2 q + {0, 1} of column 16 nt + (lane & 15).  Two parities: a workgroup can only run one step ahead of the
+// slowest of its group (it waits for all 16 arrivals of step s before it reads), so the buffer it overwrites at step s + 1 was read at step s.
+template <int NKC>
+__device__ __forceinline__ float* xslot(float* xws, int group, int par, int kc, int nt, int q, int lane) {
+    return xws + ((((((long)group * 2 + par) * NKC + kc) * 2 + nt) * 4 + q) * 64 + lane) * 2;
+}
+// B fragment (8 consecutive k of this lane's column) of chunk kc: four 8-byte agent-scope loads, each instruction 512 contiguous bytes
+template <int NKC>
+__device__ __forceinline__ void xload(float* xws, int group, int par, int kc, int nt, int lane, float (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u64 x = ld_agent(xslot<NKC>(xws, group, par, kc, nt, q, lane));
+        v[2 * q] = __uint_as_float((unsigned)x);
+        v[2 * q + 1] = __uint_as_float((unsigned)(x >> 32));
+    }
+}
+
 // gi [T][N][2*768] (b_ih added), whh [2][768][256] fp32 master, bhh [2][768], out [T][N][512], saved [T][N][2][4][256] (nullable)
-// sync: ngroups arrival counters (zeroed before the launch); err: sticky error word (set when a wait times out).
+// sync: per group SYNC_STRIDE words (zeroed before the launch); err: sticky error word (set when a wait times out); xws: exchange workspace.
+// Waves: wave = 4 nt + kk owns the 16-column tile nt and the K quarter kk (chunks 2 kk, 2 kk + 1) for all three gates.
 template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ whh, const float* __restrict__ bhh,
-                                                        float* out, float* __restrict__ saved, int T, int N, unsigned* sync, unsigned* err, int ngroups,
-                                                        int try_fast) {
-    __shared__ float red[SNW][3][2][16][17];
+                                                        float* __restrict__ out, float* __restrict__ saved, int T, int N, unsigned* sync, unsigned* err,
+                                                        float* xws, int ngroups, int try_fast) {
+    __shared__ float red[4][3][2][16][17];
     __shared__ int s_ok, s_fast;
     int group, jt;
     if (!seq_role(ngroups, group, jt)) return;
     const int d = group & 1, b0 = (group >> 1) * SNB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, kq = lane >> 4;
+    const int l15 = lane & 15, kq = lane >> 4, wnt = wave >> 2, kk = wave & 3;
     unsigned* cnt = sync + group * SYNC_STRIDE;
     if (tid == 0) {
         bool ok;
@@ -151,26 +171,29 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
     if (!s_ok) return;
     const bool fast = s_fast != 0;
 
-    // this wave's slice of W_hh: rows (gate g, unit 16 jt + l15), K = 32 wave + 8 kq .. + 7
-    float wf[EXACT ? 3 : 1][8];
-    bf16x8 whi[EXACT ? 1 : 3], wlo[EXACT ? 1 : 3];
+    // this wave's slice of W_hh: rows (gate g, unit 16 jt + l15), K = 64 kk + 32 c + 8 kq .. + 7
+    float wf[EXACT ? 3 : 1][EXACT ? 2 : 1][8];
+    bf16x8 whi[EXACT ? 1 : 3][EXACT ? 1 : 2], wlo[EXACT ? 1 : 3][EXACT ? 1 : 2];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const float* wr = whh + ((long)d * S3 + g * SH + jt * 16 + l15) * SH + wave * 32 + kq * 8;
-        float v[8];
-        const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        if constexpr (EXACT) {
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wf[g][i] = v[i];
-        } else {
-            split8(v, whi[g], wlo[g]);
+        for (int c = 0; c < 2; ++c) {
+            const float* wr = whh + ((long)d * S3 + g * SH + jt * 16 + l15) * SH + kk * 64 + c * 32 + kq * 8;
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(wr), b = *reinterpret_cast<const float4*>(wr + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if constexpr (EXACT) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wf[g][c][i] = v[i];
+            } else {
+                split8(v, whi[g][c], wlo[g][c]);
+            }
         }
-    }
-    // epilogue role: one (unit, column) pair per thread
+    // epilogue role: one (unit, column) pair per thread; its exchange slot: k = j -> chunk jt >> 1, position 16 (jt & 1) + jl
     const int jl = tid & 15, bl = tid >> 4;
     const int b = b0 + bl, j = jt * 16 + jl;
     const bool bv = b < N;
+    const int xkc = jt >> 1, xpos = (jt & 1) * 16 + jl, xlane = (bl & 15) + 16 * (xpos >> 3), xq = (xpos & 7) >> 1, xnt = bl >> 4;
     const float bh_r = bhh[d * S3 + j], bh_z = bhh[d * S3 + SH + j], bh_n = bhh[d * S3 + 2 * SH + j];
     float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f;
     auto load_gi = [&](int t) {
@@ -184,85 +207,81 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
     load_gi(d == 0 ? 0 : T - 1);
 
 #ifdef OCRS_GRU_SEQ_PROF
-    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
 #define PROF_MARK(i) { const unsigned long long now = __builtin_readcyclecounter(); pt[i] += now - pc; pc = now; }
 #else
 #define PROF_MARK(i)
 #endif
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
-        const int tp = d == 0 ? t - 1 : t + 1;
         float gh[3] = {0.f, 0.f, 0.f};
         if (s > 0) {
             if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
             __syncthreads();
             PROF_MARK(0)
             if (!s_ok) return;  // (uniform)
-            // recurrent GEMM: gh[gate][unit][column] += W_hh[., K slab] h_{t-1}[column][K slab]
-            f32x4 acc[3][2];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[g][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // recurrent GEMM: gh[gate][unit][column] += W_hh[., K quarter] h_{t-1}[column][K quarter]
             float hb[2][8];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int row = b0 + nt * 16 + l15;
-                if (row < N) {
-                    ld8_agent(out + ((long)tp * N + row) * 512 + d * SH + wave * 32 + kq * 8, hb[nt]);
-                } else {
+            for (int c = 0; c < 2; ++c) xload<8>(xws, group, (s - 1) & 1, 2 * kk + c, wnt, lane, hb[c]);
+            f32x4 acc[3];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) hb[nt][i] = 0.f;
-                }
-            }
+            for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef OCRS_GRU_SEQ_PROF
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PROF_MARK(1)
 #endif
             if constexpr (EXACT) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g)
+                    for (int i = 0; i < 8; ++i)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][i], hb[nt][i], acc[g][nt], 0, 0, 0);
+                        for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][c][i], hb[c][i], acc[g], 0, 0, 0);
             } else {
-                bf16x8 hhi[2], hlo[2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) split8(hb[nt], hhi[nt], hlo[nt]);
+                for (int c = 0; c < 2; ++c) {
+                    bf16x8 hhi, hlo;
+                    split8(hb[c], hhi, hlo);
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g], hhi[nt], acc[g][nt], 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g], hlo[nt], c, 0, 0, 0);
-                        acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g], hhi[nt], c, 0, 0, 0);
+                    for (int g = 0; g < 3; ++g) {
+                        f32x4 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][c], hhi, acc[g], 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][c], hlo, cc, 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][c], hhi, cc, 0, 0, 0);
                     }
+                }
             }
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[wave][g][nt][kq * 4 + r][l15] = acc[g][nt][r];
+                for (int r = 0; r < 4; ++r) red[kk][g][wnt][kq * 4 + r][l15] = acc[g][r];
             __syncthreads();
             PROF_MARK(2)
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const float* rp = &red[0][g][bl >> 4][jl][bl & 15];
                 constexpr int WS = 3 * 2 * 16 * 17;
-                gh[g] = ((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS])) + ((rp[4 * WS] + rp[5 * WS]) + (rp[6 * WS] + rp[7 * WS]));
+                gh[g] = (rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS]);
             }
         }
         const float rv = sigm(gi_r + gh[0] + bh_r);
         const float zv = sigm(gi_z + gh[1] + bh_z);
         const float hn = gh[2] + bh_n;
         const float nv = tanhf(gi_n + rv * hn);
-        const float hv = (1.f - zv) * nv + zv * hp;
+        const float hv = bv ? (1.f - zv) * nv + zv * hp : 0.f;
         hp = hv;
         const float hv1 = __shfl_down(hv, 1);  // unit j + 1 of the same column (adjacent lane)
+        PROF_MARK(3)
+        if (s + 1 < T) {
+            // publish h_t first (the only store the peers wait for): exchange store, drain, barrier, one lane signals
+            if ((jl & 1) == 0) st_x(fast, xslot<8>(xws, group, s & 1, xkc, xnt, xq, xlane), hv, hv1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) seq_signal(fast, cnt);
+        }
+        PROF_MARK(4)
         if (bv) {
-            if ((jl & 1) == 0) st_x(fast, out + ((long)t * N + b) * 512 + d * SH + j, hv, hv1);
+            if ((jl & 1) == 0) *reinterpret_cast<float2*>(out + ((long)t * N + b) * 512 + d * SH + j) = make_float2(hv, hv1);
             if (saved) {
                 float* sv = saved + (((long)t * N + b) * 2 + d) * 4 * SH + j;
                 sv[0] = rv;
@@ -271,37 +290,31 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                 sv[3 * SH] = hn;
             }
         }
-        PROF_MARK(3)
-        if (s + 1 < T) {
-            // publish h_t: every storing wave drains, the workgroup barriers, one lane signals
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) seq_signal(fast, cnt);
-            load_gi(d == 0 ? s + 1 : T - 2 - s);  // next step's operands: in flight during the wait
-        }
-        PROF_MARK(4)
+        if (s + 1 < T) load_gi(d == 0 ? s + 1 : T - 2 - s);  // next step's operands: in flight during the wait
+        PROF_MARK(5)
     }
 #ifdef OCRS_GRU_SEQ_PROF
     if (tid == 0 && jt == 0) {
         cnt[1] = fast ? 1u : 0u;
-        for (int i = 0; i < 5; ++i) cnt[2 + i] = (unsigned)(pt[i] / (unsigned long long)T);
+        for (int i = 0; i < 6; ++i) cnt[2 + i] = (unsigned)(pt[i] / (unsigned long long)T);
     }
 #endif
 }
 
 // BPTT.  dout [T][N][512], saved / out from the forward, whh [2][768][256] master; dgi, dgh [T][N][1536] (gradients w.r.t. gi and gh).
 // Step s: direction 0 processes t = T-1-s, direction 1 processes t = s;  dh = dout[t] + z * dh (carry) + W_hh^T dgh[previous step].
+// Waves: wave = 4 nt + kk owns the column tile nt and K chunks 6 kk .. 6 kk + 5 of the 24 (K = 768 gate rows).
 template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
-                                                        const float* __restrict__ whh, float* __restrict__ dgi, float* dgh, int T, int N, unsigned* sync,
-                                                        unsigned* err, int ngroups, int try_fast) {
-    __shared__ float red[SNW][2][16][17];
+                                                        const float* __restrict__ whh, float* __restrict__ dgi, float* __restrict__ dgh, int T, int N,
+                                                        unsigned* sync, unsigned* err, float* xws, int ngroups, int try_fast) {
+    __shared__ float red[4][2][16][17];
     __shared__ int s_ok, s_fast;
     int group, jt;
     if (!seq_role(ngroups, group, jt)) return;
     const int d = group & 1, b0 = (group >> 1) * SNB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, kq = lane >> 4;
+    const int l15 = lane & 15, kq = lane >> 4, wnt = wave >> 2, kk = wave & 3;
     unsigned* cnt = sync + group * SYNC_STRIDE;
     if (tid == 0) {
         bool ok;
@@ -313,14 +326,14 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
     if (!s_ok) return;
     const bool fast = s_fast != 0;
 
-    // this wave's slice of W_hh^T: rows = unit 16 jt + l15, K = gate rows 96 wave + 32 c + 8 kq .. + 7
-    float wf[EXACT ? 3 : 1][8];
-    bf16x8 whi[EXACT ? 1 : 3], wlo[EXACT ? 1 : 3];
+    // this wave's slice of W_hh^T: rows = unit 16 jt + l15, K = gate rows 192 kk + 32 c + 8 kq .. + 7
+    float wf[EXACT ? 6 : 1][8];
+    bf16x8 whi[EXACT ? 1 : 6], wlo[EXACT ? 1 : 6];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 6; ++c) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = whh[((long)d * S3 + wave * 96 + c * 32 + kq * 8 + i) * SH + jt * 16 + l15];
+        for (int i = 0; i < 8; ++i) v[i] = whh[((long)d * S3 + kk * 192 + c * 32 + kq * 8 + i) * SH + jt * 16 + l15];
         if constexpr (EXACT) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) wf[c][i] = v[i];
@@ -331,6 +344,8 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
     const int jl = tid & 15, bl = tid >> 4;
     const int b = b0 + bl, j = jt * 16 + jl;
     const bool bv = b < N;
+    // exchange slot of gate g: k = 256 g + j -> chunk 8 g + (jt >> 1)
+    const int xkc = jt >> 1, xpos = (jt & 1) * 16 + jl, xlane = (bl & 15) + 16 * (xpos >> 3), xq = (xpos & 7) >> 1, xnt = bl >> 4;
     float e_dout = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_hn = 0.f, e_hp = 0.f, carry = 0.f;
     auto load_ep = [&](int t) {
         if (bv) {
@@ -348,59 +363,56 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
-        const int tq = d == 0 ? t + 1 : t - 1;  // time processed at the previous step
         float dh = e_dout;
         if (s > 0) {
             if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
             __syncthreads();
             if (!s_ok) return;
-            f32x4 acc[2];
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int half = 0; half < 2; ++half) {
+                float gb[3][8];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float gb[2][8];
+                for (int c = 0; c < 3; ++c) xload<24>(xws, group, (s - 1) & 1, 6 * kk + 3 * half + c, wnt, lane, gb[c]);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int row = b0 + nt * 16 + l15;
-                    if (row < N) {
-                        ld8_agent(dgh + ((long)tq * N + row) * (2 * S3) + d * S3 + wave * 96 + c * 32 + kq * 8, gb[nt]);
+                for (int c = 0; c < 3; ++c) {
+                    const int cw = 3 * half + c;
+                    if constexpr (EXACT) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cw][i], gb[c][i], acc, 0, 0, 0);
                     } else {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) gb[nt][i] = 0.f;
-                    }
-                }
-                if constexpr (EXACT) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][i], gb[nt][i], acc[nt], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
                         bf16x8 ghi, glo;
-                        split8(gb[nt], ghi, glo);
-                        f32x4 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[c], ghi, acc[nt], 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[c], glo, cc, 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[c], ghi, cc, 0, 0, 0);
+                        split8(gb[c], ghi, glo);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[cw], ghi, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[cw], glo, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[cw], ghi, acc, 0, 0, 0);
                     }
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave][nt][kq * 4 + r][l15] = acc[nt][r];
+            for (int r = 0; r < 4; ++r) red[kk][wnt][kq * 4 + r][l15] = acc[r];
             __syncthreads();
             const float* rp = &red[0][bl >> 4][jl][bl & 15];
             constexpr int WS = 2 * 16 * 17;
-            dh += carry + (((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS])) + ((rp[4 * WS] + rp[5 * WS]) + (rp[6 * WS] + rp[7 * WS])));
+            dh += carry + ((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS]));
         }
-        const float dn_pre = dh * (1.f - e_z) * (1.f - e_n * e_n);
-        const float dz = dh * (e_hp - e_n) * e_z * (1.f - e_z);
-        const float dr = dn_pre * e_hn * e_r * (1.f - e_r);
-        const float dnr = dn_pre * e_r;
+        float dn_pre = dh * (1.f - e_z) * (1.f - e_n * e_n);
+        float dz = dh * (e_hp - e_n) * e_z * (1.f - e_z);
+        float dr = dn_pre * e_hn * e_r * (1.f - e_r);
+        float dnr = dn_pre * e_r;
+        if (!bv) dn_pre = dz = dr = dnr = 0.f;
         carry = dh * e_z;
         const float dr1 = __shfl_down(dr, 1), dz1 = __shfl_down(dz, 1), dnr1 = __shfl_down(dnr, 1);
+        if (s + 1 < T) {
+            if ((jl & 1) == 0) {
+                st_x(fast, xslot<24>(xws, group, s & 1, xkc, xnt, xq, xlane), dr, dr1);
+                st_x(fast, xslot<24>(xws, group, s & 1, 8 + xkc, xnt, xq, xlane), dz, dz1);
+                st_x(fast, xslot<24>(xws, group, s & 1, 16 + xkc, xnt, xq, xlane), dnr, dnr1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) seq_signal(fast, cnt);
+        }
         if (bv) {
             float* gi_ = dgi + ((long)t * N + b) * (2 * S3) + d * S3 + j;
             gi_[0] = dr;
@@ -408,17 +420,12 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
             gi_[2 * SH] = dn_pre;
             if ((jl & 1) == 0) {
                 float* gh_ = dgh + ((long)t * N + b) * (2 * S3) + d * S3 + j;
-                st_x(fast, gh_, dr, dr1);
-                st_x(fast, gh_ + SH, dz, dz1);
-                st_x(fast, gh_ + 2 * SH, dnr, dnr1);
+                *reinterpret_cast<float2*>(gh_) = make_float2(dr, dr1);
+                *reinterpret_cast<float2*>(gh_ + SH) = make_float2(dz, dz1);
+                *reinterpret_cast<float2*>(gh_ + 2 * SH) = make_float2(dnr, dnr1);
             }
         }
-        if (s + 1 < T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) seq_signal(fast, cnt);
-            load_ep(d == 0 ? T - 2 - s : s + 1);
-        }
+        if (s + 1 < T) load_ep(d == 0 ? T - 2 - s : s + 1);
     }
 }
 
@@ -452,34 +459,37 @@ long ocrs_gru_seq_supported(int N) {
     return seq_grid(N) <= cap;
 }
 long ocrs_gru_seq_sync_words(int N) { return (long)seq_groups(N) * SYNC_STRIDE; }
+// floats of the exchange workspace of one launch (the backward needs 3x the forward: size for the backward, both passes take it)
+long ocrs_gru_seq_ws_floats(int N) { return (long)seq_groups(N) * 2 * 24 * 2 * 4 * 64 * 2; }
 
 // Recurrent part of one bidirectional GRU layer, all T steps in one launch.  whh: the fp32 master [2][768][256] (no fragment packing);
-// sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed here);  err: ONE caller-owned 32-bit word, zeroed by the caller once and sticky: set
+// sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed here);  xws: ocrs_gru_seq_ws_floats(N) floats (exchange workspace, no initialisation);
+// err: ONE caller-owned 32-bit word, zeroed by the caller once and sticky: set
 // when a wait inside the launch timed out (outputs incomplete) -- check it with ocrs_gru_seq_status or from the host side at a convenient
 // point;  exact != 0: fp32 MFMA, 0: split-bf16 x3.  Other arguments as ocrs_gru_layer_fwd.  Returns OCRS_ERR_ARG when the grid cannot be
 // co-resident (use the per-step entry point then).
-int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* saved, int T, int N, unsigned* sync, unsigned* err, int exact,
-                     hipStream_t st) {
-    OCRS_CHECK_ARG(gi && whh && bhh && out && sync && err && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
+int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* saved, int T, int N, unsigned* sync, unsigned* err, float* xws,
+                     int exact, hipStream_t st) {
+    OCRS_CHECK_ARG(gi && whh && bhh && out && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
     if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
     if (exact)
-        hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, xws, ng, seq_try_fast());
     else
-        hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_fwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, xws, ng, seq_try_fast());
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 
 int ocrs_gru_seq_bwd(const float* dout, const float* saved, const float* out, const float* whh, float* dgi, float* dgh, int T, int N, unsigned* sync,
-                     unsigned* err, int exact, hipStream_t st) {
-    OCRS_CHECK_ARG(dout && saved && out && whh && dgi && dgh && sync && err && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
+                     unsigned* err, float* xws, int exact, hipStream_t st) {
+    OCRS_CHECK_ARG(dout && saved && out && whh && dgi && dgh && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
     if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
     if (exact)
-        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast());
     else
-        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast());
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

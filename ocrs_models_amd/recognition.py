@@ -57,8 +57,9 @@ class _RecRun:
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
 
     def seq_sync(self):
-        """arrival counters of one persistent GRU launch (zeroed by the entry point)"""
-        return torch.empty(self.L.gru_seq_sync_words(self.N), dtype=torch.int32, device=self.dev)
+        """arrival counters (zeroed by the entry point) and exchange workspace of one persistent GRU launch"""
+        return (torch.empty(self.L.gru_seq_sync_words(self.N), dtype=torch.int32, device=self.dev),
+                torch.empty(self.L.gru_seq_ws_floats(self.N), dtype=torch.float32, device=self.dev))
 
     def pack(self, src, K, M, K2, s1, s2, sm, dt=None, offset=0):
         dt = self.dt if dt is None else dt
@@ -162,8 +163,8 @@ class _RecRun:
             out = self.empty(T, N, 512, dtype=torch.float32)
             saved = self.empty(T, N, 2, 4, 256, dtype=torch.float32) if self.train else None
             if self.gru_seq:
-                sync = self.seq_sync()  # (kept alive across the call: a temporary would be freed -- and its block re-used -- before the launch)
-                L.gru_seq_fwd(ptr(gi), ptr(w_hh), ptr(b_hh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(_gru_err(self.dev)), self.gru_exact)
+                sync, xws = self.seq_sync()  # (kept alive across the call: a temporary would be freed -- and its block re-used -- before the launch)
+                L.gru_seq_fwd(ptr(gi), ptr(w_hh), ptr(b_hh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(_gru_err(self.dev)), ptr(xws), self.gru_exact)
             else:
                 nfl = 8 * 48 * 64 * 8
                 whh_pk = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
@@ -280,9 +281,9 @@ class _RecRun:
             dgi = self.empty(rows, 1536, dtype=torch.float32)
             dgh = self.empty(rows, 1536, dtype=torch.float32)
             if self.gru_seq:
-                sync = self.seq_sync()
+                sync, xws = self.seq_sync()
                 L.gru_seq_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(gl["w_hh"]), ptr(dgi), ptr(dgh), T, N, ptr(sync),
-                              ptr(_gru_err(self.dev)), self.gru_exact)
+                              ptr(_gru_err(self.dev)), ptr(xws), self.gru_exact)
             else:
                 nfl = 24 * 16 * 64 * 8
                 whhT = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)

@@ -63,7 +63,8 @@ def _hip_fwd(L, mode, gi, whh, bhh, T, N, dev, train=True):
     else:
         sync = torch.empty(L.gru_seq_sync_words(N), dtype=torch.int32, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.gru_seq_fwd(ptr(gi), ptr(whh), ptr(bhh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(err), 1 if mode == "seq_exact" else 0)
+        xws = torch.empty(L.gru_seq_ws_floats(N), device=dev)
+        L.gru_seq_fwd(ptr(gi), ptr(whh), ptr(bhh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(err), ptr(xws), 1 if mode == "seq_exact" else 0)
         L.gru_seq_status(ptr(err))
         assert int(err.item()) == 0
     return out, saved
@@ -84,7 +85,8 @@ def _hip_bwd(L, mode, dout, saved, out, whh, T, N, dev):
     else:
         sync = torch.empty(L.gru_seq_sync_words(N), dtype=torch.int32, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
-        L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync), ptr(err), 1 if mode == "seq_exact" else 0)
+        xws = torch.empty(L.gru_seq_ws_floats(N), device=dev)
+        L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync), ptr(err), ptr(xws), 1 if mode == "seq_exact" else 0)
         L.gru_seq_status(ptr(err))
         assert int(err.item()) == 0
     return dgi, dgh
