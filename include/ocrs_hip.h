@@ -171,7 +171,7 @@ int ocrs_gru_layer_bwd(const float* dout, const float* saved, const float* out, 
 /* The same recurrence as ONE persistent launch per layer and pass (csrc/rec_gru_seq.hip): groups of 16 workgroups own (direction, 32 batch
    columns) and exchange h_t / dgh_t per step with agent-scope 8-byte accesses and an arrival counter.  whh: the fp32 master [2][768][256]
    (weight_hh_l*, weight_hh_l*_reverse stacked; no fragment packing);  sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed by the call);
-   xws: ocrs_gru_seq_ws_floats(N) floats, the per-step exchange buffer (MFMA-fragment order, no initialisation needed);
+   xws: ocrs_gru_seq_ws_floats(N) floats, the per-step exchange buffer (MFMA-fragment order; initialised by the call);
    err: ONE caller-owned 32-bit word, zeroed once by the caller and sticky -- set if a wait inside a launch timed out (outputs incomplete);
    exact != 0: fp32 MFMA (reference arithmetic), 0: split-bf16 x3 (fp32-class).  ocrs_gru_seq_supported: 1 when every workgroup of the launch
    can be resident on the current device (otherwise use the per-step entry points above; OCRS_GRU_SEQ=0 forces that). */

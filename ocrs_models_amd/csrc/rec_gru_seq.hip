@@ -146,6 +146,55 @@ __device__ __forceinline__ void xload(float* xws, int group, int par, int kc, in
     }
 }
 
+// ---- split-bf16 exchange (EXACT = false): the data is the flag.  A value travels as ONE 32-bit word (hi bf16 << 16 | lo bf16) whose lowest bit
+// -- the last mantissa bit of lo, 2^-17 of the value -- carries a tag that alternates between successive writes of the same slot
+// (tag = (step >> 1) & 1; the workspace is preset to all-ones and the first two writes carry 0).  Consumers simply load their fragment and
+// re-load until every word shows the tag of the step they need: no drain, no barrier, no arrival counter, no second round trip for a flag
+// (Guideline 16, form R2: single aligned word per granule, so a reader can never pair a new tag with an old value).  The split is done once
+// by the producer instead of by each of the 16 consumers.
+__device__ __forceinline__ unsigned pack_hilo(float v, unsigned tag) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | ((unsigned)__builtin_bit_cast(unsigned short, l) & 0xfffeu) | tag;
+}
+// 8 packed words -> the hi and lo MFMA operands
+__device__ __forceinline__ void unpack_hilo(const unsigned (&w)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (w[2 * i] >> 16) | (w[2 * i + 1] & 0xffff0000u);
+        l[i] = (w[2 * i] & 0xffffu) | (w[2 * i + 1] << 16);
+    }
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+// this wave's fragments of NC consecutive chunks, polled until every word carries `tag`; false on timeout / error elsewhere
+template <int NKC, int NC>
+__device__ __forceinline__ bool xpoll(float* xws, int group, int par, int kc0, int nt, int lane, unsigned tag, unsigned* err, unsigned (&w)[NC][8]) {
+    for (unsigned spins = 0;; ++spins) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u64 x = ld_agent(xslot<NKC>(xws, group, par, kc0 + c, nt, q, lane));
+                w[c][2 * q] = (unsigned)x;
+                w[c][2 * q + 1] = (unsigned)(x >> 32);
+                bad |= (w[c][2 * q] ^ tag) | (w[c][2 * q + 1] ^ tag);
+            }
+        if (!__any((int)(bad & 1u))) return true;
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins >= (SPIN_LIMIT >> 2)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+__device__ __forceinline__ void st_xw(bool fast, float* p, unsigned a, unsigned b) { st_x(fast, p, __uint_as_float(a), __uint_as_float(b)); }
+
 // gi [T][N][2*768] (b_ih added), whh [2][768][256] fp32 master, bhh [2][768], out [T][N][512], saved [T][N][2][4][256] (nullable)
 // sync: per group SYNC_STRIDE words (zeroed before the launch); err: sticky error word (set when a wait times out); xws: exchange workspace.
 // Waves: wave = 4 nt + kk owns the 16-column tile nt and the K quarter kk (chunks 2 kk, 2 kk + 1) for all three gates.
@@ -153,8 +202,8 @@ template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict__ gi, const float* __restrict__ whh, const float* __restrict__ bhh,
                                                         float* __restrict__ out, float* __restrict__ saved, int T, int N, unsigned* sync, unsigned* err,
                                                         float* xws, int ngroups, int try_fast) {
-    __shared__ float red[4][3][2][16][17];
-    __shared__ int s_ok, s_fast;
+    __shared__ float red[EXACT ? 1 : 2][4][3][2][16][17];  // (tagged exchange: one barrier per step, so the partials alternate between two buffers)
+    __shared__ int s_ok, s_fast, s_fail;
     int group, jt;
     if (!seq_role(ngroups, group, jt)) return;
     const int d = group & 1, b0 = (group >> 1) * SNB;
@@ -166,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
         const bool same = seq_same_xcd(cnt, jt, err, ok);
         s_ok = ok ? 1 : 0;
         s_fast = (same && try_fast) ? 1 : 0;
+        s_fail = 0;
     }
     __syncthreads();
     if (!s_ok) return;
@@ -216,22 +266,18 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
         const int t = d == 0 ? s : T - 1 - s;
         float gh[3] = {0.f, 0.f, 0.f};
         if (s > 0) {
-            if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
-            __syncthreads();
-            PROF_MARK(0)
-            if (!s_ok) return;  // (uniform)
-            // recurrent GEMM: gh[gate][unit][column] += W_hh[., K quarter] h_{t-1}[column][K quarter]
-            float hb[2][8];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) xload<8>(xws, group, (s - 1) & 1, 2 * kk + c, wnt, lane, hb[c]);
             f32x4 acc[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef OCRS_GRU_SEQ_PROF
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PROF_MARK(1)
-#endif
+            // recurrent GEMM: gh[gate][unit][column] += W_hh[., K quarter] h_{t-1}[column][K quarter]
             if constexpr (EXACT) {
+                if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
+                __syncthreads();
+                PROF_MARK(0)
+                if (!s_ok) return;  // (uniform)
+                float hb[2][8];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) xload<8>(xws, group, (s - 1) & 1, 2 * kk + c, wnt, lane, hb[c]);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -239,10 +285,13 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
 #pragma unroll
                         for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][c][i], hb[c][i], acc[g], 0, 0, 0);
             } else {
+                unsigned w[2][8];
+                if (!xpoll<8, 2>(xws, group, (s - 1) & 1, 2 * kk, wnt, lane, (unsigned)(((s - 1) >> 1) & 1), err, w)) s_fail = 1;
+                PROF_MARK(0)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     bf16x8 hhi, hlo;
-                    split8(hb[c], hhi, hlo);
+                    unpack_hilo(w[c], hhi, hlo);
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         f32x4 cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][c], hhi, acc[g], 0, 0, 0);
@@ -251,15 +300,19 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                     }
                 }
             }
+            const int rb = EXACT ? 0 : (s & 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[kk][g][wnt][kq * 4 + r][l15] = acc[g][r];
+                for (int r = 0; r < 4; ++r) red[rb][kk][g][wnt][kq * 4 + r][l15] = acc[g][r];
             __syncthreads();
             PROF_MARK(2)
+            if constexpr (!EXACT) {
+                if (s_fail) return;  // (uniform: written before the barrier)
+            }
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const float* rp = &red[0][g][bl >> 4][jl][bl & 15];
+                const float* rp = &red[rb][0][g][bl >> 4][jl][bl & 15];
                 constexpr int WS = 3 * 2 * 16 * 17;
                 gh[g] = (rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS]);
             }
@@ -273,11 +326,17 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
         const float hv1 = __shfl_down(hv, 1);  // unit j + 1 of the same column (adjacent lane)
         PROF_MARK(3)
         if (s + 1 < T) {
-            // publish h_t first (the only store the peers wait for): exchange store, drain, barrier, one lane signals
-            if ((jl & 1) == 0) st_x(fast, xslot<8>(xws, group, s & 1, xkc, xnt, xq, xlane), hv, hv1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) seq_signal(fast, cnt);
+            if constexpr (EXACT) {
+                // publish h_t first (the only store the peers wait for): exchange store, drain, barrier, one lane signals
+                if ((jl & 1) == 0) st_x(fast, xslot<8>(xws, group, s & 1, xkc, xnt, xq, xlane), hv, hv1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) seq_signal(fast, cnt);
+            } else {
+                const unsigned w0 = pack_hilo(hv, (unsigned)((s >> 1) & 1));
+                const unsigned w1 = __shfl_down(w0, 1);
+                if ((jl & 1) == 0) st_xw(fast, xslot<8>(xws, group, s & 1, xkc, xnt, xq, xlane), w0, w1);
+            }
         }
         PROF_MARK(4)
         if (bv) {
@@ -304,6 +363,8 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
 // BPTT.  dout [T][N][512], saved / out from the forward, whh [2][768][256] master; dgi, dgh [T][N][1536] (gradients w.r.t. gi and gh).
 // Step s: direction 0 processes t = T-1-s, direction 1 processes t = s;  dh = dout[t] + z * dh (carry) + W_hh^T dgh[previous step].
 // Waves: wave = 4 nt + kk owns the column tile nt and K chunks 6 kk .. 6 kk + 5 of the 24 (K = 768 gate rows).
+// (Both arithmetic modes use the arrival-counter hand-off here: with 3x the forward's exchange volume a poll pass over the wave's 24 fragment
+// loads is so long that the tagged-word form measured SLOWER -- 455 vs 407 us per launch at T = 101, N = 256.)
 template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
                                                         const float* __restrict__ whh, float* __restrict__ dgi, float* __restrict__ dgh, int T, int N,
@@ -463,7 +524,7 @@ long ocrs_gru_seq_sync_words(int N) { return (long)seq_groups(N) * SYNC_STRIDE; 
 long ocrs_gru_seq_ws_floats(int N) { return (long)seq_groups(N) * 2 * 24 * 2 * 4 * 64 * 2; }
 
 // Recurrent part of one bidirectional GRU layer, all T steps in one launch.  whh: the fp32 master [2][768][256] (no fragment packing);
-// sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed here);  xws: ocrs_gru_seq_ws_floats(N) floats (exchange workspace, no initialisation);
+// sync: ocrs_gru_seq_sync_words(N) 32-bit words (zeroed here);  xws: ocrs_gru_seq_ws_floats(N) floats (exchange workspace, initialised here);
 // err: ONE caller-owned 32-bit word, zeroed by the caller once and sticky: set
 // when a wait inside the launch timed out (outputs incomplete) -- check it with ocrs_gru_seq_status or from the host side at a convenient
 // point;  exact != 0: fp32 MFMA, 0: split-bf16 x3.  Other arguments as ocrs_gru_layer_fwd.  Returns OCRS_ERR_ARG when the grid cannot be
@@ -473,6 +534,7 @@ int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float*
     OCRS_CHECK_ARG(gi && whh && bhh && out && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
     if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (!exact && hipMemsetAsync(xws, 0xff, (size_t)ng * 2 * 8 * 2 * 4 * 64 * 2 * sizeof(float), st) != hipSuccess) return OCRS_ERR_HIP;  // tags
     if (exact)
         hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, xws, ng, seq_try_fast());
     else
