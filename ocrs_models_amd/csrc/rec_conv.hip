@@ -977,6 +977,10 @@ static inline int ew_grid(long items) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+bool conv3x3_c128_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype);  // rec_conv2.hip
+int conv3x3_c128_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int N, int H, int W,
+                        hipStream_t st);
+
 template <class T, int TH, int TW>
 static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M,
                         int N, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, hipStream_t st) {
@@ -1129,6 +1133,8 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && wpk && out && Cin % 32 == 0 && ldx >= Cin && M > 0 && ldo >= M && ldo % 4 == 0 && KH >= 1 && KW >= 1 && KH * KW <= 9);
     if (gstat && hipMemsetAsync(gstat, 0, 2 * M * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (conv3x3_c128_supported(ldx, ldo, Cin, M, Hi, Wi, Ho, Wo, KH, KW, padh, padw, dtype))  // the 128-output-channel 3x3 layers: 128 x 256 block tiles (rec_conv2.hip)
+        return conv3x3_c128_launch(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, Hi, Wi, st);
     const bool gemm = Ho == 1 && KH == 1;
     if (dtype == 1)
         return gemm ? launch_igemm<bf16, 1, 128>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st)

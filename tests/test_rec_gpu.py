@@ -39,7 +39,10 @@ def _run(dev, dtype, N, H=64, W=64):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("ci,co,k,pad,H,W", [(32, 64, 3, 1, 12, 20), (64, 128, 3, 1, 9, 17), (128, 128, 3, 1, 8, 33), (128, 128, 2, 1, 4, 19)])
+@pytest.mark.parametrize("ci,co,k,pad,H,W", [(32, 64, 3, 1, 12, 20), (64, 128, 3, 1, 9, 17), (128, 128, 3, 1, 8, 33), (128, 128, 2, 1, 4, 19),
+                                             # the 128-output-channel 3x3 layers at their real sizes (csrc/rec_conv2.hip: one image x 16 rows and two images
+                                             # x 8 rows per tile, odd batch, partial tiles in both directions)
+                                             (64, 128, 3, 1, 16, 100), (128, 128, 3, 1, 16, 37), (128, 128, 3, 1, 8, 100), (128, 128, 3, 1, 21, 16)])
 def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W):
     from ocrs_models_amd._lib import ptr
 
