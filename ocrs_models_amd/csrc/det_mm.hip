@@ -45,6 +45,9 @@
 #ifndef OCRS_MM_BDB_EXCL
 #define OCRS_MM_BDB_EXCL 1  // single-buffer the dgrad B fragments of the 12-row 8 -> 16 and pooled 16 -> 16 tiles (register diet)
 #endif
+#ifndef OCRS_MM_GPIPE
+#define OCRS_MM_GPIPE 0     // weight-gradient phase: explicit one-step-ahead fragment prefetch (1) or straight-line code scheduled by hipcc (0)
+#endif
 #ifndef OCRS_MM_C32_BPC
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
@@ -567,34 +570,65 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
             }
         }
         // ================= phase 2b: G_tap += x~^T dz(shifted), K = the tile's pixels, operands by LDS transpose reads =================
+        // Straight-line code: the wave's own unit has a compile-time number of k-steps starting at a scalar first step, so every read address
+        // is (per-tile base register + immediate) and hipcc can issue the transpose reads of the following steps under the current MFMAs.  (As a
+        // loop over all k-steps with wave-uniform `continue`s every step was: 4 reads -> s_waitcnt lgkmcnt(0) -> 1 MFMA, a full LDS round trip
+        // per MFMA.)
         {
+            constexpr int LOWN = (C::TAPU == 9) ? KS : KS / 2;
+            const bf16* xo = tileX + (ks_own0 * 32 + prow) * PX + pcol;
+            const bf16* dq = tileD + ks_own0 * DW_ * PD + off_own;
+#if OCRS_MM_GPIPE
+            bf16x8 afc[MT], bfc[NTO];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bool own = ks >= ks_own0 && ks < ks_own1, shr = ks >= sh_k0 && ks < sh_k1;
-                if (!own && !shr) continue;  // (wave-uniform)
+            for (int a = 0; a < MT; ++a) afc[a] = lds_tr8(xo + a * 16, xo + a * 16 + 16 * PX);
+#pragma unroll
+            for (int bb = 0; bb < NTO; ++bb) bfc[bb] = lds_tr8(dq + bb * 16, dq + bb * 16 + 16 * PD);
+#pragma unroll
+            for (int i = 0; i < LOWN; ++i) {
+                bf16x8 afn[MT], bfn[NTO];
+                if (i + 1 < LOWN) {
+                    const bf16* xn = xo + (i + 1) * 32 * PX;
+                    const bf16* dn = dq + (i + 1) * DW_ * PD;
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) afn[a] = lds_tr8(xn + a * 16, xn + a * 16 + 16 * PX);
+#pragma unroll
+                    for (int bb = 0; bb < NTO; ++bb) bfn[bb] = lds_tr8(dn + bb * 16, dn + bb * 16 + 16 * PD);
+                }
+#pragma unroll
+                for (int bb = 0; bb < NTO; ++bb)
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) accO[a][bb] = mfma16(afc[a], bfc[bb], accO[a][bb]);
+                if (i + 1 < LOWN) {
+#pragma unroll
+                    for (int a = 0; a < MT; ++a) afc[a] = afn[a];
+#pragma unroll
+                    for (int bb = 0; bb < NTO; ++bb) bfc[bb] = bfn[bb];
+                }
+            }
+#else
+#pragma unroll
+            for (int i = 0; i < LOWN; ++i) {
+                const bf16* xn = xo + i * 32 * PX;
+                const bf16* dn = dq + i * DW_ * PD;
                 bf16x8 af[MT];
 #pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const bf16* xa = tileX + (ks * 32 + prow) * PX + a * 16 + pcol;
-                    af[a] = lds_tr8(xa, xa + 16 * PX);
-                }
-                const bf16* dks = tileD + ks * DW_ * PD;
-                if (own) {
+                for (int a = 0; a < MT; ++a) af[a] = lds_tr8(xn + a * 16, xn + a * 16 + 16 * PX);
 #pragma unroll
-                    for (int b = 0; b < NTO; ++b) {
-                        const bf16* da = dks + off_own + b * 16;
-                        const bf16x8 bfr = lds_tr8(da, da + 16 * PD);
+                for (int bb = 0; bb < NTO; ++bb) {
+                    const bf16x8 bfr = lds_tr8(dn + bb * 16, dn + bb * 16 + 16 * PD);
 #pragma unroll
-                        for (int a = 0; a < MT; ++a) accO[a][b] = mfma16(af[a], bfr, accO[a][b]);
-                    }
+                    for (int a = 0; a < MT; ++a) accO[a][bb] = mfma16(af[a], bfr, accO[a][bb]);
                 }
-                if (shr) {
-                    // (its A fragment is read again with the wave's own M-tile offset: selecting between af[0] / af[1] at run time makes hipcc
-                    //  put the fragments into a scratch array)
-                    const bf16* da = dks + off_sh;
-                    const bf16* xa = tileX + (ks * 32 + prow) * PX + sh_a * 16 + pcol;
-                    accS = mfma16(lds_tr8(xa, xa + 16 * PX), lds_tr8(da, da + 16 * PD), accS);
-                }
+            }
+#endif
+            // this wave's sub-tile of the shared last unit over its k-step range (1 .. KS / NKR + 1 steps)
+            const bf16* xs0 = tileX + prow * PX + sh_a * 16 + pcol;
+            const bf16* ds0 = tileD + off_sh;
+            for (int ks = sh_k0; ks < sh_k1; ++ks) {
+                const bf16* xa = xs0 + ks * 32 * PX;
+                const bf16* da = ds0 + ks * DW_ * PD;
+                accS = mfma16(lds_tr8(xa, xa + 16 * PX), lds_tr8(da, da + 16 * PD), accS);
             }
         }
         lds_barrier();  // all readers of the tiles are done before the next commit
