@@ -61,6 +61,9 @@
 #ifndef OCRS_MF_TH16
 #define OCRS_MF_TH16 8     // forward tile rows, Cin = 16 (16 spills)
 #endif
+#ifndef OCRS_MF_BPC16_8
+#define OCRS_MF_BPC16_8 3  // forward blocks per CU, Cin = 16 -> Cout = 8 (80 registers: 490 -> 438 us at level 0; every other Cin = 16 shape spills at 85)
+#endif
 #ifndef OCRS_MF_BPC8
 #define OCRS_MF_BPC8 2     // forward blocks per CU, Cin = 8
 #endif
@@ -128,8 +131,8 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
 }
 
 // forward: Cin = 8 needs < 80 registers and ~10 KB of LDS: three blocks per CU (more bytes in flight: these launches are latency-bound)
-template <int CINB>
-constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : 4; }
+template <int CINB, int COUT>
+constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : ((CINB == 16 && COUT == 8) ? 2 * OCRS_MF_BPC16_8 : 4); }
 template <int CIN, int COUT>
 constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT>::BPC; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
@@ -897,7 +900,7 @@ struct MfCfg {
 }  // namespace
 
 template <int CINB, int NST, int COUT, bool POOL>
-__global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
                                                    bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
                                                    const float* __restrict__ gamma, bf16* __restrict__ pooled) {
@@ -912,7 +915,12 @@ __global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x,
     float* s_wp = s_w9 + 9 * CIN;                                // [COUT][CIN]
     float* s_stat = s_wp + COUT * CIN;                           // [wave][MT*16][2]
     const int H = tg.H, W = tg.W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15;
+#if OCRS_MM_SW
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: tile rows / first columns of the wave's N tiles become scalar code)
+#else
+    const int wave = tid >> 6;
+#endif
 
     fill_tr8(s_trx, x, tra, trb, CIN, tid);
     for (int i = tid; i < 9 * CIN; i += NT) s_w9[i] = wdw[i];
@@ -982,12 +990,12 @@ __global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x,
         }
     };
     // N tiles of this wave: unit u = wave * UPW + i -> row pair u >> 1, column half u & 1; tile a = 2 * i + (row within the pair)
-    int pty[NPW], ptx[NPW];
+    int pty[NPW], ptx0[NPW];  // (wave-uniform: row and first column of N tile a; the lane adds lane & 15)
 #pragma unroll
     for (int a = 0; a < NPW; ++a) {
         const int u = wave * C::UPW + (a >> 1);
         pty[a] = 2 * (u >> 1) + (a & 1);
-        ptx[a] = (u & 1) * 16 + (lane & 15);
+        ptx0[a] = (u & 1) * 16;
     }
     float s1[MT][4], s2[MT][4];
 #pragma unroll
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x,
             // ---- MFMA: all K chunks of this stage
             int pbase[NPW];
 #pragma unroll
-            for (int a = 0; a < NPW; ++a) pbase[a] = (pty[a] * DW_ + ptx[a]) * PX;
+            for (int a = 0; a < NPW; ++a) pbase[a] = (pty[a] * DW_ + ptx0[a] + l15) * PX;
             uint4 bcur[NPW], bnxt[NPW];
             auto load_b = [&](uint4 (&dst)[NPW], int kc) {
                 bool bv;
@@ -1082,14 +1090,14 @@ __global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x,
         const long tb = ((long)org.n * H + org.h0) * W + org.w0;
 #pragma unroll
         for (int a = 0; a < NPW; ++a) {
-            const bool pv = org.h0 + pty[a] < H && org.w0 + ptx[a] < W;
-            const long pix = tb + (long)pty[a] * W + ptx[a];
+            const bool pv = org.h0 + pty[a] < H && org.w0 + ptx0[a] + l15 < W;
+            bf16* zrow = z + (tb + (long)pty[a] * W + ptx0[a]) * COUT;  // (scalar)
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int m0 = b * 16 + (lane >> 4) * 4;
                 if (pv && m0 < COUT) {
                     const f32x4 v = acc[a][b];
-                    store4(z + pix * COUT + m0, v[0], v[1], v[2], v[3]);
+                    store4(zrow + l15 * COUT + m0, v[0], v[1], v[2], v[3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float q = Elem<bf16>::round(v[i]);
@@ -1105,7 +1113,7 @@ __global__ __launch_bounds__(512, mm_fwd_lb<CINB>()) void k_mm_fwd(Src2<bf16> x,
             const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
             for (int a = 0; a < NPW; a += 2) {
-                const int ph = (org.h0 + pty[a]) >> 1, pw = (org.w0 + ptx[a]) >> 1;
+                const int ph = (org.h0 + pty[a]) >> 1, pw = (org.w0 + ptx0[a] + l15) >> 1;
 #pragma unroll
                 for (int b = 0; b < MT; ++b) {
                     const int m0 = b * 16 + (lane >> 4) * 4;
@@ -1219,7 +1227,7 @@ long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
 long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int cinb = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int th = mm_th(cinb, Cout);
-    return mm_grid(th, N, H, W, 0, cinb == 8 ? OCRS_MF_BPC8 : 2);
+    return mm_grid(th, N, H, W, 0, cinb == 8 ? OCRS_MF_BPC8 : ((cinb == 16 && Cout == 8) ? OCRS_MF_BPC16_8 : 2));
 }
 
 // DepthwiseConv block forward on the matrix cores up to the pre-BatchNorm output (replaces ocrs_dwpw_fwd for bf16, Cin / Cout in {8, 16, 32}
