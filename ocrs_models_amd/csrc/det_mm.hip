@@ -48,6 +48,9 @@
 #ifndef OCRS_MM_GPIPE
 #define OCRS_MM_GPIPE 0     // weight-gradient phase: explicit one-step-ahead fragment prefetch (1) or straight-line code scheduled by hipcc (0)
 #endif
+#ifndef OCRS_MM_B3_16_8
+#define OCRS_MM_B3_16_8 0   // backward, Cin = 16 -> Cout = 8: three blocks per CU (<= 85 registers: needs per-tile LDS statistics + single-buffered dgrad + 8 B of spills; measured 706 vs 673 us: off)
+#endif
 #ifndef OCRS_MM_C32_BPC
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
@@ -80,12 +83,13 @@ struct MmCfg {
     static constexpr int NT = 512, NW = NT / 64;                       // 8 waves
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
-    static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : 2;  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
+    static constexpr bool T3 = OCRS_MM_B3_16_8 && CIN == 16 && COUT == 8 && !PPOOL;
+    static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : (T3 ? 3 : 2);  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
     static constexpr int TW = 32;
     static constexpr int TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : ((PPOOL && CIN == 16 && COUT == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(CIN, COUT));
     static constexpr int TP = TW * TH;
     static constexpr bool T12P = PPOOL && CIN == 16 && COUT == 16 && TH == 12;  // 12-row pooled tile: needs the two register diets below to fit 128
-    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P));  // dgrad B fragments double-buffered across K chunks
+    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3;  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -133,15 +137,15 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
 // forward: Cin = 8 needs < 80 registers and ~10 KB of LDS: three blocks per CU (more bytes in flight: these launches are latency-bound)
 template <int CINB, int COUT>
 constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : ((CINB == 16 && COUT == 8) ? 2 * OCRS_MF_BPC16_8 : 4); }
-template <int CIN, int COUT>
-constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT>::BPC; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
+template <int CIN, int COUT, bool PPOOL>
+constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
-__global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
         for (int b = 0; b < NTO; ++b) accO[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // producers' BatchNorm-backward sums: per-lane register accumulators (one M tile), or -- with two M tiles, where 16 more live registers
     // spill -- per-tile sums added to this wave's own LDS slots (single writer, fixed order: deterministic)
-    constexpr bool STL = STATS && (MT == 2 || C::T12P);
+    constexpr bool STL = STATS && (MT == 2 || C::T12P || C::T3);
     float* s_st = s_wp + COUT * CIN;  // [wave][2][MT*16] (STL only)
     float st1[(STATS && !STL) ? MT : 1][4], st2[(STATS && !STL) ? MT : 1][4];
     if constexpr (STATS && !STL) {
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT>())) void k_mm_bwd(Src2<b
             }
     }
     if constexpr (STL) {
-        static_assert(!STL || C::SLOT_FLOATS * 4 <= C::OFF_PAR, "the flush slots must not reach the LDS-resident stats");
+        static_assert(!STL || C::NW * (MT * NTO + 1) * 256 * 4 <= C::OFF_PAR, "the G flush slots must not reach the LDS-resident stats");
         sstat = s_st;
     }
     __syncthreads();
@@ -775,7 +779,10 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
     return persistent_grid(ntiles, bpc);
 }
 static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : (Cin == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16); }  // forward tiles
-static int mm_bwd_bpc(int Cin, int Cout) { return (Cin == 32 && Cout == 32) ? OCRS_MM_C32_BPC : 2; }
+static int mm_bwd_bpc(int Cin, int Cout, int pooled = 0) {
+    if (Cin == 32 && Cout == 32) return OCRS_MM_C32_BPC;
+    return (OCRS_MM_B3_16_8 && Cin == 16 && Cout == 8 && !pooled) ? 3 : 2;
+}
 static int mm_bwd_th(int Cin, int Cout, int pooled) {
     if (Cin == 32 || Cout == 32) return mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8;
     return (pooled && Cin == 16 && Cout == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(Cin, Cout);
@@ -824,7 +831,7 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 }
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
-    const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout));
+    const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout, 0)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout, 1));
     return (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin);
 }
 
@@ -855,7 +862,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const float* svB = split ? nullptr : saved_b;
         double* gsB = split ? nullptr : gsum_b;
         const bool stats = gsA || gsB;
-        const int nb = mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout));
+        const int nb = mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout, pooled ? 1 : 0));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
 #define MM_CASE(CI_, CO_)                                                                                                             \
