@@ -116,6 +116,11 @@ long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype)
 int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                    const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st);
 long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
+/* The same pass in two calls -- parts bit 0: input gradient dx; bit 1: weight + bias gradients (off the backward's critical path: may run on another
+ * stream) -- where ocrs_convt_bwd_splittable() (the generic deep-level path; the tiled path of levels 0-2 needs parts == 3). */
+long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype);
+int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
+                         const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
 /* autograd of out_conv + sigmoid. */
 /* acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients; see ocrs_dwpw_c1_bwd). */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,

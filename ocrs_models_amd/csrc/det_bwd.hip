@@ -1524,8 +1524,22 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
 
 // saved / gsum (nullable, need ws and ocrs_convt_bwd_stats_supported): x is the raw output of a block consumed ONLY by this ConvTranspose;
 // its BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
+int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
+                         const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
+// 1 if ocrs_convt_bwd_parts can run the input gradient and the weight / bias gradients of this shape as separate calls (the generic deep-level path)
+long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype) { return convt_wgrad_tr_ok(Cup, Cout, dtype) ? 0 : 1; }
+
 int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                    const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int dtype, hipStream_t st) {
+    return ocrs_convt_bwd_parts(x, tr, g, wpk_d, dx, dW, dbias, dbias64, ws, saved, gsum, Cup, Cout, N, h, w, H, W, 3, dtype, st);
+}
+
+// parts: bit 0 = input gradient dx, bit 1 = weight + bias gradients.  Separate calls only where ocrs_convt_bwd_splittable(): the weight-gradient
+// half is off the backward's critical path (nothing downstream reads it), so the caller may put it on another stream, where it overlaps the
+// latency-bound deep-level kernels that follow.  The tiled path (levels 0-2) computes everything from one staged tile and needs parts == 3.
+int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
+                         const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(parts >= 1 && parts <= 3 && (parts == 3 || !convt_wgrad_tr_ok(Cup, Cout, dtype)));
     // dbias64 [Cout] fp64 (caller-zeroed): the generic (deep-level) path accumulates the bias gradient there (order-independent fp64 sums of
     // per-block fp32 partials) and the caller adds it to dbias; the tiled path (levels 0-2) adds to dbias itself from its single-writer reduce
     OCRS_CHECK_ARG(x && tr && g && wpk_d && dx && dW && dbias && dbias64 && Cup % 16 == 0 && Cout % 8 == 0 && Cup <= 256);
@@ -1556,6 +1570,7 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
     const long P = (long)N * h * w;
     const long ntiles = (P + 63) / 64;
     const int gx = persistent_grid(ntiles, 8);
+    if (parts & 1) {
 #define DG_CASE(T_, MT_)                                                                                                                     \
     hipLaunchKernelGGL((k_convt_dgrad<T_, MT_>), dim3(gx, MT_total / MT_), dim3(256), 0, st, (const T_*)g, wpk_d, (T_*)dx, Cup, Cout, h, w, H, \
                        W, N, MT_total);
@@ -1577,6 +1592,8 @@ int ocrs_convt_bwd(const void* x, const float* tr, const void* g, const void* wp
 #undef DG_DISPATCH
 #undef DG_CASE
     OCRS_LAUNCH_CHECK();
+    }
+    if (!(parts & 2)) return OCRS_OK;
     {
         const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;

@@ -113,6 +113,8 @@ class _DetRun:
         self.use_mm = os.environ.get("OCRS_MM", "1") != "0"
         # max-pool written by the producing block's forward kernel (levels 0-2) instead of a separate pass over the full-size z
         self.fuse_pool = os.environ.get("OCRS_FUSE_POOL", "1") != "0"
+        # deep-level ConvTranspose weight gradients on a side stream (they overlap the latency-bound kernels that follow)
+        self.overlap = os.environ.get("OCRS_OVERLAP", "1") != "0"
         self.pooled_by_block = None
         self.x = x
 
@@ -360,11 +362,28 @@ class _DetRun:
             stage_end[stage] = off
         bucketer = getattr(self.mod, "_grad_bucketer", None)
         done = [0]
+        # Side stream for work that nothing downstream in the backward reads (the deep-level ConvTranspose weight / bias gradients): it overlaps the
+        # latency-bound deep-level kernels that follow on the main stream.  A stage is reported to the gradient bucketer only after the main stream
+        # has waited for the side work issued during it (the report of such a stage is deferred by one block so that the overlap survives DDP).
+        main = torch.cuda.current_stream()
+        side = _side_stream(self.dev) if self.overlap else None
+        pending, keep = [], []  # stages whose report waits for the side stream; tensors the side stream still reads
 
-        def stage_done(stage):
+        def stage_done(stage, side_work=False):
+            if side_work:
+                pending.append(stage)
+                return
             if bucketer is not None:
                 bucketer.ready(flat, done[0], stage_end[stage])
             done[0] = stage_end[stage]
+
+        def flush_pending():
+            if pending:
+                main.wait_stream(side)
+                for st in pending:
+                    stage_done(st)
+                pending.clear()
+                keep.clear()
         gpred = gpred.contiguous().float()
         up = self.head_in
         g = self.empty(N, H, W, 8)
@@ -381,6 +400,8 @@ class _DetRun:
         skip_g = [[] for _ in range(7)]
         for i in range(6):
             g1, _ = self.block_bwd(f"up.{i}.contract.seq.1", g, None, 0)
+            if bucketer is not None:
+                flush_pending()  # (DDP: the previous stage's report, deferred by one block)
             gxa, gxb = self.block_bwd(f"up.{i}.contract.seq.0", g1, None, 0)
             skip_g[i].append(gxb)
             up_in, ta = self.convt[i]
@@ -394,25 +415,50 @@ class _DetRun:
                 sv, gs_up = self.recs[up_in.src].saved, self.zeros64(2 * Cup)
                 self.fused[up_in.src] = gs_up
             db64 = self.zeros64(Cout)
-            L.convt_bwd(ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]),
-                        ptr(self.G[f"up.{i}.up.bias"]), ptr(db64), ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W, self.dt)
-            self.G[f"up.{i}.up.bias"].add_(db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
-            stage_done(f"up.{i}")
+            args = (ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]), ptr(self.G[f"up.{i}.up.bias"]), ptr(db64),
+                    ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W)
+            if side is not None and L.convt_bwd_splittable(Cup, Cout, self.dt):
+                flush_pending()
+                side.wait_stream(main)  # its operands (x, the output gradient, the zeroed accumulators) are ready in main-stream order
+                with torch.cuda.stream(side):
+                    L.convt_bwd_parts(*args, 2, self.dt)
+                    self.G[f"up.{i}.up.bias"].add_(db64)
+                keep.extend((gxa, ws, db64, wpk_d, up_in.t))
+                L.convt_bwd_parts(*args, 1, self.dt)
+                stage_done(f"up.{i}", side_work=True)
+            else:
+                flush_pending()
+                L.convt_bwd(*args, self.dt)
+                self.G[f"up.{i}.up.bias"].add_(db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
+                stage_done(f"up.{i}")
             g = dx
         skip_g[6].append(g)
         for i in reversed(range(6)):
             gs = skip_g[i + 1]
             g1, _ = self.block_bwd(f"down.{i}.seq.0.seq.1", gs[0], gs[1] if len(gs) > 1 else None, 1)
+            if bucketer is not None:
+                flush_pending()
             gx, _ = self.block_bwd(f"down.{i}.seq.0.seq.0", g1, None, 0)
             stage_done(f"down.{i}")
             skip_g[i].append(gx)
         gs = skip_g[0]
         g1, _ = self.block_bwd("in_conv.seq.1", gs[0], gs[1], 0)
         self.block_bwd("in_conv.seq.0", g1, None, 0)
+        flush_pending()
         stage_done("in_conv")
         if bucketer is not None:
             bucketer.finish(flat)
         return [self.G[k] for k in self.names]
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 def _check_versions(ctx):
