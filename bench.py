@@ -26,6 +26,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+import numpy as np
 import statistics
 import sys
 import time
@@ -80,6 +82,7 @@ FAMILIES = list(ALG_BYTES_ARGS)
 # pass -> the C-ABI families whose launches belong to it.  The BYTES of a block backward are booked once per block, on the launch that
 # every block backward has exactly once (mm_bwd on the matrix-core path, else pw_bwd); dw_bwd / bn_bwd_reduce launches of the same
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
+PROF_STEPS = 2  # timed steps whose dominant-pass launches are individually timed (dispatch-packet timestamps, csrc/prof.hip)
 PASSES = {
     "block_bwd": ("mm_bwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce"),
     "block_fwd": ("mm_fwd", "dwpw_fwd"),
@@ -459,18 +462,41 @@ def main():
             warm, L.timing = L.timing, None
             ptime = {p: sum(e0.elapsed_time(e1) for f in fams for e0, e1, _ in warm.get(f, [])) for p, fams in PASSES.items()}
             dom = max(ptime, key=ptime.get)
-            L.timing = {f: [] for f in PASSES[dom]}
+            # timed region: the dominant pass's launches record their durations from the dispatch packets' own timestamps (csrc/prof.hip) --
+            # stream events around ~80 launches per step cost ~4 us of queue bubble each (15.5 vs 15.1 ms per step)
+            L.prof = {f: [] for f in PASSES[dom]}
+            L.prof_enable(1)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        recs = None
+        for i in range(steps):
+            if L.prof is not None and i == PROF_STEPS:  # per-launch timestamps on the first PROF_STEPS timed steps only: a launch that reports
+                recs, L.prof = L.prof, None           # its own completion cannot overlap its successor's ramp-up (~4.5 us each, ~80 per step)
+                L.prof_enable(0)
             loss = step()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        timing, L.timing = L.timing, None
+        timing = None
+        if L.prof is not None:
+            recs, L.prof = L.prof, None
+        if recs is not None:
+            n = int(L.prof_count())
+            dur = np.zeros(max(n, 1), dtype=np.float32)
+            L.prof_read(dur.ctypes.data, 0, n)
+            L.prof_enable(0)
+
+            class _Dur:  # (same interface as the event pairs of the warm-up pass)
+                def __init__(self, ms):
+                    self.ms = ms
+
+                def elapsed_time(self, _other):
+                    return self.ms
+
+            timing = {f: [(_Dur(float(dur[a:b].sum())), None, args) for a, b, args in lst] for f, lst in recs.items()}
         final_loss = float(loss.item())
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -510,7 +536,7 @@ def main():
 
         rows, src = pmc_profile()
         dom = next(p for p, fams in PASSES.items() if set(fams) == set(timing))
-        st = pass_stats(timing, dom, args.steps)
+        st = pass_stats(timing, dom, min(PROF_STEPS, args.steps))
         if st:
             tr = pass_traffic(rows, dom)
             n_units = max(1, st["units_per_step"])
@@ -522,6 +548,8 @@ def main():
                 "byte_model": "SURVEY 8(d): per block backward 2*(Cin+Cout) elements/pixel (x, z, g read once; dL/dx written once)",
                 "passes_per_step": n_units, "launches_per_step": st["launches_per_step"], "avg_pass_ms": round(st["ms_per_step"] / n_units, 4),
                 "alg_bytes_per_pass": round(st["alg_GB_per_step"] * 1e9 / n_units), "ms_per_step": st["ms_per_step"],
+                "timing": f"per-launch dispatch timestamps (hipExtLaunchKernelGGL start/stop, no stream events) on the first {min(PROF_STEPS, args.steps)} "
+                          f"of the {args.steps} timed steps, on the launch stream",
             }
             alg_step = 3 * sz * det_alg_elems_per_image(S, S) * B
             out["roofline"]["whole_step_alg_GB"] = round(alg_step / 1e9, 2)

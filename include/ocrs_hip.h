@@ -229,6 +229,13 @@ int ocrs_adam_step(const long long* table, const int* chunks, int nchunks, float
                    const float* gscale, hipStream_t st);
 int ocrs_fill_f32(float* p, float v, long n, hipStream_t st);
 
+/* Measurement support (csrc/prof.hip): while enabled, every launch of the DepthwiseConv block-backward families records its start / stop timestamps
+   from the dispatch packet itself (hipExtLaunchKernelGGL) -- no event barrier packets between the kernels.  ocrs_prof_count: launches recorded
+   so far;  ocrs_prof_read: durations in ms of launches [first, first + n) into a HOST array (synchronises the stream). */
+int ocrs_prof_enable(int on);
+long ocrs_prof_count(void);
+int ocrs_prof_read(float* ms, long first, long n, hipStream_t st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,9 @@ class _Lib:
     # name (without the ocrs_ prefix) -> list of (start_event, end_event, args); None = timing off.
     # Used by bench.py to time the dominant kernel family live, with events on the launch stream.
     timing = None
+    # name -> list of (first, end, args): launch-index range in the C library's dispatch-timestamp recorder (ocrs_prof_enable / _read: no stream
+    # events, the kernels stay back to back); None = off.  Used for the launches inside bench.py's TIMED region.
+    prof = None
 
     def _wrap(self, name, fn, res, sig):
         has_stream = sig.endswith("s")
@@ -88,10 +91,13 @@ class _Lib:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rec = (e0, e1, args)
+            pr0 = owner._dll.ocrs_prof_count() if (owner.prof is not None and short in owner.prof) else -1
             if has_stream:
                 r = fn(*args, torch.cuda.current_stream().cuda_stream)
             else:
                 r = fn(*args)
+            if pr0 >= 0:
+                owner.prof[short].append((pr0, owner._dll.ocrs_prof_count(), args))
             if rec is not None:
                 rec[1].record()
                 owner.timing[short].append(rec)

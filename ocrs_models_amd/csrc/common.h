@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #define OCRS_OK 0
+#include <hip/hip_ext.h>
 #define OCRS_ERR_ARG 1
 #define OCRS_ERR_HIP 2
 
@@ -351,6 +352,24 @@ struct TileSched {
 };
 
 #include <stdlib.h>
+// Per-launch timestamps from the dispatch packet (csrc/prof.hip): OCRS_LAUNCH_T == hipLaunchKernelGGL unless ocrs_prof_enable(1)
+struct OcrsProf {
+    int on, used, cap;
+    hipEvent_t* ev;  // [2 * cap]: start / stop pairs
+};
+OcrsProf& ocrs_prof();
+#define OCRS_LAUNCH_T(kernel, grid, block, smem, st, ...)                                                   \
+    do {                                                                                                    \
+        OcrsProf& pf_ = ocrs_prof();                                                                        \
+        if (pf_.on && pf_.used < pf_.cap) {                                                                 \
+            hipEvent_t e0_ = pf_.ev[2 * pf_.used], e1_ = pf_.ev[2 * pf_.used + 1];                          \
+            ++pf_.used;                                                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, st, e0_, e1_, 0, __VA_ARGS__);                 \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);                                 \
+        }                                                                                                   \
+    } while (0)
+
 static inline int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;

@@ -1274,10 +1274,10 @@ int ocrs_bn_bwd_reduce(const void* g1, const void* g2, int pooled, const void* z
     const size_t smem = (2 * C + 256 * 16) * sizeof(float);
     if (dtype == 1) {
         GradSrc<bf16> gs{(const bf16*)g1, (const bf16*)g2, pooled};
-        hipLaunchKernelGGL(k_bn_bwd_reduce<bf16>, dim3(grid), dim3(256), smem, st, gs, (const bf16*)z, bn, saved, gsum, C, H, W, P);
+        OCRS_LAUNCH_T(k_bn_bwd_reduce<bf16>, dim3(grid), dim3(256), smem, st, gs, (const bf16*)z, bn, saved, gsum, C, H, W, P);
     } else {
         GradSrc<float> gs{(const float*)g1, (const float*)g2, pooled};
-        hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(grid), dim3(256), smem, st, gs, (const float*)z, bn, saved, gsum, C, H, W, P);
+        OCRS_LAUNCH_T(k_bn_bwd_reduce<float>, dim3(grid), dim3(256), smem, st, gs, (const float*)z, bn, saved, gsum, C, H, W, P);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1320,11 +1320,11 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};
     const Tiling2 tg = make_tiling2(N, H, W, Cfg::TW, Cfg::TH);
     const int gx = pw_bwd_gx<CIN, COUT>(N, H, W);
-    hipLaunchKernelGGL((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
+    OCRS_LAUNCH_T((k_pw_bwd<T, CIN, COUT>), dim3(gx, Cfg::NBI * Cfg::NBO), dim3(256), smem, st, x, tra, trb, wdw, gs, (const T*)z, bn, coef,
                        wpk_d, (T*)du, dwpw, ws, tg);
     if (ws) {
         const int ne = CIN * COUT;
-        hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, gx, ne, dwpw, CIN, CIN);
+        OCRS_LAUNCH_T(k_wgrad_partials_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, gx, ne, dwpw, CIN, CIN);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1343,7 +1343,7 @@ extern "C" {
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
 void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_partials_reduce, dim3((nelem + 31) / 32), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
+    OCRS_LAUNCH_T(k_wgrad_partials_reduce, dim3((nelem + 31) / 32), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
 }
 // det_pw2.hip: two-pixel-per-thread pipelined kernel for bf16, Cin, Cout <= 32 (levels 0-2)
 long det_pw2_supported(int Cin, int Cout, int dtype);
@@ -1456,10 +1456,10 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const size_t smem = (tile_fl > red_fl ? tile_fl : red_fl) * sizeof(float);                                                        \
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         if (stat_mask)                                                                                                                    \
-            hipLaunchKernelGGL((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
+            OCRS_LAUNCH_T((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
                                dwdw, ws, saved_a, saved_b, stat_mask, tg);                                                                \
         else                                                                                                                              \
-            hipLaunchKernelGGL((k_dw_bwd<T_, CG_, false>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
+            OCRS_LAUNCH_T((k_dw_bwd<T_, CG_, false>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
                                dwdw, ws, saved_a, saved_b, 0, tg);                                                                        \
     }
     if (dtype == 1) {
@@ -1470,7 +1470,7 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 #undef DWB
     if (ws) {
         const int nrow = stat_mask ? 11 : 9;
-        hipLaunchKernelGGL(k_dw_partials_reduce, dim3((C * nrow + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
+        OCRS_LAUNCH_T(k_dw_partials_reduce, dim3((C * nrow + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
                            gsum_b, saved_a, saved_b);
     }
     OCRS_LAUNCH_CHECK();

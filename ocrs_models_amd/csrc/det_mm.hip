@@ -800,7 +800,7 @@ static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* t
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
+    OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
                        ws, tg);
 }
 
@@ -871,7 +871,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
 #undef MM_CASE
         const int ne = Cout * Cin + 11 * Cin;
-        hipLaunchKernelGGL(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA,
+        OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA,
                            svB, tA, tB);
     }
     OCRS_LAUNCH_CHECK();

@@ -289,10 +289,10 @@ int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
         using CC = Pw2Cfg<CI_, CO_>;                                                                                                        \
         const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);                                                                           \
         if (pooled)                                                                                                                         \
-            hipLaunchKernelGGL((k_pw_bwd2<CI_, CO_, true>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
+            OCRS_LAUNCH_T((k_pw_bwd2<CI_, CO_, true>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
                                (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg, ldu, ldw);                                                   \
         else                                                                                                                                \
-            hipLaunchKernelGGL((k_pw_bwd2<CI_, CO_, false>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
+            OCRS_LAUNCH_T((k_pw_bwd2<CI_, CO_, false>), dim3(nb), dim3(256), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, \
                                (const bf16*)z, bn, coef, wpk_d, (bf16*)du, dwpw, ws, tg, ldu, ldw);                                                   \
     }
     PW2_CASE(8, 8) PW2_CASE(8, 16) PW2_CASE(16, 8) PW2_CASE(16, 16) PW2_CASE(16, 32) PW2_CASE(32, 16) PW2_CASE(32, 32)

@@ -229,7 +229,7 @@ int det_pw8_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
                 return OCRS_ERR_HIP;                                                                                                       \
             attr_set = true;                                                                                                               \
         }                                                                                                                                  \
-        hipLaunchKernelGGL((k_pw_bwd8<CI_, CO_>), dim3(gx, CC::NBI * CC::NBO), dim3(512), CC::SMEM, st, x, tra, trb, wdw, gs, (const bf16*)z, bn, coef, \
+        OCRS_LAUNCH_T((k_pw_bwd8<CI_, CO_>), dim3(gx, CC::NBI * CC::NBO), dim3(512), CC::SMEM, st, x, tra, trb, wdw, gs, (const bf16*)z, bn, coef, \
                            wpk_d, (bf16*)du, dwpw, ws, tg);                                                                                \
     }
     PW8_CASE(128, 128) PW8_CASE(128, 256) PW8_CASE(256, 128) PW8_CASE(256, 256)
