@@ -72,10 +72,12 @@ ALG_BYTES_ARGS = {
     "mm_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "mm_bwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
     "bn_bwd_reduce": ("N", "H", "W", "C"),
     "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
     "convt_bwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
+    "convt_bwd_parts": ("N", "h", "w", "H", "W", "Cup", "Cout", "parts"),
     "maxpool_fwd": ("N", "H", "W", "C"),
 }
 FAMILIES = list(ALG_BYTES_ARGS)
@@ -84,10 +86,10 @@ FAMILIES = list(ALG_BYTES_ARGS)
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
 PROF_STEPS = 2  # timed steps whose dominant-pass launches are individually timed (dispatch-packet timestamps, csrc/prof.hip)
 PASSES = {
-    "block_bwd": ("mm_bwd", "pw_bwd", "dw_bwd", "bn_bwd_reduce"),
+    "block_bwd": ("mm_bwd", "mm_bwd_fin", "pw_bwd", "dw_bwd", "bn_bwd_reduce"),
     "block_fwd": ("mm_fwd", "dwpw_fwd"),
     "convt_fwd": ("convt_fwd",),
-    "convt_bwd": ("convt_bwd",),
+    "convt_bwd": ("convt_bwd", "convt_bwd_parts"),
     "maxpool_fwd": ("maxpool_fwd",),
 }
 PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
@@ -106,13 +108,15 @@ def alg_bytes(name, a, sz):
     v = dict(zip(ARG_NAMES["ocrs_" + name], a))
     if name in ("dwpw_fwd", "mm_fwd"):  # x (Ca+Cb) in, z (Cout) out
         return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
-    if name in ("pw_bwd", "mm_bwd"):  # the whole block backward: x, z, g in; dL/dx out
+    if name in ("pw_bwd", "mm_bwd", "mm_bwd_fin"):  # the whole block backward: x, z, g in; dL/dx out
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
     if name in ("dw_bwd", "bn_bwd_reduce"):
         return 0.0
     if name == "convt_fwd":  # x in, out out
         return v["N"] * (v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
-    if name == "convt_bwd":  # x + g in, dx out (+ nothing else under the model: 2 x (in + out))
+    if name in ("convt_bwd", "convt_bwd_parts"):  # x + g in, dx out (+ nothing else under the model: 2 x (in + out))
+        if name == "convt_bwd_parts" and not (v["parts"] & 1):
+            return 0.0  # (the weight-gradient half of a split ConvTranspose backward: its bytes are booked on the input-gradient call)
         return 2 * v["N"] * (v["h"] * v["w"] * v["Cup"] + v["H"] * v["W"] * v["Cout"]) * sz
     if name == "maxpool_fwd":
         return v["N"] * v["H"] * v["W"] * v["C"] * 1.25 * sz

@@ -104,6 +104,12 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
                 const void* g1, const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw,
                 float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H,
                 int W, int dtype, hipStream_t st);
+/* ocrs_mm_bwd with ocrs_bn_bwd_finalize folded into the kernel prologue: instead of `coef`, this block's complete BatchNorm-backward sums gsum [2][Cout]
+   (fp64), gamma and saved [mean | rstd]; dgamma / dbeta [Cout] are written (models.py:23 backward). */
+int ocrs_mm_bwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
+                    const void* g2, int pooled, const void* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma,
+                    float* dbeta, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b,
+                    double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* acc64 [17] fp64 = dWpw [8] | dWdw [9], ACCUMULATED (caller-zeroed; the caller adds it to the fp32 gradients): fp64 sums of the per-block
  * fp32 partials are exact, hence independent of the order the blocks finish in (float atomics into the fp32 gradients were not). */
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,

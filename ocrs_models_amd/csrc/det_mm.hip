@@ -144,13 +144,25 @@ constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minim
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
+// BatchNorm-backward finalisation folded into the block kernel's prologue (what k_bn_bwd_finalize computes, det_bwd.hip): with gsum set, every
+// block derives the dz coefficients of its Cout channels from the block's complete sums instead of reading `coef`, and block 0 writes dgamma /
+// dbeta -- one ~5 us launch less per block on the backward's critical path.
+struct BnFin {
+    const double* gsum;   // [2][Cout] sum ghat | sum ghat*zhat of THIS block (complete: produced by the consumers' launches), or null
+    const float* gamma;   // [Cout]
+    const float* saved;   // [2][Cout] mean | rstd
+    float* dgamma;        // [Cout] (written)
+    float* dbeta;
+    long count;           // N * H * W
+};
+
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
                                                    const float* __restrict__ bn, const float* __restrict__ coef, bf16* __restrict__ gxa,
-                                                   bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg) {
+                                                   bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg, BnFin fin) {
     using C = MmCfg<CIN, COUT, PPOOL>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, TP = C::TP, DW_ = C::DW_, DP = C::DP, CGI = C::CGI, CGO = C::CGO, PD = C::PD, PX = C::PX;
     constexpr int MT = C::MT, NTO = C::NTO, KC = C::KC, NPW = C::NPW, KS = C::KS;
@@ -173,9 +185,23 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 
     // ---- prologue: parameters, effective-weight fragments
     fill_tr8(s_trx, x, tra, trb, CIN, tid);
-    for (int i = tid; i < 3 * COUT; i += NT) {
-        s_bn[i] = bn[i];
-        s_cf[i] = coef[i];
+    for (int i = tid; i < 3 * COUT; i += NT) s_bn[i] = bn[i];
+    if (fin.gsum) {
+        for (int c = tid; c < COUT; c += NT) {  // (same arithmetic as k_bn_bwd_finalize)
+            const double s1 = fin.gsum[c], s2 = fin.gsum[COUT + c];
+            const double m1 = s1 / (double)fin.count, m2 = s2 / (double)fin.count;
+            const double mean = fin.saved[c], rstd = fin.saved[COUT + c];
+            const double A = (double)fin.gamma[c] * rstd;
+            s_cf[c] = (float)A;
+            s_cf[COUT + c] = (float)(-A * rstd * m2);
+            s_cf[2 * COUT + c] = (float)(A * (-m1 + mean * rstd * m2));
+            if (blockIdx.x == 0) {
+                fin.dgamma[c] = (float)s2;
+                fin.dbeta[c] = (float)s1;
+            }
+        }
+    } else {
+        for (int i = tid; i < 3 * COUT; i += NT) s_cf[i] = coef[i];
     }
     for (int i = tid; i < 9 * CIN; i += NT) s_w9[i] = wdw[i];
     for (int i = tid; i < COUT * CIN; i += NT) s_wp[i] = wpw[(i / CIN) * ldw + (i % CIN)];
@@ -790,7 +816,8 @@ static int mm_bwd_th(int Cin, int Cout, int pooled) {
 
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
-                           const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, int N, int H, int W, int nb, hipStream_t st) {
+                           const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, int N, int H, int W, int nb, const BnFin& fin,
+                           hipStream_t st) {
     using CC = MmCfg<CIN, COUT, PPOOL>;
     Tiling2 tg = make_tiling2(N, H + (PPOOL ? 1 : 0), W + (PPOOL ? 1 : 0), CC::TW, CC::TH);  // pooled: origins shifted by -1 -> one more row / column of tiles may be needed
     tg.H = H;
@@ -801,14 +828,14 @@ static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* t
         attr_set = true;
     }
     OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
-                       ws, tg);
+                       ws, tg, fin);
 }
 
 template <int CIN, int COUT>
 static void mm_bwd_dispatch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                             int pooled, const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int N, int H, int W,
-                            int nb, hipStream_t st) {
-#define MMB(PP, GG, SS) mm_bwd_launch1<CIN, COUT, PP, GG, SS>(x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb, ws, N, H, W, nb, st)
+                            int nb, const BnFin& fin, hipStream_t st) {
+#define MMB(PP, GG, SS) mm_bwd_launch1<CIN, COUT, PP, GG, SS>(x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb, ws, N, H, W, nb, fin, st)
     if (pooled) {
         if (g2) { if (stats) MMB(true, true, true); else MMB(true, true, false); }
         else    { if (stats) MMB(true, false, true); else MMB(true, false, false); }
@@ -840,10 +867,11 @@ long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
 //   g1 (+ g2): gradient w.r.t. the block output, at half resolution when pooled (routed through MaxPool2d(2));  z, bn, coef: as ocrs_pw_bwd;
 //   gxa | gxb: dL/dx~;  dwpw / dwdw: ACCUMULATED (+=, single writer: deterministic);  ws: ocrs_mm_bwd_ws_floats() floats;
 //   saved_a/gsum_a, saved_b/gsum_b (nullable): as ocrs_dw_bwd.
-int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
-                const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
-                const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(xa && tra && wdw && wpw && g1 && z && bn && coef && gxa && dwpw && dwdw && ws && (Cb == 0 || (xb && trb && gxb)));
+static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
+                       const void* g2, int pooled, const void* z, const float* bn, const float* coef, const BnFin& fin, void* gxa, void* gxb, float* dwpw,
+                       float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W,
+                       int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && wpw && g1 && z && bn && (coef || fin.gsum) && gxa && dwpw && dwdw && ws && (Cb == 0 || (xb && trb && gxb)));
     OCRS_CHECK_ARG(ocrs_mm_bwd_supported(Ca, Cb, Cout, dtype) && (long)N * (H + 2) * (W + 2) < (1L << 31) && H >= 2 && W >= 2);
     OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
     const int CinTot = Ca + Cb;
@@ -867,7 +895,7 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         const float* wp = wpw + c_off;
 #define MM_CASE(CI_, CO_)                                                                                                             \
     if (Cin == CI_ && Cout == CO_)                                                                                                    \
-        mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, st);
+        mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, fin, st);
         MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
 #undef MM_CASE
         const int ne = Cout * Cin + 11 * Cin;
@@ -876,6 +904,26 @@ int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
+}
+
+int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
+                const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
+                const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    const BnFin fin{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return mm_bwd_impl(xa, xb, Ca, Cb, tra, trb, wdw, wpw, g1, g2, pooled, z, bn, coef, fin, gxa, gxb, dwpw, dwdw, ws, saved_a, gsum_a, saved_b, gsum_b, Cout, N, H,
+                       W, dtype, st);
+}
+
+// ocrs_mm_bwd with ocrs_bn_bwd_finalize folded in: instead of `coef`, the block's complete BatchNorm-backward sums gsum [2][Cout] (fp64), its gamma and
+// saved [mean | rstd]; the kernel derives the dz coefficients in its prologue and writes dgamma / dbeta [Cout] (one launch less per block).
+int ocrs_mm_bwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
+                    const void* g2, int pooled, const void* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma,
+                    float* dbeta, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b,
+                    double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(gsum && gamma && saved && dgamma && dbeta);
+    const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
+    return mm_bwd_impl(xa, xb, Ca, Cb, tra, trb, wdw, wpw, g1, g2, pooled, z, bn, nullptr, fin, gxa, gxb, dwpw, dwdw, ws, saved_a, gsum_a, saved_b, gsum_b, Cout, N,
+                       H, W, dtype, st);
 }
 
 }  // extern "C"

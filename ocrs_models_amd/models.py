@@ -115,6 +115,8 @@ class _DetRun:
         self.fuse_pool = os.environ.get("OCRS_FUSE_POOL", "1") != "0"
         # deep-level ConvTranspose weight gradients on a side stream (they overlap the latency-bound kernels that follow)
         self.overlap = os.environ.get("OCRS_OVERLAP", "1") != "0"
+        # BatchNorm-backward finalisation in the prologue of the matrix-core block backward instead of its own launch
+        self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
         self.pooled_by_block = None
         self.x = x
 
@@ -300,9 +302,15 @@ class _DetRun:
         if gsum is None:
             gsum = self.zeros64(2 * C)
             L.bn_bwd_reduce(ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(r.saved), ptr(gsum), C, N, H, W, self.dt)
-        coef = self.empty(3, C, dtype=torch.float32)
-        L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(P[f"{prefix}.seq.2.weight"]), ptr(r.saved), ptr(coef),
-                          ptr(self.G[f"{prefix}.seq.2.weight"]), ptr(self.G[f"{prefix}.seq.2.bias"]))
+        gam, dgam, dbet = P[f"{prefix}.seq.2.weight"], self.G[f"{prefix}.seq.2.weight"], self.G[f"{prefix}.seq.2.bias"]
+        a, b = r.a, r.b
+        use_mm = (r.Cin != 1 and self.use_mm and need_gx and H >= 2 and W >= 2
+                  and L.mm_bwd_supported(a.C, b.C if b is not None else 0, C, self.dt))
+        coef = None
+        fold = use_mm and self.fold_fin
+        if not fold:  # (the matrix-core kernel derives the coefficients from gsum in its prologue: one launch less per block)
+            coef = self.empty(3, C, dtype=torch.float32)
+            L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(gam), ptr(r.saved), ptr(coef), ptr(dgam), ptr(dbet))
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
         if r.Cin == 1:
             acc = self.zeros64(17)  # fp64 accumulators (order-independent), folded into the fp32 gradients below
@@ -321,16 +329,22 @@ class _DetRun:
             if act.src not in self.fused:
                 self.fused[act.src] = self.zeros64(2 * act.C)
             return self.recs[act.src].saved, self.fused[act.src]
-        if self.use_mm and need_gx and L.mm_bwd_supported(Ca, Cb, C, self.dt) and H >= 2 and W >= 2:
+        if use_mm:
             # dz, dgrad of both convs, both weight gradients and the producers' BatchNorm-backward sums from ONE staged copy of (g, z, x)
             gxa = self.empty(N, H, W, Ca)
             gxb = self.empty(N, H, W, Cb) if b is not None else None
             sva, gsa = stat_target(a)
             svb, gsb = stat_target(b)
             ws = self.empty(L.mm_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
-            L.mm_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
-                     ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
-                     ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
+            if fold:
+                L.mm_bwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                             ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(gxb),
+                             ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb),
+                             C, N, H, W, self.dt)
+            else:
+                L.mm_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                         ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
+                         ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
             return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)

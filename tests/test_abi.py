@@ -61,7 +61,8 @@ def test_bench_byte_model_reads_existing_abi_arguments():
             assert n in have, (fam, n, have)
     # and the model returns a positive number for a plausible call of each family
     for fam in bench.FAMILIES:
-        args = [8 if n in ("Ca", "Cb", "C", "Cout", "Cup") else (64 if n in ("H", "W", "h", "w") else (2 if n == "N" else 0)) for n in ARG_NAMES["ocrs_" + fam]]
+        args = [8 if n in ("Ca", "Cb", "C", "Cout", "Cup") else (64 if n in ("H", "W", "h", "w") else (2 if n == "N" else (3 if n == "parts" else 0)))
+                for n in ARG_NAMES["ocrs_" + fam]]
         # (dw_bwd / bn_bwd_reduce launches add time to their block's backward pass and no bytes: 8(d) books a block backward once)
         assert bench.alg_bytes(fam, args, 2) > 0 or fam in ("dw_bwd", "bn_bwd_reduce"), fam
 
