@@ -1353,6 +1353,11 @@ int det_pw2_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
                    int H, int W, int ldu, int ldw, hipStream_t st);
 // det_pw8.hip: eight-wave kernel for the deep levels (bf16, Cin, Cout in {64, 128, 256}); same tiling and workspace rule as k_pw_bwd
 long det_pw8_supported(int Cin, int Cout, int dtype);
+long det_pwb_supported(int Cin, int Cout, int dtype);  // det_pwb.hip
+int det_pwb_gx(int Cin, int Cout, int N, int H, int W, int pooled);
+int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                   int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
+                   int H, int W, hipStream_t st);
 int det_pw8_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
                    int H, int W, int gx, hipStream_t st);
@@ -1369,7 +1374,11 @@ long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W) {
 #undef X
         return a;
     }
-    const long half = (Cin == 64 && det_pw2_supported(32, Cout, 1)) ? det_pw2_ws_floats(32, Cout, N, H, W) : 0;  // two-launch split (32 | 32)
+    long half = (Cin == 64 && det_pw2_supported(32, Cout, 1)) ? det_pw2_ws_floats(32, Cout, N, H, W) : 0;  // two-launch split (32 | 32)
+    if (det_pwb_supported(Cin, Cout, 1)) {
+        const long c = (long)det_pwb_gx(Cin, Cout, N, H, W, 0) * Cin * Cout;  // (the not-pooled grid is the larger one)
+        half = c > half ? c : half;
+    }
 #define X(CI, CO) \
     if (Cin == CI && Cout == CO) { const long b = (long)pw_bwd_gx<CI, CO>(N, H, W) * CI * CO; return b > half ? b : half; }
     PW_BWD_COMBOS(X)
@@ -1399,6 +1408,8 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         return det_pw2_launch(xb, nullptr, 32, 0, trb, nullptr, wdw + 32 * 9, g1, g2, pooled, z, bn, coef, wp + half_frag_bytes,
                               static_cast<bf16*>(du) + 32, dwpw + 32, ws, Cout, N, H, W, 64, 64, st);
     }
+    if (det_pwb_supported(Cin, Cout, dtype))  // deep levels, up to 64 input channels: a whole tile in three barriers (det_pwb.hip)
+        return det_pwb_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, st);
     if (det_pw8_supported(Cin, Cout, dtype)) {
 #define X(CI, CO)                 \
     if (Cin == CI && Cout == CO)  \
