@@ -318,13 +318,14 @@ def test_matrix_core_block_backward_matches_separate_kernels(dev, C0, Ca, Cb, Cc
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_block_bwd_through_maxpool(dev, dtype):
+@pytest.mark.parametrize("C,Cout", [(16, 16), (64, 64), (32, 64), (128, 128)])  # matrix-core, k_pwb (two shapes) and k_pw_bwd8 routing
+def test_block_bwd_through_maxpool(dev, dtype, C, Cout):
     """gradient source = pooled gradient (two consumers) routed through MaxPool2d(2), odd sizes (floor mode)."""
     from ocrs_models_amd._lib import ptr
     from ocrs_models_amd.models import _Act
 
     g = torch.Generator().manual_seed(5)
-    N, C, Cout, H, W = 2, 16, 16, 11, 15
+    N, H, W = 2, 11, 15
     x = torch.randn(N, C, H, W, generator=g).to(dev)
     tr = rand_tr(C, dev, g)
     pfx = "blk"
