@@ -13,6 +13,9 @@
 //      (128 per wave at 256 x 256), flushed once per block as a partial for the deterministic reducer.
 #include "det_common.h"
 
+#ifndef OCRS_PWB_TH_BIG
+#define OCRS_PWB_TH_BIG 4  // tile rows at >= 128 channels (32-pixel tiles: half the per-thread items)
+#endif
 #ifndef OCRS_PWB_PF
 #define OCRS_PWB_PF 1  // prefetch the next tile's raw vectors behind barrier 1
 #endif
@@ -22,7 +25,7 @@ template <int CIN, int COUT>
 struct PwbCfg {
     // (256-thread blocks -- more resident blocks to hide a tile's ~7 k-cycle latency chain -- double the per-thread items and spill 0.5-1 KB)
     static constexpr int NT = 512, NW = NT / 64;
-    static constexpr int TW = 8, TH = 8, TP = 64, HWp = TW + 2, HP = HWp * (TH + 2);
+    static constexpr int TW = 8, TH = (CIN >= 128 || COUT > 128) ? OCRS_PWB_TH_BIG : 8, TP = TW * TH, NNT = TP / 16, HWp = TW + 2, HP = HWp * (TH + 2);
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PXC = CIN + 8, PZC = COUT + 8;              // bf16 pitches (16-byte pad: conflict-free fragment / transpose reads)
     static constexpr int NZI = (TP * CGO + NT - 1) / NT;             // (pixel, cout group) items per thread
@@ -30,16 +33,16 @@ struct PwbCfg {
     static constexpr int NUI = (TP * CGI + NT - 1) / NT;             // (pixel, cin group) depthwise items per thread
     static constexpr int MTD = CIN / 16, NKD = COUT / 32;            // dgrad: M tiles, K chunks
     static constexpr int MPW = MTD >= NW ? MTD / NW : 1;             // dgrad M tiles per wave
-    static constexpr int NPW = MTD >= NW ? 4 : 4 * MTD / NW;         // dgrad N tiles (16 pixels) per wave
+    static constexpr int NPW = MTD >= NW ? NNT : NNT * MTD / NW;     // dgrad N tiles (16 pixels) per wave
     static constexpr int WTI = CIN / 16, WTO = COUT / 16, NTW = (WTI * WTO + NW - 1) / NW;  // wgrad output tiles: per wave
     static constexpr bool PF = OCRS_PWB_PF && !(CIN == 256 && COUT == 256);  // next tile loads in flight under the MFMA phases (registers)
     static constexpr int OFF_DZ = HP * PXC * 2, OFF_U = OFF_DZ + TP * PZC * 2, OFF_PAR = (OFF_U + TP * PXC * 2 + 15) & ~15;
     static constexpr int SMEM = OFF_PAR + (3 * CIN + 9 * CIN + 6 * COUT) * 4;
-    static_assert(NT % CGO == 0 && NT % CGI == 0 && (MTD >= 2) && NPW >= 1 && MPW * NW * (4 / NPW) >= MTD * 1, "role mapping");
+    static_assert(NT % CGO == 0 && NT % CGI == 0 && (MTD >= 2) && NPW >= 1 && TP % 32 == 0, "role mapping");
 };
 
 // resident 512-thread blocks per CU: two where the registers fit 128 (not-pooled launches up to 64 x 64 channels), else one
-constexpr int pwb_bpc(int cin, int cout, bool pooled) { return (!pooled && cin <= 64 && cout <= 64) ? 2 : 1; }
+constexpr int pwb_bpc(int cin, int cout, bool pooled) { return (!pooled && ((cin <= 64 && cout <= 64) || (cin == 128 && cout == 64))) ? 2 : 1; }
 
 __device__ __forceinline__ void unpack8u(const uint4& r, float (&v)[8]) {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -67,10 +70,16 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
     float* s_cf = s_bn + 3 * COUT;                                // [3][COUT]
     const int H = tg.H, W = tg.W;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    fill_tr8(s_trx, x, tra, trb, CIN, tid);
+    // grid.y splits the block input's channels into ranges of CIN (256 input channels = two launches' worth of the 128-channel kernel side by
+    // side: du, dWpw and u separate by input channel, dz is recomputed by both): this block owns channels c_off .. c_off + CIN of cin_total
+    const int c_off = blockIdx.y * CIN, cin_total = CIN * gridDim.y;
+    for (int i = tid; i < 3 * CIN; i += NT) {
+        const int g = i / 24, r = (i - g * 24) >> 3, c = c_off + g * 8 + (i & 7);
+        s_trx[i] = c < x.Ca ? tra[r * x.Ca + c] : trb[r * x.Cb + (c - x.Ca)];
+    }
     for (int i = tid; i < 9 * CIN; i += NT) {
         const int t = i / CIN, c = i - t * CIN;
-        s_wdw[i] = wdw[c * 9 + t];
+        s_wdw[i] = wdw[(c_off + c) * 9 + t];
     }
     for (int i = tid; i < 3 * COUT; i += NT) {
         s_bn[i] = bn[i];
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
             r.okz |= act ? 1u << j : 0u;
             r.okg |= inw ? 1u << j : 0u;
         }
-        const int c0 = cgi * 8;
+        const int c0 = c_off + cgi * 8;
         const bool from_a = c0 < x.Ca;
         const bf16* xb = from_a ? x.a + c0 : x.b + (c0 - x.Ca);
         const int pitch = from_a ? x.Ca : x.Cb;
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
 #pragma unroll
             for (int kc = 0; kc < NKD; ++kc)
 #pragma unroll
-                for (int a = 0; a < MPW; ++a) wf[kc][a] = Mma<bf16>::load_w(wpk_d, (long)kc * MTD + d_m0 + a, lane);
+                for (int a = 0; a < MPW; ++a) wf[kc][a] = Mma<bf16>::load_w(wpk_d, (long)kc * (cin_total / 16) + c_off / 16 + d_m0 + a, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (C::PF && t + ts.step < ts.end) issue(cur, tile_origin2<TW, C::TH>(tg, (int)(t + ts.step)));
             __builtin_amdgcn_sched_barrier(0);
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
                 const int oq = (d_n0 + b) * 16 + (lane & 15);
                 const int qh = org.h0 + oq / TW, qw = org.w0 + oq % TW;
                 if (qh < H && qw < W) {
-                    bf16* dst = du + (((long)org.n * H + qh) * W + qw) * CIN + d_m0 * 16 + (lane >> 4) * 4;
+                    bf16* dst = du + (((long)org.n * H + qh) * W + qw) * cin_total + c_off + d_m0 * 16 + (lane >> 4) * 4;
 #pragma unroll
                     for (int a = 0; a < MPW; ++a) store4(dst + a * 16, accd[a][b][0], accd[a][b][1], accd[a][b][2], accd[a][b][3]);
                 }
@@ -330,7 +339,8 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
             const int ti = tt % C::WTI, to = tt / C::WTI;
             const int co = to * 16 + (lane & 15);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ws[(long)blockIdx.x * (CIN * COUT) + (long)co * CIN + ti * 16 + (lane >> 4) * 4 + r] = accw[j][r];
+            for (int r = 0; r < 4; ++r)
+                ws[(long)blockIdx.x * (cin_total * COUT) + (long)co * cin_total + c_off + ti * 16 + (lane >> 4) * 4 + r] = accw[j][r];
         }
     }
 }
@@ -340,10 +350,12 @@ extern "C" {
 void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st);  // det_bwd.hip
 
 // blocks of the launch (= workspace slots of Cin * Cout floats each)
+static int pwb_th(int Cin, int Cout) { return (Cin >= 128 || Cout > 128) ? OCRS_PWB_TH_BIG : 8; }
+static int pwb_ny(int Cin) { return Cin == 256 ? 2 : 1; }  // 256 input channels: two channel ranges of the 128-channel kernel (grid.y)
 int det_pwb_gx(int Cin, int Cout, int N, int H, int W, int pooled) {
-    const Tiling2 tg = make_tiling2(N, H, W, 8, 8);
+    const Tiling2 tg = make_tiling2(N, H, W, 8, pwb_th(Cin, Cout));
     long g = tg.ntiles / 2;  // at least two tiles per flushing block
-    const long cap = (long)kNumCU * pwb_bpc(Cin, Cout, pooled != 0);  // resident blocks: a second round of blocks would double the launch
+    const long cap = (long)kNumCU * pwb_bpc(Cin / pwb_ny(Cin), Cout, pooled != 0) / pwb_ny(Cin);  // resident blocks: a second round of blocks would double the launch
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     if (g >= 8) g &= ~7L;
@@ -352,7 +364,7 @@ int det_pwb_gx(int Cin, int Cout, int N, int H, int W, int pooled) {
 long det_pwb_supported(int Cin, int Cout, int dtype) {
     static const int on = env_int("OCRS_PWB", 1);
     // (the instantiations with Cin >= 128 spill at 256 registers -- up to 2 KB per lane at 256 x 256 -- and stay on k_pw_bwd8)
-    return on && dtype == 1 && (Cin == 32 || Cin == 64) && (Cout == 64 || Cout == 128);
+    return on && dtype == 1 && (Cin == 32 || Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128 || Cout == 256) && Cin * 8 >= Cout;
 }
 
 int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
@@ -361,8 +373,8 @@ int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG(det_pwb_supported(Cin, Cout, 1) && Ca % 8 == 0 && Cb % 8 == 0 && ws);
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
-    const Tiling2 tg = make_tiling2(N, H, W, 8, 8);
-    const int gx = det_pwb_gx(Cin, Cout, N, H, W, pooled);
+    const Tiling2 tg = make_tiling2(N, H, W, 8, pwb_th(Cin, Cout));
+    const int gx = det_pwb_gx(Cin, Cout, N, H, W, pooled), ny = pwb_ny(Cin), Cb_ = Cin / ny;  // Cb_: channels per block
     bool done = false;
 #define PWB_LAUNCH(CI_, CO_, PP_, GG_)                                                                                                              \
     {                                                                                                                                               \
@@ -374,19 +386,19 @@ int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
                 return OCRS_ERR_HIP;                                                                                                                \
             attr_set = true;                                                                                                                        \
         }                                                                                                                                           \
-        OCRS_LAUNCH_T((k_pwb<CI_, CO_, PP_, GG_>), dim3(gx), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, \
+        OCRS_LAUNCH_T((k_pwb<CI_, CO_, PP_, GG_>), dim3(gx, ny), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, \
                       bn, coef, wpk_d, (bf16*)du, ws, tg);                                                                                          \
         done = true;                                                                                                                                \
     }
 #define PWB_CASE(CI_, CO_)                                                      \
-    if (!done && Cin == CI_ && Cout == CO_) {                                   \
+    if (!done && Cb_ == CI_ && Cout == CO_) {                                   \
         if (pooled) {                                                           \
             if (g2) PWB_LAUNCH(CI_, CO_, true, true) else PWB_LAUNCH(CI_, CO_, true, false) \
         } else {                                                                \
             if (g2) PWB_LAUNCH(CI_, CO_, false, true) else PWB_LAUNCH(CI_, CO_, false, false) \
         }                                                                       \
     }
-    PWB_CASE(32, 64) PWB_CASE(64, 64) PWB_CASE(64, 128)
+    PWB_CASE(32, 64) PWB_CASE(64, 64) PWB_CASE(64, 128) PWB_CASE(128, 64) PWB_CASE(128, 128) PWB_CASE(128, 256)
 #undef PWB_CASE
 #undef PWB_LAUNCH
     OCRS_CHECK_ARG(done);
