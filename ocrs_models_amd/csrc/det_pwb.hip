@@ -13,6 +13,9 @@
 //      (128 per wave at 256 x 256), flushed once per block as a partial for the deterministic reducer.
 #include "det_common.h"
 
+#ifndef OCRS_PWB_TH_SMALL
+#define OCRS_PWB_TH_SMALL 8  // tile rows at 64 input channels (32: always 8 -- eight waves need eight (M, N) tile pairs)
+#endif
 #ifndef OCRS_PWB_TH_BIG
 #define OCRS_PWB_TH_BIG 4  // tile rows at >= 128 channels (32-pixel tiles: half the per-thread items)
 #endif
@@ -25,7 +28,7 @@ template <int CIN, int COUT>
 struct PwbCfg {
     // (256-thread blocks -- more resident blocks to hide a tile's ~7 k-cycle latency chain -- double the per-thread items and spill 0.5-1 KB)
     static constexpr int NT = 512, NW = NT / 64;
-    static constexpr int TW = 8, TH = (CIN >= 128 || COUT > 128) ? OCRS_PWB_TH_BIG : 8, TP = TW * TH, NNT = TP / 16, HWp = TW + 2, HP = HWp * (TH + 2);
+    static constexpr int TW = 8, TH = (CIN >= 128 || COUT > 128) ? OCRS_PWB_TH_BIG : (CIN == 64 ? OCRS_PWB_TH_SMALL : 8), TP = TW * TH, NNT = TP / 16, HWp = TW + 2, HP = HWp * (TH + 2);
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PXC = CIN + 8, PZC = COUT + 8;              // bf16 pitches (16-byte pad: conflict-free fragment / transpose reads)
     static constexpr int NZI = (TP * CGO + NT - 1) / NT;             // (pixel, cout group) items per thread
@@ -350,7 +353,7 @@ extern "C" {
 void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st);  // det_bwd.hip
 
 // blocks of the launch (= workspace slots of Cin * Cout floats each)
-static int pwb_th(int Cin, int Cout) { return (Cin >= 128 || Cout > 128) ? OCRS_PWB_TH_BIG : 8; }
+static int pwb_th(int Cin, int Cout) { return (Cin >= 128 || Cout > 128) ? OCRS_PWB_TH_BIG : (Cin == 64 ? OCRS_PWB_TH_SMALL : 8); }
 static int pwb_ny(int Cin) { return Cin == 256 ? 2 : 1; }  // 256 input channels: two channel ranges of the 128-channel kernel (grid.y)
 int det_pwb_gx(int Cin, int Cout, int N, int H, int W, int pooled) {
     const Tiling2 tg = make_tiling2(N, H, W, 8, pwb_th(Cin, Cout));
