@@ -563,7 +563,13 @@ extern "C" {
 //   z     : [P][Cout] pre-BN output; gstat: [2][Cout] double, sum z and sum z^2 ACCUMULATED (the caller zeroes it: one
 //           memset for all layers of a step instead of one per launch)
 // 1 if ocrs_dwpw_fwd can also write the 2x2-max-pooled (pre-BatchNorm) output: two-pixel tile configurations, Cout <= 64
-long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) { return Cout <= 64 && (Cin < 32 || Cin % 32 == 0) ? 1 : 0; }
+long det_dwf_supported(int Cin, int Cout, int dtype);  // det_dwf.hip: deep-level forward, a whole tile at once (no fused max-pool)
+int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
+                   double* gstat, int Cout, int N, int H, int W, hipStream_t st);
+long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) {
+    if (det_dwf_supported(Cin, Cout, 1)) return 0;  // (the deep-level kernel is faster than the fusion saves: the max-pool stays its own pass there)
+    return Cout <= 64 && (Cin < 32 || Cin % 32 == 0) ? 1 : 0;
+}
 
 //   gamma / pooled (nullable, need ocrs_dwpw_fwd_pool_supported): also write MaxPool2d(2) of the block output in its pre-BatchNorm form
 //           (the selected element's z, chosen by the sign of the BatchNorm weight gamma [Cout]) to pooled [N][H/2][W/2][Cout]
@@ -575,6 +581,7 @@ int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* t
     OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
+    if (!pooled && det_dwf_supported(Cin, Cout, dtype)) return det_dwf_launch(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st);
     return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st)
                       : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st);
 }
