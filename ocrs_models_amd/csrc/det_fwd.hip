@@ -781,6 +781,9 @@ static int dispatch_convt_fwd(const void* x, const float* tr, const void* wpk, c
 }
 extern "C" {
 
+long det_ctf_supported(int Cup, int Cout, int dtype);  // det_ctf.hip
+int det_ctf_launch(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h, int w, int H, int W,
+                   hipStream_t st);
 // ConvTranspose2d(Cup->Cout, k=3, s=2, bias) cropped to (H, W)  (models.py:76-78,82-87).
 //   x [N][h][w][Cup] with load transform tr [3][Cup]; wpk = ocrs_pack_frags(mode 1, K=4*Cup, M=4*Cout); out [N][H][W][Cout]
 int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h, int w,
@@ -798,6 +801,7 @@ int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float*
     }
     CTF_CASE(16, 8) CTF_CASE(32, 16) CTF_CASE(32, 32)
 #undef CTF_CASE
+    if (det_ctf_supported(Cup, Cout, dtype)) return det_ctf_launch(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st);  // deep levels (det_ctf.hip)
     return dtype == 1 ? dispatch_convt_fwd<bf16>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st)
                       : dispatch_convt_fwd<float>(x, tr, wpk, bias, out, Cup, Cout, N, h, w, H, W, st);
 }
