@@ -1537,6 +1537,8 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
 // its BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
 int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                          const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
+long det_ctd_supported(int Cup, int Cout, int dtype);  // det_ctd.hip
+int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, int N, int h, int w, int H, int W, hipStream_t st);
 // 1 if ocrs_convt_bwd_parts can run the input gradient and the weight / bias gradients of this shape as separate calls (the generic deep-level path)
 long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype) { return convt_wgrad_tr_ok(Cup, Cout, dtype) ? 0 : 1; }
 
@@ -1581,7 +1583,10 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
     const long P = (long)N * h * w;
     const long ntiles = (P + 63) / 64;
     const int gx = persistent_grid(ntiles, 8);
-    if (parts & 1) {
+    if ((parts & 1) && det_ctd_supported(Cup, Cout, dtype)) {  // deep levels, bf16: the gradient region staged once (det_ctd.hip)
+        const int rc = det_ctd_launch(g, wpk_d, dx, Cup, Cout, N, h, w, H, W, st);
+        if (rc != OCRS_OK) return rc;
+    } else if (parts & 1) {
 #define DG_CASE(T_, MT_)                                                                                                                     \
     hipLaunchKernelGGL((k_convt_dgrad<T_, MT_>), dim3(gx, MT_total / MT_), dim3(256), 0, st, (const T_*)g, wpk_d, (T_*)dx, Cup, Cout, h, w, H, \
                        W, N, MT_total);
