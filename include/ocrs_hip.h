@@ -83,6 +83,11 @@ long ocrs_pw_bwd_ws_floats(int Cin, int Cout, int N, int H, int W);
 int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1,
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw,
                 float* ws, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_bn_bwd_finalize + ocrs_pw_bwd in one call (the deep-level bf16 kernel folds the finalisation into its prologue): gsum [2][Cout] fp64 complete
+   sums of this block, gamma, saved [mean | rstd]; dgamma / dbeta written; coef [3][Cout] is scratch. */
+int ocrs_pw_bwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                    int pooled, const void* z, const float* bn, float* coef, const double* gsum, const float* gamma, const float* saved, float* dgamma,
+                    float* dbeta, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* autograd of the depthwise 3x3 conv (dL/dx~ split at channel Ca into gxa|gxb; dwdw [C][1][3][3] accumulated). */
 /*   ws: ocrs_dw_bwd_ws_floats() floats of workspace (per-block partials, two-stage reduction) or NULL (float atomics). */
 long ocrs_dw_bwd_ws_floats(int C, int N, int H, int W);

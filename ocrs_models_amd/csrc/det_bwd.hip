@@ -1357,7 +1357,7 @@ long det_pwb_supported(int Cin, int Cout, int dtype);  // det_pwb.hip
 int det_pwb_gx(int Cin, int Cout, int N, int H, int W, int pooled);
 int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
-                   int H, int W, hipStream_t st);
+                   int H, int W, const BnFin* fin, hipStream_t st);
 int det_pw8_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
                    int H, int W, int gx, hipStream_t st);
@@ -1409,7 +1409,7 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
                               static_cast<bf16*>(du) + 32, dwpw + 32, ws, Cout, N, H, W, 64, 64, st);
     }
     if (det_pwb_supported(Cin, Cout, dtype))  // deep levels, up to 64 input channels: a whole tile in three barriers (det_pwb.hip)
-        return det_pwb_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, st);
+        return det_pwb_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, nullptr, st);
     if (det_pw8_supported(Cin, Cout, dtype)) {
 #define X(CI, CO)                 \
     if (Cin == CI && Cout == CO)  \
@@ -1424,6 +1424,23 @@ int ocrs_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
     PW_BWD_COMBOS(X)
 #undef X
     return OCRS_ERR_ARG;
+}
+
+// ocrs_bn_bwd_finalize + ocrs_pw_bwd in one call: gsum [2][Cout] (fp64, complete), gamma, saved [mean | rstd] of this block; dgamma / dbeta written;
+// coef [3][Cout]: scratch (the deep-level bf16 kernel derives the coefficients in its prologue and leaves it untouched, every other path runs
+// the finalize kernel into it first).
+int ocrs_pw_bwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
+                    int pooled, const void* z, const float* bn, float* coef, const double* gsum, const float* gamma, const float* saved, float* dgamma,
+                    float* dbeta, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(coef && gsum && gamma && saved && dgamma && dbeta && xa && tra && wdw && g1 && z && bn && wpk_d && du && dwpw);
+    const int Cin = Ca + Cb;
+    if (det_pwb_supported(Cin, Cout, dtype) && ws) {
+        const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
+        return det_pwb_launch(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, nullptr, wpk_d, du, dwpw, ws, Cout, N, H, W, &fin, st);
+    }
+    const int rc = ocrs_bn_bwd_finalize(gsum, (long)N * H * W, Cout, gamma, saved, coef, dgamma, dbeta, st);
+    if (rc != OCRS_OK) return rc;
+    return ocrs_pw_bwd(xa, xb, Ca, Cb, tra, trb, wdw, g1, g2, pooled, z, bn, coef, wpk_d, du, dwpw, ws, Cout, N, H, W, dtype, st);
 }
 
 // Depthwise-conv backward: gxa/gxb (either may be null) receive dL/dx~ split at channel Ca; dwdw accumulated in master layout [C][1][3][3].

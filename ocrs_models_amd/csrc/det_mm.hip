@@ -144,18 +144,6 @@ constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minim
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
-// BatchNorm-backward finalisation folded into the block kernel's prologue (what k_bn_bwd_finalize computes, det_bwd.hip): with gsum set, every
-// block derives the dz coefficients of its Cout channels from the block's complete sums instead of reading `coef`, and block 0 writes dgamma /
-// dbeta -- one ~5 us launch less per block on the backward's critical path.
-struct BnFin {
-    const double* gsum;   // [2][Cout] sum ghat | sum ghat*zhat of THIS block (complete: produced by the consumers' launches), or null
-    const float* gamma;   // [Cout]
-    const float* saved;   // [2][Cout] mean | rstd
-    float* dgamma;        // [Cout] (written)
-    float* dbeta;
-    long count;           // N * H * W
-};
-
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
@@ -187,19 +175,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
     fill_tr8(s_trx, x, tra, trb, CIN, tid);
     for (int i = tid; i < 3 * COUT; i += NT) s_bn[i] = bn[i];
     if (fin.gsum) {
-        for (int c = tid; c < COUT; c += NT) {  // (same arithmetic as k_bn_bwd_finalize)
-            const double s1 = fin.gsum[c], s2 = fin.gsum[COUT + c];
-            const double m1 = s1 / (double)fin.count, m2 = s2 / (double)fin.count;
-            const double mean = fin.saved[c], rstd = fin.saved[COUT + c];
-            const double A = (double)fin.gamma[c] * rstd;
-            s_cf[c] = (float)A;
-            s_cf[COUT + c] = (float)(-A * rstd * m2);
-            s_cf[2 * COUT + c] = (float)(A * (-m1 + mean * rstd * m2));
-            if (blockIdx.x == 0) {
-                fin.dgamma[c] = (float)s2;
-                fin.dbeta[c] = (float)s1;
-            }
-        }
+        bn_fin_coef(fin, COUT, s_cf, tid, NT, blockIdx.x == 0);
     } else {
         for (int i = tid; i < 3 * COUT; i += NT) s_cf[i] = coef[i];
     }

@@ -59,7 +59,7 @@ template <int CIN, int COUT, bool PPOOL, bool G2>
 __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw,
                                              const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
                                              const float* __restrict__ bn, const float* __restrict__ coef, const void* __restrict__ wpk_d,
-                                             bf16* __restrict__ du, float* __restrict__ ws, Tiling2 tg) {
+                                             bf16* __restrict__ du, float* __restrict__ ws, Tiling2 tg, BnFin fin) {
     using C = PwbCfg<CIN, COUT>;
     constexpr int NT = C::NT, TW = C::TW, TP = C::TP, HWp = C::HWp, HP = C::HP, CGI = C::CGI, CGO = C::CGO, PXC = C::PXC, PZC = C::PZC;
     constexpr int NZI = C::NZI, NXI = C::NXI, NUI = C::NUI, MTD = C::MTD, NKD = C::NKD, MPW = C::MPW, NPW = C::NPW;
@@ -84,9 +84,11 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
         const int t = i / CIN, c = i - t * CIN;
         s_wdw[i] = wdw[(c_off + c) * 9 + t];
     }
-    for (int i = tid; i < 3 * COUT; i += NT) {
-        s_bn[i] = bn[i];
-        s_cf[i] = coef[i];
+    for (int i = tid; i < 3 * COUT; i += NT) s_bn[i] = bn[i];
+    if (fin.gsum) {
+        bn_fin_coef(fin, COUT, s_cf, tid, NT, blockIdx.x == 0 && blockIdx.y == 0);
+    } else {
+        for (int i = tid; i < 3 * COUT; i += NT) s_cf[i] = coef[i];
     }
     {
         const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -372,8 +374,9 @@ long det_pwb_supported(int Cin, int Cout, int dtype) {
 
 int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* g1, const void* g2,
                    int pooled, const void* z, const float* bn, const float* coef, const void* wpk_d, void* du, float* dwpw, float* ws, int Cout, int N,
-                   int H, int W, hipStream_t st) {
+                   int H, int W, const BnFin* finp, hipStream_t st) {
     const int Cin = Ca + Cb;
+    const BnFin fin = finp ? *finp : BnFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     OCRS_CHECK_ARG(det_pwb_supported(Cin, Cout, 1) && Ca % 8 == 0 && Cb % 8 == 0 && ws);
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
     const Tiling2 tg = make_tiling2(N, H, W, 8, pwb_th(Cin, Cout));
@@ -390,7 +393,7 @@ int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
             attr_set = true;                                                                                                                        \
         }                                                                                                                                           \
         OCRS_LAUNCH_T((k_pwb<CI_, CO_, PP_, GG_>), dim3(gx, ny), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, \
-                      bn, coef, wpk_d, (bf16*)du, ws, tg);                                                                                          \
+                      bn, coef, wpk_d, (bf16*)du, ws, tg, fin);                                                                                          \
         done = true;                                                                                                                                \
     }
 #define PWB_CASE(CI_, CO_)                                                      \

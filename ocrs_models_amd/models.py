@@ -308,9 +308,11 @@ class _DetRun:
                   and L.mm_bwd_supported(a.C, b.C if b is not None else 0, C, self.dt))
         coef = None
         fold = use_mm and self.fold_fin
+        fold_pw = (not use_mm) and r.Cin != 1 and self.fold_fin  # ocrs_pw_bwd_fin: finalize + pointwise backward in one call
         if not fold:  # (the matrix-core kernel derives the coefficients from gsum in its prologue: one launch less per block)
             coef = self.empty(3, C, dtype=torch.float32)
-            L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(gam), ptr(r.saved), ptr(coef), ptr(dgam), ptr(dbet))
+            if not fold_pw:
+                L.bn_bwd_finalize(ptr(gsum), N * H * W, C, ptr(gam), ptr(r.saved), ptr(coef), ptr(dgam), ptr(dbet))
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
         if r.Cin == 1:
             acc = self.zeros64(17)  # fp64 accumulators (order-independent), folded into the fp32 gradients below
@@ -348,9 +350,14 @@ class _DetRun:
             return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
-        L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
-                 ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W,
-                 self.dt)
+        if fold_pw:
+            L.pw_bwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
+                         ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(wpk_d), ptr(du),
+                         ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W, self.dt)
+        else:
+            L.pw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
+                     ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(wpk_d), ptr(du), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(ws), C, N, H, W,
+                     self.dt)
         gxa = self.empty(N, H, W, Ca) if need_gx else None
         gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
         ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
