@@ -94,10 +94,10 @@ PASSES = {
     "maxpool_fwd": ("maxpool_fwd",),
 }
 PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
-    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<"),
-    "block_fwd": ("k_mm_fwd<", "k_dwpw_fwd<"),
-    "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<"),
-    "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_wgrad_gather<", "k_channel_sum<"),
+    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_pwb<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<"),
+    "block_fwd": ("k_mm_fwd<", "k_dwpw_fwd<", "k_dwf<"),
+    "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<", "k_ctf<"),
+    "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_ctd<", "k_wgrad_gather<", "k_channel_sum<"),
     "maxpool_fwd": ("k_maxpool_fwd<",),
 }
 
@@ -546,7 +546,7 @@ def main():
             tr = pass_traffic(rows, dom)
             n_units = max(1, st["units_per_step"])
             out["roofline"] = {
-                "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_mm_bwd at levels 0-2, k_pw_bwd*+k_dw_bwd[+k_bn_bwd_reduce] below)",
+                "kernel": {"block_bwd": "DepthwiseConv block backward (one pass per block: k_mm_bwd at levels 0-2, k_pwb | k_pw_bwd* + k_dw_bwd [+ k_bn_bwd_reduce] below)",
                            "block_fwd": "DepthwiseConv block forward (k_mm_fwd at levels 0-2, k_dwpw_fwd below)"}.get(dom, dom),
                 "bound": "hbm", "achieved": st["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["frac"],
                 "traffic": round(tr / n_units) if tr else None, "traffic_source": src,
