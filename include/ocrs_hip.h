@@ -147,7 +147,9 @@ int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* l
                           const float* gout, float* gpred, long P, hipStream_t st);
 
 /* ------------------------------------------------------------------ recognition (CRNN) ------ */
-/* nn.Conv2d forward / dgrad, GRU input projections, nn.Linear as one implicit-GEMM kernel (ocrs_models/models.py:189-240, 245, 248). */
+/* nn.Conv2d forward / dgrad, GRU input projections, nn.Linear as one implicit-GEMM kernel (ocrs_models/models.py:189-240, 245, 248).
+ * gstat (nullable) [2][M] fp64 (sum z | sum z^2 of the stored outputs) is ACCUMULATED: the caller zeroes it (one fill for all layers of a
+ * step); the same holds for gsum of ocrs_rec_bn_reduce / ocrs_avgpool_bn_reduce. */
 int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st);
 /* weight gradients of Conv2d / Linear / GRU (autograd of the calls above). */

@@ -314,8 +314,12 @@ __global__ __launch_bounds__(256) void k_multi_sumsq(const long long* __restrict
     const long n = table[5 * t + 4];
     float s = 0.f;
     for (long i = (long)ch * OPT_CHUNK + threadIdx.x; i < n && i < (long)(ch + 1) * OPT_CHUNK; i += 256) s = fmaf(g[i], g[i], s);
+    // one fp64 atomic per block (they all hit ONE address and serialise at ~11 ns each: per-wave atomics made this launch 62 us for 12 MB)
+    __shared__ float s_w[4];
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, (double)s);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (double)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])));
 }
 
 // norm_out = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))

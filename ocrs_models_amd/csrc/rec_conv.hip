@@ -25,12 +25,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);  // [(TH+KH-1)*(TW+KW-1)][PITCH]
     const int HWp = TW + KW - 1, HHp = TH + KH - 1, HP = HWp * HHp;
-    float* s_stat = reinterpret_cast<float*>(smem + ((HP * PITCH * sizeof(T) + 15) & ~15));  // [2][MT*16]
+    float* s_stat = reinterpret_cast<float*>(smem + ((HP * PITCH * sizeof(T) + 15) & ~15));  // [4 / WM][2][MT*16]: one slot per pixel-wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt0 = blockIdx.y * MT;
     const int mw0 = (wave % WM) * MTW;  // first M tile (within the block's MT) of this wave
     if (gstat) {
-        for (int i = tid; i < 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+        for (int i = tid; i < (4 / WM) * 2 * MT * 16; i += 256) s_stat[i] = 0.f;
+        __syncthreads();
     }
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
     const int ntiles = N * tiles_x * tiles_y;
@@ -115,9 +116,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const float a1 = quad16_sum(s1[r4]), a2 = quad16_sum(s2[r4]);
-                    if ((lane & 15) == 0) {
-                        atomicAdd(&s_stat[(mw0 + b) * 16 + (lane >> 4) * 4 + r4], a1);
-                        atomicAdd(&s_stat[MT * 16 + (mw0 + b) * 16 + (lane >> 4) * 4 + r4], a2);
+                    if ((lane & 15) == 0) {  // (wave, channel) has exactly one owner lane: plain adds in program order -> run-to-run bit-stable
+                        float* slot = s_stat + (wave / WM) * 2 * MT * 16 + (mw0 + b) * 16 + (lane >> 4) * 4 + r4;
+                        slot[0] += a1;
+                        slot[MT * 16] += a2;
                     }
                 }
             }
@@ -128,8 +130,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const T* __restrict__ x, int
         for (int i = tid; i < MT * 16; i += 256) {
             const int m = mt0 * 16 + i;
             if (m < M) {
-                atomicAdd(&gstat[m], (double)s_stat[i]);
-                atomicAdd(&gstat[M + m], (double)s_stat[MT * 16 + i]);
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int wn = 0; wn < 4 / WM; ++wn) {
+                    a1 += s_stat[wn * 2 * MT * 16 + i];
+                    a2 += s_stat[wn * 2 * MT * 16 + MT * 16 + i];
+                }
+                atomicAdd(&gstat[m], (double)a1);  // fp64 sums of fp32 partials are exact, hence order-independent (DESIGN.md "Reproducibility")
+                atomicAdd(&gstat[M + m], (double)a2);
             }
         }
     }
@@ -743,15 +751,33 @@ __global__ __launch_bounds__(256) void k_act_pool_fwd(const T* __restrict__ z, c
     }
 }
 
+// Block-level sums of the per-thread partials s1 / s2 (thread t holds the 8 channels of group t % (C / 8)) in a FIXED order -- every thread
+// parks its values in LDS, thread o < 2 C then adds the 256 / CG contributions of its channel in thread order (float LDS atomics complete in
+// arrival order: the statistics differed in their last bits from run to run) -- then ONE fp64 atomic per block and channel (an fp64 sum of
+// fp32 partials is exact, hence order-independent; DESIGN.md "Reproducibility").
+__device__ __forceinline__ void group_sums_to_gsum(const float (&s1)[8], const float (&s2)[8], int C, double* __restrict__ gsum) {
+    __shared__ float s_all[256][17];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s_all[threadIdx.x][i] = s1[i];
+        s_all[threadIdx.x][8 + i] = s2[i];
+    }
+    __syncthreads();
+    const int CG = C / 8;
+    for (int o = threadIdx.x; o < 2 * C; o += 256) {
+        const int which = o >= C ? 1 : 0, c = o - which * C, col = which * 8 + (c & 7);
+        float a = 0.f;
+        for (int t = c >> 3; t < 256; t += CG) a += s_all[t][col];
+        atomicAdd(&gsum[o], (double)a);
+    }
+}
+
 // BN-backward reductions through ReLU (+ max-pool PHxPW, gradient to the FIRST maximum of each window):
 // gsum[0][c] = sum ghat, gsum[1][c] = sum ghat * zhat.  g is at pooled resolution.
 template <class T>
 __global__ __launch_bounds__(256) void k_rec_bn_reduce(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
                                                        const float* __restrict__ saved, double* __restrict__ gsum, int C, int N, int H, int W,
                                                        int PH, int PW) {
-    extern __shared__ float s_acc[];
-    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
     const int CG = C / 8, Hp = H / PH, Wp = W / PW;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;
@@ -780,13 +806,7 @@ __global__ __launch_bounds__(256) void k_rec_bn_reduce(const T* __restrict__ g, 
             s2[i] = fmaf(gh, (bz[i] - saved[c0 + i]) * saved[C + c0 + i], s2[i]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        atomicAdd(&s_acc[c0 + i], s1[i]);
-        atomicAdd(&s_acc[C + c0 + i], s2[i]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+    group_sums_to_gsum(s1, s2, C, gsum);
 }
 
 // dz = coefA * ghat + coefB * z + coefC for every pixel (ghat routed through ReLU and the PHxPW max-pool); pixels outside
@@ -865,9 +885,6 @@ __global__ __launch_bounds__(256) void k_avgpool_fwd(const T* __restrict__ z, co
 template <class T>
 __global__ __launch_bounds__(256) void k_avgpool_bn_reduce(const float* __restrict__ gseq, const T* __restrict__ z, const float* __restrict__ saved,
                                                            double* __restrict__ gsum, int C, int N, int H, int W) {
-    extern __shared__ float s_acc[];
-    for (int i = threadIdx.x; i < 2 * C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
     const int CG = C / 8;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;
@@ -889,13 +906,7 @@ __global__ __launch_bounds__(256) void k_avgpool_bn_reduce(const float* __restri
             s2[i] = fmaf(gv[i] * 0.25f, zs[i], s2[i]);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        atomicAdd(&s_acc[c0 + i], s1[i]);
-        atomicAdd(&s_acc[C + c0 + i], s2[i]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&gsum[i], (double)s_acc[i]);
+    group_sums_to_gsum(s1, s2, C, gsum);
 }
 
 template <class T>
@@ -989,7 +1000,7 @@ static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int 
     const int HP = (TH + KH - 1) * (TW + KW - 1);
 #define IG(MT_)                                                                                                                                  \
     {                                                                                                                                            \
-        const size_t smem = ((HP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + 2 * MT_ * 16 * sizeof(float);                                    \
+        const size_t smem = ((HP * Mma<T>::LDS_PITCH * sizeof(T) + 15) & ~15) + 4 * 2 * MT_ * 16 * sizeof(float);                                   \
         const int gy = (MT_total + MT_ - 1) / MT_;                                                                                               \
         constexpr int WM_ = (Elem<T>::is_bf16 && TH > 1) ? (MT_ >= 8 ? 4 : (MT_ >= 4 ? 2 : 1)) : 1; /* measured: 1382 -> 974 us, 270 -> 230 us */ \
         hipLaunchKernelGGL((k_conv_igemm<T, MT_, TH, TW, WM_>), dim3(persistent_grid(tiles, gy >= 4 ? 2 : 4), gy), dim3(256), smem, st, (const T*)x, ldx, \
@@ -1128,11 +1139,10 @@ extern "C" {
 // Implicit-GEMM convolution / GEMM:  out[n][ho][wo][m] = sum_{ky,kx,c} W[m][(ky,kx,c)] * x[n][ho+ky-padh][wo+kx-padw][c]  (+bias, ReLU)
 //   nn.Conv2d forward (models.py:189-240), its dgrad (flipped packed weights), GRU input projections and nn.Linear (KH=KW=1, Hi=Ho=1).
 //   x [N][Hi][Wi][ldx] (Cin % 32 == 0, ldx >= Cin); wpk = ocrs_pack_frags(K = KH*KW*Cin ordered (tap, c), M); out [N][Ho][Wo][ldo];
-//   gstat (nullable): [2][M] double batch sums of the (rounded) outputs, zeroed here.  Outputs rows m in [M, ldo) are written as 0(+0 bias).
+//   gstat (nullable): [2][M] double batch sums of the (rounded) outputs, ACCUMULATED: the caller zeroes it (one fill for all layers of a step, like ocrs_dwpw_fwd).  Outputs rows m in [M, ldo) are written as 0(+0 bias).
 int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && wpk && out && Cin % 32 == 0 && ldx >= Cin && M > 0 && ldo >= M && ldo % 4 == 0 && KH >= 1 && KW >= 1 && KH * KW <= 9);
-    if (gstat && hipMemsetAsync(gstat, 0, 2 * M * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     if (conv3x3_c128_supported(ldx, ldo, Cin, M, Hi, Wi, Ho, Wo, KH, KW, padh, padw, dtype))  // the 128-output-channel 3x3 layers: 128 x 256 block tiles (rec_conv2.hip)
         return conv3x3_c128_launch(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, Hi, Wi, st);
     const bool gemm = Ho == 1 && KH == 1;
@@ -1454,11 +1464,10 @@ int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, i
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
-// backward reductions (gsum [2][C] double zeroed here) and dz materialisation
+// backward reductions (gsum [2][C] double, ACCUMULATED: the caller zeroes it) and dz materialisation
 int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,
                        int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(g && z && bn && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0 && PH * PW <= 4);
-    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     const int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
     if (dtype == 1)
         hipLaunchKernelGGL(k_rec_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, (const bf16*)g, (const bf16*)z, bn, saved, gsum, C,
@@ -1494,7 +1503,6 @@ int ocrs_avgpool_fwd(const void* z, const float* tr, float* seq, int C, int N, i
 }
 int ocrs_avgpool_bn_reduce(const float* gseq, const void* z, const float* saved, double* gsum, int C, int N, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(gseq && z && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0);
-    if (hipMemsetAsync(gsum, 0, 2 * C * sizeof(double), st) != hipSuccess) return OCRS_ERR_HIP;
     const int grid = ew_grid((long)N * W * (C / 8));
     if (dtype == 1)
         hipLaunchKernelGGL(k_avgpool_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, gseq, (const bf16*)z, saved, gsum, C, N, H, W);

@@ -27,7 +27,7 @@ constexpr int C2_PITCH = Mma<bf16>::LDS_PITCH;              // 40 bf16 = 80 B pe
 constexpr int C2_MAXHP = 2 * 10 * C2_HW;                    // staged pixels: NI * (TH + 2) * 18 -- 324 (1 x 16 rows) or 360 (2 x 8 rows)
 constexpr int C2_XBYTES = C2_MAXHP * C2_PITCH * 2;          // 28800
 constexpr int C2_WBYTES = 8 * 64 * 16;                      // 8 M tiles x 64 lanes x 16 B
-constexpr int C2_SMEM = 2 * C2_XBYTES + 2 * C2_WBYTES + 2 * 128 * 4;
+constexpr int C2_SMEM = 2 * C2_XBYTES + 2 * C2_WBYTES + 2 * 2 * 128 * 4;
 }  // namespace
 
 template <int TH /* rows per image in the tile: 16 (NI = 1) or 8 (NI = 2) */>
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c128(const bf16* __restrict_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* xbuf = reinterpret_cast<bf16*>(smem);                                  // [2][HP][PITCH]
     uint4* wbuf = reinterpret_cast<uint4*>(smem + 2 * C2_XBYTES);                // [2][8][64]
-    float* s_stat = reinterpret_cast<float*>(smem + 2 * C2_XBYTES + 2 * C2_WBYTES);  // [2][128]
+    float* s_stat = reinterpret_cast<float*>(smem + 2 * C2_XBYTES + 2 * C2_WBYTES);  // [2 row halves][2][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;  // M half (tiles 4 wm ..), row half (rows 8 wn ..)
     const int l15 = lane & 15, kq = lane >> 4;
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c128(const bf16* __restrict_
     const int ngrp = (N + NI - 1) / NI;
     const long ntiles = (long)ngrp * tpi;
     if (gstat) {
-        for (int i = tid; i < 256; i += 256) s_stat[i] = 0.f;
+        for (int i = tid; i < 512; i += 256) s_stat[i] = 0.f;
+        __syncthreads();
     }
 
     // staging roles.  Input: item = (staged pixel, 8-channel group); the HP * 4 items of a chunk are spread over taps 0..7 of the chunk before it.
@@ -214,9 +215,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c128(const bf16* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
-                    if (l15 == 0) {
-                        atomicAdd(&s_stat[m0 + r], a1);
-                        atomicAdd(&s_stat[128 + m0 + r], a2);
+                    if (l15 == 0) {  // (wave, channel) has exactly one owner lane: plain adds in program order -> run-to-run bit-stable
+                        s_stat[wn * 256 + m0 + r] += a1;
+                        s_stat[wn * 256 + 128 + m0 + r] += a2;
                     }
                 }
             }
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c128(const bf16* __restrict_
     if (gstat) {
         __syncthreads();
         for (int i = tid; i < 128; i += 256) {
-            atomicAdd(&gstat[i], (double)s_stat[i]);
-            atomicAdd(&gstat[128 + i], (double)s_stat[128 + i]);
+            atomicAdd(&gstat[i], (double)(s_stat[i] + s_stat[256 + i]));  // fp64 sums of fp32 partials: exact, order-independent
+            atomicAdd(&gstat[128 + i], (double)(s_stat[128 + i] + s_stat[256 + 128 + i]));
         }
     }
 }

@@ -148,7 +148,7 @@ __device__ __forceinline__ void xload(float* xws, int group, int par, int kc, in
 
 // ---- split-bf16 exchange (EXACT = false): the data is the flag.  A value travels as ONE 32-bit word (hi bf16 << 16 | lo bf16) whose lowest bit
 // -- the last mantissa bit of lo, 2^-17 of the value -- carries a tag that alternates between successive writes of the same slot
-// (tag = (step >> 1) & 1; the workspace is preset to all-ones and the first two writes carry 0).  Consumers simply load their fragment and
+// (tag = ~(step >> 1) & 1; the workspace is preset to zero and the first two writes carry 1).  Consumers simply load their fragment and
 // re-load until every word shows the tag of the step they need: no drain, no barrier, no arrival counter, no second round trip for a flag
 // (Guideline 16, form R2: single aligned word per granule, so a reader can never pair a new tag with an old value).  The split is done once
 // by the producer instead of by each of the 16 consumers.
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                         for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][c][i], hb[c][i], acc[g], 0, 0, 0);
             } else {
                 unsigned w[2][8];
-                if (!xpoll<8, 2>(xws, group, (s - 1) & 1, 2 * kk, wnt, lane, (unsigned)(((s - 1) >> 1) & 1), err, w)) s_fail = 1;
+                if (!xpoll<8, 2>(xws, group, (s - 1) & 1, 2 * kk, wnt, lane, (unsigned)((((s - 1) >> 1) & 1) ^ 1), err, w)) s_fail = 1;
                 PROF_MARK(0)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                 __syncthreads();
                 if (tid == 0) seq_signal(fast, cnt);
             } else {
-                const unsigned w0 = pack_hilo(hv, (unsigned)((s >> 1) & 1));
+                const unsigned w0 = pack_hilo(hv, (unsigned)(((s >> 1) & 1) ^ 1));
                 const unsigned w1 = __shfl_down(w0, 1);
                 if ((jl & 1) == 0) st_xw(fast, xslot<8>(xws, group, s & 1, xkc, xnt, xq, xlane), w0, w1);
             }
@@ -533,8 +533,14 @@ int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float*
                      int exact, hipStream_t st) {
     OCRS_CHECK_ARG(gi && whh && bhh && out && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
-    if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
-    if (!exact && hipMemsetAsync(xws, 0xff, (size_t)ng * 2 * 8 * 2 * 4 * 64 * 2 * sizeof(float), st) != hipSuccess) return OCRS_ERR_HIP;  // tags
+    const size_t sync_bytes = (size_t)ng * SYNC_STRIDE * sizeof(unsigned);
+    const size_t tag_bytes = exact ? 0 : (size_t)ng * 2 * 8 * 2 * 4 * 64 * 2 * sizeof(float);  // split-bf16 form: the exchange words carry tags
+    if (reinterpret_cast<char*>(xws) == reinterpret_cast<char*>(sync) + sync_bytes) {            // one fill when the two are one allocation
+        if (hipMemsetAsync(sync, 0, sync_bytes + tag_bytes, st) != hipSuccess) return OCRS_ERR_HIP;
+    } else {
+        if (hipMemsetAsync(sync, 0, sync_bytes, st) != hipSuccess) return OCRS_ERR_HIP;
+        if (tag_bytes && hipMemsetAsync(xws, 0, tag_bytes, st) != hipSuccess) return OCRS_ERR_HIP;
+    }
     if (exact)
         hipLaunchKernelGGL(k_gru_seq_fwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, gi, whh, bhh, out, saved, T, N, sync, err, xws, ng, seq_try_fast());
     else

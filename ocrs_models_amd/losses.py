@@ -130,4 +130,7 @@ class CTCLoss(torch.nn.Module):
         if (smax or 2 * targets.shape[1] + 1) > MAX_CTC_STATES:
             raise RuntimeError(f"CTC lattices wider than {MAX_CTC_STATES} states (targets longer than {(MAX_CTC_STATES - 1) // 2} labels) are not "
                                "supported by the LDS-resident alpha/beta kernels; pass host-side target_lengths so that the padding does not count")
+        if not il.is_cuda and not tl.is_cuda:
+            both = torch.stack([il, tl]).to(dev, non_blocking=True)  # one host -> device copy for both length vectors
+            il, tl = both[0], both[1]
         return _CTC.apply(log_probs, targets.to(dev), il.to(dev, non_blocking=True), tl.to(dev, non_blocking=True), smax, self.h16)

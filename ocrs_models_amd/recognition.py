@@ -58,11 +58,25 @@ class _RecRun:
 
     def seq_sync(self):
         """arrival counters (zeroed by the entry point) and exchange workspace of one persistent GRU launch"""
-        return (torch.empty(self.L.gru_seq_sync_words(self.N), dtype=torch.int32, device=self.dev),
-                torch.empty(self.L.gru_seq_ws_floats(self.N), dtype=torch.float32, device=self.dev))
+        nsync, nws = self.L.gru_seq_sync_words(self.N), self.L.gru_seq_ws_floats(self.N)
+        buf = torch.empty(nsync + nws, dtype=torch.int32, device=self.dev)  # one allocation: the entry point initialises both with one fill
+        return buf[:nsync], buf[nsync:].view(torch.float32)
+
+    def stat(self, C):
+        """zeroed fp64 [2][C] accumulator (BatchNorm batch sums / their backward counterparts): a slice of ONE zero-filled arena per step"""
+        n = 2 * C
+        arena = getattr(self, "_arena", None)
+        if arena is None or self._arena_off + n > arena.numel():
+            arena = self._arena = torch.zeros(2 * 2 * (64 + 3 * 128), dtype=torch.float64, device=self.dev)
+            self._arena_off = 0
+        self._arena_off += n
+        return arena[self._arena_off - n:self._arena_off]
 
     def pack(self, src, K, M, K2, s1, s2, sm, dt=None, offset=0):
         dt = self.dt if dt is None else dt
+        hit = getattr(self, "packs", {}).get((src.data_ptr() + 4 * offset, dt, K, M, s1, s2, sm))
+        if hit is not None:
+            return hit
         out = torch.empty(self.L.pack_frags_bytes(K, M, dt), dtype=torch.uint8, device=self.dev)
         self.L.pack_frags(src.data_ptr() + 4 * offset, 0, K, M, K2, s1, s2, sm, ptr(out), dt)
         return out
@@ -75,6 +89,46 @@ class _RecRun:
         co, ci, kh, kw = w.shape
         nt = kh * kw
         return self.pack(w, nt * co, ci, co, -1, ci * nt, nt, offset=nt - 1)
+
+    _CONVS = ("conv.3.weight", "conv.7.weight", "conv.9.weight", "conv.13.weight", "conv.15.weight", "conv.19.weight")
+
+    def prepack(self):
+        """All weight-fragment packs of the step in one launch per dtype (conv layers: forward + input-gradient layouts; the output Linear: both
+        layouts, fp32).  The table of (source pointer, layout) rows is built once per module / dtype and reused while the parameter storage
+        stays in place (same scheme as models.py::_Run.prepack)."""
+        P = self.P
+        cache = getattr(self.mod, "_pack_cache", None)
+        key = (self.dt, self.train, tuple(p.data_ptr() for p in P.values()))
+        if cache is None or cache[0] != key:
+            rows = []  # (src tensor, dtype code, K, M, K2, s1, s2, sm, element offset)
+            for name in self._CONVS:
+                co, ci, kh, kw = P[name].shape
+                nt = kh * kw
+                rows.append((P[name], self.dt, nt * ci, co, ci, 1, nt, ci * nt, 0))
+                if self.train:
+                    rows.append((P[name], self.dt, nt * co, ci, co, -1, ci * nt, nt, nt - 1))
+            C = self.ncls
+            rows.append((P["output.0.weight"], 0, 512, C, 512, 0, 1, 512, 0))
+            if self.train:
+                rows.append((P["output.0.weight"], 0, C, 512, C, 0, 512, 1, 0))
+            sizes = [self.L.pack_frags_bytes(r[2], r[3], r[1]) for r in rows]
+            offs = [0]
+            for n in sizes:
+                offs.append(offs[-1] + ((n + 255) // 256) * 256)
+            buf = torch.empty(offs[-1], dtype=torch.uint8, device=self.dev)
+            views, tables = {}, []
+            for dt in sorted({r[1] for r in rows}):
+                sel = [(r, o) for r, o in zip(rows, offs) if r[1] == dt]
+                table = torch.tensor([[r[0].data_ptr() + 4 * r[8], buf.data_ptr() + o, 0, r[2], r[3], r[4], r[5], r[6], r[7]] for r, o in sel],
+                                     dtype=torch.int64).to(self.dev)
+                tables.append((table, len(sel), max(((r[2] + 31) // 32) * ((r[3] + 15) // 16) * 64 for r, _ in sel), dt))
+            for r, o, n in zip(rows, offs, sizes):
+                views[(r[0].data_ptr() + 4 * r[8], r[1], r[2], r[3], r[5], r[6], r[7])] = buf[o:o + n]
+            cache = (key, tables, buf, views)
+            self.mod._pack_cache = cache
+        for table, n, maxthr, dt in cache[1]:
+            self.L.pack_frags_multi(ptr(table), n, maxthr, dt)
+        self.packs = cache[3]
 
     def bn(self, prefix, gstat, count, C, lo):
         P, Bf = self.P, self.Bf
@@ -94,7 +148,7 @@ class _RecRun:
         co, ci, kh, kw = w.shape
         Ho, Wo = Ho or Hi, Wo or Wi
         out = self.empty(self.N, Ho, Wo, co)
-        gstat = self.empty(2 * co, dtype=torch.float64) if stats else None
+        gstat = self.stat(co) if stats else None
         self.L.conv_igemm(ptr(x), ci, ptr(self.pack_conv(w)), ptr(out), co, ptr(bias), 1 if relu else 0, ptr(gstat), ci, co, self.N, Hi, Wi, Ho, Wo,
                           kh, kw, pad, pad, self.dt)
         return out, gstat
@@ -122,6 +176,7 @@ class _RecRun:
         if W % 4 != 0:
             raise RuntimeError(f"input width must be a multiple of 4 (two 2x2 max-pools), got {W}")
         S = self
+        self.prepack()
         S.a0 = self.empty(N, 32, W // 2, 32)
         L.conv0_fwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(S.a0), N, H, W, self.dt)
         H1, W1 = 32, W // 2
@@ -151,11 +206,7 @@ class _RecRun:
         S.gru = []
         xin, I = S.seq, 128
         for layer in (0, 1):
-            sfx = [f"_l{layer}", f"_l{layer}_reverse"]
-            w_ih = torch.cat([P["gru.weight_ih" + s] for s in sfx], 0)  # (1536, I)
-            b_ih = torch.cat([P["gru.bias_ih" + s] for s in sfx], 0)
-            b_hh = torch.cat([P["gru.bias_hh" + s] for s in sfx], 0)
-            w_hh = torch.stack([P["gru.weight_hh" + s] for s in sfx], 0).contiguous()  # (2, 768, 256)
+            w_ih, w_hh, b_ih, b_hh = self.mod._gru_stacked(layer, P)  # (1536, I), (2, 768, 256), (1536,), (1536,): both directions
             if self.use_x3(I, 1536):
                 gi = self.gemm_x3(xin, I, I, w_ih, I, 0, b_ih, 1536, 1536, rows)  # W_ih [1536][I]
             else:
@@ -224,7 +275,7 @@ class _RecRun:
 
     def bn_pool_bwd(self, prefix, g, z, tr, saved, C, H, W, PH, PW):
         L = self.L
-        gsum = self.empty(2 * C, dtype=torch.float64)
+        gsum = self.stat(C)
         L.rec_bn_reduce(ptr(g), ptr(z), ptr(tr), ptr(saved), ptr(gsum), C, self.N, H, W, PH, PW, self.dt)
         coef = self.empty(3, C, dtype=torch.float32)
         L.bn_bwd_finalize(ptr(gsum), self.N * H * W, C, ptr(self.P[f"{prefix}.weight"]), ptr(saved), ptr(coef), ptr(self.G[f"{prefix}.weight"]),
@@ -306,7 +357,7 @@ class _RecRun:
             stage_done(f"gru.bias_hh_l{layer}")
         dseq = dout  # [T][N][128] fp32
         # ---- conv.20 (BN, no ReLU) + AvgPool ----
-        gsum = self.empty(256, dtype=torch.float64)
+        gsum = self.stat(128)
         L.avgpool_bn_reduce(ptr(dseq), ptr(S.z19), ptr(S.sv19), ptr(gsum), 128, N, 5, T, self.dt)
         coef = self.empty(3, 128, dtype=torch.float32)
         L.bn_bwd_finalize(ptr(gsum), N * 5 * T, 128, ptr(P["conv.20.weight"]), ptr(S.sv19), ptr(coef), ptr(G["conv.20.weight"]), ptr(G["conv.20.bias"]))
@@ -337,6 +388,12 @@ class _RecRun:
         if bucketer is not None:
             bucketer.finish(flat)
         return [G[k] for k in self.names]
+
+
+def _adjacent(a, b):
+    """b starts where a ends, inside ONE storage (tensors that merely happen to be neighbours in the allocator's pool do not count)"""
+    return (a.is_contiguous() and b.is_contiguous() and b.data_ptr() == a.data_ptr() + 4 * a.numel()
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
 
 
 _GRU_ERR = {}  # device -> (sticky device error word of the persistent GRU launches, pinned host copy)
@@ -400,6 +457,30 @@ class RecognitionModel(nn.Module):
         self.output = nn.Sequential(nn.Linear(512, n_classes), nn.LogSoftmax(dim=2))
         self.act_dtype = act_dtype
 
+    def _gru_flatten(self):
+        """Re-home the forward and reverse direction's GRU parameters of each layer into adjacent halves of a common buffer (what
+        nn.GRU.flatten_parameters does for its library), ONCE: the kernels take both directions as one stacked tensor, which is then a view --
+        no per-step concatenation.  Parameters that were re-allocated since (``.to()``, ``.data = ...``) are re-homed at the next forward."""
+        for layer in (0, 1):
+            for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                pa, pb = getattr(self.gru, f"{kind}_l{layer}"), getattr(self.gru, f"{kind}_l{layer}_reverse")
+                if not _adjacent(pa, pb):
+                    with torch.no_grad():
+                        buf = torch.stack([pa.detach(), pb.detach()], 0).contiguous()
+                        pa.data, pb.data = buf[0], buf[1]
+
+    @staticmethod
+    def _gru_stacked(layer, P):
+        """(w_ih (1536, I), w_hh (2, 768, 256), b_ih (1536,), b_hh (1536,)): both directions of one layer as views (see _gru_flatten)"""
+        out = []
+        for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            a, b = P[f"gru.{kind}_l{layer}"], P[f"gru.{kind}_l{layer}_reverse"]
+            if not _adjacent(a, b):
+                raise RuntimeError("GRU parameters of the two directions are not adjacent (RecognitionModel._gru_flatten was bypassed)")
+            st = torch.as_strided(a, (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
+            out.append(st if kind == "weight_hh" else st.reshape((2 * a.shape[0],) + tuple(a.shape[1:])))
+        return out
+
     def _act_dtype(self):
         if self.act_dtype is not None:
             return self.act_dtype
@@ -413,6 +494,7 @@ class RecognitionModel(nn.Module):
         if x.dim() != 4 or x.shape[1] != 1:
             raise RuntimeError(f"expected (B,1,64,W) input, got {tuple(x.shape)}")
         x = x.contiguous().float()
+        self._gru_flatten()
         names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
         for p in params:

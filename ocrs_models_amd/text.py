@@ -50,18 +50,43 @@ def ctc_greedy_decode_text(x, alphabet) -> str:
     return "".join(out)
 
 
-def greedy_decode_batch(log_probs: torch.Tensor, input_lengths):
-    """(T,N,C) log-probs on the GPU -> list of N collapsed label lists (arg-max + collapse on the device, one D2H copy)."""
+class _Decode:
+    """Result handle of greedy_decode_batch_async: the collapsed labels are on their way into pinned host memory."""
+
+    def __init__(self, host, event, amax, N, T):
+        self.host, self.event, self.amax, self.N, self.T = host, event, amax, N, T
+
+    def result(self):
+        """list of N collapsed label lists (waits for the copy only, not for work queued after it)"""
+        self.event.synchronize()
+        N, T = self.N, self.T
+        labels_h, lens_h = self.host[:N * T].view(N, T).tolist(), self.host[N * T:].tolist()
+        return [row[:n] for row, n in zip(labels_h, lens_h)]
+
+
+def greedy_decode_batch_async(log_probs: torch.Tensor, input_lengths) -> _Decode:
+    """(T,N,C) log-probs on the GPU -> handle; arg-max + collapse run on the device, ONE non-blocking copy brings labels | lengths to the
+    host.  A caller that queues more GPU work (the backward pass) before asking for ``result()`` overlaps the host-side part with it."""
     lp = log_probs.contiguous().float()
     T, N, C = lp.shape
     dev = lp.device
-    il = torch.as_tensor(input_lengths, dtype=torch.int64).to(dev)
+    il = torch.as_tensor(input_lengths, dtype=torch.int64)
+    if not il.is_cuda:
+        il = il.pin_memory().to(dev, non_blocking=True)
     amax = torch.empty(N, T, dtype=torch.int32, device=dev)
-    labels = torch.zeros(N, T, dtype=torch.int32, device=dev)
-    lens = torch.empty(N, dtype=torch.int32, device=dev)
-    lib().ctc_greedy_decode(ptr(lp), ptr(il), ptr(amax), ptr(labels), ptr(lens), T, N, C)
-    labels_h, lens_h = labels.cpu().tolist(), lens.cpu().tolist()
-    return [row[:n] for row, n in zip(labels_h, lens_h)], amax
+    buf = torch.zeros(N * T + N, dtype=torch.int32, device=dev)  # labels | lens
+    lib().ctc_greedy_decode(ptr(lp), ptr(il), ptr(amax), ptr(buf), buf.data_ptr() + 4 * N * T, T, N, C)
+    host = torch.empty(N * T + N, dtype=torch.int32, pin_memory=True)
+    host.copy_(buf, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return _Decode(host, ev, amax, N, T)
+
+
+def greedy_decode_batch(log_probs: torch.Tensor, input_lengths):
+    """(T,N,C) log-probs on the GPU -> list of N collapsed label lists (arg-max + collapse on the device, one D2H copy)."""
+    h = greedy_decode_batch_async(log_probs, input_lengths)
+    return h.result(), h.amax
 
 
 def levenshtein(a, b) -> int:
@@ -83,12 +108,24 @@ class RecognitionAccuracyStats:
     def update(self, targets, target_lengths, preds, pred_lengths):
         """targets [batch, seq]; preds [seq, batch, class] log-probs; lengths per sample."""
         assert len(target_lengths) == targets.size(0) and len(pred_lengths) == preds.size(1)
-        decoded, _ = greedy_decode_batch(preds, pred_lengths)
-        for y, labels in zip(targets.tolist(), decoded):
-            want = decode_text(y, self.alphabet)
-            got = "".join(self.alphabet[c - 1] for c in labels)
-            self.char_errors += levenshtein(want, got)
-        self.total_chars += int(sum(int(v) for v in target_lengths))
+        self.update_async(targets, target_lengths, preds, pred_lengths)()
+
+    def update_async(self, targets, target_lengths, preds, pred_lengths):
+        """Queue the device part of ``update`` (arg-max, CTC collapse, copy to the host) and return the function that finishes it.  Calling that
+        AFTER the backward pass and the optimizer step have been queued keeps the edit-distance work on the host off the GPU's critical path
+        (the reference's loop blocks on it between forward and backward, train_rec.py:123)."""
+        assert len(target_lengths) == targets.size(0) and len(pred_lengths) == preds.size(1)
+        handle = greedy_decode_batch_async(preds, pred_lengths)
+        rows, ntarget = targets.tolist(), int(sum(int(v) for v in target_lengths))
+
+        def finish():
+            for y, labels in zip(rows, handle.result()):
+                want = decode_text(y, self.alphabet)
+                got = "".join(self.alphabet[c - 1] for c in labels)
+                self.char_errors += levenshtein(want, got)
+            self.total_chars += ntarget
+
+        return finish
 
     def char_error_rate(self) -> float:
         return self.char_errors / self.total_chars

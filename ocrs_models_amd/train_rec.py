@@ -35,13 +35,16 @@ def train_step(model, optimizer, batch: dict, device, stats: RecognitionAccuracy
     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
         pred_seq = model(img)
         batch_loss = loss_fn(pred_seq, text_seq, input_lengths, target_lengths)
-    if stats is not None:
-        stats.update(batch["text_seq"], target_lengths.tolist(), pred_seq.detach(), input_lengths.tolist())
+    finish_stats = None
+    if stats is not None:  # device part now, host part (edit distances) after the backward pass has been queued
+        finish_stats = stats.update_async(batch["text_seq"], target_lengths.tolist(), pred_seq.detach(), input_lengths.tolist())
     if check_nan and math.isnan(batch_loss.item()):
         raise Exception("Training produced invalid loss. Check input and target lengths are compatible with CTC loss")
     batch_loss.backward()
     grad_norm = clip_grad_norm_(model.parameters(), max_norm=max_norm)
     optimizer.step()
+    if finish_stats is not None:
+        finish_stats()
     return batch_loss.detach(), grad_norm
 
 

@@ -254,6 +254,39 @@ def test_recognition_bf16_autocast_mode(dev):
             assert e_k < 2.0 * f_k + 2e-2, (k, e_k, f_k)
 
 
+def test_recognition_bf16_step_is_bit_stable(dev):
+    """Two identical bf16-autocast train steps at a size where every kernel runs many workgroups: the BatchNorm batch statistics (conv
+    epilogues) and their backward sums go through fixed-order block sums + exact fp64 accumulation, the GRU / CTC / weight-gradient flushes
+    have no floating-point atomics on data -- log-probs, loss and every gradient except the float-atomic bias / first-layer sums must be
+    identical bit for bit."""
+    import ocrs_models_amd as oa
+
+    torch.manual_seed(7)
+    B, W = 48, 320
+    x = torch.rand(B, 1, 64, W, device=dev)
+    text = torch.randint(1, 90, (B, 12), dtype=torch.int32)
+    il, tl = torch.full((B,), W // 4, dtype=torch.int64), torch.full((B,), 12, dtype=torch.int64)
+    m = oa.RecognitionModel(oa.text.DEFAULT_ALPHABET).to(dev)
+    m.train()
+    runs = []
+    for _ in range(2):
+        m.zero_grad()
+        for b in m.buffers():  # same running statistics in both runs
+            b.zero_() if b.dtype != torch.float32 else b.fill_(0.5)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lp = m(x)
+            loss = oa.CTCLoss()(lp, text.to(dev), il, tl)
+        loss.backward()
+        runs.append((lp.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    float_atomic = ("conv.0.", "conv.7.bias", "conv.13.bias", "gru.bias", "output.0.bias")  # k_conv0_bwd / k_col_sum: fp32 atomics across blocks
+    differ = [k for k in runs[0][2] if not torch.equal(runs[0][2][k], runs[1][2][k])]
+    print("gradients that differ between identical runs:", differ)
+    assert all(k.startswith(float_atomic) for k in differ), differ
+    for k in differ:
+        assert rel(runs[0][2][k], runs[1][2][k]) < 1e-5, k
+
+
 def test_recognition_eval_mode(dev):
     import ocrs_models_amd as oa
     from oracle import recognition as orec
