@@ -564,6 +564,8 @@ extern "C" {
 //           memset for all layers of a step instead of one per launch)
 // 1 if ocrs_dwpw_fwd can also write the 2x2-max-pooled (pre-BatchNorm) output: two-pixel tile configurations, Cout <= 64
 long det_dwf_supported(int Cin, int Cout, int dtype);  // det_dwf.hip: deep-level forward, a whole tile at once (no fused max-pool)
+long det_c1v2_supported(int N, int H, int W);  // det_c1.hip
+int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st);
 int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
                    double* gstat, int Cout, int N, int H, int W, hipStream_t st);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) {
@@ -590,6 +592,7 @@ int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* t
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st) {
     OCRS_CHECK_ARG(img && wdw && wpw && z && gstat);
+    if (det_c1v2_supported(N, H, W)) return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st);  // det_c1.hip
     const long P = (long)N * H * W;
     const int grid = ew_grid(P);
     if (dtype == 1)

@@ -390,9 +390,9 @@ def test_block_bwd_through_maxpool(dev, dtype, C, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_first_block_c1(dev, dtype):
+@pytest.mark.parametrize("N,H,W", [(2, 19, 23), (2, 6, 128), (3, 10, 64), (1, 2, 192)])  # per-pixel kernels | 64 columns x 2 rows per wave (det_c1.hip)
+def test_first_block_c1(dev, dtype, N, H, W):
     g = torch.Generator().manual_seed(9)
-    N, H, W = 2, 19, 23
     img = (torch.rand(N, 1, H, W, generator=g) - 0.5).to(dev)
     pfx = "blk"
     P = {
