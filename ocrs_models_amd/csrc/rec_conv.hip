@@ -857,6 +857,145 @@ __global__ __launch_bounds__(256) void k_dz_apply(const T* __restrict__ g, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The three window kernels above for the window shapes the model has -- (2,2), (2,1), (1,1) -- on tensors the windows tile exactly: window
+// shape known at compile time, every load of a cell issued before the first use (the generic kernels wait for each window element in turn,
+// 3.3-3.9 TB/s), same arithmetic and same first-maximum rule.
+template <class T, int PH, int PW>
+__global__ __launch_bounds__(256) void k_act_pool_fwd_t(const T* __restrict__ z, const float* __restrict__ tr, T* __restrict__ out, int C, int N, int H,
+                                                        int W) {
+    const int CG = C / 8, Hp = H / PH, Wp = W / PW;
+    // the grid's thread count is a multiple of CG (256 % CG == 0): a thread keeps its channel group, whose parameters live in registers
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float sc[8], sh[8], lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = tr[c0 + i];
+        sh[i] = tr[C + c0 + i];
+        lo[i] = tr[2 * C + c0 + i];
+    }
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        const T* zb = z + (((long)q.n * H + q.h * PH) * W + q.w * PW) * C + c0;
+        Raw8<T> raw[PH * PW];
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) raw[k] = load8_raw(zb + ((long)(k / PW) * W + k % PW) * C);
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) {
+            float v[8];
+            unpack8(raw[k], v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                m[i] = k == 0 ? y : fmaxf(m[i], y);
+            }
+        }
+        store8(out + pp * C + c0, m);
+    }
+}
+
+template <class T, int PH, int PW>
+__global__ __launch_bounds__(256) void k_rec_bn_reduce_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
+                                                         const float* __restrict__ saved, double* __restrict__ gsum, int C, int N, int H, int W) {
+    const int CG = C / 8, Hp = H / PH, Wp = W / PW;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = bn[c0 + i];
+        sh[i] = bn[C + c0 + i];
+        mu[i] = saved[c0 + i];
+        rs[i] = saved[C + c0 + i];
+    }
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        const T* zb = z + (((long)q.n * H + q.h * PH) * W + q.w * PW) * C + c0;
+        const Raw8<T> graw = load8_raw(g + pp * C + c0);
+        Raw8<T> raw[PH * PW];
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) raw[k] = load8_raw(zb + ((long)(k / PW) * W + k % PW) * C);
+        float gv[8], best[8], bz[8];
+        unpack8(graw, gv);
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) {
+            float zv[8];
+            unpack8(raw[k], zv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = fmaxf(fmaf(zv[i], sc[i], sh[i]), 0.f);
+                if (k == 0 || y > best[i]) {
+                    best[i] = y;
+                    bz[i] = zv[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gh = best[i] > 0.f ? gv[i] : 0.f;
+            s1[i] += gh;
+            s2[i] = fmaf(gh, (bz[i] - mu[i]) * rs[i], s2[i]);
+        }
+    }
+    group_sums_to_gsum(s1, s2, C, gsum);
+}
+
+template <class T, int PH, int PW>
+__global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
+                                                    const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W) {
+    const int CG = C / 8, Hp = H / PH, Wp = W / PW;
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid % CG) * 8;  // (fixed per thread, see k_act_pool_fwd_t)
+    float sc[8], sh[8], ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = bn[c0 + i];
+        sh[i] = bn[C + c0 + i];
+        ca[i] = coef[c0 + i];
+        cb[i] = coef[C + c0 + i];
+        cc[i] = coef[2 * C + c0 + i];
+    }
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
+        const PixIdx q = decode_pixel(pp, Hp, Wp);
+        const long zoff = (((long)q.n * H + q.h * PH) * W + q.w * PW) * C + c0;
+        const Raw8<T> graw = load8_raw(g + pp * C + c0);
+        Raw8<T> raw[PH * PW];
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) raw[k] = load8_raw(z + zoff + ((long)(k / PW) * W + k % PW) * C);
+        float gv[8], zs[PH * PW][8], best[8];
+        int bk[8];
+        unpack8(graw, gv);
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) {
+            unpack8(raw[k], zs[k]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = fmaxf(fmaf(zs[k][i], sc[i], sh[i]), 0.f);
+                if (k == 0 || y > best[i]) {
+                    best[i] = y;
+                    bk[i] = k;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PH * PW; ++k) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gh = (bk[i] == k && best[i] > 0.f) ? gv[i] : 0.f;
+                o[i] = fmaf(ca[i], gh, fmaf(cb[i], zs[k][i], cc[i]));
+            }
+            store8(dz + zoff + ((long)(k / PW) * W + k % PW) * C, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // BatchNorm2d (no ReLU) + AvgPool2d((4,1)) on H=5 (models.py:234-242) written as the GRU input seq[t=w][n][c] (fp32):
 //   seq = mean_{h<4}(z[n][h][w][c]) * scale + shift
 template <class T>
@@ -1454,9 +1593,23 @@ int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const vo
         hipLaunchKernelGGL(KERNEL<float>, dim3(GRID), dim3(256), SMEM, st, __VA_ARGS__);
 
 // BN+ReLU(+MaxPool PHxPW) forward on a pre-BN tensor z (models.py:197-199, 214-216, 231-233); tr = [3][C] load transform.
+static bool window_fast() {  // OCRS_REC_WINDOW_FAST=0: the generic (run-time window shape) kernels everywhere
+    static const int on = env_int("OCRS_REC_WINDOW_FAST", 1);
+    return on != 0;
+}
 int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int PH, int PW, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(z && tr && out && C % 8 == 0 && PH * PW <= 4 && PH >= 1 && PW >= 1);
     const int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
+#define APF(T_, PH_, PW_)                                                                                                          \
+    if (PH == PH_ && PW == PW_) {                                                                                                  \
+        hipLaunchKernelGGL((k_act_pool_fwd_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)z, tr, (T_*)out, C, N, H, W); \
+        OCRS_LAUNCH_CHECK();                                                                                                       \
+        return OCRS_OK;                                                                                                            \
+    }
+    if (window_fast() && 256 % (C / 8) == 0) {
+        if (dtype == 1) { APF(bf16, 2, 2) APF(bf16, 2, 1) } else { APF(float, 2, 2) APF(float, 2, 1) }
+    }
+#undef APF
     if (dtype == 1)
         hipLaunchKernelGGL(k_act_pool_fwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, (bf16*)out, C, N, H, W, PH, PW);
     else
@@ -1468,7 +1621,19 @@ int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, i
 int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,
                        int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(g && z && bn && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0 && PH * PW <= 4);
-    const int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
+    int grid = ew_grid((long)N * (H / PH) * (W / PW) * (C / 8));
+    static const int bpc = env_int("OCRS_REC_REDUCE_BPC", 4);  // every block ends in 2 C same-address fp64 atomics (~11 ns each, serial per address)
+    if (grid > bpc * kNumCU) grid = bpc * kNumCU;
+#define RBR(T_, PH_, PW_)                                                                                                                      \
+    if (PH == PH_ && PW == PW_) {                                                                                                              \
+        hipLaunchKernelGGL((k_rec_bn_reduce_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, saved, gsum, C, N, H, W); \
+        OCRS_LAUNCH_CHECK();                                                                                                                   \
+        return OCRS_OK;                                                                                                                        \
+    }
+    if (window_fast() && H % PH == 0 && W % PW == 0) {
+        if (dtype == 1) { RBR(bf16, 2, 2) RBR(bf16, 2, 1) RBR(bf16, 1, 1) } else { RBR(float, 2, 2) RBR(float, 2, 1) RBR(float, 1, 1) }
+    }
+#undef RBR
     if (dtype == 1)
         hipLaunchKernelGGL(k_rec_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, (const bf16*)g, (const bf16*)z, bn, saved, gsum, C,
                            N, H, W, PH, PW);
@@ -1482,6 +1647,16 @@ int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* co
                   hipStream_t st) {
     OCRS_CHECK_ARG(g && z && bn && coef && dz && C % 8 == 0 && PH * PW <= 4);
     const int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
+#define DZA(T_, PH_, PW_)                                                                                                                    \
+    if (PH == PH_ && PW == PW_) {                                                                                                            \
+        hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W); \
+        OCRS_LAUNCH_CHECK();                                                                                                                 \
+        return OCRS_OK;                                                                                                                      \
+    }
+    if (window_fast() && H % PH == 0 && W % PW == 0 && 256 % (C / 8) == 0) {
+        if (dtype == 1) { DZA(bf16, 2, 2) DZA(bf16, 2, 1) DZA(bf16, 1, 1) } else { DZA(float, 2, 2) DZA(float, 2, 1) DZA(float, 1, 1) }
+    }
+#undef DZA
     if (dtype == 1)
         hipLaunchKernelGGL(k_dz_apply<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)g, (const bf16*)z, bn, coef, (bf16*)dz, C, N, H, W, PH, PW);
     else

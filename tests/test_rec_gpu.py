@@ -287,6 +287,45 @@ def test_recognition_bf16_step_is_bit_stable(dev):
         assert rel(runs[0][2][k], runs[1][2][k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,C,PH,PW", [(2, 8, 12, 64, 2, 2), (2, 9, 13, 64, 2, 2), (3, 8, 7, 128, 2, 1), (2, 7, 5, 128, 2, 1), (2, 5, 9, 128, 1, 1)])
+def test_bn_relu_pool_forward_and_backward_pieces(dev, dtype, N, H, W, C, PH, PW):
+    """BatchNorm2d + ReLU + MaxPool2d((PH,PW)) forward (ocrs_act_pool_fwd) and the pieces of its backward (ocrs_rec_bn_reduce, ocrs_dz_apply) vs
+    torch autograd through the same operators -- window shapes of models.py:197-199 / 214-216 on tensors the windows tile exactly (the
+    compile-time-window kernels) and on tensors with a partial last row / column (floor mode: the generic kernels)."""
+    from ocrs_models_amd._lib import lib, ptr
+    from ocrs_models_amd.models import _DT
+
+    L, dt = lib(), _DT[dtype]
+    g = torch.Generator().manual_seed(H * W + C + PH)
+    z = nhwc(torch.randn(N, C, H, W, generator=g).to(dev), dtype)
+    sc, sh = (0.5 + torch.rand(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    tr = torch.stack([sc, sh, torch.zeros(C, device=dev)]).contiguous()
+    Hp, Wp = H // PH, W // PW
+    out = torch.empty(N, Hp, Wp, C, dtype=dtype, device=dev)
+    if PH * PW > 1:
+        L.act_pool_fwd(ptr(z), ptr(tr), ptr(out), C, N, H, W, PH, PW, dt)
+    zr = nchw(z).requires_grad_(True)
+    y = F.max_pool2d(torch.relu(zr * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)), (PH, PW))
+    if PH * PW > 1:
+        assert rel(nchw(out), y) < TOL[dtype]
+    gy = nhwc(torch.randn(N, C, Hp, Wp, generator=g).to(dev), dtype)
+    y.backward(nchw(gy))
+    ghat = zr.grad / sc.view(1, C, 1, 1)  # the pooled gradient routed to each window's first maximum, through the ReLU
+    mean, rstd = (0.1 * torch.randn(C, generator=g)).to(dev), (0.5 + torch.rand(C, generator=g)).to(dev)
+    saved = torch.stack([mean, rstd]).contiguous()
+    gsum = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    L.rec_bn_reduce(ptr(gy), ptr(z), ptr(tr), ptr(saved), ptr(gsum), C, N, H, W, PH, PW, dt)
+    s1 = ghat.sum((0, 2, 3))
+    s2 = (ghat * (nchw(z) - mean.view(1, C, 1, 1)) * rstd.view(1, C, 1, 1)).sum((0, 2, 3))
+    assert rel(gsum[:C], s1) < 1e-5 and rel(gsum[C:], s2) < 1e-5
+    coef = torch.randn(3, C, generator=g).to(dev)
+    dz = torch.empty_like(z)
+    L.dz_apply(ptr(gy), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, N, H, W, PH, PW, dt)
+    want = coef[0].view(1, C, 1, 1) * ghat + coef[1].view(1, C, 1, 1) * nchw(z) + coef[2].view(1, C, 1, 1)
+    assert rel(nchw(dz), want) < TOL[dtype]
+
+
 def test_recognition_eval_mode(dev):
     import ocrs_models_amd as oa
     from oracle import recognition as orec

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_rec_gpu.py tests/test_gru_gpu.py tests/test_train_loop_gpu.py -x -q -m gpu -s 2>&1 | grep -v Warning | tail -8
+timeout 900 python -m pytest tests/test_rec_gpu.py tests/test_train_loop_gpu.py tests/test_full_size_gpu.py -x -q -m gpu 2>&1 | grep -v Warning | tail -8
 rm -rf gpurun_out/trace_crnn
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_crnn -- python tools/prof_crnn.py --steps 3 --warmup 2 > gpurun_out/trace_crnn.log 2>&1
 python tools/trace_step.py gpurun_out/trace_crnn k_conv0_fwd > gpurun_out/crnn_step_trace.txt 2>&1
