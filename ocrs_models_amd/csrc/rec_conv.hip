@@ -615,10 +615,19 @@ template <class T>
 __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img, const float* __restrict__ w /*[32][9]*/,
                                                    const float* __restrict__ bias, T* __restrict__ out /*[N][H/2][W/2][32]*/, int N, int H, int W) {
     const int Hp = H >> 1, Wp = W >> 1;
-    const long total = (long)N * Hp * Wp * 4;
-    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
-        const long pp = it >> 2;
-        const int c0 = (int)(it & 3) * 8;
+    // a thread keeps its group of 8 output channels (the grid's thread count is a multiple of 4): their 72 weights + 8 biases live in registers
+    // (re-loading them per pixel made 20 of the kernel's 37 load instructions per store)
+    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const int c0 = (int)(gtid & 3) * 8;
+    float wk[8][9], bs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bs[i] = bias[c0 + i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[i][k] = w[(c0 + i) * 9 + k];
+    }
+    const long Pp = (long)N * Hp * Wp;
+    for (long pp = gtid >> 2; pp < Pp; pp += nthr >> 2) {
         const PixIdx q = decode_pixel(pp, Hp, Wp);
         float patch[4][4];
 #pragma unroll
@@ -626,22 +635,21 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 const int h = 2 * q.h + dy - 1, ww = 2 * q.w + dx - 1;
-                patch[dy][dx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? img[((long)q.n * H + h) * W + ww] : 0.f;
+                const bool ok = h >= 0 && h < H && ww >= 0 && ww < W;
+                const float v = img[ok ? ((long)q.n * H + h) * W + ww : 0];  // (unconditional load, selected address)
+                patch[dy][dx] = ok ? v : 0.f;
             }
         float m[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float wk[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wk[k] = w[(c0 + i) * 9 + k];
             float best = 0.f;  // ReLU floor: max(relu(a), relu(b), ...) = max(0, a, b, ...)
 #pragma unroll
             for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
                 for (int ox = 0; ox < 2; ++ox) {
-                    float s = bias[c0 + i];
+                    float s = bs[i];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) s = fmaf(wk[k], patch[oy + k / 3][ox + k % 3], s);
+                    for (int k = 0; k < 9; ++k) s = fmaf(wk[i][k], patch[oy + k / 3][ox + k % 3], s);
                     best = fmaxf(best, s);
                 }
             m[i] = best;
