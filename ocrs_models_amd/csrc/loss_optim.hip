@@ -162,7 +162,23 @@ __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ l
         if (pass == 0 || (key >> hs) == pf) atomicAdd(&s_h[(c - 1) * 2048 + ((key >> shift) & (nb - 1))], 1u);
     };
     const long nq = P / VEC;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    // four quads' loads in flight per thread (one per iteration left these passes latency-bound: 2-3 TB/s)
+    const long stride = (long)gridDim.x * 256;
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; q + 3 * stride < nq; q += 4 * stride) {
+        QuadB<VEC> cq[4];
+        Quad<VEC> lq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cq[u] = ldqb<VEC>(cls, q + u * stride);
+            lq[u] = ldq<VEC>(lpx, q + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) visit(cq[u].v[e], lq[u].v[e]);
+    }
+    for (; q < nq; q += stride) {
         const QuadB<VEC> cq = ldqb<VEC>(cls, q);
         const Quad<VEC> lq = ldq<VEC>(lpx, q);
 #pragma unroll
@@ -232,7 +248,23 @@ __global__ __launch_bounds__(256) void k_topk_sum(const float* __restrict__ lpx,
         }
     };
     const long nq = P / VEC;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    // four quads' loads in flight per thread (one per iteration left these passes latency-bound: 2-3 TB/s)
+    const long stride = (long)gridDim.x * 256;
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; q + 3 * stride < nq; q += 4 * stride) {
+        QuadB<VEC> cq[4];
+        Quad<VEC> lq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cq[u] = ldqb<VEC>(cls, q + u * stride);
+            lq[u] = ldq<VEC>(lpx, q + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) visit(cq[u].v[e], lq[u].v[e]);
+    }
+    for (; q < nq; q += stride) {
         const QuadB<VEC> cq = ldqb<VEC>(cls, q);
         const Quad<VEC> lq = ldq<VEC>(lpx, q);
 #pragma unroll
