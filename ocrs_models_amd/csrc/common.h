@@ -197,6 +197,28 @@ __device__ __forceinline__ float block_sum_det(const float (&v)[N], float* s_slo
     return i < N ? (s_slots[i] + s_slots[N + i]) + (s_slots[2 * N + i] + s_slots[3 * N + i]) : 0.f;
 }
 
+// Deterministic column sum of per-block partials ws[nb][nelem] for element e: 256-thread blocks = 32 columns x 8 interleaved chains, eight
+// loads in flight per chain, fixed association order, ONE writer per element (no atomics).  Returns true (with the total) in the writer.
+__device__ __forceinline__ bool det_column_sum(const float* __restrict__ ws, int nb, long nelem, long e, float& total) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
+    float s = 0.f;
+    if (e < nelem) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = chain;
+        for (; b + 56 < nb; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ws[(long)(b + 8 * u) * nelem + e];
+        }
+        for (int u = 0; b < nb; b += 8, ++u) a[u & 7] += ws[(long)b * nelem + e];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[chain][col] = s;
+    __syncthreads();
+    total = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+    return chain == 0 && e < nelem;
+}
+
 // sum over the 16 lanes sharing (lane >> 4) = one DPP row; every lane of the row gets the sum (4 DPP adds, no LDS traffic)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {

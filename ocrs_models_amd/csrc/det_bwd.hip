@@ -155,27 +155,6 @@ __device__ __forceinline__ void flush_w(float* __restrict__ dw, float* __restric
     else
         atomicAdd(&dw[idx], v);
 }
-// Deterministic column sum of per-block partials ws[nb][nelem] for element e: 256-thread blocks = 32 columns x 8 interleaved chains, eight
-// loads in flight per chain, fixed association order, ONE writer per element (no atomics).  Returns true (with the total) in the writer.
-__device__ __forceinline__ bool det_column_sum(const float* __restrict__ ws, int nb, long nelem, long e, float& total) {
-    __shared__ float red[8][32];
-    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
-    float s = 0.f;
-    if (e < nelem) {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int b = chain;
-        for (; b + 56 < nb; b += 64) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += ws[(long)(b + 8 * u) * nelem + e];
-        }
-        for (int u = 0; b < nb; b += 8, ++u) a[u & 7] += ws[(long)b * nelem + e];
-        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-    red[chain][col] = s;
-    __syncthreads();
-    total = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
-    return chain == 0 && e < nelem;
-}
 // dw[(e / cin) * ldw + e % cin] += sum_b ws[b][e]  (ldw = cin: plain dw[e]);  grid ceil(nelem / 32)
 __global__ __launch_bounds__(256) void k_wgrad_partials_reduce(const float* __restrict__ ws, int nb, int nelem, float* __restrict__ dw, int cin,
                                                                int ldw) {

@@ -350,19 +350,19 @@ __global__ __launch_bounds__(256) void k_wgrad_gather(const T* __restrict__ A, i
     }
 }
 
-// dW[(ra*CB + cb)*ntaps + tap] += sum_bx ws[bx][jc = tap*CB + cb][ra]
+// dW[(ra*CB + cb)*ntaps + tap] += sum_bx ws[bx][jc = tap*CB + cb][ra];  grid ceil(n / 32), n = ntaps * CB * CA8 (det_column_sum: 32 elements x
+// 8 interleaved chains per block, eight loads in flight per chain -- one thread per element walking its gx partials in turn was a pure
+// latency chain: 15-60 us per launch for a few MB)
 __global__ __launch_bounds__(256) void k_wgrad_gather_reduce(const float* __restrict__ ws, int gx, int CA, int CA8, int CB, int ntaps,
                                                              float* __restrict__ dW) {
     const long n = (long)ntaps * CB * CA8;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int ra = (int)(i % CA8);
-        if (ra >= CA) continue;
-        float s = 0.f;
-        for (int b = 0; b < gx; ++b) s += ws[(long)b * n + i];
-        const long jc = i / CA8;
-        const int tap = (int)(jc / CB), cb = (int)(jc - (long)tap * CB);
-        dW[((long)ra * CB + cb) * ntaps + tap] += s;
-    }
+    const long i = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+    const int ra = (int)(i % CA8);
+    float s;
+    if (!det_column_sum(ws, gx, n, (i < n && ra < CA) ? i : n, s)) return;
+    const long jc = i / CA8;
+    const int tap = (int)(jc / CB), cb = (int)(jc - (long)tap * CB);
+    dW[((long)ra * CB + cb) * ntaps + tap] += s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1351,7 +1351,7 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     if (ws) {
         const int CA8 = (CA + 7) & ~7;
         const long n = (long)KH * KW * CB * CA8;
-        hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, ws, (int)gx, CA, CA8, CB,
+        hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 31) / 32)), dim3(256), 0, st, ws, (int)gx, CA, CA8, CB,
                            KH * KW, dW);
     }
     OCRS_LAUNCH_CHECK();
@@ -1480,13 +1480,12 @@ static int wgrad3x3_gx(int Cin, int N, int H, int W) {
 }
 
 __global__ __launch_bounds__(256) void k_wgrad3x3_reduce(const float* __restrict__ ws, int gx, int Cout, int Cin, float* __restrict__ dW) {
-    const long n = 9L * Cin * Cout;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int b = 0; b < gx; ++b) s += ws[(long)b * n + i];
-        const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((long)Cout * Cin));
-        dW[((long)co * Cin + ci) * 9 + tap] += s;
-    }
+    const long n = 9L * Cin * Cout;  // grid ceil(n / 32): see k_wgrad_gather_reduce
+    const long i = (long)blockIdx.x * 32 + (threadIdx.x & 31);
+    float s;
+    if (!det_column_sum(ws, gx, n, i, s)) return;
+    const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), tap = (int)(i / ((long)Cout * Cin));
+    dW[((long)co * Cin + ci) * 9 + tap] += s;
 }
 
 // Split-bf16 weight-gradient GEMM for fp32 operands (throughput mode of the GRU / Linear weight gradients):
@@ -1505,7 +1504,7 @@ int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB,
     hipLaunchKernelGGL(k_wgrad_gemm_x3, dim3(gx, gy), dim3(256), 4 * 32 * 136 * 2, st, A, ldA, CA, B, ldB, CB, P, ws, ta, cpb);
     const int CA8 = (CA + 7) & ~7;
     const long n = (long)CB * CA8;
-    hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, ws, gx, CA, CA8, CB, 1, dW);
+    hipLaunchKernelGGL(k_wgrad_gather_reduce, dim3((int)((n + 31) / 32)), dim3(256), 0, st, ws, gx, CA, CA8, CB, 1, dW);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -1566,7 +1565,7 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
     else
         hipLaunchKernelGGL(k_conv3x3_wgrad<float>, dim3((int)gx, gy), dim3(256), (128 * 132 + 96 * 164) * 4, st, (const float*)dz, Cout,
                            (const float*)x, Cin, dW, N, H, W, ws);
-    if (ws) hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((9 * Cin * Cout + 255) / 256), dim3(256), 0, st, ws, (int)gx, Cout, Cin, dW);
+    if (ws) hipLaunchKernelGGL(k_wgrad3x3_reduce, dim3((9 * Cin * Cout + 31) / 32), dim3(256), 0, st, ws, (int)gx, Cout, Cin, dW);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
