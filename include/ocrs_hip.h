@@ -158,8 +158,10 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
 long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P);
 int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st);
 /* Split-bf16 GEMM for fp32 operands (GRU input projections and their input gradients in throughput mode, models.py:264-266):
- * out [P][ldo] = X [P][ldx] (K columns) * W (+ bias), W[m][k] = Wm[m * ldw + k] (km = 0) or Wm[k * ldw + m] (km = 1). */
-int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P,
+ * out [P][ldo] = X [P][ldx] (K columns) * W (+ bias), W[m][k] = Wm[m * ldw + k] (km = 0) or Wm[k * ldw + m] (km = 1).
+ * Kw (0: K): the k extent Wm really has; X columns [Kw, K) meet zero weights.  km = 0 also takes M % 4 != 0 (nn.Linear(512, n_classes) and
+ * its input gradient, models.py:245-248): output columns [M, round_up(M, 4)) are written as 0. */
+int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P, int Kw,
                  hipStream_t st);
 long ocrs_wgrad_gather_ws_floats(int CA, int CB, int ntaps, long P, int dtype);
 int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const void* B, int ldB, int CB, float* dW, float* ws, int N, int hA,

@@ -1036,16 +1036,26 @@ __global__ __launch_bounds__(256) void k_avgpool_bn_reduce(const float* __restri
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;
     float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mu[8], rs[8];  // (per-thread channel group: parameters in registers, all five loads of a column issued before the first use)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mu[i] = saved[c0 + i];
+        rs[i] = saved[C + c0 + i];
+    }
     for (long nw = gtid / CG; nw < (long)N * W; nw += nthr / CG) {
         const int n = (int)(nw / W), w = (int)(nw - (long)n * W);
         float gv[8];
+        Raw8<T> raw[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) raw[h] = load8_raw(z + (((long)n * H + h) * W + w) * C + c0);
         load8(gseq + ((long)w * N + n) * C + c0, gv);
         float zs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
         for (int h = 0; h < 4; ++h) {
             float v[8];
-            load8(z + (((long)n * H + h) * W + w) * C + c0, v);
+            unpack8(raw[h], v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) zs[i] += (v[i] - saved[c0 + i]) * saved[C + c0 + i];
+            for (int i = 0; i < 8; ++i) zs[i] += (v[i] - mu[i]) * rs[i];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1173,7 +1183,7 @@ static int launch_igemm(const void* x, int ldx, const void* wpk, void* out, int 
 // through the LDS transpose read.  Next chunk register-prefetched.
 template <bool KM>
 __global__ __launch_bounds__(256) void k_gemm_x3(const float* __restrict__ X, int ldx, const float* __restrict__ Wm, int ldw, const float* __restrict__ bias,
-                                                 float* __restrict__ out, int ldo, int K, int M, long P) {
+                                                 float* __restrict__ out, int ldo, int K, int M, long P, int Kw) {
     constexpr int BP = 128, BM = 128, KC = 32, PK = KC + 8, PM = BM + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Xh = reinterpret_cast<bf16*>(smem);  // [BP][PK]
@@ -1195,10 +1205,10 @@ __global__ __launch_bounds__(256) void k_gemm_x3(const float* __restrict__ X, in
             }
             if (KM) {
                 const int k = f >> 5, m4 = (f & 31) * 4;
-                rw[j] = m0 + m4 < M ? *reinterpret_cast<const float4*>(Wm + (long)(k0 + k) * ldw + m0 + m4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rw[j] = (m0 + m4 < M && k0 + k < Kw) ? *reinterpret_cast<const float4*>(Wm + (long)(k0 + k) * ldw + m0 + m4) : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 const int m = f >> 3, k4 = (f & 7) * 4;
-                rw[j] = m0 + m < M ? *reinterpret_cast<const float4*>(Wm + (long)(m0 + m) * ldw + k0 + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rw[j] = (m0 + m < M && k0 + k4 < Kw) ? *reinterpret_cast<const float4*>(Wm + (long)(m0 + m) * ldw + k0 + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -1268,7 +1278,12 @@ __global__ __launch_bounds__(256) void k_gemm_x3(const float* __restrict__ X, in
         const int m = m0 + (wm * 4 + i) * 16 + kg * 4;
         if (m >= M) continue;
         float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bs = *reinterpret_cast<const float4*>(bias + m);
+        if (bias) {
+            if (m + 3 < M)
+                bs = *reinterpret_cast<const float4*>(bias + m);
+            else  // last, partial quad of a ragged M (km = 0 only): columns [M, round_up(M, 4)) are written as 0
+                bs = make_float4(bias[m], m + 1 < M ? bias[m + 1] : 0.f, m + 2 < M ? bias[m + 2] : 0.f, 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long p = p0 + (wn * 4 + j) * 16 + i16;
@@ -1511,15 +1526,19 @@ int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB,
 
 // Split-bf16 GEMM for fp32 operands: out [P][ldo] (first M columns) = X [P][ldx] (first K columns) * W (+ bias [M]);
 //   km = 0: W[m][k] at Wm[m * ldw + k];  km = 1: W[k][m] at Wm[k * ldw + m].   K % 32 == 0, M % 4 == 0, 16-byte aligned rows.
-int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P,
+int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P, int Kw,
                  hipStream_t st) {
-    OCRS_CHECK_ARG(X && Wm && out && P > 0 && K > 0 && K % 32 == 0 && M % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && ldx >= K && ldo >= M);
+    // Kw (0: K): the k extent Wm really has -- X columns [Kw, K) meet zero weights (a K padded up to the 32-column chunk, e.g. the
+    // zero-padded class columns of the output layer's gradient); km = 0 also takes a ragged M (rows of Wm), ldo >= round_up(M, 4)
+    if (Kw <= 0) Kw = K;
+    OCRS_CHECK_ARG(X && Wm && out && P > 0 && K > 0 && K % 32 == 0 && Kw <= K && ldx % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && ldx >= K &&
+                   ldo >= ((M + 3) & ~3) && (km ? (M % 4 == 0) : (Kw % 4 == 0)));
     OCRS_CHECK_ARG(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wm) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
     const dim3 grid((unsigned)((P + 127) / 128), (unsigned)((M + 127) / 128));
     if (km)
-        hipLaunchKernelGGL(k_gemm_x3<true>, grid, dim3(256), (2 * 128 * 40 + 2 * 32 * 136) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P);
+        hipLaunchKernelGGL(k_gemm_x3<true>, grid, dim3(256), (2 * 128 * 40 + 2 * 32 * 136) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P, Kw);
     else
-        hipLaunchKernelGGL(k_gemm_x3<false>, grid, dim3(256), (4 * 128 * 40) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P);
+        hipLaunchKernelGGL(k_gemm_x3<false>, grid, dim3(256), (4 * 128 * 40) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P, Kw);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -1685,7 +1704,8 @@ int ocrs_avgpool_fwd(const void* z, const float* tr, float* seq, int C, int N, i
 }
 int ocrs_avgpool_bn_reduce(const float* gseq, const void* z, const float* saved, double* gsum, int C, int N, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(gseq && z && saved && gsum && C % 8 == 0 && 256 % (C / 8) == 0);
-    const int grid = ew_grid((long)N * W * (C / 8));
+    int grid = ew_grid((long)N * W * (C / 8));
+    if (grid > 4 * kNumCU) grid = 4 * kNumCU;  // (ends in 2 C same-address fp64 atomics per block: see ocrs_rec_bn_reduce)
     if (dtype == 1)
         hipLaunchKernelGGL(k_avgpool_bn_reduce<bf16>, dim3(grid), dim3(256), 2 * C * sizeof(float), st, gseq, (const bf16*)z, saved, gsum, C, N, H, W);
     else

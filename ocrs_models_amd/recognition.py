@@ -108,9 +108,10 @@ class _RecRun:
                 if self.train:
                     rows.append((P[name], self.dt, nt * co, ci, co, -1, ci * nt, nt, nt - 1))
             C = self.ncls
-            rows.append((P["output.0.weight"], 0, 512, C, 512, 0, 1, 512, 0))
-            if self.train:
-                rows.append((P["output.0.weight"], 0, C, 512, C, 0, 512, 1, 0))
+            if not self.use_x3(512, C, 0):  # (throughput mode: the output layer runs on the split-bf16 GEMM, straight from the master layout)
+                rows.append((P["output.0.weight"], 0, 512, C, 512, 0, 1, 512, 0))
+                if self.train:
+                    rows.append((P["output.0.weight"], 0, C, 512, C, 0, 512, 1, 0))
             sizes = [self.L.pack_frags_bytes(r[2], r[3], r[1]) for r in rows]
             offs = [0]
             for n in sizes:
@@ -153,14 +154,14 @@ class _RecRun:
                           kh, kw, pad, pad, self.dt)
         return out, gstat
 
-    def gemm_x3(self, x, ldx, K, w, ldw, km, bias, M, ldo, rows):
+    def gemm_x3(self, x, ldx, K, w, ldw, km, bias, M, ldo, rows, kw=0):
         """Throughput-mode fp32 GEMM as split-bf16 (see csrc/rec_conv.hip::k_gemm_x3): W straight from the master layout."""
         out = self.empty(rows, ldo, dtype=torch.float32)
-        self.L.gemm_x3(ptr(x), ldx, K, ptr(w), ldw, km, ptr(bias), ptr(out), ldo, M, rows)
+        self.L.gemm_x3(ptr(x), ldx, K, ptr(w), ldw, km, ptr(bias), ptr(out), ldo, M, rows, kw)
         return out
 
-    def use_x3(self, K, M):
-        return self.dt == 1 and self.x3 and K % 32 == 0 and M % 4 == 0
+    def use_x3(self, K, M, km=1):
+        return self.dt == 1 and self.x3 and K % 32 == 0 and (M % 4 == 0 or not km)
 
     def gemm(self, x, ldx, K, wpk, bias, M, ldo, rows):
         """fp32 GEMM: out[rows][ldo] = x[rows][K] @ W^T (+bias), W given as packed fragments (K, M)."""
@@ -228,7 +229,10 @@ class _RecRun:
         C = self.ncls
         S.ldl = (C + 31) // 32 * 32
         wout = P["output.0.weight"]
-        logits = self.gemm(xin, 512, 512, self.pack(wout, 512, C, 512, 0, 1, 512, dt=0), P["output.0.bias"], C, S.ldl, rows)
+        if self.use_x3(512, C, 0):
+            logits = self.gemm_x3(xin, 512, 512, wout, 512, 0, P["output.0.bias"], C, S.ldl, rows)
+        else:
+            logits = self.gemm(xin, 512, 512, self.pack(wout, 512, C, 512, 0, 1, 512, dt=0), P["output.0.bias"], C, S.ldl, rows)
         S.lp = self.empty(T, N, C, dtype=torch.float32)
         L.log_softmax_fwd(ptr(logits), ptr(S.lp), rows, C, S.ldl, 0)
         return S.lp
@@ -323,7 +327,10 @@ class _RecRun:
         top = S.gru[1]["out"]
         self.wgrad(dlog, S.ldl, C, top, 512, 512, G["output.0.weight"], 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
         L.col_sum(ptr(dlog), S.ldl, C, ptr(G["output.0.bias"]), rows, 0)
-        dout = self.gemm(dlog, S.ldl, S.ldl, self.pack(P["output.0.weight"], C, 512, C, 0, 512, 1, dt=0), None, 512, 512, rows)
+        if self.use_x3(S.ldl, 512):  # dlog's columns [C, ldl) are zero and meet no weights (kw = C)
+            dout = self.gemm_x3(dlog, S.ldl, S.ldl, P["output.0.weight"], 512, 1, None, 512, 512, rows, kw=C)
+        else:
+            dout = self.gemm(dlog, S.ldl, S.ldl, self.pack(P["output.0.weight"], C, 512, C, 0, 512, 1, dt=0), None, 512, 512, rows)
         stage_done("output.")
         dhz = self.empty(2, 2, N, 256, dtype=torch.float32)
         for layer in (1, 0):

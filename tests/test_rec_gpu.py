@@ -371,27 +371,32 @@ def test_split_bf16_wgrad_gemm(dev, P, CA, ldA, CB, ldB):
     assert err < 0.05 * err_bf, (err, err_bf)
 
 
-@pytest.mark.parametrize("P,K,M,km", [(25856, 128, 1536, 0), (3000, 512, 1536, 0), (25856, 1536, 128, 1), (777, 1536, 512, 1), (130, 64, 36, 0)])
-def test_split_bf16_gemm(dev, P, K, M, km):
-    """ocrs_gemm_x3 (bf16x3 emulation of the fp32 GRU projection / input-gradient GEMMs, throughput mode only) against float64:
-    within 5e-5 of the exact result relative to ||x_row||.||w_col||, both weight layouts, bias, ragged P and M."""
+@pytest.mark.parametrize("P,K,M,km,kw", [(25856, 128, 1536, 0, 0), (3000, 512, 1536, 0, 0), (25856, 1536, 128, 1, 0), (777, 1536, 512, 1, 0),
+                                         (130, 64, 36, 0, 0), (5000, 512, 97, 0, 0), (333, 64, 5, 0, 60), (5000, 128, 512, 1, 97)])
+def test_split_bf16_gemm(dev, P, K, M, km, kw):
+    """ocrs_gemm_x3 (bf16x3 emulation of the fp32 GRU projection / input-gradient GEMMs and of the output Linear, throughput mode only)
+    against float64: within 5e-5 of the exact result relative to ||x_row||.||w_col||, both weight layouts, bias, ragged P and M, a ragged
+    number of classes (M = 97 rows of W; W with only kw = 97 of the K = 128 rows the zero-padded gradient has columns for)."""
     from ocrs_models_amd._lib import lib, ptr
 
     L = lib()
     g = torch.Generator().manual_seed(P + K + M)
+    Kw = kw or K
     X = torch.randn(P, K, generator=g).to(dev)
-    W = (torch.randn(K, M, generator=g) if km else torch.randn(M, K, generator=g)).to(dev)
+    W = (torch.randn(Kw, M, generator=g) if km else torch.randn(M, Kw, generator=g)).to(dev)  # exactly the extent the kernel may read
     bias = torch.randn(M, generator=g).to(dev)
-    ldo = M + 4
+    M4 = (M + 3) // 4 * 4
+    ldo = M4 + 4
     out = torch.full((P, ldo), 7.0, device=dev)
-    L.gemm_x3(ptr(X), K, K, ptr(W), M if km else K, km, ptr(bias), ptr(out), ldo, M, P)
+    L.gemm_x3(ptr(X), K, K, ptr(W), M if km else Kw, km, ptr(bias), ptr(out), ldo, M, P, kw)
     torch.cuda.synchronize()
     Wkm = W.double() if km else W.double().T
-    ref = X.double() @ Wkm + bias.double()
-    scale = X.double().norm(dim=1)[:, None] * Wkm.norm(dim=0)[None, :]
+    ref = X[:, :Kw].double() @ Wkm + bias.double()
+    scale = X[:, :Kw].double().norm(dim=1)[:, None] * Wkm.norm(dim=0)[None, :]
     err = ((out[:, :M].double() - ref).abs() / scale).max().item()
     assert err < 5e-5, err
-    assert float((out[:, M:] - 7.0).abs().max()) == 0.0  # columns beyond M untouched
+    assert float(out[:, M:M4].abs().max()) == 0.0 if M4 > M else True  # the partial last quad of a ragged M is written as 0
+    assert float((out[:, M4:] - 7.0).abs().max()) == 0.0  # columns beyond that untouched
 
 
 def test_ctc_fp16_lattice_variant_and_determinism(dev):
