@@ -154,7 +154,8 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st);
 /* weight gradients of Conv2d / Linear / GRU (autograd of the calls above). */
 /* Split-bf16 (bf16x3) weight-gradient GEMM for fp32 operands: dW [CA][CB] += A^T B over P rows (throughput mode of the GRU / Linear
- * weight gradients, train_rec.py:140 backward of models.py:264-268); <= ~1.1e-5 relative error per product, fp32 accumulation. */
+ * weight gradients, train_rec.py:140 backward of models.py:264-268); <= ~1.1e-5 relative error per product, fp32 accumulation.
+ * CB % 4 == 0; CA may be ragged (the class count) when ldA >= round_up(CA, 4). */
 long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P);
 int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st);
 /* Split-bf16 GEMM for fp32 operands (GRU input projections and their input gradients in throughput mode, models.py:264-266):

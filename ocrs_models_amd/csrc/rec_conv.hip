@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(256) void k_wgrad_gemm_x3(const float* __restrict__
         for (int j = 0; j < 4; ++j) {
             const int f = tid + j * 256, row = f >> 5, col = (f & 31) * 4;
             const long p = c * KC + row;
-            const bool oka = p < P && a0 + col < CA, okb = p < P && b0 + col < CB;  // CA, CB multiples of 4 (checked by the host)
+            const bool oka = p < P && a0 + col < CA, okb = p < P && b0 + col < CB;  // CB a multiple of 4, A rows padded to one (checked by the host)
             ra[j] = oka ? *reinterpret_cast<const float4*>(A + p * ldA + a0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[j] = okb ? *reinterpret_cast<const float4*>(B + p * ldB + b0 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1512,7 +1512,9 @@ long ocrs_wgrad_gemm_x3_ws_floats(int CA, int CB, long P) {
     return (long)gx * CB * ((CA + 7) & ~7);
 }
 int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB, int CB, float* dW, float* ws, long P, hipStream_t st) {
-    OCRS_CHECK_ARG(A && B && dW && ws && P > 0 && CA % 4 == 0 && CB % 4 == 0 && ldA % 4 == 0 && ldB % 4 == 0 && ldA >= CA && ldB >= CB);
+    // (a ragged CA -- the class count of the output Linear -- is fine as long as the rows of A extend to the next multiple of 4: the extra
+    // columns are loaded, their partials land in the CA8-padded workspace rows and the reduce skips them)
+    OCRS_CHECK_ARG(A && B && dW && ws && P > 0 && CB % 4 == 0 && ldA % 4 == 0 && ldB % 4 == 0 && ldA >= ((CA + 3) & ~3) && ldB >= CB);
     OCRS_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0);
     int gx, gy, ta, cpb;
     wgrad_x3_grid(CA, CB, P, gx, gy, ta, cpb);

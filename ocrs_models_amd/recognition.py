@@ -259,7 +259,7 @@ class _RecRun:
         L = self.L
         a_ptr = A if isinstance(A, int) else ptr(A)
         b_ptr = B if isinstance(B, int) else ptr(B)
-        if (dt == 0 and self.dt == 1 and self.x3 and KH * KW == 1 and padw == 0 and N == 1 and (hA, wA) == (HB, WB) and CA % 4 == 0
+        if (dt == 0 and self.dt == 1 and self.x3 and KH * KW == 1 and padw == 0 and N == 1 and (hA, wA) == (HB, WB) and ldA >= (CA + 3) // 4 * 4
                 and CB % 4 == 0 and ldA % 4 == 0 and ldB % 4 == 0):
             # throughput (autocast) mode: the fp32 GRU weight gradients as split-bf16 (bf16x3) GEMMs -- ~1e-5 relative per product, fp32
             # accumulation; parity mode (self.dt == 0) keeps the exact-fp32 MFMA kernel.

@@ -345,7 +345,7 @@ def test_recognition_eval_mode(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,CA,ldA,CB,ldB", [(25856, 1536, 1536, 256, 256), (4001, 768, 1536, 256, 512), (77, 100, 128, 36, 40)])
+@pytest.mark.parametrize("P,CA,ldA,CB,ldB", [(25856, 1536, 1536, 256, 256), (4001, 768, 1536, 256, 512), (77, 100, 128, 36, 40), (6000, 97, 128, 512, 512)])
 def test_split_bf16_wgrad_gemm(dev, P, CA, ldA, CB, ldB):
     """ocrs_wgrad_gemm_x3 (bf16x3 emulation of the fp32 GRU weight-gradient GEMMs, throughput mode only) against a float64 matmul:
     products carry <= ~1.1e-5 relative error, fp32 accumulation -> the result must be within 5e-5 of the exact one relative to
