@@ -1117,6 +1117,14 @@ __global__ __launch_bounds__(256) void k_col_sum4(const T* __restrict__ a, int l
         if (c < C) {
             float s[4] = {0.f, 0.f, 0.f, 0.f};
             long r = (long)blockIdx.x * 4 + ph;
+            for (; r + 7 * rstep < rows; r += 8 * rstep) {  // eight rows in flight per thread (2 blocks per CU: 64 KB in flight per CU)
+                float v[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) load4(a + (r + u * rstep) * ld + c, v[u]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    s[i] += ((v[0][i] + v[1][i]) + (v[2][i] + v[3][i])) + ((v[4][i] + v[5][i]) + (v[6][i] + v[7][i]));
+            }
             for (; r + 3 * rstep < rows; r += 4 * rstep) {
                 float v[4][4];
 #pragma unroll

@@ -8,3 +8,4 @@ python tools/trace_step.py gpurun_out/trace_crnn k_conv0_fwd > gpurun_out/crnn_s
 find gpurun_out/trace_crnn -name "*kernel_trace.csv" -delete
 tail -2 gpurun_out/crnn_step_trace.txt
 python bench.py --no-cpu-baseline --no-fp32 --no-gru-exact 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['crnn']['value'], d['crnn']['ms_per_step'])"
+for v in "OCRS_REC_REDUCE_BPC=2" "OCRS_REC_REDUCE_BPC=8"; do env $v python tools/prof_crnn.py --steps 10 --warmup 3 2>&1 | tail -1 | cut -c1-200; done
