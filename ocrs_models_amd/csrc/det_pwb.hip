@@ -47,6 +47,16 @@ struct PwbCfg {
 // resident 512-thread blocks per CU: two where the registers fit 128 (not-pooled launches up to 64 x 64 channels), else one
 constexpr int pwb_bpc(int cin, int cout, bool pooled) { return (!pooled && ((cin <= 64 && cout <= 64) || (cin == 128 && cout == 64))) ? 2 : 1; }
 
+__device__ __forceinline__ void unpack4u(const uint2& r, float (&v)[4]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4_opaque(bf16* p, const float (&v)[4]) {  // (see store8_opaque)
+    unsigned pk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[i]) : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pk[0], pk[1]);
+}
 __device__ __forceinline__ void unpack8u(const uint4& r, float (&v)[8]) {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
     v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
@@ -107,37 +117,52 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
     for (int j = 0; j < C::NTW; ++j) accw[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---- raw vectors of one tile
+    // PPOOL: the gradient arrives at half resolution and goes to the FIRST maximum of each 2x2 window.  An item is then a whole window x 4
+    // channels (8-byte vectors): its four z and its g are loaded ONCE and the window's winner is found once -- with (pixel, 8 channels) items
+    // every pixel re-loaded and re-compared its three neighbours (16 z loads and ~1000 VALU instructions per window and channel group
+    // instead of 4 and ~210: the commit phase was 40 % of a pooled tile's time at two waves per SIMD).
+    constexpr int CQO = COUT / 4, NWIN = TP / 4, NQI = PPOOL ? (NWIN * CQO + NT - 1) / NT : 1;
     struct Raw {
-        uint4 z[NZI], ga[NZI], gb[G2 ? NZI : 1], zo[PPOOL ? 3 * NZI : 1], xr[NXI];
+        uint4 z[PPOOL ? 1 : NZI], ga[PPOOL ? 1 : NZI], gb[(G2 && !PPOOL) ? NZI : 1];
+        uint2 zq[PPOOL ? 4 * NQI : 1], gq1[PPOOL ? NQI : 1], gq2[(PPOOL && G2) ? NQI : 1];
+        uint4 xr[NXI];
         unsigned okz, okg, okx;
     };
     auto issue = [&](Raw& r, const TileOrg& org) {
         r.okz = r.okg = r.okx = 0;
-        const int Hp = H >> 1, Wp = W >> 1;
+        if constexpr (PPOOL) {
+            const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
-        for (int j = 0; j < NZI; ++j) {
-            const int pxl = (tid + j * NT) / CGO, ty = pxl / TW, tx = pxl - ty * TW;
-            const int h = org.h0 + ty, w = org.w0 + tx;
-            const bool act = (TP * CGO % NT == 0 || tid + j * NT < TP * CGO) && h < H && w < W;
-            const long p = ((long)org.n * H + h) * W + w;
-            r.z[j] = *reinterpret_cast<const uint4*>(act ? z + p * COUT + cgo * 8 : z);
-            bool inw = act;
-            long pg = p;
-            if constexpr (PPOOL) {
-                inw = act && h < 2 * Hp && w < 2 * Wp;  // floor mode: the last odd row / column is in no window
-                pg = ((long)org.n * Hp + (h >> 1)) * Wp + (w >> 1);
-                const int own = ((h & 1) << 1) | (w & 1);
-                const long base = ((long)org.n * H + (h & ~1)) * W + (w & ~1);
+            for (int j = 0; j < NQI; ++j) {
+                const int it = tid + j * NT, wq = it / CQO, cq = it - wq * CQO, wy = wq / (TW / 2), wx = wq - wy * (TW / 2);
+                const int h = org.h0 + 2 * wy, w = org.w0 + 2 * wx;  // (tile origins are even: the tile holds whole windows)
+                const bool item = NWIN * CQO % NT == 0 || it < NWIN * CQO;
+                const bool inw = item && h + 1 < H && w + 1 < W;  // floor mode: a last odd row / column is in no window
+                const long p = ((long)org.n * H + h) * W + w;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int k = q < own ? q : q + 1;  // the three OTHER elements of the window, in window order
-                    r.zo[3 * j + q] = *reinterpret_cast<const uint4*>(inw ? z + (base + (long)(k >> 1) * W + (k & 1)) * COUT + cgo * 8 : z);
+                for (int e = 0; e < 4; ++e) {
+                    const bool act = item && h + (e >> 1) < H && w + (e & 1) < W;
+                    r.zq[4 * j + e] = *reinterpret_cast<const uint2*>(act ? z + (p + (long)(e >> 1) * W + (e & 1)) * COUT + cq * 4 : z);
+                    r.okz |= act ? 1u << (4 * j + e) : 0u;
                 }
+                const long pg = ((long)org.n * Hp + (h >> 1)) * Wp + (w >> 1);
+                r.gq1[j] = *reinterpret_cast<const uint2*>(inw ? g1 + pg * COUT + cq * 4 : g1);
+                if constexpr (G2) r.gq2[j] = *reinterpret_cast<const uint2*>(inw ? g2 + pg * COUT + cq * 4 : g2);
+                r.okg |= inw ? 1u << j : 0u;
             }
-            r.ga[j] = *reinterpret_cast<const uint4*>(inw ? g1 + pg * COUT + cgo * 8 : g1);
-            if constexpr (G2) r.gb[j] = *reinterpret_cast<const uint4*>(inw ? g2 + pg * COUT + cgo * 8 : g2);
-            r.okz |= act ? 1u << j : 0u;
-            r.okg |= inw ? 1u << j : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) {
+                const int pxl = (tid + j * NT) / CGO, ty = pxl / TW, tx = pxl - ty * TW;
+                const int h = org.h0 + ty, w = org.w0 + tx;
+                const bool act = (TP * CGO % NT == 0 || tid + j * NT < TP * CGO) && h < H && w < W;
+                const long p = ((long)org.n * H + h) * W + w;
+                r.z[j] = *reinterpret_cast<const uint4*>(act ? z + p * COUT + cgo * 8 : z);
+                r.ga[j] = *reinterpret_cast<const uint4*>(act ? g1 + p * COUT + cgo * 8 : g1);
+                if constexpr (G2) r.gb[j] = *reinterpret_cast<const uint4*>(act ? g2 + p * COUT + cgo * 8 : g2);
+                r.okz |= act ? 1u << j : 0u;
+                r.okg |= act ? 1u << j : 0u;
+            }
         }
         const int c0 = c_off + cgi * 8;
         const bool from_a = c0 < x.Ca;
@@ -155,53 +180,79 @@ __global__ __launch_bounds__(512, (pwb_bpc(CIN, COUT, PPOOL) * 2)) void k_pwb(Sr
     };
     auto commit = [&](const Raw& r, const TileOrg& org) {
         // dz = A * ghat + B * z + C, ghat = (g1 [+ g2]) where the block's ReLU (and, pooled, the window's first maximum) lets it through
-        float bs[8], bt[8], ca[8], cb[8], cc[8];
-        load8(s_bn + cgo * 8, bs);
-        load8(s_bn + COUT + cgo * 8, bt);
-        load8(s_cf + cgo * 8, ca);
-        load8(s_cf + COUT + cgo * 8, cb);
-        load8(s_cf + 2 * COUT + cgo * 8, cc);
+        if constexpr (PPOOL) {
 #pragma unroll
-        for (int j = 0; j < NZI; ++j) {
-            if (TP * CGO % NT != 0 && tid + j * NT >= TP * CGO) break;
-            const int pxl = (tid + j * NT) / CGO;
-            float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (r.okz & (1u << j)) {
-                float zv[8], g[8], y[8];
-                unpack8u(r.z[j], zv);
-                unpack8u(r.ga[j], g);
+            for (int j = 0; j < NQI; ++j) {
+                const int it = tid + j * NT;
+                if (NWIN * CQO % NT != 0 && it >= NWIN * CQO) break;
+                const int wq = it / CQO, cq = it - wq * CQO, wy = wq / (TW / 2), wx = wq - wy * (TW / 2);
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(s_bn + cq * 4), bt = *reinterpret_cast<const f32x4*>(s_bn + COUT + cq * 4);
+                const f32x4 ca = *reinterpret_cast<const f32x4*>(s_cf + cq * 4), cb = *reinterpret_cast<const f32x4*>(s_cf + COUT + cq * 4),
+                            cc = *reinterpret_cast<const f32x4*>(s_cf + 2 * COUT + cq * 4);
+                float g[4], zv[4][4], best[4];
+                int bk[4];
+                unpack4u(r.gq1[j], g);
                 if constexpr (G2) {
-                    float gq[8];
-                    unpack8u(r.gb[j], gq);
+                    float gq[4];
+                    unpack4u(r.gq2[j], gq);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) g[i] += gq[i];
+                    for (int i = 0; i < 4; ++i) g[i] += gq[i];
                 }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = fmaf(zv[i], bs[i], bt[i]);
-                bool win[8];
                 const bool inw = (r.okg >> j) & 1u;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) win[i] = inw && y[i] > 0.f;
-                if constexpr (PPOOL) {
-                    const int ty = pxl / TW, tx = pxl - ty * TW;
-                    const int own = (((org.h0 + ty) & 1) << 1) | ((org.w0 + tx) & 1);
+                for (int e = 0; e < 4; ++e) {
+                    unpack4u(r.zq[4 * j + e], zv[e]);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        float zo[8];
-                        unpack8u(r.zo[3 * j + q], zo);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float yo = fmaxf(fmaf(zo[i], bs[i], bt[i]), 0.f);
-                            const float ym = fmaxf(y[i], 0.f);
-                            win[i] = win[i] && (q < own ? ym > yo : ym >= yo);  // ties go to the first element of the window
+                    for (int i = 0; i < 4; ++i) {
+                        const float ym = fmaxf(fmaf(zv[e][i], bs[i], bt[i]), 0.f);  // the pool sees relu(bn(z)); a strictly larger later element wins
+                        if (e == 0 || ym > best[i]) {
+                            best[i] = ym;
+                            bk[i] = e;
                         }
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dz[i] = fmaf(ca[i], win[i] ? g[i] : 0.f, fmaf(cb[i], zv[i], cc[i]));
+                for (int e = 0; e < 4; ++e) {
+                    float dz[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (r.okz & (1u << (4 * j + e))) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool win = inw && bk[i] == e && best[i] > 0.f;
+                            dz[i] = fmaf(ca[i], win ? g[i] : 0.f, fmaf(cb[i], zv[e][i], cc[i]));
+                        }
+                    }
+                    store4_opaque(dzN + ((2 * wy + (e >> 1)) * TW + 2 * wx + (e & 1)) * PZC + cq * 4, dz);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            store8_opaque(dzN + pxl * PZC + cgo * 8, dz);
-            __builtin_amdgcn_sched_barrier(0);  // (one item's unpacked vectors at a time)
+        } else {
+            float bs[8], bt[8], ca[8], cb[8], cc[8];
+            load8(s_bn + cgo * 8, bs);
+            load8(s_bn + COUT + cgo * 8, bt);
+            load8(s_cf + cgo * 8, ca);
+            load8(s_cf + COUT + cgo * 8, cb);
+            load8(s_cf + 2 * COUT + cgo * 8, cc);
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) {
+                if (TP * CGO % NT != 0 && tid + j * NT >= TP * CGO) break;
+                const int pxl = (tid + j * NT) / CGO;
+                float dz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (r.okz & (1u << j)) {
+                    float zv[8], g[8];
+                    unpack8u(r.z[j], zv);
+                    unpack8u(r.ga[j], g);
+                    if constexpr (G2) {
+                        float gq[8];
+                        unpack8u(r.gb[j], gq);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) g[i] += gq[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dz[i] = fmaf(ca[i], fmaf(zv[i], bs[i], bt[i]) > 0.f ? g[i] : 0.f, fmaf(cb[i], zv[i], cc[i]));
+                }
+                store8_opaque(dzN + pxl * PZC + cgo * 8, dz);
+                __builtin_amdgcn_sched_barrier(0);  // (one item's unpacked vectors at a time)
+            }
         }
         float sc[8], sh[8], lo[8];
         load8(s_trx + cgi * 24, sc);
