@@ -45,7 +45,7 @@ struct PwbCfg {
 };
 
 // resident 512-thread blocks per CU: two where the registers fit 128 (not-pooled launches up to 64 x 64 channels), else one
-constexpr int pwb_bpc(int cin, int cout, bool pooled) { return (!pooled && ((cin <= 64 && cout <= 64) || (cin == 128 && cout == 64))) ? 2 : 1; }
+constexpr int pwb_bpc(int cin, int cout, bool pooled) { return ((cin <= 64 && cout <= 64) || (!pooled && cin == 128 && cout == 64)) ? 2 : 1; }
 
 __device__ __forceinline__ void unpack4u(const uint2& r, float (&v)[4]) {
     v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
