@@ -202,7 +202,8 @@ long ocrs_gru_seq_ws_floats(int N);
 int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float* out, float* saved, int T, int N, unsigned* sync, unsigned* err, float* xws,
                      int exact, hipStream_t st);
 int ocrs_gru_seq_bwd(const float* dout, const float* saved, const float* out, const float* whh, float* dgi, float* dgh, int T, int N, unsigned* sync,
-                     unsigned* err, float* xws, int exact, hipStream_t st);
+                     unsigned* err, float* xws, int exact, float* dbih, float* dbhh, hipStream_t st);
+/* dbih / dbhh (nullable) [2 * 768]: the bias gradients (column sums of dgi / dgh over time and batch) are ACCUMULATED there by the same launch. */
 int ocrs_gru_seq_status(const unsigned* err, hipStream_t st);
 /* nn.LogSoftmax(dim=2) (models.py:250). */
 int ocrs_log_softmax_fwd(const void* logits, float* out, long rows, int C, int ld, int dtype, hipStream_t st);

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
 template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
                                                         const float* __restrict__ whh, float* __restrict__ dgi, float* __restrict__ dgh, int T, int N,
-                                                        unsigned* sync, unsigned* err, float* xws, int ngroups, int try_fast) {
+                                                        unsigned* sync, unsigned* err, float* xws, int ngroups, int try_fast,
+                                                        float* __restrict__ dbih, float* __restrict__ dbhh) {
     __shared__ float red[4][2][16][17];
     __shared__ int s_ok, s_fast;
     int group, jt;
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
     // exchange slot of gate g: k = 256 g + j -> chunk 8 g + (jt >> 1)
     const int xkc = jt >> 1, xpos = (jt & 1) * 16 + jl, xlane = (bl & 15) + 16 * (xpos >> 3), xq = (xpos & 7) >> 1, xnt = bl >> 4;
     float e_dout = 0.f, e_r = 0.f, e_z = 0.f, e_n = 0.f, e_hn = 0.f, e_hp = 0.f, carry = 0.f;
+    float sb_r = 0.f, sb_z = 0.f, sb_n = 0.f, sb_nr = 0.f;  // this (unit, column)'s share of the bias gradients: the gate gradients summed over time
     auto load_ep = [&](int t) {
         if (bv) {
             e_dout = dout[((long)t * N + b) * 512 + d * SH + j];
@@ -462,6 +464,10 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
         float dr = dn_pre * e_hn * e_r * (1.f - e_r);
         float dnr = dn_pre * e_r;
         if (!bv) dn_pre = dz = dr = dnr = 0.f;
+        sb_r += dr;
+        sb_z += dz;
+        sb_n += dn_pre;
+        sb_nr += dnr;
         carry = dh * e_z;
         const float dr1 = __shfl_down(dr, 1), dz1 = __shfl_down(dz, 1), dnr1 = __shfl_down(dnr, 1);
         if (s + 1 < T) {
@@ -487,6 +493,34 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
             }
         }
         if (s + 1 < T) load_ep(d == 0 ? T - 2 - s : s + 1);
+    }
+    // bias gradients (nullable): db_ih = column sums of dgi, db_hh = column sums of dgh over (t, n) -- the two 159-MB re-reads of dgi / dgh by
+    // k_col_sum4 (0.17 ms per CRNN step) are not needed.  Lanes -> the wave's four batch columns (lanes 16 apart), waves through LDS in a fixed
+    // order, then one fp32 atomic per (group, unit, gate) -- 8 groups per direction at N = 256 (like k_col_sum4's per-block atomics).
+    if (dbih || dbhh) {
+        float v[4] = {sb_r, sb_z, sb_n, sb_nr};
+        __syncthreads();  // (red is free: every wave is past its last read)
+        float* rs = &red[0][0][0][0];  // [8 waves][4 sums][16 units]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] += __shfl_xor(v[q], 16, 64);
+            v[q] += __shfl_xor(v[q], 32, 64);
+            if (lane < 16) rs[(wave * 4 + q) * 16 + lane] = v[q];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int q = tid >> 4, u = tid & 15;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += rs[(w * 4 + q) * 16 + u];
+            const int col = d * S3 + jt * 16 + u;
+            if (q < 3) {
+                if (dbih) atomicAdd(&dbih[col + q * SH], a);
+                if (dbhh && q < 2) atomicAdd(&dbhh[col + q * SH], a);
+            } else if (dbhh) {
+                atomicAdd(&dbhh[col + 2 * SH], a);
+            }
+        }
     }
 }
 
@@ -550,14 +584,14 @@ int ocrs_gru_seq_fwd(const float* gi, const float* whh, const float* bhh, float*
 }
 
 int ocrs_gru_seq_bwd(const float* dout, const float* saved, const float* out, const float* whh, float* dgi, float* dgh, int T, int N, unsigned* sync,
-                     unsigned* err, float* xws, int exact, hipStream_t st) {
+                     unsigned* err, float* xws, int exact, float* dbih, float* dbhh, hipStream_t st) {
     OCRS_CHECK_ARG(dout && saved && out && whh && dgi && dgh && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
     if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
     if (exact)
-        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh);
     else
-        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast());
+        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -341,7 +341,7 @@ class _RecRun:
             if self.gru_seq:
                 sync, xws = self.seq_sync()
                 L.gru_seq_bwd(ptr(dout), ptr(gl["saved"]), ptr(gl["out"]), ptr(gl["w_hh"]), ptr(dgi), ptr(dgh), T, N, ptr(sync),
-                              ptr(_gru_err(self.dev)), ptr(xws), self.gru_exact)
+                              ptr(_gru_err(self.dev)), ptr(xws), self.gru_exact, ptr(G[f"gru.bias_ih_l{layer}"]), ptr(G[f"gru.bias_hh_l{layer}"]))
             else:
                 nfl = 24 * 16 * 64 * 8
                 whhT = torch.empty(2 * nfl, dtype=torch.float32, device=self.dev)
@@ -355,8 +355,9 @@ class _RecRun:
             for d in (0, 1):
                 self.wgrad(dgh.data_ptr() + 4 * d * 768, 1536, 768, gl["out"].data_ptr() + 4 * d * 256, 512, 256, G["gru.weight_hh" + sfx[d]], 1,
                            T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
-            L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
-            L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
+            if not self.gru_seq:  # (the persistent launch accumulates the bias gradients itself)
+                L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
+                L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
             if self.use_x3(1536, I):
                 dout = self.gemm_x3(dgi, 1536, 1536, gl["w_ih"], I, 1, None, I, I, rows)  # dx = dgi W_ih: W(m, k) = W_ih[k][m]
             else:

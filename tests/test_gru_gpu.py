@@ -86,9 +86,15 @@ def _hip_bwd(L, mode, dout, saved, out, whh, T, N, dev):
         sync = torch.empty(L.gru_seq_sync_words(N), dtype=torch.int32, device=dev)
         err = torch.zeros(1, dtype=torch.int32, device=dev)
         xws = torch.empty(L.gru_seq_ws_floats(N), device=dev)
-        L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync), ptr(err), ptr(xws), 1 if mode == "seq_exact" else 0)
+        # the persistent launch also accumulates the bias gradients (column sums of dgi / dgh) into caller-owned, pre-filled buffers
+        dbih, dbhh = torch.full((2 * G3,), 0.5, device=dev), torch.full((2 * G3,), -0.25, device=dev)
+        L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync), ptr(err), ptr(xws), 1 if mode == "seq_exact" else 0,
+                      ptr(dbih), ptr(dbhh))
         L.gru_seq_status(ptr(err))
         assert int(err.item()) == 0
+        si, sh = dgi.double().sum((0, 1)), dgh.double().sum((0, 1))
+        assert float(((dbih.double() - 0.5) - si).norm() / (si.norm() + 1e-30)) < 2e-5
+        assert float(((dbhh.double() + 0.25) - sh).norm() / (sh.norm() + 1e-30)) < 2e-5
     return dgi, dgh
 
 

@@ -18,6 +18,6 @@ for fast in ("0", "1"):
             e0.record()
             L.gru_seq_fwd(ptr(gi), ptr(whh), ptr(bhh), ptr(out), ptr(saved), T, N, ptr(sync), ptr(err), ptr(xws), exact)
             e1.record()
-            L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync2), ptr(err), ptr(xws), exact)
+            L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(sync2), ptr(err), ptr(xws), exact, None, None)
             e2.record(); torch.cuda.synchronize()
         print("fast env", fast, "exact", exact, "fwd us", round(e0.elapsed_time(e1) * 1e3, 1), "bwd us", round(e1.elapsed_time(e2) * 1e3, 1), "err", int(err.item()), "cycles/step [wait, load, mfma+red, epi, publish, tail]", sync.view(-1, 32)[0, 2:8].tolist())
