@@ -182,3 +182,47 @@ def test_ctc_front_end_argument_checks():
         loss(lp, torch.zeros(2, 4, dtype=torch.int32), [5, 5], [1, 1])  # CPU tensors: no CPU path
     with pytest.raises(NotImplementedError):
         oa.CTCLoss(blank=1)
+
+
+def test_gru_direction_pairs_are_rehomed_once_and_keep_the_state_dict():
+    """RecognitionModel._gru_flatten: the forward / reverse GRU parameters of a layer become adjacent halves of one buffer (the kernels take
+    both directions as one stacked view) without changing any state-dict key, shape or value; a second call is a no-op, parameters stay
+    leaf tensors, a checkpoint round trip and a deepcopy keep working, and parameters re-allocated by ``.to()`` are re-homed again."""
+    import copy
+    import io
+
+    import ocrs_models_amd as oa
+
+    torch.manual_seed(3)
+    m = oa.RecognitionModel("abc")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m._gru_flatten()
+    P = {n: p.detach() for n, p in m.named_parameters()}
+    for layer in (0, 1):
+        w_ih, w_hh, b_ih, b_hh = m._gru_stacked(layer, P)
+        sfx = [f"_l{layer}", f"_l{layer}_reverse"]
+        assert torch.equal(w_ih, torch.cat([before["gru.weight_ih" + s] for s in sfx], 0))
+        assert torch.equal(w_hh, torch.stack([before["gru.weight_hh" + s] for s in sfx], 0))
+        assert torch.equal(b_ih, torch.cat([before["gru.bias_ih" + s] for s in sfx], 0))
+        assert torch.equal(b_hh, torch.cat([before["gru.bias_hh" + s] for s in sfx], 0))
+        assert w_ih.data_ptr() == P["gru.weight_ih" + sfx[0]].data_ptr()  # views, not copies
+    after = m.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    ptrs = [p.data_ptr() for p in m.parameters()]
+    versions = [p._version for p in m.parameters()]
+    m._gru_flatten()
+    assert ptrs == [p.data_ptr() for p in m.parameters()] and versions == [p._version for p in m.parameters()]
+    assert all(p.is_leaf and p.requires_grad for p in m.parameters())
+    buf = io.BytesIO()
+    torch.save(m.state_dict(), buf)
+    buf.seek(0)
+    m2 = oa.RecognitionModel("abc")
+    m2.load_state_dict(torch.load(buf))
+    assert all(torch.equal(v, before[k]) for k, v in m2.state_dict().items())
+    m3 = copy.deepcopy(m)
+    m3._gru_flatten()
+    assert all(torch.equal(v, before[k]) for k, v in m3.state_dict().items())
+    m.double().float()  # re-allocates every parameter: not adjacent any more
+    m._gru_flatten()
+    m._gru_stacked(0, {n: p.detach() for n, p in m.named_parameters()})
+    assert all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
