@@ -1323,7 +1323,143 @@ int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo,
                 : launch_igemm<float, 8, 16>(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KH, KW, padh, padw, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The gathered weight gradient in the natural-layout + LDS-transpose-read form of k_wgrad_gemm_x3 (bf16, workspace flush):
+//   D[ra][jc] = sum_pos A~[pos][ra] * B[pos * stride + tap(jc) - pad][cb(jc)],   jc = tap * CB + cb.
+// k_wgrad_gather<bf16> builds TRANSPOSED [channel][position] tiles with two-byte scatter stores and holds 16 accumulator tiles + two tiles of
+// prefetch per thread (256 VGPRs + 127 AGPRs: one block owns a CU, ~50 TFLOP/s -- and on the detection step's side stream such a block keeps a CU
+// from the main stream's kernels for 100 us).  Here a chunk of 32 positions is staged as it lies in memory ([position][channel], 16-byte
+// vectors; gathered rows outside B are zero) and both MFMA operands come from ds_read_b64_tr_b16; block = 128 x 128 outputs over a contiguous
+// range of chunks, next chunk register-prefetched, partial -> the workspace layout of k_wgrad_gather_reduce.
+__global__ __launch_bounds__(256, 2) void k_wgrad_gather_tr(const bf16* __restrict__ A, int ldA, int CA, const float* __restrict__ trA, const bf16* __restrict__ B,
+                                                            int ldB, int CB, int N, int hA, int wA, int HB, int WB, int stride, int padh, int padw, int KW,
+                                                            int ntaps, float* __restrict__ ws, int tiles_a, int chunks_per_block) {
+    constexpr int BM = 128, KC = 32, PA = BM + 8;
+    __shared__ __attribute__((aligned(16))) bf16 At[KC * PA];
+    __shared__ __attribute__((aligned(16))) bf16 Bt[KC * PA];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ta = blockIdx.y % tiles_a, tj = blockIdx.y / tiles_a;
+    const int a0 = ta * BM, j0 = tj * BM;
+    const int J = ntaps * CB, CA8 = (CA + 7) & ~7;
+    const long P = (long)N * hA * wA;
+    const long nchunks = (P + KC - 1) / KC;
+    const long c_first = (long)blockIdx.x * chunks_per_block, c_end = c_first + chunks_per_block < nchunks ? c_first + chunks_per_block : nchunks;
+    // staging map: item f = tid + 256 j (j < 2): row f >> 4 of the chunk, columns (f & 15) * 8 .. + 7 of the block's 128
+    const int col8 = (tid & 15) * 8;
+    const bool cola = a0 + col8 < CA8, colb = j0 + col8 < J;
+    const int tapb = colb ? (j0 + col8) / CB : 0, cb0 = j0 + col8 - tapb * CB;
+    const int dyb = tapb / KW - padh, dxb = tapb % KW - padw;
+    float sc[8], sh[8], lo[8];
+    if (trA && cola) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = a0 + col8 + i < CA ? a0 + col8 + i : 0;
+            sc[i] = trA[c];
+            sh[i] = trA[CA + c];
+            lo[i] = trA[2 * CA + c];
+        }
+    }
+    uint4 ra[2], rb[2];
+    unsigned ok = 0;  // bits 0-1: A rows inside P, bits 2-3: B rows inside the gathered tensor
+    auto issue = [&](long c) {
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long p = c * KC + (tid >> 4) + 16 * j;
+            const bool inp = p < P;
+            const PixIdx q = decode_pixel(inp ? p : 0, hA, wA);
+            const bool oka = inp && cola;
+            ra[j] = *reinterpret_cast<const uint4*>(oka ? A + p * ldA + a0 + col8 : A);
+            const int Y = q.h * stride + dyb, X = q.w * stride + dxb;
+            const bool okb = inp && colb && (unsigned)Y < (unsigned)HB && (unsigned)X < (unsigned)WB;
+            rb[j] = *reinterpret_cast<const uint4*>(okb ? B + (((long)q.n * HB + Y) * WB + X) * ldB + cb0 : B);
+            ok |= (oka ? 1u : 0u) << j | (okb ? 4u : 0u) << j;
+        }
+    };
+    const int wm = wave & 1, wn = wave >> 1;  // 2 x 2 waves, each 4 x 4 MFMA tiles of 16 x 16
+    const int prow = 4 * (lane >> 4) + ((lane & 15) >> 2), pcol = (lane & 3) * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c_first < c_end) issue(c_first);
+    for (long c = c_first; c < c_end; ++c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = ((tid >> 4) + 16 * j) * PA + col8;
+            uint4 va = make_uint4(0, 0, 0, 0);
+            if (ok & (1u << j)) {
+                va = ra[j];
+                if (trA) {
+                    float v[8];
+                    unpack8(Raw8<bf16>{va}, v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), lo[i]);
+                    va = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                }
+            }
+            *reinterpret_cast<uint4*>(At + off) = va;
+            *reinterpret_cast<uint4*>(Bt + off) = (ok & (4u << j)) ? rb[j] : make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < c_end) issue(c + 1);
+        lds_barrier();
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = prow * PA + (wm * 4 + i) * 16 + pcol;
+            af[i] = lds_tr8(At + o, At + o + 16 * PA);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = prow * PA + (wn * 4 + j) * 16 + pcol;
+            const bf16x8 bfr = lds_tr8(Bt + o, Bt + o + 16 * PA);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+        }
+        lds_barrier();
+    }
+    // partial -> ws[blockIdx.x][jc][ra] (CA8-padded rows), 4 consecutive ra per lane
+    float* wb = ws + (long)blockIdx.x * J * CA8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r0 = a0 + (wm * 4 + i) * 16 + (lane >> 4) * 4, jc = j0 + (wn * 4 + j) * 16 + (lane & 15);
+            if (r0 < CA8 && jc < J) {
+                const f32x4 v = acc[i][j];
+                *reinterpret_cast<float4*>(wb + (long)jc * CA8 + r0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+
+// bf16 with a workspace: k_wgrad_gather_tr (OCRS_WGRAD_GATHER_TR=0: the transposed-tile kernel everywhere)
+static bool wgrad_gather_tr_on(int dtype) {
+    static const int on = env_int("OCRS_WGRAD_GATHER_TR", 1);
+    return on && dtype == 1;
+}
+static void wgrad_gather_tr_grid(int CA, int CB, int ntaps, long P, int& gx, int& gy, int& tiles_a, int& cpb) {
+    tiles_a = (((CA + 7) & ~7) + 127) / 128;
+    gy = tiles_a * ((ntaps * CB + 127) / 128);
+    const long nchunks = (P + 31) / 32;
+    static const int target = env_int("OCRS_WGRAD_TR_BLOCKS", 1024);  // K splits: >= 8 chunks per block, ~4 blocks per CU in total
+    long g = target / gy;
+    if (g > nchunks / 8) g = nchunks / 8;
+    // every K split writes (and the reducer re-reads) a full ntaps * CB * CA8 partial: keep the workspace around 16 MB
+    const long part_bytes = (long)ntaps * CB * ((CA + 7) & ~7) * 4, by_ws = (16L << 20) / part_bytes;
+    if (g > by_ws) g = by_ws < 8 ? 8 : by_ws;
+    if (g < 1) g = 1;
+    cpb = (int)((nchunks + g - 1) / g);
+    gx = (int)((nchunks + cpb - 1) / cpb);
+}
 static void wgrad_gather_grid(int CA, int CB, int ntaps, long P, int dtype, long& gx, int& gy) {
+    if (wgrad_gather_tr_on(dtype)) {
+        int g, ta, cpb;
+        wgrad_gather_tr_grid(CA, CB, ntaps, P, g, gy, ta, cpb);
+        gx = g;
+        return;
+    }
     const int TP = dtype == 1 ? 128 : 64;
     const long ntiles = (P + TP - 1) / TP;
     const int CA8 = (CA + 7) & ~7;
@@ -1365,7 +1501,12 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
             return OCRS_ERR_HIP;
         attr_set = true;
     }
-    if (dtype == 1)
+    if (dtype == 1 && ws && wgrad_gather_tr_on(dtype)) {
+        int g, gy2, ta, cpb;
+        wgrad_gather_tr_grid(CA, CB, KH * KW, P, g, gy2, ta, cpb);
+        hipLaunchKernelGGL(k_wgrad_gather_tr, dim3(g, gy2), dim3(256), 0, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B, ldB, CB, N, hA, wA, HB, WB, stride,
+                           padh, padw, KW, KH * KW, ws, ta, cpb);
+    } else if (dtype == 1)
         hipLaunchKernelGGL((k_wgrad_gather<bf16, 128>), dim3((int)gx, gy), dim3(256), 2 * 128 * 136 * 2, st, (const bf16*)A, ldA, CA, trA, (const bf16*)B,
                            ldB, CB, dW, N, hA, wA, HB, WB, stride, padh, padw, KH, KW, ws);
     else
