@@ -345,12 +345,19 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         for (int i = tid; i < C::NW * 2 * MT * 16; i += NT) s_st[i] = 0.f;  // (ordered before its first use by the tile loop's barriers)
     }
 
+#ifdef OCRS_MM_PROF  // (debug build: per-phase cycle totals of block 0 / thread 0 land in the first bytes of gxa)
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
+#define MM_MARK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); pt[i] += now_ - pc; pc = now_; }
+#else
+#define MM_MARK(i)
+#endif
     TileSched ts(tg.ntiles);
     TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);
     TileOrg org_next = tit.org();
     if (ts.first < ts.end) issue(org_next);
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const TileOrg org = org_next;
+        MM_MARK(4)
         // ================= phase 1: commit the prefetched tile: dz -> tileD, x~ -> tileX =================
         // Four channels at a time (the five per-channel coefficient vectors of a half are 20 registers instead of 40; 8-byte LDS stores).
         if constexpr (!PPOOL) {
@@ -452,12 +459,14 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        MM_MARK(0)
         if (t + ts.step < ts.end) {
             tit.next();
             org_next = tit.org();
             issue(org_next);
         }
         lds_barrier();
+        MM_MARK(1)
         // ================= phase 2a: dx~ = Weff * dz (shifted), MFMA; epilogue: store + the producers' BatchNorm-backward sums =================
         // One M tile (16 input channels) at a time: the second pass re-reads the B fragments from LDS instead of holding 2x the accumulators.
         {
@@ -578,6 +587,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 }
             }
         }
+        MM_MARK(2)
         // ================= phase 2b: G_tap += x~^T dz(shifted), K = the tile's pixels, operands by LDS transpose reads =================
         // Straight-line code: the wave's own unit has a compile-time number of k-steps starting at a scalar first step, so every read address
         // is (per-tile base register + immediate) and hipcc can issue the transpose reads of the following steps under the current MFMAs.  (As a
@@ -640,8 +650,16 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 accS = mfma16(lds_tr8(xa, xa + 16 * PX), lds_tr8(da, da + 16 * PD), accS);
             }
         }
+        MM_MARK(3)
         lds_barrier();  // all readers of the tiles are done before the next commit
     }
+#ifdef OCRS_MM_PROF
+    if (blockIdx.x == 0 && tid == 0 && gxa) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(gxa);
+        for (int i = 0; i < 5; ++i) o[i] = pt[i];
+        o[5] = (ts.end - ts.first + ts.step - 1) / ts.step;
+    }
+#endif
 
     // ================= flush: G slots -> dWpw / dWdw partials of this block (workspace); stats partials =================
     __syncthreads();
