@@ -179,7 +179,7 @@ int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, i
 int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,
                        int dtype, hipStream_t st);
 int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* coef, void* dz, int C, int N, int H, int W, int PH, int PW, int dtype,
-                  hipStream_t st);
+                  float* dsum /* nullable [C]: += column sums of dz (the bias gradient of a biased conv, models.py:201, 218) */, hipStream_t st);
 /* BatchNorm2d + AvgPool2d((4,1)) + permute/reshape to (W, N, C*H) (models.py:241-242, 259-262). */
 int ocrs_avgpool_fwd(const void* z, const float* tr, float* seq, int C, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_avgpool_bn_reduce(const float* gseq, const void* z, const float* saved, double* gsum, int C, int N, int H, int W, int dtype, hipStream_t st);

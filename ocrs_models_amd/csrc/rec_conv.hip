@@ -954,7 +954,8 @@ __global__ __launch_bounds__(256) void k_rec_bn_reduce_t(const T* __restrict__ g
 
 template <class T, int PH, int PW>
 __global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
-                                                    const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W) {
+                                                    const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W,
+                                                    float* __restrict__ dsum /*nullable [C]: += column sums of the stored dz (a bias gradient)*/) {
     const int CG = C / 8, Hp = H / PH, Wp = W / PW;
     const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
     const int c0 = (int)(gtid % CG) * 8;  // (fixed per thread, see k_act_pool_fwd_t)
@@ -967,6 +968,7 @@ __global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, con
         cb[i] = coef[C + c0 + i];
         cc[i] = coef[2 * C + c0 + i];
     }
+    float ds[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const long Pp = (long)N * Hp * Wp;
     for (long pp = gtid / CG; pp < Pp; pp += nthr / CG) {
         const PixIdx q = decode_pixel(pp, Hp, Wp);
@@ -997,8 +999,20 @@ __global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, con
             for (int i = 0; i < 8; ++i) {
                 const float gh = (bk[i] == k && best[i] > 0.f) ? gv[i] : 0.f;
                 o[i] = fmaf(ca[i], gh, fmaf(cb[i], zs[k][i], cc[i]));
+                if (dsum) ds[i] += Elem<T>::round(o[i]);
             }
             store8(dz + zoff + ((long)(k / PW) * W + k % PW) * C, o);
+        }
+    }
+    if (dsum) {  // (kernel-uniform) fixed-order block sums, then one fp32 atomic per block and channel, like k_col_sum4's
+        __shared__ float s_all[256][9];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_all[threadIdx.x][i] = ds[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f;
+            for (int t = c >> 3; t < 256; t += CG) a += s_all[t][c & 7];
+            atomicAdd(&dsum[c], a);
         }
     }
 }
@@ -1820,17 +1834,20 @@ int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const floa
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
+int ocrs_col_sum(const void* a, int ld, int C, float* out, long rows, int dtype, hipStream_t st);
 int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* coef, void* dz, int C, int N, int H, int W, int PH, int PW, int dtype,
-                  hipStream_t st) {
+                  float* dsum, hipStream_t st) {
     OCRS_CHECK_ARG(g && z && bn && coef && dz && C % 8 == 0 && PH * PW <= 4);
-    const int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
+    int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
+    const bool fast = window_fast() && H % PH == 0 && W % PW == 0 && 256 % (C / 8) == 0;
+    if (dsum && fast && grid > 4 * kNumCU) grid = 4 * kNumCU;  // (every block ends in C same-address atomics)
 #define DZA(T_, PH_, PW_)                                                                                                                    \
     if (PH == PH_ && PW == PW_) {                                                                                                            \
-        hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W); \
+        hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, dsum); \
         OCRS_LAUNCH_CHECK();                                                                                                                 \
         return OCRS_OK;                                                                                                                      \
     }
-    if (window_fast() && H % PH == 0 && W % PW == 0 && 256 % (C / 8) == 0) {
+    if (fast) {
         if (dtype == 1) { DZA(bf16, 2, 2) DZA(bf16, 2, 1) DZA(bf16, 1, 1) } else { DZA(float, 2, 2) DZA(float, 2, 1) DZA(float, 1, 1) }
     }
 #undef DZA
@@ -1839,6 +1856,7 @@ int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* co
     else
         hipLaunchKernelGGL(k_dz_apply<float>, dim3(grid), dim3(256), 0, st, (const float*)g, (const float*)z, bn, coef, (float*)dz, C, N, H, W, PH, PW);
     OCRS_LAUNCH_CHECK();
+    if (dsum) return ocrs_col_sum(dz, C, C, dsum, (long)N * H * W, dtype, st);  // (generic window shapes: a separate pass over dz)
     return OCRS_OK;
 }
 

@@ -285,12 +285,13 @@ class _RecRun:
         L.bn_bwd_finalize(ptr(gsum), self.N * H * W, C, ptr(self.P[f"{prefix}.weight"]), ptr(saved), ptr(coef), ptr(self.G[f"{prefix}.weight"]),
                           ptr(self.G[f"{prefix}.bias"]))
         dz = self.empty(self.N, H, W, C)
-        L.dz_apply(ptr(g), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, self.N, H, W, PH, PW, self.dt)
+        L.dz_apply(ptr(g), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, self.N, H, W, PH, PW, self.dt, None)
         return dz
 
-    def relu_bwd(self, g, a, C, H, W):
+    def relu_bwd(self, g, a, C, H, W, dbias):
+        """gradient through a ReLU (dz = g where a > 0) and, in the same pass, the conv's bias gradient (column sums of dz)"""
         dz = self.empty(self.N, H, W, C)
-        self.L.dz_apply(ptr(g), ptr(a), ptr(_identity_tr(C, self.dev)), ptr(_unit_coef(C, self.dev)), ptr(dz), C, self.N, H, W, 1, 1, self.dt)
+        self.L.dz_apply(ptr(g), ptr(a), ptr(_identity_tr(C, self.dev)), ptr(_unit_coef(C, self.dev)), ptr(dz), C, self.N, H, W, 1, 1, self.dt, ptr(dbias))
         return dz
 
     def backward(self, g_lp):
@@ -376,15 +377,13 @@ class _RecRun:
         dz15 = self.bn_pool_bwd("conv.16", g15, S.z15, S.tr15, S.sv15, 128, 8, W2, 2, 1)
         g13 = self.conv_bwd("conv.15.weight", dz15, S.a13, 8, W2, 8, W2, 1)
         stage_done("conv.15.")
-        dz13 = self.relu_bwd(g13, S.a13, 128, 8, W2)
-        L.col_sum(ptr(dz13), 128, 128, ptr(G["conv.13.bias"]), N * 8 * W2, self.dt)
+        dz13 = self.relu_bwd(g13, S.a13, 128, 8, W2, G["conv.13.bias"])
         g9 = self.conv_bwd("conv.13.weight", dz13, S.a9, 8, W2, 8, W2, 1)
         stage_done("conv.13.")
         dz9 = self.bn_pool_bwd("conv.10", g9, S.z9, S.tr9, S.sv9, 128, 16, W2, 2, 1)
         g7 = self.conv_bwd("conv.9.weight", dz9, S.a7, 16, W2, 16, W2, 1)
         stage_done("conv.9.")
-        dz7 = self.relu_bwd(g7, S.a7, 128, 16, W2)
-        L.col_sum(ptr(dz7), 128, 128, ptr(G["conv.7.bias"]), N * 16 * W2, self.dt)
+        dz7 = self.relu_bwd(g7, S.a7, 128, 16, W2, G["conv.7.bias"])
         g3 = self.conv_bwd("conv.7.weight", dz7, S.a3, 16, W2, 16, W2, 1)
         stage_done("conv.7.")
         dz3 = self.bn_pool_bwd("conv.4", g3, S.z3, S.tr3, S.sv3, 64, 32, W // 2, 2, 2)

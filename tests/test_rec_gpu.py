@@ -321,9 +321,11 @@ def test_bn_relu_pool_forward_and_backward_pieces(dev, dtype, N, H, W, C, PH, PW
     assert rel(gsum[:C], s1) < 1e-5 and rel(gsum[C:], s2) < 1e-5
     coef = torch.randn(3, C, generator=g).to(dev)
     dz = torch.empty_like(z)
-    L.dz_apply(ptr(gy), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, N, H, W, PH, PW, dt)
+    dsum = torch.full((C,), 0.25, device=dev)
+    L.dz_apply(ptr(gy), ptr(z), ptr(tr), ptr(coef), ptr(dz), C, N, H, W, PH, PW, dt, ptr(dsum))
     want = coef[0].view(1, C, 1, 1) * ghat + coef[1].view(1, C, 1, 1) * nchw(z) + coef[2].view(1, C, 1, 1)
     assert rel(nchw(dz), want) < TOL[dtype]
+    assert rel(dsum - 0.25, nchw(dz).sum((0, 2, 3))) < 1e-5  # the column sums of the STORED dz, accumulated into the caller's buffer
 
 
 def test_recognition_eval_mode(dev):
