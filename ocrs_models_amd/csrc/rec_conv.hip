@@ -952,12 +952,14 @@ __global__ __launch_bounds__(256) void k_rec_bn_reduce_t(const T* __restrict__ g
     group_sums_to_gsum(s1, s2, C, gsum);
 }
 
-template <class T, int PH, int PW>
-__global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
+// NTB threads per block: 256, or 1024 when the column sums are asked for (a quarter of the trailing same-address atomics at the same occupancy:
+// with 256-thread blocks the atomic tail made the fused pass slower than dz_apply + a separate column-sum kernel)
+template <class T, int PH, int PW, int NTB>
+__global__ __launch_bounds__(NTB) void k_dz_apply_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
                                                     const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W,
                                                     float* __restrict__ dsum /*nullable [C]: += column sums of the stored dz (a bias gradient)*/) {
     const int CG = C / 8, Hp = H / PH, Wp = W / PW;
-    const long gtid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    const long gtid = (long)blockIdx.x * NTB + threadIdx.x, nthr = (long)gridDim.x * NTB;
     const int c0 = (int)(gtid % CG) * 8;  // (fixed per thread, see k_act_pool_fwd_t)
     float sc[8], sh[8], ca[8], cb[8], cc[8];
 #pragma unroll
@@ -1005,13 +1007,13 @@ __global__ __launch_bounds__(256) void k_dz_apply_t(const T* __restrict__ g, con
         }
     }
     if (dsum) {  // (kernel-uniform) fixed-order block sums, then one fp32 atomic per block and channel, like k_col_sum4's
-        __shared__ float s_all[256][9];
+        __shared__ float s_all[NTB][9];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s_all[threadIdx.x][i] = ds[i];
         __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
+        for (int c = threadIdx.x; c < C; c += NTB) {
             float a = 0.f;
-            for (int t = c >> 3; t < 256; t += CG) a += s_all[t][c & 7];
+            for (int t = c >> 3; t < NTB; t += CG) a += s_all[t][c & 7];
             atomicAdd(&dsum[c], a);
         }
     }
@@ -1840,10 +1842,19 @@ int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* co
     OCRS_CHECK_ARG(g && z && bn && coef && dz && C % 8 == 0 && PH * PW <= 4);
     int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
     const bool fast = window_fast() && H % PH == 0 && W % PW == 0 && 256 % (C / 8) == 0;
-    if (dsum && fast && grid > 4 * kNumCU) grid = 4 * kNumCU;  // (every block ends in C same-address atomics)
+    static const int ds_bpc = env_int("OCRS_DZ_DSUM_BPC", 1);
+    if (dsum && fast) {  // 1024-thread blocks, every one ending in C same-address atomics
+        grid = (grid + 3) / 4;
+        if (grid > ds_bpc * kNumCU) grid = ds_bpc * kNumCU;
+    }
 #define DZA(T_, PH_, PW_)                                                                                                                    \
     if (PH == PH_ && PW == PW_) {                                                                                                            \
-        hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, dsum); \
+        if (dsum)                                                                                                                            \
+            hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_, 1024>), dim3(grid), dim3(1024), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, \
+                               dsum);                                                                                                        \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_, 256>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, \
+                               dsum);                                                                                                        \
         OCRS_LAUNCH_CHECK();                                                                                                                 \
         return OCRS_OK;                                                                                                                      \
     }
