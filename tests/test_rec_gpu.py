@@ -328,6 +328,31 @@ def test_bn_relu_pool_forward_and_backward_pieces(dev, dtype, N, H, W, C, PH, PW
     assert rel(dsum - 0.25, nchw(dz).sum((0, 2, 3))) < 1e-5  # the column sums of the STORED dz, accumulated into the caller's buffer
 
 
+@pytest.mark.parametrize("N,CA,CB,H,W,K,pad", [(3, 40, 24, 7, 9, 3, 1), (2, 128, 128, 4, 19, 2, 1), (5, 136, 64, 5, 6, 1, 0), (1, 8, 8, 3, 3, 3, 1)])
+def test_gathered_weight_gradient_matches_conv2d_autograd(dev, N, CA, CB, H, W, K, pad):
+    """ocrs_wgrad_gather (bf16, workspace flush: k_wgrad_gather_tr + the column-sum reducer) as the weight gradient of a stride-1 Conv2d, against
+    torch autograd in float64 on the same bf16-rounded operands: ragged channel counts (CA = 40 / 136: partial 128-row tiles), a number of
+    positions that is not a multiple of the 32-row chunk, 1 / 4 / 9 taps, accumulation into a non-zero dW."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    g = torch.Generator().manual_seed(N * 100 + CA + K)
+    Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+    x = torch.randn(N, CB, H, W, generator=g).bfloat16()          # conv input  -> operand B
+    dz = torch.randn(N, CA, Ho, Wo, generator=g).bfloat16()       # output grad -> operand A
+    xr = x.double().requires_grad_(False)
+    wr = torch.zeros(CA, CB, K, K, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, padding=pad).backward(dz.double())
+    dW0 = torch.randn(CA, CB, K, K, generator=g)
+    dW = dW0.clone().to(dev)
+    A, B = nhwc(dz.float(), torch.bfloat16).to(dev), nhwc(x.float(), torch.bfloat16).to(dev)
+    ws = torch.empty(L.wgrad_gather_ws_floats(CA, CB, K * K, N * Ho * Wo, 1), dtype=torch.float32, device=dev)
+    L.wgrad_gather(ptr(A), CA, CA, None, ptr(B), CB, CB, ptr(dW), ptr(ws), N, Ho, Wo, H, W, 1, pad, pad, K, K, 1)
+    torch.cuda.synchronize()
+    want = dW0.double() + wr.grad
+    assert rel(dW, want) < 2e-5, rel(dW, want)
+
+
 def test_recognition_eval_mode(dev):
     import ocrs_models_amd as oa
     from oracle import recognition as orec
