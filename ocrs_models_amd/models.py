@@ -95,6 +95,8 @@ def _identity_tr(C, device):
 class _DetRun:
     """One forward (and later backward) pass of the detection network on the current stream."""
 
+    capture = None  # (test tap, see __init__)
+
     def __init__(self, mod, x, names, params, train):
         self.L = lib()
         self.mod = mod
@@ -119,6 +121,11 @@ class _DetRun:
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
         self.pooled_by_block = None
         self.x = x
+        # test tap (tests/test_det_bf16_layerwise_gpu.py): when the module carries a dict ``_capture`` every backward stage records the gradient
+        # tensors it consumed / produced there, and the run itself (saved activations) is kept alive in it; None in production
+        self.capture = getattr(mod, "_capture", None)
+        if self.capture is not None:
+            self.capture["run"] = self
 
     # -- helpers ---------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):
@@ -296,6 +303,12 @@ class _DetRun:
     # -- backward --------------------------------------------------------------------------------
     def block_bwd(self, prefix, g1, g2, pooled, need_gx=True):
         """-> (gxa, gxb): dL/d(block input), split at the concat boundary."""
+        gxa, gxb = self._block_bwd(prefix, g1, g2, pooled, need_gx)
+        if self.capture is not None:
+            self.capture[prefix] = {"g1": g1, "g2": g2, "pooled": pooled, "gxa": gxa, "gxb": gxb}
+        return gxa, gxb
+
+    def _block_bwd(self, prefix, g1, g2, pooled, need_gx=True):
         L, P, N, r = self.L, self.P, self.N, self.recs[prefix]
         C, H, W = r.Cout, r.H, r.W
         gsum = self.fused.pop(prefix, None)  # BatchNorm-backward sums already produced by this block's consumers (their dw_bwd)?
@@ -417,6 +430,8 @@ class _DetRun:
                    N * H * W, self.dt)
         self.G["out_conv.0.weight"].view(-1).add_(acc[:8])
         self.G["out_conv.0.bias"].view(-1).add_(acc[8:9])
+        if self.capture is not None:
+            self.capture["out_conv"] = {"gpred": gpred, "g": g}
         stage_done("out_conv")
         skip_g = [[] for _ in range(7)]
         for i in range(6):
@@ -452,6 +467,8 @@ class _DetRun:
                 L.convt_bwd(*args, self.dt)
                 self.G[f"up.{i}.up.bias"].add_(db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
                 stage_done(f"up.{i}")
+            if self.capture is not None:
+                self.capture[f"up.{i}.up"] = {"g": gxa, "dx": dx}
             g = dx
         skip_g[6].append(g)
         for i in reversed(range(6)):
@@ -469,6 +486,8 @@ class _DetRun:
         stage_done("in_conv")
         if bucketer is not None:
             bucketer.finish(flat)
+        if self.capture is not None:
+            self.capture["grads"] = dict(self.G)
         return [self.G[k] for k in self.names]
 
 

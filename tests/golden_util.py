@@ -15,6 +15,8 @@ DET_CASES = {
     "det1": {"seed": 11, "B": 2, "H": 64, "W": 64},
     "det2": {"seed": 12, "B": 1, "H": 100, "W": 136},
 }
+# G-det-512: BASELINE.json configs[0]: the reference's seed-1234 default init, data Generator(seed=0)
+CONFIG1 = {"model_seed": 1234, "data_seed": 0, "B": 2, "H": 512, "W": 512}
 REC_CASE = {"seed": 21, "widths": [37, 118, 200, 256], "text_lens": [3, 10, 20, 30]}
 
 FULL_MAX = 4096
@@ -26,6 +28,38 @@ def det_inputs(case):
     x = r.uniform(-0.5, 0.5, (case["B"], 1, case["H"], case["W"])).astype(np.float32)
     m = (r.uniform(0, 1, (case["B"], 1, case["H"], case["W"])) > 0.9).astype(np.float32)
     return torch.from_numpy(x), torch.from_numpy(m)
+
+
+def config1_inputs():
+    g = torch.Generator().manual_seed(CONFIG1["data_seed"])
+    shape = (CONFIG1["B"], 1, CONFIG1["H"], CONFIG1["W"])
+    x = torch.rand(shape, generator=g) - 0.5
+    m = (torch.rand(shape, generator=g) > 0.9).float()
+    return x, m
+
+
+def config1_state(dtype=torch.float32):
+    """(params, buffers) of the reference's seed-1234 default initialisation (train_detection.py:337-338), regenerated from the seed through
+    the parameter-container module tree of ocrs_models_amd.DetectionModel (same construction order -> same RNG stream as the reference;
+    tools/gen_goldens.py stores the sha256 of the reference's own initial state in meta.json and this function checks it)."""
+    import hashlib
+    from collections import OrderedDict
+
+    import ocrs_models_amd as oa
+
+    torch.manual_seed(CONFIG1["model_seed"])
+    sd = oa.DetectionModel().state_dict()
+    flat = torch.cat([v.reshape(-1).float() for v in sd.values() if v.dtype.is_floating_point])
+    meta = load_meta()
+    assert hashlib.sha256(flat.numpy().tobytes()).hexdigest() == meta["det512/init_sha256"], "seed-1234 initial state differs from the reference's"
+    names = {n for n, _ in oa.DetectionModel().named_parameters()}
+    P, Bf = OrderedDict(), OrderedDict()
+    for k, v in sd.items():
+        if k in names:
+            P[k] = v.to(dtype).requires_grad_(True)
+        else:
+            Bf[k] = v.clone() if k.endswith("num_batches_tracked") else v.to(dtype)
+    return P, Bf
 
 
 def rec_samples(case):

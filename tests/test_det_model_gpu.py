@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_util import DET_CASES, compare_to_golden, det_inputs, golden_keys, golden_vs_golden, load_npz
+from tests.golden_util import (DET_CASES, compare_to_golden, config1_inputs, config1_state, det_inputs, golden_keys, golden_vs_golden,
+                               load_npz)
 
 pytestmark = pytest.mark.gpu
 
@@ -64,6 +65,46 @@ def test_detection_fp32_matches_golden(dev, case):
                 tol = 0 if k.endswith("num_batches_tracked") else (1e-2 if step == 0 else 2e-2)
                 e = compare_to_golden(G, f"{case}/f32/state{step + 1}/{k}", sd[k], 0, atol=1e-6)
                 assert e <= tol, (step, k, e)
+
+
+def test_detection_config1_b2_512_step_matches_golden(dev):
+    """BASELINE.json configs[0] / SURVEY.md 8(d) config 1 on the HIP path: B=2 x 1 x 512 x 512, the reference's seed-1234 default
+    initialisation, one train() step (train_detection.py:87-98: forward, balanced BCE, zero_grad, backward, Adam.step) in fp32 parity
+    mode against the reference's own outputs (tests/golden/det512.npz)."""
+    import ocrs_models_amd as oa
+
+    G = load_npz("det512.npz")
+    P, Bf = config1_state()
+    m = oa.DetectionModel()
+    m.load_state_dict({**{k: v.detach() for k, v in P.items()}, **Bf})
+    m = m.to(dev)
+    m.train()
+    x, mask = config1_inputs()
+    opt = oa.optim.Adam(m.parameters())
+    pred = m(x.to(dev))
+    loss = oa.balanced_cross_entropy_loss(pred, mask.to(dev))
+    opt.zero_grad()
+    loss.backward()
+    assert compare_to_golden(G, "det512/f32/pred", pred, 0) < 1e-4
+    assert compare_to_golden(G, "det512/f64/pred", pred, 0) < 1e-4
+    assert abs(loss.item() - float(G["det512/f32/loss"])) < 1e-4 * abs(loss.item())
+    bad, worst = {}, 0.0
+    for k, p in m.named_parameters():
+        e = compare_to_golden(G, f"det512/f64/grad/{k}", p.grad, 0, atol=1e-7)
+        ref = golden_vs_golden(G, f"det512/f32/grad/{k}", f"det512/f64/grad/{k}")
+        worst = max(worst, e)
+        if e > 2 * ref + 3e-3:  # SURVEY.md A.4 policy: no worse than 2x the reference's own fp32-vs-fp64 error (+ floor)
+            bad[k] = (e, ref)
+    assert not bad, bad
+    opt.step()
+    sd = m.state_dict()
+    for k in golden_keys(G, "det512/f32/state1"):
+        # Adam's first step moves every element by lr * g / (|g| + eps) ~ lr * sign(g).  The default initialisation has all biases at 0, so
+        # after the step a bias tensor IS that update: an element whose gradient is ~eps (1e-8) lands anywhere in [-lr, lr] -- a loose sanity
+        # bound there (one such element of 8 = 0.35), 1e-2 for the weights; the tight checks are the gradients above
+        tol = 0 if k.endswith("num_batches_tracked") else (0.4 if k.endswith(".bias") else 1e-2)
+        assert compare_to_golden(G, f"det512/f32/state1/{k}", sd[k], 0, atol=1e-6) <= tol, k
+    print(f"config 1: worst gradient relative error vs fp64 golden {worst:.2e}")
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 72, 65), (3, 127, 64)])
@@ -140,7 +181,26 @@ def test_detection_bf16_mode(dev):
     print(f"bf16: pred {e_pred:.3e} (floor {floor_pred:.3e}); grad median {np.median(errs):.3e} (floor {floor_grad:.3e})")
     assert e_pred < 1.5 * floor_pred + 1e-3, (e_pred, floor_pred)
     assert abs(loss.item() - loss_o.item()) < 2e-2 * abs(loss_o.item())
-    assert float(np.median(errs)) < 1.5 * floor_grad + 1e-2, (float(np.median(errs)), floor_grad)
+    # Gradients: the per-tensor comparison of this mode is tests/test_det_bf16_layerwise_gpu.py (all 118 tensors <= 2e-2 against the
+    # rounding-matched oracle, stage by stage).  End to end the distance to ANY other evaluation is dominated by rounding chaos (see there);
+    # what must hold -- and what a zero / sign-flipped / mis-scaled gradient fails -- is that HIP bf16 is no further from the fp32 gradient
+    # than the rounding-matched oracle itself (the same network with the same bf16 roundings in float64), and that the two agree in
+    # direction over the whole flat gradient.
+    from oracle import detection_bf16 as obf
+
+    P3, _ = make_state(detection_specs(), seed)
+    _, loss_m, grads_m = obf.forward_backward(P3, x, mask)
+    names = [k for k, _ in m.named_parameters()]
+    errs_m = [float((grads_m[k].float() - go).norm() / (go.norm() + 1e-7)) for k, go in zip(names, grads_o)]
+    flat_h = torch.cat([p.grad.detach().cpu().double().reshape(-1) for _, p in m.named_parameters()])
+    flat_m = torch.cat([grads_m[k].reshape(-1) for k in names])
+    cos = float((flat_h @ flat_m) / (flat_h.norm() * flat_m.norm()))
+    ratio = float(flat_h.norm() / flat_m.norm())
+    print(f"bf16: median grad relL2 vs fp32 oracle: hip {np.median(errs):.3f}, rounding-matched oracle {np.median(errs_m):.3f}; "
+          f"flat-gradient cosine hip vs matched {cos:.3f}, norm ratio {ratio:.3f}")
+    assert float(np.median(errs)) < 1.25 * float(np.median(errs_m)) + 0.05, (float(np.median(errs)), float(np.median(errs_m)))
+    assert cos > 0.8 and 0.8 < ratio < 1.25, (cos, ratio)
+    assert abs(loss.item() - loss_m) < 1e-3 * abs(loss_m)
     # the last layers see almost no accumulated noise: they must be tight in absolute terms
     tail = dict(zip([k for k, _ in m.named_parameters()], errs))
     assert tail["out_conv.0.weight"] < 2e-2 and tail["up.0.contract.seq.1.seq.2.weight"] < 3e-2

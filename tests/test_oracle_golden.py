@@ -13,8 +13,8 @@ from oracle import optim as ooptim
 from oracle import recognition as orec
 from oracle import text as otext
 from oracle.params import detection_specs, make_state, recognition_specs
-from tests.golden_util import (DET_CASES, REC_CASE, compare_to_golden, det_inputs, golden_keys, load_meta,
-                               load_npz, rec_samples)
+from tests.golden_util import (CONFIG1, DET_CASES, REC_CASE, compare_to_golden, config1_inputs, config1_state, det_inputs,
+                               golden_keys, load_meta, load_npz, rec_samples)
 
 torch.set_num_threads(8)
 
@@ -45,6 +45,52 @@ def test_detection_oracle_matches_reference(case, tag):
             for k in golden_keys(G, f"{case}/f32/state{step + 1}"):
                 v = P[k] if k in P else Bf[k]
                 assert compare_to_golden(G, f"{case}/f32/state{step + 1}/{k}", v, 0, atol=1e-6) < 2e-4, (step, k)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_detection_oracle_matches_reference_config1(tag):
+    """G-det-512 = BASELINE.json configs[0]: B=2 x 512^2, the reference's seed-1234 default initialisation,
+    one train() step of train_detection.py:87-98 -- the oracle against the reference's own outputs."""
+    G = load_npz("det512.npz")
+    dt = torch.float32 if tag == "f32" else torch.float64
+    P, Bf = config1_state(dt)
+    x, m = config1_inputs()
+    x, m = x.to(dt), m.to(dt)
+    tol = 2e-5 if tag == "f32" else 1e-10
+    pred = odet.forward(P, Bf, x, True)
+    loss = olosses.balanced_bce(pred, m)
+    grads = torch.autograd.grad(loss, list(P.values()))
+    assert compare_to_golden(G, f"det512/{tag}/pred", pred, 0) < tol
+    assert abs(loss.item() - float(G[f"det512/{tag}/loss"])) < tol * abs(loss.item())
+    for (k, _), g in zip(P.items(), grads):
+        assert compare_to_golden(G, f"det512/{tag}/grad/{k}", g, 0, atol=1e-7) < (2e-4 if tag == "f32" else 1e-8), k
+    if tag == "f32":
+        opt = ooptim.Adam(P.values())
+        opt.step(grads)
+        for k in golden_keys(G, "det512/f32/state1"):
+            v = P[k] if k in P else Bf[k]
+            assert compare_to_golden(G, f"det512/f32/state1/{k}", v, 0, atol=1e-6) < 2e-4, k
+
+
+@pytest.mark.parametrize("case", ["det1", "det2"])
+def test_rounding_matched_oracle_without_rounding_is_the_exact_network(case):
+    """oracle.detection_bf16 (the checker of the bf16 throughput mode) with its roundings switched off must be the reference network:
+    pins its hand-written BatchNorm backward, the composed 3x3 weight algebra and the graph wiring to the fp64 goldens."""
+    from oracle import detection_bf16 as obf
+
+    G = load_npz("det.npz")
+    c = DET_CASES[case]
+    P, _ = make_state(detection_specs(), c["seed"])
+    x, m = det_inputs(c)
+    pred, loss, grads = obf.forward_backward(P, x, m, rounding=False)
+    assert compare_to_golden(G, f"{case}/f64/pred", pred, 0) < 1e-10
+    assert abs(loss - float(G[f"{case}/f64/loss"])) < 1e-10 * abs(loss)
+    for k, g in grads.items():
+        assert compare_to_golden(G, f"{case}/f64/grad/{k}", g, 0, atol=1e-12) < 1e-8, k
+    # with the roundings on it is a different function: the gradients move by O(1) (ReLU-mask / arg-max flips), the prediction by ~2^-6
+    pred_b, loss_b, grads_b = obf.forward_backward(P, x, m, rounding=True)
+    assert 1e-3 < float((pred_b - pred).norm() / pred.norm()) < 6e-2
+    assert abs(loss_b - loss) < 2e-2 * abs(loss)
 
 
 @pytest.mark.parametrize("tag", ["f32", "bf16", "f64"])

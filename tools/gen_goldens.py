@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 from oracle.params import detection_specs, recognition_specs, make_state, state_dict_from  # noqa: E402
-from tests.golden_util import summarize, det_inputs, rec_samples, DET_CASES, REC_CASE  # noqa: E402
+from tests.golden_util import summarize, det_inputs, rec_samples, config1_inputs, DET_CASES, REC_CASE, CONFIG1  # noqa: E402
 
 
 def load_into(module, specs, seed, dtype=torch.float32):
@@ -69,6 +69,35 @@ def gen_detection(R, out, meta):
                 if step == 2:
                     out[f"{name}/{tag}/loss3"] = np.asarray(loss.item())
         meta[name] = dict(case)
+
+
+def gen_detection_config1(R, out, meta):
+    """G-det-512 = BASELINE.json configs[0] / SURVEY.md 8(d) config 1: the reference's own seed-1234 default initialisation
+    (train_detection.py:337-338), B=2 x 1 x 512 x 512 tiles from Generator(seed=0), ONE train() step (train_detection.py:87-98)."""
+    x, mask = config1_inputs()
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        torch.manual_seed(CONFIG1["model_seed"])
+        m = R.models.DetectionModel()
+        if tag == "f32":
+            flat = torch.cat([v.reshape(-1).float() for v in m.state_dict().values() if v.dtype.is_floating_point])
+            meta["det512/init_sha256"] = hashlib.sha256(flat.numpy().tobytes()).hexdigest()
+            meta["det512/init_numel"] = int(flat.numel())
+        m = m.to(dt)
+        m.train()
+        opt = torch.optim.Adam(m.parameters())
+        pred = m(x.to(dt))
+        loss = R.td.balanced_cross_entropy_loss(pred, mask.to(dt))
+        opt.zero_grad()
+        loss.backward()
+        put(out, f"det512/{tag}/pred", pred.detach())
+        out[f"det512/{tag}/loss"] = np.asarray(loss.item())
+        for k, p in m.named_parameters():
+            put(out, f"det512/{tag}/grad/{k}", p.grad)
+        opt.step()
+        if tag == "f32":
+            for k, v in m.state_dict().items():
+                put(out, f"det512/{tag}/state1/{k}", v)
+    meta["det512"] = dict(CONFIG1)
 
 
 def gen_recognition(R, out, meta):
@@ -190,17 +219,19 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     meta = OrderedDict()
     meta["torch"] = torch.__version__
-    det, rec, ops = {}, {}, {}
+    det, rec, ops, det512 = {}, {}, {}, {}
     gen_detection(R, det, meta)
+    gen_detection_config1(R, det512, meta)
     gen_recognition(R, rec, meta)
     gen_host_kats(R, meta)
     gen_op_kats(ops, meta)
     np.savez_compressed(os.path.join(args.out, "det.npz"), **det)
     np.savez_compressed(os.path.join(args.out, "rec.npz"), **rec)
     np.savez_compressed(os.path.join(args.out, "ops.npz"), **ops)
+    np.savez_compressed(os.path.join(args.out, "det512.npz"), **det512)
     with open(os.path.join(args.out, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, ensure_ascii=False)
-    for fn in ("det.npz", "rec.npz", "ops.npz", "meta.json"):
+    for fn in ("det.npz", "rec.npz", "ops.npz", "det512.npz", "meta.json"):
         print(fn, os.path.getsize(os.path.join(args.out, fn)))
 
 
