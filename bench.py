@@ -44,6 +44,27 @@ KERNEL_BOUNDARY_US = 1.45   # dependent kernel boundary, same stream (same guide
 DEPTH_SCALE = [8, 16, 32, 32, 64, 128, 256]  # models.py:112
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner on the C-level stdout when the first communicator is created; this bench's contract is ONE JSON line on
+    stdout.  Inside this context file descriptor 1 points at stderr; C stdio is flushed before it is restored."""
+
+    def __enter__(self):
+        import ctypes
+
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 # ------------------------------------------------------------------------------------------------ byte model (SURVEY 8(d))
 def det_alg_elems_per_image(H: int, W: int) -> int:
     """sum over the fused passes of the detection net of (input elements + output elements), per image (every a1 block,
@@ -141,6 +162,19 @@ def pmc_profile():
     return rows, os.path.basename(files[-1])
 
 
+def crnn_pmc_profile():
+    """Per-kernel HBM bytes / duration of one CRNN train step from the committed PMC passes (profiles/*_crnn_pmc_hbm.csv, written by
+    tools/pmc_hbm_crnn.py from two separate rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); None when missing."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_crnn_pmc_hbm.csv")))
+    if not files:
+        return None, None
+    rows = [r for r in csv.DictReader(open(files[-1])) if r["kernel"] != "TOTAL"]
+    return rows, os.path.basename(files[-1])
+
+
 def pass_traffic(rows, pname):
     if not rows:
         return None
@@ -197,8 +231,10 @@ def cpu_baseline():
     from oracle import optim as ooptim
     from oracle.params import detection_specs, make_state, recognition_specs
 
-    # the small convolutions of these nets do not scale to a 128+-core host (measured 0.18 img/s at 128 threads vs 0.47 at 32)
-    nthreads = min(32, max(1, _physical_cores() or (os.cpu_count() or 2) // 2))
+    # the small convolutions of these nets do not scale to a 128+-core host (measured 0.18 img/s at 128 threads vs 0.47 at 32): the headline
+    # figure uses 32 threads, the all-physical-core figure is reported next to it (`all_physical_cores`)
+    phys = max(1, _physical_cores() or (os.cpu_count() or 2) // 2)
+    nthreads = min(32, phys)
     torch.set_num_threads(nthreads)
     info = {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "physical_cores": _physical_cores(), "torch_threads": torch.get_num_threads()}
 
@@ -221,12 +257,17 @@ def cpu_baseline():
                 "sample": f"median of {timed} steps after {warm} warm-up, B={B} 1x64x{W}, {'bf16 autocast (train_rec.py:118)' if autocast else 'fp32'}"}
 
     d512 = det(2, 512, 2, 5)
-    d1024 = det(4, 1024, 1, 3)
+    d1024 = det(4, 1024, 2, 5)  # 8(d) protocol: median of >= 5 after 2 warm-ups (~8 s per step)
     r32 = rec(64, 400, False, 2, 5)
     rbf = rec(64, 400, True, 2, 5)
+    allc = None
+    if phys > nthreads:  # the same legs on every physical core of the host (bounded: config 1 by the protocol, 1024^2 on 3 steps after 1)
+        torch.set_num_threads(phys)
+        allc = {"torch_threads": torch.get_num_threads(), "det_config1_B2_512": det(2, 512, 2, 5), "det_B4_1024": det(4, 1024, 1, 3)}
+        torch.set_num_threads(nthreads)
     return {"value": d1024["images_per_s"], "unit": "images/s", "cores": nthreads, "kind": "port",
             "sample": d1024["sample"] + " (oracle/aten_step.py: stock ATen CPU ops, the operators the reference dispatches to)",
-            "det_config1_B2_512": d512, "det_B4_1024": d1024, "rec_B64_fp32": r32, "rec_B64_bf16_autocast": rbf, **info}
+            "det_config1_B2_512": d512, "det_B4_1024": d1024, "rec_B64_fp32": r32, "rec_B64_bf16_autocast": rbf, "all_physical_cores": allc, **info}
 
 
 # ------------------------------------------------------------------------------------------------ CRNN
@@ -362,9 +403,21 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         gf = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_fwd"] + tm["gru_seq_fwd"])
         gb = sum(e0.elapsed_time(e1) for e0, e1, _ in tm["gru_layer_bwd"] + tm["gru_seq_bwd"])
         tf = (conv_fl + wg_fl) / ((conv_ms + wg_ms) * 1e-3) / 1e12 if conv_ms + wg_ms > 0 else 0.0
+        # HBM side (north_star: achieved GB/s on the memory-bound CTC / activation kernels): from the committed PMC passes of this workload
+        prow, psrc = crnn_pmc_profile()
+        conv_traffic, hbm_kernels = None, None
+        if prow:
+            is_conv = lambda k: k.startswith(("k_conv_igemm<bf16", "k_conv3x3_c128", "k_conv3x3_wgrad_tr"))  # noqa: E731
+            conv_traffic = round(sum((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9 for r in prow if is_conv(r["kernel"])))
+            mem = ("k_dz_apply", "k_rec_bn_reduce", "k_act_pool_fwd", "k_conv0_", "k_ctc_", "k_avgpool", "k_log_softmax", "k_argmax", "k_col_sum", "k_multi_")
+            hbm_kernels = {r["kernel"]: {"launches_per_step": float(r["launches_per_step"]), "hbm_MB_per_step": round((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e3, 2),
+                                         "us_per_step": float(r["us_per_step"]), "achieved_GBps": float(r["achieved_GBps"]),
+                                         "frac_of_8TBps": round(float(r["achieved_GBps"]) / HBM_PEAK_GBS, 4)}
+                           for r in prow if r["kernel"].startswith(mem)}
         out["roofline"] = {
             "kernel": "k_conv_igemm (fwd+dgrad) + k_conv3x3_wgrad_tr", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
-            "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": conv_traffic, "traffic_source": psrc,
+            "traffic_note": "HBM bytes per step of the conv kernels named in `kernel` (PMC FETCH_SIZE x2 + WRITE_SIZE)", "hbm_bound_kernels": hbm_kernels,
             "conv_fwd_dgrad": {"ms": round(conv_ms, 3), "gflop": round(conv_fl / 1e9, 1), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else None},
             "conv_wgrad": {"ms": round(wg_ms, 3), "gflop": round(wg_fl / 1e9, 1), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms else None},
             "gru": {"bound": "latency", "form": "persistent: 1 launch per layer and pass, in-kernel group hand-off per step" if persistent else "1 launch per step",
@@ -405,6 +458,8 @@ def main():
     ap.add_argument("--no-crnn", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing")
     ap.add_argument("--no-gru-exact", action="store_true", help="skip the second CRNN timing with the other GRU GEMM mode")
+    ap.add_argument("--no-ref-style", action="store_true", help="skip the reference-style step (H2D copy + loss.item() inside the step)")
+    ap.add_argument("--no-ddp-probe", action="store_true", help="skip the 1-rank RCCL probe of the gradient bucketer at N = 1")
     ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
     ap.add_argument("--rec-width", type=int, default=400)
     ap.add_argument("--rec-config5", action="store_true", help="also time the width-bucketed variable-width CRNN workload (default at N > 1)")
@@ -427,7 +482,11 @@ def main():
     distributed = world > 1 or "RANK" in os.environ  # under torch.distributed.run, also with one rank
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        with c_stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
+            warm_t = torch.zeros(1, device=dev)
+            dist.all_reduce(warm_t)  # creates the communicator (and prints RCCL's banner) here, not inside the timed region
+            torch.cuda.synchronize()
 
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
@@ -435,20 +494,35 @@ def main():
     mask = (torch.rand(B, 1, S, S, generator=g, device=dev) > 0.9).float()
     L = lib()
 
-    def run_det(dtype_name, warmup, steps, roofline):
+    ddp_info = {}
+
+    def run_det(dtype_name, warmup, steps, roofline, use_ddp=None, ref_style=False):
+        use_ddp = distributed if use_ddp is None else use_ddp
         act = torch.bfloat16 if dtype_name == "bf16" else torch.float32
         torch.manual_seed(1234)
         model = oa.DetectionModel(act_dtype=act).to(dev)
         model.train()
-        net = DistributedDataParallel(model) if distributed else model
+        net = DistributedDataParallel(model) if use_ddp else model
         opt = oa.optim.Adam(model.parameters())
+        if ref_style:
+            # the reference's loop body as written (train_detection.py:87-98): the batch arrives as HOST tensors (8-bit greyscale pixels, the
+            # dataset's storage type; transform_image runs on the device), is copied H2D inside the step, and the loss is read back every step
+            img_u8 = ((img + 0.5) * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().pin_memory()
+            mask_u8 = mask.to(torch.uint8).cpu().pin_memory()
 
         def step():
-            pred = net(img)
-            loss = oa.balanced_cross_entropy_loss(pred, mask)
+            if ref_style:
+                x = oa.input_pipeline.transform_image(img_u8.to(dev, non_blocking=True))
+                t = mask_u8.to(dev, non_blocking=True).float()
+            else:
+                x, t = img, mask
+            pred = net(x)
+            loss = oa.balanced_cross_entropy_loss(pred, t)
             opt.zero_grad()
             loss.backward()
             opt.step()
+            if ref_style:
+                return float(loss.item())
             return loss
 
         warm = None
@@ -467,6 +541,8 @@ def main():
             # stream events around ~80 launches per step cost ~4 us of queue bubble each (15.5 vs 15.1 ms per step)
             L.prof = {f: [] for f in PASSES[dom]}
             L.prof_enable(1)
+        if use_ddp:
+            net.bucketer.timing = []
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -498,7 +574,16 @@ def main():
                     return self.ms
 
             timing = {f: [(_Dur(float(dur[a:b].sum())), None, args) for a, b, args in lst] for f, lst in recs.items()}
-        final_loss = float(loss.item())
+        final_loss = float(loss) if ref_style else float(loss.item())
+        if use_ddp:
+            ex = net.bucketer.exposed_ms()
+            nflt = sum(p.numel() for p in model.parameters())
+            ranges = getattr(net.bucketer, "last_ranges", [])
+            ddp_info.update({"rccl_ranks": world, "collectives_issued": bool(world > 1 or net.bucketer.force), "grad_MB": round(nflt * 4 / 1e6, 3),
+                             "bucket_bytes": net.bucketer.bucket_bytes, "buckets_per_step": len(ranges),
+                             "bucket_MB": [round((hi - lo) * 4 / 1e6, 3) for lo, hi in ranges],
+                             "exposed_allreduce_ms_per_step": round(sum(ex) / len(ex), 4) if ex else None,
+                             "exposed_allreduce_ms_max": round(max(ex), 4) if ex else None, "ms_per_step": round(dt / steps * 1e3, 3)})
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -560,11 +645,42 @@ def main():
                 out["roofline"]["whole_step_traffic_GB"] = round(tot / 1e9, 2)
                 out["roofline"]["traffic_ratio"] = round(tot / (3 * 2 * det_alg_elems_per_image(1024, 1024) * 32), 3)  # the PMC passes ran the default config
             out["roofline"]["passes"] = {p: pass_stats(warm, p, 1) for p in PASSES if pass_stats(warm, p, 1)}
+    if distributed and ddp_info:
+        out["ddp"] = dict(ddp_info)
     if rank == 0 and world == 1 and not args.no_fp32 and args.dtype == "bf16":
         k = max(3, args.steps // 3)
         dt32, _, _, _ = run_det("fp32", 2, k, False)
         out["fp32_exact"] = {"value": round(B * k / dt32, 2), "unit": "images/s", "ms_per_step": round(dt32 / k * 1e3, 3), "steps": k,
                              "note": "parity mode: fp32 storage, exact-fp32 MFMA"}
+    if rank == 0 and world == 1 and not args.no_ref_style:
+        # the step exactly as the reference's loop runs it (train_detection.py:87-98): uint8 H2D copy + device transform_image + loss.item()
+        k = max(5, args.steps // 2)
+        dtr, _, _, _ = run_det(args.dtype, 2, k, False, ref_style=True)
+        out["reference_style_step"] = {"value": round(B * k / dtr, 2), "unit": "images/s", "ms_per_step": round(dtr / k * 1e3, 3), "steps": k,
+                                       "h2d_in_step": True, "loss_item_per_step": True,
+                                       "note": "pinned uint8 tile + mask batch copied H2D every step, transform_image on the device, loss.item() every step"}
+    if rank == 0 and world == 1 and not distributed and not args.no_ddp_probe:
+        # the data-parallel machinery on this single GPU: a 1-rank RCCL group with OCRS_DDP_FORCE=1 -- every bucket's all-reduce is really
+        # issued and waited for, so `exposed_allreduce_ms_per_step` is the cost the overlap does not hide at N = 1 (launch + wait latency)
+        try:
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ["OCRS_DDP_FORCE"] = "1"
+            with c_stdout_to_stderr():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                k = max(5, args.steps // 2)
+                ddp_info.clear()
+                run_det(args.dtype, 2, k, False, use_ddp=True)
+                out["ddp"] = {**ddp_info, "forced_single_rank": True, "ms_per_step_without_ddp": round(ms, 3)}
+                dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001  (the probe must never cost the bench line)
+            out["ddp"] = {"error": repr(e)[:300]}
+        finally:
+            os.environ.pop("OCRS_DDP_FORCE", None)
     del img, mask
     torch.cuda.empty_cache()
     if not args.no_crnn:

@@ -71,6 +71,17 @@
 #define OCRS_MF_BPC8 2     // forward blocks per CU, Cin = 8
 #endif
 
+// floor-measurement builds (tools/r3): drop the global loads / the stores / the MFMA phases of k_mm_bwd
+#ifndef OCRS_MM_NOLOAD
+#define OCRS_MM_NOLOAD 0
+#endif
+#ifndef OCRS_MM_NOSTORE
+#define OCRS_MM_NOSTORE 0
+#endif
+#ifndef OCRS_MM_NOCOMPUTE
+#define OCRS_MM_NOCOMPUTE 0
+#endif
+
 namespace {
 
 template <int C>
@@ -246,9 +257,10 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;
                 const bool ok = (DP * CGO % NT == 0 || tid + j * NT < DP * CGO) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
                 const int goff = (dy * W + dx) * COUT + cgo * 8;
-                zr[j] = load8_raw(ok ? zb + goff : z);
-                g1r[j] = load8_raw(ok ? g1b + goff : g1);
-                if constexpr (G2) g2r[j] = load8_raw(ok ? g2b + goff : g2);
+                const bool ld = ok && !OCRS_MM_NOLOAD;
+                zr[j] = load8_raw(ld ? zb + goff : z);
+                g1r[j] = load8_raw(ld ? g1b + goff : g1);
+                if constexpr (G2) g2r[j] = load8_raw(ld ? g2b + goff : g2);
                 okg |= ok ? 1u << j : 0u;
             }
         } else {
@@ -261,14 +273,14 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const bool ok = it_ok && (unsigned)(h + (k >> 1)) < (unsigned)H && (unsigned)(w + (k & 1)) < (unsigned)W;
-                    zp[4 * j + k] = *reinterpret_cast<const uint2*>(ok ? zb + goff + ((k >> 1) * W + (k & 1)) * COUT : z);
+                    zp[4 * j + k] = *reinterpret_cast<const uint2*>((ok && !OCRS_MM_NOLOAD) ? zb + goff + ((k >> 1) * W + (k & 1)) * COUT : z);
                     okg |= ok ? 1u << (4 * j + k) : 0u;
                 }
                 const int ph = h >> 1, pw = w >> 1;
                 const bool gv = it_ok && h >= 0 && w >= 0 && ph < Hp && pw < Wp;  // floor mode: the last odd row / column is in no window
                 const long pp = ((long)o.n * Hp + ph) * Wp + pw;
-                gp1[j] = *reinterpret_cast<const uint2*>(gv ? g1 + pp * COUT + cq4 : g1);
-                if constexpr (G2) gp2[j] = *reinterpret_cast<const uint2*>(gv ? g2 + pp * COUT + cq4 : g2);
+                gp1[j] = *reinterpret_cast<const uint2*>((gv && !OCRS_MM_NOLOAD) ? g1 + pp * COUT + cq4 : g1);
+                if constexpr (G2) gp2[j] = *reinterpret_cast<const uint2*>((gv && !OCRS_MM_NOLOAD) ? g2 + pp * COUT + cq4 : g2);
                 okg |= gv ? 1u << (16 + j) : 0u;
             }
         }
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             const int p = (tid + j * NT) / CGI, ty = p / TW, tx = p % TW;
             const int h = o.h0 + ORG + ty, w = o.w0 + ORG + tx;
             const bool ok = (TP * CGI % NT == 0 || tid + j * NT < TP * CGI) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-            xr[j] = load8_raw(ok ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
+            xr[j] = load8_raw((ok && !OCRS_MM_NOLOAD) ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
             okx |= ok ? 1u << j : 0u;
         }
     };
@@ -494,7 +506,8 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                         if (!bv) dst[a] = make_uint4(0, 0, 0, 0);
                     }
                 };
-                if constexpr (C::BDB) {  // B fragments double-buffered across K chunks
+                if constexpr (OCRS_MM_NOCOMPUTE) {
+                } else if constexpr (C::BDB) {  // B fragments double-buffered across K chunks
                     load_b(bcur, 0);
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc) {
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 #pragma unroll
                 for (int a = 0; a < NPW; ++a) {
                     const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
-                    const bool pv = (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W;
+                    const bool pv = !OCRS_MM_NOSTORE && (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W;
                     const long srow = tb + (long)ty * W + tx0;  // (scalar)
                     if (m0 < CIN) {
                         const f32x4 v = acc[a];
@@ -594,7 +607,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         // loop over all k-steps with wave-uniform `continue`s every step was: 4 reads -> s_waitcnt lgkmcnt(0) -> 1 MFMA, a full LDS round trip
         // per MFMA.)
         {
-            constexpr int LOWN = (C::TAPU == 9) ? KS : KS / 2;
+            constexpr int LOWN = OCRS_MM_NOCOMPUTE ? 0 : ((C::TAPU == 9) ? KS : KS / 2);
             const bf16* xo = tileX + (ks_own0 * 32 + prow) * PX + pcol;
             const bf16* dq = tileD + ks_own0 * DW_ * PD + off_own;
 #if OCRS_MM_GPIPE
@@ -644,7 +657,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             // this wave's sub-tile of the shared last unit over its k-step range (1 .. KS / NKR + 1 steps)
             const bf16* xs0 = tileX + prow * PX + sh_a * 16 + pcol;
             const bf16* ds0 = tileD + off_sh;
-            for (int ks = sh_k0; ks < sh_k1; ++ks) {
+            for (int ks = sh_k0; ks < (OCRS_MM_NOCOMPUTE ? sh_k0 : sh_k1); ++ks) {
                 const bf16* xa = xs0 + ks * 32 * PX;
                 const bf16* da = ds0 + ks * DW_ * PD;
                 accS = mfma16(lds_tr8(xa, xa + 16 * PX), lds_tr8(da, da + 16 * PD), accS);

@@ -551,7 +551,12 @@ long ocrs_gru_seq_supported(int N) {
             cap = nb;
         }
     }
-    return seq_grid(N) <= cap;
+    // Head-room: the launch only deadlocks-until-timeout if some workgroup cannot become resident while its peers spin.  Other streams'
+    // kernels may hold workgroup slots at that moment -- the DDP bucketer's RCCL all-reduce (<= 32 channels = workgroups by default, 64 with
+    // NCCL_MAX_NCHANNELS raised) starts right before the backward recurrence -- so the grid must fit with that many slots to spare
+    // (OCRS_GRU_SEQ_HEADROOM, default 64).  N = 256 needs 256 of the 512 slots an MI355X offers these kernels.
+    static const int headroom = env_int("OCRS_GRU_SEQ_HEADROOM", 64);
+    return seq_grid(N) + headroom <= cap;
 }
 long ocrs_gru_seq_sync_words(int N) { return (long)seq_groups(N) * SYNC_STRIDE; }
 // floats of the exchange workspace of one launch (the backward needs 3x the forward: size for the backward, both passes take it)

@@ -37,6 +37,15 @@ class GradBucketer:
         self._works = []
         self.launched = []  # (lo, hi) ranges, for tests / introspection
 
+    # Measurement of the EXPOSED all-reduce time (bench.py's `ddp` object): with ``timing = []`` every finish() brackets its waits with two
+    # events on the compute stream; their distance is the time the compute stream stood still waiting for collectives that the remaining
+    # backward did not hide (0 when they finished earlier).  Read with exposed_ms() after a synchronisation.  None = off (default).
+    timing = None
+
+    def exposed_ms(self):
+        """per-step exposed all-reduce wait (ms) of the steps recorded since ``timing = []`` (call after torch.cuda.synchronize())"""
+        return [e0.elapsed_time(e1) for e0, e1 in (self.timing or [])]
+
     def ready(self, flat: torch.Tensor, lo: int, hi: int):
         """flat[lo:hi] (elements) now holds final local gradients.  Ranges must arrive contiguously."""
         if self._pending_lo is None:
@@ -64,9 +73,17 @@ class GradBucketer:
     def finish(self, flat: torch.Tensor):
         if self._pending_lo is not None:
             self._launch(flat)
+        ev = None
+        if self.timing is not None and flat.is_cuda and self._works:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()  # stream-level wait on NCCL/RCCL, blocking wait on gloo
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
         ranges = self.launched
+        self.last_ranges = ranges
         self._reset()
         return ranges
 

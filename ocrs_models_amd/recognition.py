@@ -46,7 +46,7 @@ class _RecRun:
         self.x3 = os.environ.get("OCRS_GRU_X3", "1") != "0"  # split-bf16 GEMMs for the fp32 GRU weight gradients in throughput mode
         # recurrence as one persistent launch per layer and pass (csrc/rec_gru_seq.hip) when all its workgroups can be resident; its matrix
         # products follow the projection GEMMs' arithmetic: exact fp32 MFMA in parity mode, split-bf16 x3 in throughput mode
-        self.gru_seq = bool(self.L.gru_seq_supported(x.shape[0]))
+        self.gru_seq = bool(self.L.gru_seq_supported(x.shape[0])) and not _GRU_SEQ_OFF.get(x.device, False)
         self.gru_exact = 0 if (self.dt == 1 and self.x3 and os.environ.get("OCRS_GRU_REC_X3", "1") != "0") else 1
         self.x = x
         self.N, _, self.H, self.W = x.shape
@@ -403,19 +403,38 @@ def _adjacent(a, b):
             and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
 
 
-_GRU_ERR = {}  # device -> (sticky device error word of the persistent GRU launches, pinned host copy)
+_GRU_ERR = {}      # device -> (device error word of the persistent GRU launches, pinned host copy)
+_GRU_SEQ_OFF = {}  # device -> True once a persistent launch timed out there: this process uses the per-step kernels from then on
 
 
-def _gru_err(dev):
-    """The error word the persistent GRU launches raise when a wait times out (ocrs_gru_seq_fwd / _bwd: outputs incomplete).  Checked WITHOUT a
-    device synchronisation: every backward queues a copy of the word into pinned host memory, every forward looks at the host copy first -- a
-    failure is reported loudly one step late instead of stalling the pipeline every step."""
+def _gru_err_entry(dev):
     ent = _GRU_ERR.get(dev)
     if ent is None:
         ent = _GRU_ERR[dev] = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory())
+    return ent
+
+
+def _gru_err_reset(dev):
+    """A timeout was observed: clear the word (device and host copy) and route this process to the per-step kernels (rec_gru.hip) -- a
+    transient stall (another process or stream holding the CUs the resident grid needs) must not end the training process."""
+    ent = _gru_err_entry(dev)
+    ent[0].zero_()
+    ent[1].zero_()
+    _GRU_SEQ_OFF[dev] = True
+
+
+def _gru_err(dev):
+    """The error word the persistent GRU launches raise when a wait times out (ocrs_gru_seq_fwd / _bwd: outputs incomplete).  Training checks
+    it WITHOUT a device synchronisation: every forward and every backward queue a copy of the word into pinned host memory, every forward
+    looks at the host copy first.  A failure is reported ONCE, one step late (the step whose launch timed out produced incomplete gradients:
+    the caller should discard / repeat it), the word is cleared and later forwards run on the per-step kernels.  Inference (no autograd)
+    checks synchronously and repeats the forward itself (RecognitionModel.forward)."""
+    ent = _gru_err_entry(dev)
     if int(ent[1][0]) != 0:
-        raise RuntimeError("a persistent GRU launch (ocrs_gru_seq_fwd/_bwd) timed out waiting for its peer workgroups: results since then are "
-                           "incomplete (set OCRS_GRU_SEQ=0 to use the per-step kernels)")
+        _gru_err_reset(dev)
+        raise RuntimeError("a persistent GRU launch (ocrs_gru_seq_fwd/_bwd) timed out waiting for its peer workgroups: the results of the previous "
+                           "step are incomplete -- discard or repeat it.  The error word was cleared and this process now uses the per-step GRU "
+                           "kernels (csrc/rec_gru.hip); later steps are not affected")
     return ent[0]
 
 
@@ -432,7 +451,10 @@ class _RecFn(torch.autograd.Function):
         ctx.run = run
         ctx.params = params
         ctx.versions = [p._version for p in params]
-        return run.forward()
+        out = run.forward()
+        if run.gru_seq:
+            _gru_err_poll(run.dev)  # (a timed-out forward launch is seen at the next forward even if no backward follows)
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -511,4 +533,19 @@ class RecognitionModel(nn.Module):
         with torch.autocast("cuda", enabled=False):
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 return _RecFn.apply(x, self, names, dtype, *params)
-            return _RecRun(self, x, names, [p.detach() for p in params], self.training, dtype).forward()
+            run = _RecRun(self, x, names, [p.detach() for p in params], self.training, dtype)
+            out = run.forward()
+            if run.gru_seq and not self._gru_seq_ok(run):
+                # inference / validation: a timed-out persistent launch left `out` incomplete -- one synchronous check per call is cheap here;
+                # repeat this forward on the per-step kernels instead of returning wrong log-probabilities
+                _gru_err_reset(x.device)
+                out = _RecRun(self, x, names, [p.detach() for p in params], self.training, dtype).forward()
+            return out
+
+    @staticmethod
+    def _gru_seq_ok(run):
+        try:
+            run.L.gru_seq_status(ptr(_gru_err_entry(run.dev)[0]))
+            return True
+        except RuntimeError:
+            return False

@@ -12,11 +12,9 @@ with a narrow batch idle at the gradient all-reduce while one rank runs 4x the r
   * shuffles samples within a bucket and the order of the global batches with a generator seeded by (seed, epoch) -- identical on
     every rank, no communication.
 
-``collate_samples`` (text.py) then pads each rank's batch to exactly the bucket width (the bucket is ``round_up`` of every member).
+``collate_samples(samples, pad_to=bucket)`` (text.py) then pads each rank's batch to exactly the step's bucket width.
 """
 from __future__ import annotations
-
-import math
 
 import numpy as np
 import torch
@@ -33,16 +31,20 @@ def bucket_of(width: int) -> int:
 class WidthBucketedDistributedSampler(torch.utils.data.Sampler):
     """Batch sampler: ``for batch_indices in sampler`` yields this rank's ``batch_size`` sample indices of each step.
 
-    ``widths``: the sample widths (after the dataset's resize to height 64), one per dataset index.  Incomplete global batches at the end
-    of a bucket are dropped when ``drop_last`` (default: every rank must have a batch in every step), otherwise they are completed by
-    wrapping around inside the bucket.
+    ``widths``: the sample widths (after the dataset's resize to height 64), one per dataset index.  The samples of a bucket that do not fill
+    a whole global batch are carried into the NEXT WIDER bucket (``merge_up``, default: they are padded a little further instead of never
+    being trained -- the 1024-wide bucket holds < 1 % of the HierText-like population and would otherwise lose all its samples at realistic
+    batch sizes, while the reference's plain shuffled DataLoader sees every sample); what is left over after the widest bucket is dropped
+    when ``drop_last`` (default: every rank must have a batch in every step), otherwise completed by wrapping around inside that bucket.
+    The width to pad a step's batch to is the first element of the schedule entry: ``collate_samples(samples, pad_to=bucket)``.
     """
 
-    def __init__(self, widths, batch_size: int, rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = True):
+    def __init__(self, widths, batch_size: int, rank: int = 0, world_size: int = 1, seed: int = 0, drop_last: bool = True, merge_up: bool = True):
         if not (0 <= rank < world_size):
             raise ValueError(f"rank {rank} outside world of {world_size}")
         self.widths = [int(w) for w in widths]
         self.batch_size, self.rank, self.world, self.seed, self.drop_last = int(batch_size), rank, world_size, seed, drop_last
+        self.merge_up = merge_up
         self.epoch = 0
         self.buckets: dict[int, list[int]] = {}
         for i, w in enumerate(self.widths):
@@ -56,14 +58,22 @@ class WidthBucketedDistributedSampler(torch.utils.data.Sampler):
         g = np.random.RandomState((self.seed * 1000003 + self.epoch) % (2**31 - 1))
         gb = self.batch_size * self.world
         out = []
-        for b in sorted(self.buckets):
+        carry = np.zeros(0, dtype=np.int64)
+        order_b = sorted(self.buckets)
+        for pos, b in enumerate(order_b):
             idx = np.array(self.buckets[b], dtype=np.int64)
             g.shuffle(idx)
+            if len(carry):  # the narrower bucket's remainder rides in this bucket's batches, spread over them (not all in one batch)
+                idx = np.concatenate([idx, carry])
+                g.shuffle(idx)
+                carry = np.zeros(0, dtype=np.int64)
             n_full = len(idx) // gb
             for k in range(n_full):
                 out.append((b, idx[k * gb:(k + 1) * gb].tolist()))
             rest = len(idx) - n_full * gb
-            if rest and not self.drop_last:
+            if rest and self.merge_up and pos + 1 < len(order_b):
+                carry = idx[n_full * gb:]
+            elif rest and not self.drop_last:
                 tail = idx[n_full * gb:].tolist()
                 while len(tail) < gb:
                     tail += idx[: gb - len(tail)].tolist()
@@ -82,9 +92,18 @@ class WidthBucketedDistributedSampler(torch.utils.data.Sampler):
 
     def __len__(self):
         gb = self.batch_size * self.world
-        if self.drop_last:
-            return sum(len(v) // gb for v in self.buckets.values())
-        return sum(math.ceil(len(v) / gb) for v in self.buckets.values())
+        n, carry = 0, 0
+        order_b = sorted(self.buckets)
+        for pos, b in enumerate(order_b):
+            have = len(self.buckets[b]) + carry
+            carry = 0
+            n += have // gb
+            rest = have % gb
+            if rest and self.merge_up and pos + 1 < len(order_b):
+                carry = rest
+            elif rest and not self.drop_last:
+                n += 1
+        return n
 
 
 # ------------------------------------------------------------------------------------------------

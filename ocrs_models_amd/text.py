@@ -145,9 +145,13 @@ def ctc_input_and_target_compatible(input_len: int, target) -> bool:
     return input_len >= need
 
 
-def collate_samples(samples: list[dict]) -> dict:
-    """list of {'image': (1,64,w) float, 'text_seq': (L,) int32} -> padded batch dict (train_rec.py:248-304)."""
+def collate_samples(samples: list[dict], pad_to: int | None = None) -> dict:
+    """list of {'image': (1,64,w) float, 'text_seq': (L,) int32} -> padded batch dict (train_rec.py:248-304).
+    ``pad_to`` (extension for the data-parallel path, default None = the reference's behaviour): pad the width at least to this bucket width,
+    so that every rank of a step runs the same sequence length (sampler.WidthBucketedDistributedSampler)."""
     wmax = round_up(max(s["image"].shape[-1] for s in samples), 256)
+    if pad_to is not None:
+        wmax = max(wmax, int(pad_to))
     lmax = round_up(max(s["text_seq"].shape[0] for s in samples), 64)
     keep = [s for s in samples if ctc_input_and_target_compatible(s["image"].shape[-1] // 4, s["text_seq"])]
     n = len(keep)

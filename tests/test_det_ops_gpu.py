@@ -206,9 +206,12 @@ def test_fused_bn_bwd_sums_match_reduce_pass(dev, dtype, C0, Ca, Cb, Cc):
         assert rel(res[True][k], res[False][k]) < tol, k
 
 
+# (2, 21, 37): image borders cut the tiles on both axes (register-prefetch kernel k_mm_fwd); (2, 32, 96) and (8, 256, 256): whole tiles -> the
+# LDS-DMA kernel k_mm_fwd_dma, with 1-2 tiles per block (ring prologue / blocks with fewer tiles than stages) and 4-8 tiles per block (steady state)
+@pytest.mark.parametrize("shape", [(2, 21, 37), (2, 32, 96), (8, 256, 256)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("Ca,Cb,Cout", [(8, 0, 8), (8, 0, 16), (16, 0, 8), (8, 8, 8), (16, 0, 16), (16, 0, 32), (32, 0, 16), (16, 16, 16), (32, 0, 32), (32, 32, 32)])
-def test_matrix_core_block_forward(dev, Ca, Cb, Cout, pool):
+def test_matrix_core_block_forward(dev, Ca, Cb, Cout, pool, shape):
     """ocrs_mm_fwd (csrc/det_mm.hip: depthwise + pointwise as one implicit GEMM with the effective weight) against a plain PyTorch fp32
     reference of the two convolutions on the same stored bf16 inputs, and against ocrs_dwpw_fwd: pre-BatchNorm output z, the BatchNorm batch
     statistics (deterministic per-block partials -> load transform, saved mean / rstd, running stats), and the fused 2x2 max-pool, which must
@@ -217,7 +220,7 @@ def test_matrix_core_block_forward(dev, Ca, Cb, Cout, pool):
 
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(Ca * 100 + Cb * 10 + Cout + int(pool))
-    N, H, W = 2, 21, 37
+    N, H, W = shape
     Cin = Ca + Cb
     pfx = "blk"
     P = {

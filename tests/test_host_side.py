@@ -29,7 +29,7 @@ def test_width_bucketed_sampler_same_bucket_on_every_rank_and_disjoint():
             assert len(buckets) == 1  # every rank runs the same padded width (same T) in a step
             for r in range(world):
                 assert len(sch[r][step][1]) == bs
-                assert all(bucket_of(w[i]) == sch[r][step][0] for i in sch[r][step][1])
+                assert all(bucket_of(w[i]) <= sch[r][step][0] for i in sch[r][step][1])  # (a narrower bucket's remainder may ride along)
         flat = [i for x in sch for _, idx in x for i in idx]
         assert len(flat) == len(set(flat))  # rank-disjoint, no repeats within an epoch
         if ep == 0:
@@ -40,11 +40,21 @@ def test_width_bucketed_sampler_same_bucket_on_every_rank_and_disjoint():
     assert [idx for _, idx in samplers[0].schedule()] != first
     # iterating yields the index lists (torch BatchSampler protocol)
     assert list(samplers[0])[0] == samplers[0].schedule()[0][1]
-    # drop_last=False completes the tail batches by wrapping inside the bucket
-    s2 = WidthBucketedDistributedSampler(w, bs, 0, world, seed=7, drop_last=False)
+    # merge_up (default): only the remainder of the WIDEST bucket is dropped -- every other sample is trained each epoch
+    used = {i for x in sch for _, idx in x for i in idx}
+    assert len(w) - len(used) < bs * world
+    assert len(samplers[0]) == len(sch[0]) == len(w) // (bs * world)
+    # without it every bucket drops its own remainder
+    s0 = WidthBucketedDistributedSampler(w, bs, 0, world, seed=7, merge_up=False)
     cnt = collections.Counter(bucket_of(x) for x in w)
+    assert len(s0) == len(s0.schedule()) == sum(n // (bs * world) for n in cnt.values())
+    assert all(bucket_of(w[i]) == b for b, idx in s0.schedule() for i in idx)
+    # drop_last=False completes the tail batches by wrapping inside the bucket
+    s2 = WidthBucketedDistributedSampler(w, bs, 0, world, seed=7, drop_last=False, merge_up=False)
     assert len(s2) == sum(-(-n // (bs * world)) for n in cnt.values())
     assert all(len(idx) == bs for idx in s2)
+    s3 = WidthBucketedDistributedSampler(w, bs, 0, world, seed=7, drop_last=False)
+    assert len(s3) == len(s3.schedule()) == -(-len(w) // (bs * world))
 
 
 def test_sampler_batches_collate_to_the_bucket_width():
@@ -56,7 +66,7 @@ def test_sampler_batches_collate_to_the_bucket_width():
     s = WidthBucketedDistributedSampler(w, 8, 1, 2, seed=0)
     seen = set()
     for bucket, idx in s.schedule():
-        batch = collate_samples([config5_sample(w[i], L[i], r) for i in idx])
+        batch = collate_samples([config5_sample(w[i], L[i], r) for i in idx], pad_to=bucket)
         assert batch["image"].shape == (8, 1, 64, bucket)
         assert batch["image"].shape[-1] // 4 + 1 in (65, 129, 193, 257)
         assert batch["image_width"].tolist() == [int(w[i]) for i in idx]
