@@ -53,6 +53,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
+    if any(os.path.basename(s) == "det_mm.hip" for s, _ in jobs):
+        # the hand-waited prefetch loads of det_mm.hip are only valid if hipcc left their destination registers alone until the wait
+        chk = os.path.join(os.path.dirname(HERE), "tools", "check_opaque_loads.py")
+        if os.path.exists(chk):
+            r = subprocess.run([sys.executable, chk], capture_output=True, text=True)
+            if verbose:
+                print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr, flush=True)
+            if r.returncode != 0:
+                os.remove(os.path.join(OBJ, "det_mm.hip.o"))
+                raise RuntimeError("tools/check_opaque_loads.py: hipcc touched an in-flight prefetch register in det_mm.hip:\n" + r.stdout[-3000:])
     objs = [os.path.join(OBJ, src + ".o") for src in sources()]
     if force or jobs or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -15,6 +15,7 @@
 // HBM bytes per pixel: x (Cin) + z, g (Cout, 1.1-1.3x with the ring, mostly L2 hits) in, dx~ (Cin) out -- the 2 (Cin + Cout) of
 // SURVEY.md 8(d); du is never formed.  All flushes are per-block partials reduced by ONE deterministic kernel (no atomics).
 #include "det_common.h"
+#include <type_traits>
 
 // ---- tile-shape / residency knobs (measurement builds: tools/build_variant.sh; the defaults are the measured optimum, profiles/README.md)
 #ifndef OCRS_MM_TH
@@ -145,6 +146,41 @@ __device__ __forceinline__ void st4bf(bf16* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
 }
 
+// ---- prefetch loads the compiler does not see (FULL kernels).  hipcc's own `s_waitcnt vmcnt` in front of the first use of a prefetched
+// vector must hold on every control-flow path, and with stores issued between the load and its use (the previous tile's epilogue) any
+// divergent branch or loop entry degrades it to "wait until (almost) nothing is outstanding": once per tile every wave then waits for the
+// acknowledgement of its own stores.  Here the load is an opaque asm statement and the wait is written by hand with the exact number of
+// younger operations (VMEM operations retire in order); the "+v" operand ties every use of the vector behind the wait.
+// HAZARD the build checks for (tools/check_opaque_loads.py, run by ocrs_models_amd/build.py): the register allocator must not spill or copy a
+// destination vector between the load and its wait -- it believes the asm statement has completed -- which would store stale bytes.  The
+// checker disassembles every FULL kernel and fails the build if a register written by one of these loads is ever the source of a
+// scratch store or of a plain v_mov / v_accvgpr_write (with one prefetch set hipcc keeps them in place; two sets at the 128-register cap
+// do get spilled -- and an AGPR destination, which would rule spills out, makes hipcc split the 128 registers 64 | 64 and spill far more).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 gload16_opaque(const void* p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_tied(u32x4& r) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+}
+// wait for loads 0 .. NL-1 (issue order) of a prefetch set; NS operations (stores) were issued after the last of them
+template <int NL, int NS, int K = 0>
+__device__ __forceinline__ void static_for_wait(u32x4* v) {
+    if constexpr (K < NL) {
+        wait_vm_tied<NS + NL - 1 - K>(v[K]);
+        static_for_wait<NL, NS, K + 1>(v);
+    }
+}
+__device__ __forceinline__ Raw8<bf16> raw8_of(const u32x4& v) {
+    Raw8<bf16> r;
+    r.a = make_uint4(v.x, v.y, v.z, v.w);
+    return r;
+}
+
 // forward: Cin = 8 needs < 80 registers and ~10 KB of LDS: three blocks per CU (more bytes in flight: these launches are latency-bound)
 template <int CINB, int COUT>
 constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : ((CINB == 16 && COUT == 8) ? 2 * OCRS_MF_BPC16_8 : 4); }
@@ -155,7 +191,9 @@ constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minim
 // ----------------------------------------------------------------------------------------------------------------------------------
 // backward
 // ----------------------------------------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
+// FULL: see k_mm_fwd (every tile inside the image, direct gradient: unconditional stores, opaque prefetch loads with hand-written waits,
+// first tile peeled).
+template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS, bool FULL = false>
 __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
@@ -165,6 +203,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
     using C = MmCfg<CIN, COUT, PPOOL>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, TP = C::TP, DW_ = C::DW_, DP = C::DP, CGI = C::CGI, CGO = C::CGO, PD = C::PD, PX = C::PX;
     constexpr int MT = C::MT, NTO = C::NTO, KC = C::KC, NPW = C::NPW, KS = C::KS;
+    static_assert(!(FULL && PPOOL), "pooled launches have border tiles by construction (origin shift)");
     extern __shared__ __attribute__((aligned(64))) char smem[];
     bf16* tileD = reinterpret_cast<bf16*>(smem + C::OFF_D);   // [DP][PD]  dz on the domain (0 outside the image)
     bf16* tileX = reinterpret_cast<bf16*>(smem + C::OFF_X);   // [TP][PX]  x~ on the tile (0 outside the image)
@@ -199,7 +238,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
     __syncthreads();
     for (int f = tid; f < MT * KC * 64; f += NT) {
         const int l = f & 63, kc = (f >> 6) % KC, mt = (f >> 6) / KC;
-        const int m = mt * 16 + (l & 15);
+        const int m = (FULL && CIN == 8) ? (l & 7) : mt * 16 + (l & 15);  // FULL, CIN = 8: M rows 8..15 duplicate rows 0..7 (unconditional stores)
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -241,14 +280,31 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 
     // ---- software pipeline state: raw vectors of the NEXT tile
     constexpr int NG = PPOOL ? 1 : C::NGI, NP = PPOOL ? C::NWI : 1;
-    Raw8<bf16> zr[NG], g1r[NG], g2r[G2 ? NG : 1], xr[C::NXI];
+    // one array, issue order (FULL waits walk it): [j][z | g1 | g2] for the NG (z, g) items, then the x items
+    constexpr int GW = G2 ? 3 : 2, NLOADS = NG * GW + C::NXI;
+    // prefetch depth: ONE vector set.  (Round 3 tried two sets -- the loads of tile t+2 issued behind commit(t): at the 128-register cap hipcc
+    // spills the in-flight destination vectors, which an opaque load cannot survive; tools/check_opaque_loads.py catches exactly that.)
+    constexpr int PFD = 1;
+    u32x4 pf[PFD][NLOADS];
+    constexpr int NSTORE = NPW * MT;  // FULL: dL/dx stores every wave issues per tile, all unconditional
     uint2 zp[4 * NP], gp1[NP], gp2[G2 ? NP : 1];  // pooled: raw quads of the window's four z and of the pooled gradient(s)
-    unsigned okg = 0, okx = 0;  // validity bits
-    auto issue = [&](const TileOrg& o) {
+    unsigned okg_[PFD], okx_[PFD];  // validity bits of each set
+#pragma unroll
+    for (int q = 0; q < PFD; ++q) okg_[q] = okx_[q] = 0;
+    auto ld16 = [&](const bf16* p) -> u32x4 {
+        if constexpr (FULL) {
+            return gload16_opaque(p);
+        } else {
+            const uint4 q = *reinterpret_cast<const uint4*>(p);
+            return (u32x4){q.x, q.y, q.z, q.w};
+        }
+    };
+    auto issue = [&](const TileOrg& o, auto SET) {
+        constexpr int SI = decltype(SET)::value;
+        unsigned okg = 0, okx = 0;
         const int h00 = o.h0 + ORG - 1, w00 = o.w0 + ORG - 1;  // image coordinates of the domain's corner pixel (may lie outside)
         const long corner = ((long)o.n * H + h00) * W + w00;
         const bf16* zb = z + corner * COUT;
-        okg = okx = 0;
         if constexpr (!PPOOL) {
             const bf16* g1b = g1 + corner * COUT;
             const bf16* g2b = (G2 ? g2 : g1) + corner * COUT;
@@ -258,9 +314,9 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 const bool ok = (DP * CGO % NT == 0 || tid + j * NT < DP * CGO) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
                 const int goff = (dy * W + dx) * COUT + cgo * 8;
                 const bool ld = ok && !OCRS_MM_NOLOAD;
-                zr[j] = load8_raw(ld ? zb + goff : z);
-                g1r[j] = load8_raw(ld ? g1b + goff : g1);
-                if constexpr (G2) g2r[j] = load8_raw(ld ? g2b + goff : g2);
+                pf[SI][j * GW + 0] = ld16(ld ? zb + goff : z);
+                pf[SI][j * GW + 1] = ld16(ld ? g1b + goff : g1);
+                if constexpr (G2) pf[SI][j * GW + 2] = ld16(ld ? g2b + goff : g2);
                 okg |= ok ? 1u << j : 0u;
             }
         } else {
@@ -290,9 +346,11 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             const int p = (tid + j * NT) / CGI, ty = p / TW, tx = p % TW;
             const int h = o.h0 + ORG + ty, w = o.w0 + ORG + tx;
             const bool ok = (TP * CGI % NT == 0 || tid + j * NT < TP * CGI) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-            xr[j] = load8_raw((ok && !OCRS_MM_NOLOAD) ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
+            pf[SI][NG * GW + j] = ld16((ok && !OCRS_MM_NOLOAD) ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
             okx |= ok ? 1u << j : 0u;
         }
+        okg_[SI] = okg;
+        okx_[SI] = okx;
     };
 
     // ---- dgrad (dx~) MFMA bookkeeping: B-fragment offset of chunk kc for this lane.  k = kc*32 + (lane>>4)*8 .. +7 lies inside ONE tap;
@@ -364,11 +422,22 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 #define MM_MARK(i)
 #endif
     TileSched ts(tg.ntiles);
-    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);
-    TileOrg org_next = tit.org();
-    if (ts.first < ts.end) issue(org_next);
-    for (long t = ts.first; t < ts.end; t += ts.step) {
-        const TileOrg org = org_next;
+    TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);  // (points at the newest tile whose loads were issued)
+    TileOrg orgs[PFD];
+    orgs[0] = tit.org();
+    using I0 = std::integral_constant<int, 0>;
+    if (ts.first < ts.end) issue(orgs[0], I0{});
+    // KIND: 0 = first tile of the block, 2 = steady state -- the number of operations issued after this tile's loads differs
+    auto tile_body = [&](long t, auto KIND, auto SET) __attribute__((always_inline)) {
+        constexpr int SI = decltype(SET)::value, KI = decltype(KIND)::value;
+        const TileOrg org = orgs[SI];
+        const unsigned okg = okg_[SI], okx = okx_[SI];
+        if constexpr (FULL) {
+            // the hand-written waits.  Issue order: L0 | L1 S0 | L2 S1 ... (loads of the next tile behind the commit, then this tile's NSTORE
+            // epilogue stores) -> operations younger than Lt at the top of tile t: 0 for the block's first tile, NSTORE afterwards
+            constexpr int YOUNGER = KI == 0 ? 0 : NSTORE;
+            static_for_wait<NLOADS, YOUNGER>(pf[SI]);
+        }
         MM_MARK(4)
         // ================= phase 1: commit the prefetched tile: dz -> tileD, x~ -> tileX =================
         // Four channels at a time (the five per-channel coefficient vectors of a half are 20 registers instead of 40; 8-byte LDS stores).
@@ -386,11 +455,11 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                         float dz[4] = {0.f, 0.f, 0.f, 0.f};
                         if (okg & (1u << j)) {
                             float zv[4], ga[4];
-                            half4(zr[j], hf, zv);
-                            half4(g1r[j], hf, ga);
+                            half4(raw8_of(pf[SI][j * GW + 0]), hf, zv);
+                            half4(raw8_of(pf[SI][j * GW + 1]), hf, ga);
                             if constexpr (G2) {
                                 float gb[4];
-                                half4(g2r[j], hf, gb);
+                                half4(raw8_of(pf[SI][j * GW + 2]), hf, gb);
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) ga[i] += gb[i];
                             }
@@ -463,7 +532,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             for (int j = 0; j < C::NXI; ++j) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (okx & (1u << j)) {
-                    half4(xr[j], hf, v);
+                    half4(raw8_of(pf[SI][NG * GW + j]), hf, v);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
                 }
@@ -474,8 +543,8 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         MM_MARK(0)
         if (t + ts.step < ts.end) {
             tit.next();
-            org_next = tit.org();
-            issue(org_next);
+            orgs[SI] = tit.org();
+            issue(orgs[SI], SET);
         }
         lds_barrier();
         MM_MARK(1)
@@ -531,17 +600,27 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                     }
                 }
                 const int m0 = b * 16 + (lane >> 4) * 4;
-                const bool in_a = m0 < x.Ca;
-                const int voff = l15 * (in_a ? x.Ca : x.Cb) + (in_a ? m0 : m0 - x.Ca);  // element offset of this lane's 4 channels from the N tile's first pixel
+                const int ms = (FULL && CIN == 8) ? (m0 & 7) : m0;  // (duplicate rows store to the address of the row they duplicate)
+                const bool in_a = ms < x.Ca;
+                const int voff = l15 * (in_a ? x.Ca : x.Cb) + (in_a ? ms : ms - x.Ca);  // element offset of this lane's 4 channels from the N tile's first pixel
                 float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int a = 0; a < NPW; ++a) {
                     const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
-                    const bool pv = !OCRS_MM_NOSTORE && (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W;
+                    const bool pv = FULL || (!OCRS_MM_NOSTORE && (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W);
                     const long srow = tb + (long)ty * W + tx0;  // (scalar)
+                    if constexpr (FULL) {  // unconditional store, no divergent branch around it
+                        const f32x4 v = acc[a];
+                        bf16* dst = (in_a ? gxa + srow * x.Ca : gxb + srow * x.Cb) + voff;
+                        // (H need not be a multiple of the tile height: an N tile is one tile row -- rows below the image go to the block's
+                        //  scratch lines behind the partials in ws, a wave-uniform select)
+                        const bool row_ok = org.h0 + ty < H;
+                        dst = row_ok ? dst : reinterpret_cast<bf16*>(ws + (long)gridDim.x * C::PART + (long)blockIdx.x * 1024) + tid * 4;
+                        store4(dst, v[0], v[1], v[2], v[3]);
+                    }
                     if (m0 < CIN) {
                         const f32x4 v = acc[a];
-                        if (pv) {
+                        if (pv && !FULL) {
 #if OCRS_MM_EPI == 2
                             bf16* pa = gxa + srow * x.Ca;
                             bf16* pb = gxb + srow * x.Cb;
@@ -665,6 +744,20 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         }
         MM_MARK(3)
         lds_barrier();  // all readers of the tiles are done before the next commit
+    };
+    {
+        using K0 = std::integral_constant<int, 0>;
+        using K2 = std::integral_constant<int, 2>;
+        long t = ts.first;
+        if constexpr (FULL) {
+            if (t < ts.end) {
+                tile_body(t, K0{}, I0{});
+                t += ts.step;
+            }
+            for (; t < ts.end; t += ts.step) tile_body(t, K2{}, I0{});
+        } else {
+            for (; t < ts.end; t += ts.step) tile_body(t, K2{}, I0{});
+        }
     }
 #ifdef OCRS_MM_PROF
     if (blockIdx.x == 0 && tid == 0 && gxa) {
@@ -829,13 +922,19 @@ static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* t
     Tiling2 tg = make_tiling2(N, H + (PPOOL ? 1 : 0), W + (PPOOL ? 1 : 0), CC::TW, CC::TH);  // pooled: origins shifted by -1 -> one more row / column of tiles may be needed
     tg.H = H;
     tg.W = W;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
-        attr_set = true;
+    // (the attribute is set per call: it is per device, this runs on any thread, and it is a cheap host-side update -- ADVICE r02)
+    static const int full_on = env_int("OCRS_MM_FULL", 1);
+    if constexpr (!PPOOL) {
+        if (full_on && W % CC::TW == 0) {  // every tile COLUMN inside the image: unconditional stores + hand-written prefetch waits
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+            OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef,
+                          gxa, gxb, ws, tg, fin);
+            return;
+        }
     }
-    OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
-                       ws, tg, fin);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+    OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, false>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
+                  ws, tg, fin);
 }
 
 template <int CIN, int COUT>
@@ -866,7 +965,7 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout, 0)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout, 1));
-    return (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin);
+    return (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin + 1024);  // per block: its partials + 4 KB of scratch lines (stores of rows below the image)
 }
 
 // Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
@@ -961,7 +1060,17 @@ struct MfCfg {
 };
 }  // namespace
 
-template <int CINB, int NST, int COUT, bool POOL>
+// FULL (the launcher sets it when every tile lies inside the image: H % TH == 0, W % TW == 0, even sizes when pooling): every global store of
+// the tile loop is then UNCONDITIONAL for every lane (no divergent branch around a store) and the first tile is peeled out of the loop.
+// Why it matters: hipcc derives the `s_waitcnt vmcnt(N)` in front of the first use of a prefetched vector from the operations that are
+// pending on EVERY path into that point.  The prefetch loads of tile t+1 are issued before tile t's epilogue stores, and VMEM operations
+// retire in order, so the right wait is vmcnt(#stores + younger loads).  With a store inside a divergent `if` (a skippable block) or with the
+// loop entered straight from the prologue (no stores pending on that path) the count that holds on every path is vmcnt(younger loads) -- and
+// then every wave waits, once per tile, until the previous tile's stores are ACKNOWLEDGED by memory before it may touch the next tile's
+// input (measured: that wait, not HBM latency or bandwidth, was the largest stall of these kernels).  Lanes that hold no output channel
+// (M rows 8..15 of the 16-row MFMA tile when COUT = 8) carry a duplicate of rows 0..7 (duplicated weight rows) and store the same bytes to
+// the same address; the two lanes of a max-pool pair likewise.
+template <int CINB, int NST, int COUT, bool POOL, bool FULL>
 __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
                                                    bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
@@ -994,7 +1103,7 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     __syncthreads();
     for (int f = tid; f < NST * MT * KC * 64; f += NT) {
         const int l = f & 63, kc = (f >> 6) % KC, mt = ((f >> 6) / KC) % MT, st = (f >> 6) / (KC * MT);
-        const int m = mt * 16 + (l & 15);
+        const int m = (FULL && COUT == 8) ? (l & 7) : mt * 16 + (l & 15);  // FULL, COUT = 8: rows 8..15 duplicate rows 0..7
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1013,8 +1122,10 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
         const int d = (tid + j * NT) / CGB, dy = d / DW_, dx = d - dy * DW_;
         xi_dyx[j] = dy | (dx << 16);
     }
-    Raw8<bf16> xr[NST][C::NXI];
+    u32x4 xr[NST][C::NXI];
     unsigned okx = 0;
+    constexpr int NSTORE = NPW * MT + (POOL ? (NPW / 2) * MT : 0);  // FULL: stores every wave issues per tile, all unconditional
+    constexpr int NLOAD = NST * C::NXI;
     auto issue = [&](const TileOrg& o) {
         okx = 0;
         const long corner = ((long)o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);
@@ -1029,8 +1140,24 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
             for (int j = 0; j < C::NXI; ++j) {
                 const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
                 const bool ok = (DP * CGB % NT == 0 || tid + j * NT < DP * CGB) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-                xr[st][j] = load8_raw(ok ? cb + (dy * W + dx) * pitch : base);
+                const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
+                if constexpr (FULL) {
+                    xr[st][j] = gload16_opaque(src);
+                } else {
+                    const uint4 q = *reinterpret_cast<const uint4*>(src);
+                    xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
+                }
                 okx |= ok ? 1u << (st * C::NXI + j) : 0u;
+            }
+        }
+    };
+    // FULL: the hand-written waits.  `pend_stores`: the previous tile's epilogue stores were issued after these loads (false for the first tile)
+    auto wait_loads = [&](bool pend_stores) {
+        if constexpr (FULL) {
+            if (pend_stores) {
+                static_for_wait<NLOAD, NSTORE>(&xr[0][0]);
+            } else {
+                static_for_wait<NLOAD, 0>(&xr[0][0]);
             }
         }
     };
@@ -1070,7 +1197,8 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
         for (int b = 0; b < MT; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = b * 16 + (lane >> 4) * 4 + i;
+                int m = b * 16 + (lane >> 4) * 4 + i;
+                if (FULL && COUT == 8) m &= 7;  // (the duplicate rows must select like the rows they duplicate)
                 sg[b][i] = (m < COUT && gamma[m] < 0.f) ? -1.f : 1.f;
             }
     }
@@ -1079,8 +1207,9 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     TileIter<TW, TH> tit(tg, ts.first < ts.end ? ts.first : 0, ts.step);
     TileOrg org_next = tit.org();
     if (ts.first < ts.end) issue(org_next);
-    for (long t = ts.first; t < ts.end; t += ts.step) {
+    auto tile_body = [&](long t, bool first) __attribute__((always_inline)) {
         const TileOrg org = org_next;
+        wait_loads(!first);
         f32x4 acc[NPW][MT];
 #pragma unroll
         for (int a = 0; a < NPW; ++a)
@@ -1100,7 +1229,7 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                     if (DP * CGB % NT == 0 || it < DP * CGB) {
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (okx & (1u << (st * C::NXI + j))) {
-                            half4(xr[st][j], hf, v);
+                            half4(raw8_of(xr[st][j]), hf, v);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
                         }
@@ -1152,14 +1281,18 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
         const long tb = ((long)org.n * H + org.h0) * W + org.w0;
 #pragma unroll
         for (int a = 0; a < NPW; ++a) {
-            const bool pv = org.h0 + pty[a] < H && org.w0 + ptx0[a] + l15 < W;
+            const bool pv = FULL || (org.h0 + pty[a] < H && org.w0 + ptx0[a] + l15 < W);
             bf16* zrow = z + (tb + (long)pty[a] * W + ptx0[a]) * COUT;  // (scalar)
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int m0 = b * 16 + (lane >> 4) * 4;
+                const f32x4 v = acc[a][b];
+                if constexpr (FULL) {  // unconditional store (duplicate rows -> same bytes, same address); statistics from the real rows only
+                    store4(zrow + l15 * COUT + (COUT == 8 ? (m0 & 7) : m0), v[0], v[1], v[2], v[3]);
+                } else {
+                    if (pv && m0 < COUT) store4(zrow + l15 * COUT + m0, v[0], v[1], v[2], v[3]);
+                }
                 if (pv && m0 < COUT) {
-                    const f32x4 v = acc[a][b];
-                    store4(zrow + l15 * COUT + m0, v[0], v[1], v[2], v[3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float q = Elem<bf16>::round(v[i]);
@@ -1186,12 +1319,28 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                         const float vv = fmaxf(v0, v1);
                         m4[i] = sg[b][i] * fmaxf(vv, dpp_f<0xB1>(vv));  // quad_perm [1,0,3,2]: the horizontally adjacent pixel
                     }
-                    if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
-                        store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
+                    if constexpr (FULL) {  // (both lanes of a pair hold the same maximum and store it to the same address)
+                        store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + (COUT == 8 ? (m0 & 7) : m0), m4[0], m4[1], m4[2], m4[3]);
+                    } else {
+                        if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
+                            store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
+                    }
                 }
             }
         }
         lds_barrier();  // all readers of tileX are done before the next commit
+    };
+    {
+        long t = ts.first;
+        if constexpr (FULL) {  // peeled first tile: the loop header then only sees states with the previous tile's stores pending
+            if (t < ts.end) {
+                tile_body(t, true);
+                t += ts.step;
+            }
+            for (; t < ts.end; t += ts.step) tile_body(t, false);
+        } else {
+            for (; t < ts.end; t += ts.step) tile_body(t, false);
+        }
     }
     // ---- statistics: lanes -> wave slots -> block partial [COUT][sum | sum of squares] (fixed order: deterministic)
 #pragma unroll
@@ -1264,16 +1413,20 @@ static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* tr
                           bf16* pooled, int N, int H, int W, int nb, hipStream_t st) {
     using CC = MfCfg<CINB, NST, COUT>;
     const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
-        attr_set = true;
+    // (set per call: the attribute is per device and this is called from any thread; it is a cheap host-side table update)
+    static const int full_on = env_int("OCRS_MM_FULL", 1);
+    const bool full = full_on && H % CC::TH == 0 && W % CC::TW == 0 && (!pooled || ((H | W) & 1) == 0);
+#define MF_LAUNCH(PO_, FU_)                                                                                                                          \
+    {                                                                                                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, PO_, FU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled); \
     }
-    if (pooled)
-        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled);
-    else
-        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, false>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled);
+    if (pooled) {
+        if (full) MF_LAUNCH(true, true) else MF_LAUNCH(true, false)
+    } else {
+        if (full) MF_LAUNCH(false, true) else MF_LAUNCH(false, false)
+    }
+#undef MF_LAUNCH
 }
 
 extern "C" {

@@ -351,9 +351,12 @@ def test_matrix_core_block_backward_matches_separate_kernels(dev, C0, Ca, Cb, Cc
         assert torch.equal(rep[0][4][k], rep[1][4][k]), k  # the producers' fused BatchNorm-backward sums (fp64, single writer)
 
 
+# (2, 21, 37): border-cut tiles; (4, 192, 256): whole tiles (the unconditional-store kernels with hand-written prefetch waits), 1-2 tiles per block;
+# (3, 45, 64): whole tile columns, last tile row cut (its stores go to the scratch lines)
+@pytest.mark.parametrize("shape", [(2, 21, 37), (4, 192, 256), (3, 45, 64)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("pooled", [0, 1])
 @pytest.mark.parametrize("C0,Ca,Cb,Cc", MM_CASES)
-def test_matrix_core_block_backward_matches_autograd_of_rounding_matched_oracle(dev, C0, Ca, Cb, Cc, pooled):
+def test_matrix_core_block_backward_matches_autograd_of_rounding_matched_oracle(dev, C0, Ca, Cb, Cc, pooled, shape):
     """ocrs_mm_fwd + ocrs_mm_bwd (the kernels the benchmark runs at levels 0-2) DIRECTLY against torch autograd over the rounding-matched
     oracle block -- not against the repository's other kernels: stored z, dL/dx of both concat halves, dWdw, dWpw, dgamma, dbeta; direct
     and max-pool-routed gradient sources, two gradient tensors, every instantiated channel shape incl. the 32|32 split, border-cut tiles."""
@@ -361,7 +364,7 @@ def test_matrix_core_block_backward_matches_autograd_of_rounding_matched_oracle(
 
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(11 + Ca + 3 * Cb + 7 * Cc + pooled)
-    N, H, W = 2, 21, 37
+    N, H, W = shape
     P, Bf = {}, {}
     cin = Ca + Cb
     P["C.seq.0.weight"] = (torch.randn(cin, 1, 3, 3, generator=g) / 3).to(dev)
