@@ -244,6 +244,10 @@ int ocrs_clip_grad_norm(const long long* table, const int* chunks, int nchunks, 
 /* torch.optim.Adam.step (ocrs_models/train_detection.py:97,378; train_rec.py:151,381). */
 int ocrs_adam_step(const long long* table, const int* chunks, int nchunks, float b1, float b2, float eps, float step_size, float bc2_sqrt,
                    const float* gscale, hipStream_t st);
+/* The same step in capturable form (a train step recorded into a hipGraph, ocrs_models_amd/graph.py): the step count is a device fp32 [1]
+   (incremented by this call before use), bias corrections are derived on the device; lr is the only per-step host scalar. */
+int ocrs_adam_step_dev(const long long* table, const int* chunks, int nchunks, double b1, double b2, float eps, double lr, float* step,
+                       const float* gscale, hipStream_t st);
 int ocrs_fill_f32(float* p, float v, long n, hipStream_t st);
 
 /* Measurement support (csrc/prof.hip): while enabled, every launch of the DepthwiseConv block-backward families records its start / stop timestamps

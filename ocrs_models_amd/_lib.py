@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OCRS_LIB_PATH") or os.path.join(_HERE, "libocrs_hip.so")  # (OCRS_LIB_PATH: measurement builds, tools/build_variant.sh)
 
-_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "s": ctypes.c_void_p}
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double, "s": ctypes.c_void_p}
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ocrs_hip.h")
 
@@ -41,6 +41,8 @@ def parse_header(path: str = HEADER_PATH):
                     sig += "i"
                 elif a.startswith("float"):
                     sig += "f"
+                elif a.startswith("double"):
+                    sig += "d"
                 else:
                     raise RuntimeError(f"unparsed argument {a!r} of {name}")
         sigs[name] = ("i" if res == "int" else "l", sig)

@@ -390,6 +390,33 @@ __global__ __launch_bounds__(256) void k_multi_adam(const long long* __restrict_
     }
 }
 
+// Capturable form (hipGraph replay): the step count lives on the device; every block derives the bias corrections from it (double powers of
+// the betas, as torch.optim.Adam's capturable path does), a one-thread launch in front increments it.
+__global__ void k_step_inc(float* step) { *step += 1.f; }
+__global__ __launch_bounds__(256) void k_multi_adam_dev(const long long* __restrict__ table, const int* __restrict__ chunks, double b1d, double b2d,
+                                                        float eps, double lr, const float* __restrict__ step, const float* __restrict__ gscale) {
+    const float b1 = (float)b1d, b2 = (float)b2d;  // (the moment updates use fp32 betas like k_multi_adam; the bias corrections the exact doubles)
+    const int t = chunks[2 * blockIdx.x], ch = chunks[2 * blockIdx.x + 1];
+    float* p = reinterpret_cast<float*>(table[5 * t + 0]);
+    const float* g = reinterpret_cast<const float*>(table[5 * t + 1]);
+    float* m = reinterpret_cast<float*>(table[5 * t + 2]);
+    float* v = reinterpret_cast<float*>(table[5 * t + 3]);
+    const long n = table[5 * t + 4];
+    const double st = (double)*step;
+    const float step_size = (float)(lr / (1.0 - pow(b1d, st)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(b2d, st));
+    const float gs = gscale ? *gscale : 1.f;
+    for (long i = (long)ch * OPT_CHUNK + threadIdx.x; i < n && i < (long)(ch + 1) * OPT_CHUNK; i += 256) {
+        const float gi = g[i] * gs;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
 __global__ void k_fill_f32(float* p, float v, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
@@ -472,6 +499,17 @@ int ocrs_adam_step(const long long* table, const int* chunks, int nchunks, float
                    const float* gscale, hipStream_t st) {
     OCRS_CHECK_ARG(table && chunks && nchunks > 0);
     hipLaunchKernelGGL(k_multi_adam, dim3(nchunks), dim3(256), 0, st, table, chunks, b1, b2, eps, step_size, bc2_sqrt, gscale);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// The same step with the step count on the device (fp32 [1], incremented here before use) and the learning rate as the only host scalar:
+// nothing in the launch arguments changes from step to step, so a captured train step (hipGraph) replays correctly.
+int ocrs_adam_step_dev(const long long* table, const int* chunks, int nchunks, double b1, double b2, float eps, double lr, float* step,
+                       const float* gscale, hipStream_t st) {
+    OCRS_CHECK_ARG(table && chunks && nchunks > 0 && step);
+    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step);
+    hipLaunchKernelGGL(k_multi_adam_dev, dim3(nchunks), dim3(256), 0, st, table, chunks, b1, b2, eps, lr, step, gscale);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -1758,7 +1758,7 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
 
 // Conv2d(1,32,3,p1)+ReLU+MaxPool2d(2) fused (models.py:180-187): img fp32 (N,1,H,W) -> out [N][H/2][W/2][32].
 int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(img && w && bias && out && H % 2 == 0 && W % 2 == 0);
+    OCRS_CHECK_ARG(img && w && bias && out && H >= 2 && W >= 2);  // (odd sizes: floor-mode pooling, the last row / column is in no window)
     const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
     if (dtype == 1)
         hipLaunchKernelGGL(k_conv0_fwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (bf16*)out, N, H, W);

@@ -14,7 +14,7 @@ from ._lib import lib, ptr
 class _Table:
     """Device pointer table {param, grad, exp_avg, exp_avg_sq, numel} + (tensor, chunk) work list."""
 
-    def __init__(self, params, grads, m=None, v=None):
+    def __init__(self, params, grads, m=None, v=None, reuse=None):
         L = lib()
         chunk = L.opt_chunk()
         dev = params[0].device
@@ -23,9 +23,20 @@ class _Table:
             rows.append([p.data_ptr(), g.data_ptr(), m[i].data_ptr() if m else 0, v[i].data_ptr() if v else 0, p.numel()])
             chunks += [[i, c] for c in range((p.numel() + chunk - 1) // chunk)]
         # gradient pointers change every step (autograd allocates fresh .grad tensors), so this table is rebuilt per step:
-        # stage it in pinned memory and copy asynchronously -- a pageable H2D copy would synchronise the host with the GPU
-        self.table = torch.tensor(rows, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
-        self.chunks = torch.tensor(chunks, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+        # stage it in pinned memory and copy asynchronously -- a pageable H2D copy would synchronise the host with the GPU.
+        # The pinned staging tensors and the device tensors are kept and RE-USED by the next rebuild of the same shape (`reuse`): no
+        # allocation call on the rebuild path (a pinned allocation is not permitted while a stream is capturing), and a copy recorded
+        # into a hipGraph finds its source bytes again at every replay.
+        if reuse is not None and reuse._host[0].shape == (len(rows), 5) and reuse._host[1].shape == (len(chunks), 2):
+            self._host, self.table, self.chunks = reuse._host, reuse.table, reuse.chunks
+            self._host[0].copy_(torch.tensor(rows, dtype=torch.int64))
+            self._host[1].copy_(torch.tensor(chunks, dtype=torch.int32))
+            self.table.copy_(self._host[0], non_blocking=True)
+            self.chunks.copy_(self._host[1], non_blocking=True)
+        else:
+            self._host = (torch.tensor(rows, dtype=torch.int64).pin_memory(), torch.tensor(chunks, dtype=torch.int32).pin_memory())
+            self.table = self._host[0].to(dev, non_blocking=True)
+            self.chunks = self._host[1].to(dev, non_blocking=True)
         self.nchunks = len(chunks)
         self.key = tuple(r[1] for r in rows)
 
@@ -33,10 +44,15 @@ class _Table:
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam (lr 1e-3, betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) as one kernel launch."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
         self.grad_scale = None  # optional device fp32[1] multiplied into every gradient (fused clip)
+        # capturable (torch.optim.Adam's flag of the same name): the step count lives on the device and the bias corrections are derived
+        # there, so step() can be recorded into a hipGraph and replayed (graph.GraphedTrainStep); the per-parameter state["step"] mirrors
+        # the host-side count for checkpoints
+        self.capturable = capturable
+        self._dev_step = {}
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -73,17 +89,25 @@ class Adam(torch.optim.Optimizer):
                    + tuple(self.state[p]["exp_avg"].data_ptr() for p in ps) + tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in ps))
             tb = self._tables.get(gi)
             if tb is None or tb[0] != key:
-                t = _Table(ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps])
+                t = _Table(ps, [p.grad for p in ps], [self.state[p]["exp_avg"] for p in ps], [self.state[p]["exp_avg_sq"] for p in ps],
+                           reuse=tb[1] if tb is not None else None)
                 tb = (key, t)
                 self._tables[gi] = tb
             t = tb[1]
+            if self.capturable:
+                ds = self._dev_step.get(gi)
+                if ds is None:
+                    ds = self._dev_step[gi] = torch.full((1,), float(self.state[ps[0]]["step"]), dtype=torch.float32, device=ps[0].device)
             for p in ps:
                 self.state[p]["step"] += 1
             step = self.state[ps[0]]["step"]
             b1, b2 = group["betas"]
-            step_size = group["lr"] / (1.0 - b1 ** step)
-            bc2_sqrt = math.sqrt(1.0 - b2 ** step)
-            L.adam_step(ptr(t.table), ptr(t.chunks), t.nchunks, b1, b2, group["eps"], step_size, bc2_sqrt, ptr(self.grad_scale))
+            if self.capturable:
+                L.adam_step_dev(ptr(t.table), ptr(t.chunks), t.nchunks, b1, b2, group["eps"], group["lr"], ptr(ds), ptr(self.grad_scale))
+            else:
+                step_size = group["lr"] / (1.0 - b1 ** step)
+                bc2_sqrt = math.sqrt(1.0 - b2 ** step)
+                L.adam_step(ptr(t.table), ptr(t.chunks), t.nchunks, b1, b2, group["eps"], step_size, bc2_sqrt, ptr(self.grad_scale))
         self.grad_scale = None
         return loss
 

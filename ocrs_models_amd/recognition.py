@@ -174,8 +174,9 @@ class _RecRun:
         L, P, N, H, W = self.L, self.P, self.N, self.H, self.W
         if H != 64:
             raise RuntimeError(f"RecognitionModel expects input height 64 (models.py:153), got {H}")
-        if W % 4 != 0:
-            raise RuntimeError(f"input width must be a multiple of 4 (two 2x2 max-pools), got {W}")
+        if W < 4:
+            raise RuntimeError(f"input width must be at least 4 (two floor-mode 2x2 max-pools, models.py:187,199), got {W}")
+        # any width: nn.MaxPool2d floors (the last odd column is in no window), exactly as the kernels' W // 2 -> W // 4 below
         S = self
         self.prepack()
         S.a0 = self.empty(N, 32, W // 2, 32)
