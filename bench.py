@@ -460,6 +460,7 @@ def main():
     ap.add_argument("--no-gru-exact", action="store_true", help="skip the second CRNN timing with the other GRU GEMM mode")
     ap.add_argument("--no-ref-style", action="store_true", help="skip the reference-style step (H2D copy + loss.item() inside the step)")
     ap.add_argument("--no-ddp-probe", action="store_true", help="skip the 1-rank RCCL probe of the gradient bucketer at N = 1")
+    ap.add_argument("--no-config1", action="store_true", help="skip the config-1-sized (B=2 x 512^2) eager vs hipGraph step")
     ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
     ap.add_argument("--rec-width", type=int, default=400)
     ap.add_argument("--rec-config5", action="store_true", help="also time the width-bucketed variable-width CRNN workload (default at N > 1)")
@@ -659,6 +660,52 @@ def main():
         out["reference_style_step"] = {"value": round(B * k / dtr, 2), "unit": "images/s", "ms_per_step": round(dtr / k * 1e3, 3), "steps": k,
                                        "h2d_in_step": True, "loss_item_per_step": True,
                                        "note": "pinned uint8 tile + mask batch copied H2D every step, transform_image on the device, loss.item() every step"}
+    if rank == 0 and world == 1 and not args.no_config1:
+        # BASELINE configs[0] sized step ON THE HIP PATH (B = 2 x 512^2; the CPU figure for the same step is cpu_baseline.det_config1_B2_512):
+        # eager (one ctypes call per launch: host-bound) vs graph.GraphedTrainStep (hipGraph replay: one host call per step)
+        out["config1_hip"] = {}
+        gB, gS = 2, 512
+        gg = torch.Generator(device=dev).manual_seed(0)
+        gx = torch.rand(gB, 1, gS, gS, generator=gg, device=dev) - 0.5
+        gt = (torch.rand(gB, 1, gS, gS, generator=gg, device=dev) > 0.9).float()
+        for name, act in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            torch.manual_seed(1234)
+            m1 = oa.DetectionModel(act_dtype=act).to(dev)
+            m1.train()
+            o1 = oa.optim.Adam(m1.parameters())
+
+            def eager():
+                loss = oa.balanced_cross_entropy_loss(m1(gx), gt)
+                o1.zero_grad()
+                loss.backward()
+                o1.step()
+
+            for _ in range(5):
+                eager()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                eager()
+            torch.cuda.synchronize()
+            te = (time.perf_counter() - t0) / 30
+            torch.manual_seed(1234)
+            m2 = oa.DetectionModel(act_dtype=act).to(dev)
+            m2.train()
+            o2 = oa.optim.Adam(m2.parameters(), capturable=True)
+            gstep = oa.graph.GraphedTrainStep(m2, o2, oa.balanced_cross_entropy_loss, gx, gt)
+            for _ in range(5):
+                gstep(gx, gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                gstep(gx, gt)
+            torch.cuda.synchronize()
+            tgr = (time.perf_counter() - t0) / 100
+            out["config1_hip"][name] = {"eager_ms_per_step": round(te * 1e3, 3), "eager_images_per_s": round(gB / te, 1),
+                                        "hipgraph_ms_per_step": round(tgr * 1e3, 3), "hipgraph_images_per_s": round(gB / tgr, 1)}
+            del m1, o1, m2, o2, gstep
+            torch.cuda.empty_cache()
+        out["config1_hip"]["workload"] = "detection train step, 2x1x512x512 (BASELINE configs[0]), seed 1234; eager = one C-ABI call per launch from Python, hipgraph = graph.GraphedTrainStep replay"
     if rank == 0 and world == 1 and not distributed and not args.no_ddp_probe:
         # the data-parallel machinery on this single GPU: a 1-rank RCCL group with OCRS_DDP_FORCE=1 -- every bucket's all-reduce is really
         # issued and waited for, so `exposed_allreduce_ms_per_step` is the cost the overlap does not hide at N = 1 (launch + wait latency)
