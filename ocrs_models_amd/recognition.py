@@ -514,7 +514,7 @@ class RecognitionModel(nn.Module):
     def _act_dtype(self):
         if self.act_dtype is not None:
             return self.act_dtype
-        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
             return torch.bfloat16
         return torch.float32
 

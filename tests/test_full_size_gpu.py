@@ -344,3 +344,55 @@ def test_recognition_wide_buckets_match_oracle(dev, W):
     assert max(eo) < 5e-3 and float(np.median(eo)) < 3e-4, (max(eo), float(np.median(eo)))
     dec, amax = oa.text.greedy_decode_batch(lp, il.tolist())
     assert torch.equal(amax.cpu().long(), lp_o.detach().argmax(-1).T)
+
+
+def test_recognition_config5_rank_share_bucketed_b256_fp16_lattice(dev):
+    """BASELINE configs[4] (SURVEY 8(d) "Config 5") as ONE rank of the 8-GPU job sees it: the width-bucketed distributed sampler's first
+    512-wide step for rank 3 of 8 (256 variable-width crops of the synthetic HierText-like population, collated to the bucket width), the
+    CRNN train step under bf16 autocast with the fp16 CTC lattice variant.  Checked: (i) the fp16-lattice loss equals the fp32-lattice loss
+    bit for bit and its gradients stay within 5e-3 of it (the variant's stated tolerance) on every tensor; (ii) run-to-run bit-stability of
+    log-probs / loss; (iii) the same batch's first 24 crops in fp32 parity mode against the CPU oracle (a size the host finishes in seconds)."""
+    import ocrs_models_amd as oa
+    from ocrs_models_amd.sampler import WidthBucketedDistributedSampler, config5_population, config5_sample
+    from ocrs_models_amd.text import collate_samples
+    from oracle import ctc as octc
+    from oracle import recognition as orec
+
+    torch.set_num_threads(32)
+    B, world, rank = 256, 8, 3
+    w, L = config5_population(B * world * 12, seed=5)
+    sch = WidthBucketedDistributedSampler(w, B, rank, world, seed=5).schedule()
+    bucket, idx = next((b, i) for b, i in sch if b == 512)
+    r = np.random.RandomState(17)
+    batch = collate_samples([config5_sample(w[i], L[i], r) for i in idx], pad_to=bucket)
+    assert batch["image"].shape == (B, 1, 64, 512)
+    il = batch["image_width"] // 4
+    m, P, Bf = _rec(91, dev)
+    m.train()
+    img = batch["image"].to(dev)
+    res = {}
+    for name, dt in (("f32", torch.float32), ("f16", torch.float16), ("f16b", torch.float16)):
+        m.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lp = m(img)
+            loss = oa.CTCLoss(lattice_dtype=dt)(lp, batch["text_seq"].to(dev), il, batch["text_len"])
+        loss.backward()
+        torch.cuda.synchronize()
+        res[name] = (lp.detach().clone(), loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    assert torch.isfinite(res["f32"][1]) and torch.equal(res["f16"][1], res["f32"][1])
+    assert torch.equal(res["f16"][0], res["f16b"][0]) and torch.equal(res["f16"][1], res["f16b"][1])
+    worst = max(rel(res["f16"][2][k], res["f32"][2][k]) for k in res["f32"][2])
+    print(f"config 5 rank share: T = {lp.shape[0]}, loss {float(res['f32'][1]):.4f}, fp16-lattice gradients within {worst:.1e} of the fp32-lattice ones")
+    assert worst < 5e-3
+    # (iii) fp32 parity on a sub-batch of the same crops
+    nb = 24
+    sub = {k: v[:nb] for k, v in batch.items()}
+    m2, P2, Bf2 = _rec(91, dev)
+    m2.train()
+    lp2, loss2, g2 = _rec_step(m2, sub["image"].to(dev), sub["text_seq"], sub["text_len"], il[:nb], False)
+    lp_o = orec.forward(P2, Bf2, sub["image"], True)
+    loss_o = octc.ctc_loss_torch(lp_o, sub["text_seq"], il[:nb].tolist(), sub["text_len"].tolist())
+    grads_o = torch.autograd.grad(loss_o, list(P2.values()))
+    assert rel(lp2, lp_o) < 1e-4 and abs(loss2 - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    eo = [rel(g2[k], go) for k, go in zip(P2, grads_o)]
+    assert max(eo) < 2e-2 and float(np.median(eo)) < 3e-4, (max(eo), float(np.median(eo)))
