@@ -14,6 +14,8 @@ from torch.optim import Optimizer
 
 def save_checkpoint(filename: str, model: nn.Module, optimizer: Optimizer, epoch: int):
     sd = optimizer.state_dict()
+    # Optimizer.state_dict() hands out the LIVE per-parameter state dicts: convert on a copy, never rewrite the running optimiser's ``step``
+    sd = {"state": {k: dict(v) for k, v in sd["state"].items()}, "param_groups": sd["param_groups"]}
     # torch.optim.Adam (>= 1.12) stores ``step`` as a 0-d fp32 tensor; write it that way so the file also loads into the stock optimiser
     for st in sd["state"].values():
         if "step" in st and not torch.is_tensor(st["step"]):

@@ -55,8 +55,15 @@ class Adam(torch.optim.Optimizer):
         self._dev_step = {}
 
     def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", []):
+            # a checkpoint of a stock torch.optim.Adam configured with features this kernel does not implement must not load silently
+            if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+                raise RuntimeError("ocrs_models_amd.optim.Adam implements plain Adam only (weight_decay = 0, amsgrad = False, maximize = False); "
+                                   f"the checkpoint's param_group has weight_decay={g.get('weight_decay')}, amsgrad={g.get('amsgrad')}, "
+                                   f"maximize={g.get('maximize')}")
         super().load_state_dict(state_dict)
         self._tables = {}  # the moment tensors were replaced: cached pointer tables are stale
+        self._dev_step = {}
 
     def __setstate__(self, state):
         super().__setstate__(state)

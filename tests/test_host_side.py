@@ -163,6 +163,21 @@ def test_checkpoint_file_format_roundtrip_with_stock_adam(tmp_path):
     for p, q in zip(m.parameters(), m3.parameters()):
         assert torch.equal(ref_opt.state[p]["exp_avg_sq"], opt3.state[q]["exp_avg_sq"])
         assert float(opt3.state[q]["step"]) == 2
+    # saving must not rewrite the RUNNING optimiser's state (Optimizer.state_dict() returns the live per-parameter dicts) ...
+    opt4 = oa.optim.Adam(m2.parameters())
+    for p in m2.parameters():
+        opt4.state[p] = {"step": 3, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+    save_checkpoint(os.path.join(tmp_path, "ckpt3.pt"), m2, opt4, epoch=1)
+    assert all(isinstance(st["step"], int) and st["step"] == 3 for st in opt4.state.values())
+    # ... and a stock checkpoint that relies on features the fused kernel lacks must not load silently
+    wd_opt = torch.optim.Adam(m.parameters(), weight_decay=0.01)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    wd_opt.step()
+    f4 = os.path.join(tmp_path, "ckpt4.pt")
+    save_checkpoint(f4, m, wd_opt, epoch=1)
+    with pytest.raises(RuntimeError, match="plain Adam only"):
+        load_checkpoint(f4, oa.DetectionModel(), oa.optim.Adam(oa.DetectionModel().parameters()), torch.device("cpu"))
 
 
 def test_reduce_lr_on_plateau_schedule_drives_adam_lr():

@@ -1,7 +1,7 @@
 """Round-3 experiment: bf16 HIP gradients vs the rounding-matched oracle, every parameter tensor."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ocrs_models_amd as oa
 from oracle import detection_bf16 as ob
 from oracle.params import detection_specs, make_state, state_dict_from

@@ -1,7 +1,7 @@
 """Layer-by-layer: stored z of every block, HIP bf16 vs rounding-matched oracle."""
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ocrs_models_amd as oa
 from ocrs_models_amd.models import _DetRun
 from oracle import detection_bf16 as ob
