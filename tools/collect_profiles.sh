@@ -1,5 +1,5 @@
-# Collects every profile artefact of a round into gpurun_out/prof_<tag>/ (copy to profiles/ afterwards).  usage: bash tools/collect_profiles.sh r02_final
-TAG=${1:-r02_final}
+# Collects every profile artefact of a round into gpurun_out/prof_<tag>/ (copy to profiles/ afterwards).  usage: bash tools/collect_profiles.sh r03_final
+TAG=${1:-r03_final}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
@@ -21,5 +21,8 @@ python tools/pmc_summary.py gpurun_out/pmc_mfma "k_conv_igemm<bf16|k_conv3x3_c12
 # 7. per-launch trace of one CRNN step
 rm -rf gpurun_out/trace_crnn; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_crnn -- python tools/prof_crnn.py --steps 3 --warmup 2 > gpurun_out/trace_crnn.log 2>&1
 python tools/trace_step.py gpurun_out/trace_crnn k_conv0_fwd > $OUT/${TAG}_crnn_step_trace.txt 2>&1
+# 8. CRNN: HBM bytes and achieved GB/s per kernel (two separate PMC passes)
+bash tools/run_pmc_hbm_crnn.sh ${TAG}_crnn_pmc_hbm.csv > $OUT/${TAG}_crnn_pmc_hbm.txt 2>&1; cp gpurun_out/${TAG}_crnn_pmc_hbm.csv $OUT/
+rm -rf gpurun_out/cpmc_f gpurun_out/cpmc_w
 rm -rf gpurun_out/ks gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/pmc_mfma gpurun_out/trace_crnn
 ls -la $OUT; head -c 700 $OUT/${TAG}_bench.json; echo; tail -3 $OUT/${TAG}_step_trace.txt; tail -2 $OUT/${TAG}_pmc_hbm.csv; head -30 $OUT/${TAG}_crnn_pmc_mfma.txt
