@@ -152,7 +152,7 @@ def pmc_profile():
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))  # rNN_ prefix: name order == round order (mtime does not survive a checkout)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")) if "_crnn_" not in os.path.basename(f))  # rNN_ prefix: name order == round order (mtime does not survive a checkout)
     if not files:
         return None, None
     rows = {}

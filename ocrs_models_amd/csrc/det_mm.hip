@@ -303,22 +303,31 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         constexpr int SI = decltype(SET)::value;
         unsigned okg = 0, okx = 0;
         const int h00 = o.h0 + ORG - 1, w00 = o.w0 + ORG - 1;  // image coordinates of the domain's corner pixel (may lie outside)
-        const long corner = ((long)o.n * H + h00) * W + w00;
-        const bf16* zb = z + corner * COUT;
+        // (pixel indices fit 32 bits: N (H + 2) (W + 2) < 2^31 is checked by the launcher; only the final element offset is 64-bit)
+        const int corner = (o.n * H + h00) * W + w00;
+        const bf16* zb = z + (long)corner * COUT;
+        // FULL: a tile whose whole domain lies inside the image (all but the outermost ring of tiles: >= 85 % of them from 512^2 up) skips
+        // the per-item bounds tests and address selects -- a scalar branch, both sides issue the same loads in the same order
+        const bool inside = FULL && h00 >= 0 && w00 >= 0 && h00 + C::DH_ <= H && w00 + DW_ <= W;
         if constexpr (!PPOOL) {
-            const bf16* g1b = g1 + corner * COUT;
-            const bf16* g2b = (G2 ? g2 : g1) + corner * COUT;
+            const bf16* g1b = g1 + (long)corner * COUT;
+            const bf16* g2b = (G2 ? g2 : g1) + (long)corner * COUT;
+            auto items = [&](auto INSIDE) {
 #pragma unroll
-            for (int j = 0; j < C::NGI; ++j) {
-                const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;
-                const bool ok = (DP * CGO % NT == 0 || tid + j * NT < DP * CGO) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-                const int goff = (dy * W + dx) * COUT + cgo * 8;
-                const bool ld = ok && !OCRS_MM_NOLOAD;
-                pf[SI][j * GW + 0] = ld16(ld ? zb + goff : z);
-                pf[SI][j * GW + 1] = ld16(ld ? g1b + goff : g1);
-                if constexpr (G2) pf[SI][j * GW + 2] = ld16(ld ? g2b + goff : g2);
-                okg |= ok ? 1u << j : 0u;
-            }
+                for (int j = 0; j < C::NGI; ++j) {
+                    const int dy = gi_dyx[j] & 0xffff, dx = gi_dyx[j] >> 16, h = h00 + dy, w = w00 + dx;
+                    const bool it_ok = (j + 1) * NT <= DP * CGO || tid + j * NT < DP * CGO;  // (a compile-time `true` for all but the last round)
+                    const bool ok = it_ok && (decltype(INSIDE)::value || ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W));
+                    const int goff = (dy * W + dx) * COUT + cgo * 8;
+                    const bool ld = ok && !OCRS_MM_NOLOAD;
+                    pf[SI][j * GW + 0] = ld16(ld ? zb + goff : z);
+                    pf[SI][j * GW + 1] = ld16(ld ? g1b + goff : g1);
+                    if constexpr (G2) pf[SI][j * GW + 2] = ld16(ld ? g2b + goff : g2);
+                    okg |= ok ? 1u << j : 0u;
+                }
+            };
+            if (inside) items(std::true_type{});
+            else items(std::false_type{});
         } else {
             const int Hp = H >> 1, Wp = W >> 1;
 #pragma unroll
@@ -334,21 +343,26 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 }
                 const int ph = h >> 1, pw = w >> 1;
                 const bool gv = it_ok && h >= 0 && w >= 0 && ph < Hp && pw < Wp;  // floor mode: the last odd row / column is in no window
-                const long pp = ((long)o.n * Hp + ph) * Wp + pw;
+                const long pp = (o.n * Hp + ph) * Wp + pw;
                 gp1[j] = *reinterpret_cast<const uint2*>((gv && !OCRS_MM_NOLOAD) ? g1 + pp * COUT + cq4 : g1);
                 if constexpr (G2) gp2[j] = *reinterpret_cast<const uint2*>((gv && !OCRS_MM_NOLOAD) ? g2 + pp * COUT + cq4 : g2);
                 okg |= gv ? 1u << (16 + j) : 0u;
             }
         }
-        const long tb = ((long)o.n * H + (o.h0 + ORG)) * W + (o.w0 + ORG);
+        const int tb = (o.n * H + (o.h0 + ORG)) * W + (o.w0 + ORG);
+        auto xitems = [&](auto INSIDE) {
 #pragma unroll
-        for (int j = 0; j < C::NXI; ++j) {
-            const int p = (tid + j * NT) / CGI, ty = p / TW, tx = p % TW;
-            const int h = o.h0 + ORG + ty, w = o.w0 + ORG + tx;
-            const bool ok = (TP * CGI % NT == 0 || tid + j * NT < TP * CGI) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-            pf[SI][NG * GW + j] = ld16((ok && !OCRS_MM_NOLOAD) ? xi_base + (tb + (long)ty * W + tx) * xi_pitch : xi_base);
-            okx |= ok ? 1u << j : 0u;
-        }
+            for (int j = 0; j < C::NXI; ++j) {
+                const int p = (tid + j * NT) / CGI, ty = p / TW, tx = p % TW;
+                const int h = o.h0 + ORG + ty, w = o.w0 + ORG + tx;
+                const bool it_ok = (j + 1) * NT <= TP * CGI || tid + j * NT < TP * CGI;
+                const bool ok = it_ok && (decltype(INSIDE)::value || ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W));
+                pf[SI][NG * GW + j] = ld16((ok && !OCRS_MM_NOLOAD) ? xi_base + (long)(tb + ty * W + tx) * xi_pitch : xi_base);
+                okx |= ok ? 1u << j : 0u;
+            }
+        };
+        if (FULL && inside) xitems(std::true_type{});
+        else xitems(std::false_type{});
         okg_[SI] = okg;
         okx_[SI] = okx;
     };
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
                 pbase[a] = (ty * DW_ + tx0 + l15) * PD;
             }
-            const long tb = ((long)org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
+            const int tb = (org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 f32x4 acc[NPW];
@@ -608,7 +622,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 for (int a = 0; a < NPW; ++a) {
                     const int k = wave * NPW + a, ty = k / (TW / 16), tx0 = (k % (TW / 16)) * 16;
                     const bool pv = FULL || (!OCRS_MM_NOSTORE && (unsigned)(org.h0 + ORG + ty) < (unsigned)H && (unsigned)(org.w0 + ORG + tx0 + l15) < (unsigned)W);
-                    const long srow = tb + (long)ty * W + tx0;  // (scalar)
+                    const long srow = tb + ty * W + tx0;  // (scalar)
                     if constexpr (FULL) {  // unconditional store, no divergent branch around it
                         const f32x4 v = acc[a];
                         bf16* dst = (in_a ? gxa + srow * x.Ca : gxb + srow * x.Cb) + voff;
@@ -755,6 +769,9 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 t += ts.step;
             }
             for (; t < ts.end; t += ts.step) tile_body(t, K2{}, I0{});
+            // (nothing is in flight here -- the last tile issues no prefetch -- but only this wait lets tools/check_opaque_loads.py, which
+            //  follows every static path, see it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             for (; t < ts.end; t += ts.step) tile_body(t, K2{}, I0{});
         }
@@ -1128,27 +1145,34 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     constexpr int NLOAD = NST * C::NXI;
     auto issue = [&](const TileOrg& o) {
         okx = 0;
-        const long corner = ((long)o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);
+        const int corner = (o.n * H + (o.h0 - 1)) * W + (o.w0 - 1);  // (pixel indices fit 32 bits, see the launcher's check)
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             const int c0 = st * CINB + cgb * 8;
             const bool in_a = c0 < x.Ca;
             const bf16* base = in_a ? x.a + c0 : x.b + (c0 - x.Ca);
             const int pitch = in_a ? x.Ca : x.Cb;
-            const bf16* cb = base + corner * pitch;
+            const bf16* cb = base + (long)corner * pitch;
+            auto items = [&](auto INSIDE) {
 #pragma unroll
-            for (int j = 0; j < C::NXI; ++j) {
-                const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
-                const bool ok = (DP * CGB % NT == 0 || tid + j * NT < DP * CGB) && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-                const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
-                if constexpr (FULL) {
-                    xr[st][j] = gload16_opaque(src);
-                } else {
-                    const uint4 q = *reinterpret_cast<const uint4*>(src);
-                    xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
+                for (int j = 0; j < C::NXI; ++j) {
+                    const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
+                    const bool it_ok = (j + 1) * NT <= DP * CGB || tid + j * NT < DP * CGB;  // (a compile-time `true` for all but the last round)
+                    const bool ok = it_ok && (decltype(INSIDE)::value || ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W));
+                    const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
+                    if constexpr (FULL) {
+                        xr[st][j] = gload16_opaque(src);
+                    } else {
+                        const uint4 q = *reinterpret_cast<const uint4*>(src);
+                        xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
+                    }
+                    okx |= ok ? 1u << (st * C::NXI + j) : 0u;
                 }
-                okx |= ok ? 1u << (st * C::NXI + j) : 0u;
-            }
+            };
+            // FULL: a tile whose whole domain lies inside the image skips the per-item bounds tests and address selects (scalar branch; both
+            // sides issue the same loads in the same order)
+            if (FULL && o.h0 >= 1 && o.w0 >= 1 && o.h0 + TH + 1 <= H && o.w0 + TW + 1 <= W) items(std::true_type{});
+            else items(std::false_type{});
         }
     };
     // FULL: the hand-written waits.  `pend_stores`: the previous tile's epilogue stores were issued after these loads (false for the first tile)
@@ -1278,11 +1302,11 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
             }
         }
         // ---- epilogue: store z (4 consecutive channels per lane), statistics of the STORED values, optional 2x2 max-pool
-        const long tb = ((long)org.n * H + org.h0) * W + org.w0;
+        const int tb = (org.n * H + org.h0) * W + org.w0;
 #pragma unroll
         for (int a = 0; a < NPW; ++a) {
             const bool pv = FULL || (org.h0 + pty[a] < H && org.w0 + ptx0[a] + l15 < W);
-            bf16* zrow = z + (tb + (long)pty[a] * W + ptx0[a]) * COUT;  // (scalar)
+            bf16* zrow = z + (long)(tb + pty[a] * W + ptx0[a]) * COUT;  // (scalar)
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int m0 = b * 16 + (lane >> 4) * 4;
@@ -1320,10 +1344,10 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                         m4[i] = sg[b][i] * fmaxf(vv, dpp_f<0xB1>(vv));  // quad_perm [1,0,3,2]: the horizontally adjacent pixel
                     }
                     if constexpr (FULL) {  // (both lanes of a pair hold the same maximum and store it to the same address)
-                        store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + (COUT == 8 ? (m0 & 7) : m0), m4[0], m4[1], m4[2], m4[3]);
+                        store4(pooled + (long)((org.n * Hp + ph) * Wp + pw) * COUT + (COUT == 8 ? (m0 & 7) : m0), m4[0], m4[1], m4[2], m4[3]);
                     } else {
                         if ((lane & 1) == 0 && ph < Hp && pw < Wp && m0 < COUT)
-                            store4(pooled + (((long)org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
+                            store4(pooled + (long)((org.n * Hp + ph) * Wp + pw) * COUT + m0, m4[0], m4[1], m4[2], m4[3]);
                     }
                 }
             }
@@ -1338,6 +1362,7 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                 t += ts.step;
             }
             for (; t < ts.end; t += ts.step) tile_body(t, false);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (for the static checker: see k_mm_bwd)
         } else {
             for (; t < ts.end; t += ts.step) tile_body(t, false);
         }
