@@ -48,8 +48,8 @@ def main():
         if t and (t[0] == "s_branch" or t[0].startswith("s_cbranch")) and len(t) > 1 and labels.get(t[1], 1 << 60) < i:
             loops.append((labels[t[1]], i))
 
-    def leaves_loop(src, dst):
-        return any(a <= src <= b and not (a <= dst <= b) for a, b in loops)
+    def leaves_loop(src, dst):  # (only loops that issue opaque loads: a backward branch to an out-of-line block is not a loop)
+        return any(a <= src <= b and not (a <= dst <= b) for a, b in tile_loops)
 
     # text behind the last loop of a kernel = the code after the tile loop (flush / statistics): reached only with nothing in flight, for the
     # same reason (a block with a single tile leaves through the peeled first tile, whose prefetch is skipped by the same test)
@@ -67,6 +67,7 @@ def main():
             in_a = False
         elif in_a and st.startswith("global_load_dwordx4"):
             asm_load_lines.append(i)
+    tile_loops = [(a, b) for a, b in loops if any(a <= x <= b for x in asm_load_lines)]
     last_loop_end = {}  # kernel -> end of its last loop that issues opaque loads (= the tile loop)
     for a, b in loops:
         if any(a <= x <= b for x in asm_load_lines):
@@ -185,6 +186,41 @@ def main():
         hit = set().union(*[st[0] for st in states]) & used
         if hit:
             bad.append((name, i, s, sorted(hit)))
+    # warm-up loads (`global_load_dword` asm statements, OCRS_MM_WARM): nothing ever waits for them individually, so their destination
+    # registers count as in flight from the first one to the end of the tile loop -- no compiler-emitted instruction may name them there
+    warm, first = {}, {}
+    in_a = False
+    for i, line in enumerate(txt):
+        st = line.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_a = True
+        elif st.startswith(";;#ASMEND"):
+            in_a = False
+        elif in_a and st.startswith("global_load_dword "):
+            k = kernel_of[i]
+            for r in regs(st.replace(",", " ").split()[1]):
+                warm.setdefault(k, set()).add(r)
+                first.setdefault((k, r), i)
+    in_a = False
+    for i, line in enumerate(txt):
+        st = line.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_a = True
+        elif st.startswith(";;#ASMEND"):
+            in_a = False
+        k = kernel_of[i]
+        if in_a or k not in warm or i > last_loop_end.get(k, 0):
+            continue
+        t = st.replace(",", " ").split()
+        if not t or st.startswith((";", ".")) or re.match(r"^\.?\w+:", st):
+            continue
+        used = set().union(*[regs(x) for x in t[1:]]) if len(t) > 1 else set()
+        hit = {r for r in used & warm[k] if first[(k, r)] < i}
+        if hit:
+            bad.append((k, i, st, sorted(hit), "warm-up destination"))
+    unseen = {kernel_of[x] for x in asm_load_lines} - kernels
+    for k in sorted(unseen):
+        bad.append((k, 0, "the walk never reached this kernel's opaque loads (checker blind spot)", []))
     nk = len(kernels)
     for b in bad:
         print("VIOLATION", b)
