@@ -374,6 +374,19 @@ struct TileSched {
 };
 
 #include <stdlib.h>
+#include <atomic>
+// "done once per device" flag for hipFuncSetAttribute(MaxDynamicSharedMemorySize): the attribute is per device, launchers run on the forward
+// and on the autograd thread (setting it twice is harmless, skipping it on a second device is not)
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    static unsigned long long bit() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        return 1ull << (dev & 63);
+    }
+    bool need() const { return !(mask.load(std::memory_order_relaxed) & bit()); }
+    void done() { mask.fetch_or(bit(), std::memory_order_relaxed); }
+};
 // Per-launch timestamps from the dispatch packet (csrc/prof.hip): OCRS_LAUNCH_T == hipLaunchKernelGGL unless ocrs_prof_enable(1)
 struct OcrsProf {
     int on, used, cap;

@@ -1312,12 +1312,12 @@ static int launch_pw_bwd(const void* xa, const void* xb, int Ca, int Cb, const f
     constexpr int TPP = Elem<T>::is_bf16 ? Cfg::TPP_BF : Cfg::TPP_F;
     const size_t smem = (((Cfg::TP * Mma<T>::LDS_PITCH + Cfg::mid_el(TPP)) * sizeof(T) + 15) & ~15) +
                         (Cfg::HP * Cfg::CGI * 8 + 12 * CIN + 6 * COUT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd<T, CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess)
             return OCRS_ERR_HIP;
-        attr_set = true;
+        attr_set.done();
     }
     Src2<T> x{(const T*)xa, (const T*)xb, Ca, Cb};
     GradSrc<T> gs{(const T*)g1, (const T*)g2, pooled};

@@ -114,12 +114,12 @@ int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, 
 #define CTD_CASE(CU_, CO_)                                                                                                                  \
     if (Cup == CU_ && Cout == CO_) {                                                                                                        \
         using CC = CtdCfg<CU_, CO_>;                                                                                                        \
-        static bool attr_set = false;                                                                                                       \
-        if (!attr_set) {                                                                                                                    \
+        static DevOnce attr_set;                                                                                                       \
+        if (attr_set.need()) {                                                                                                                    \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctd<CU_, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
                 hipSuccess)                                                                                                                 \
                 return OCRS_ERR_HIP;                                                                                                        \
-            attr_set = true;                                                                                                                \
+            attr_set.done();                                                                                                                \
         }                                                                                                                                   \
         hipLaunchKernelGGL((k_ctd<CU_, CO_>), dim3((int)gsz), dim3(512), CC::SMEM, st, (const bf16*)g, wpk, (bf16*)dx, h, w, H, W, N);      \
     }

@@ -148,12 +148,12 @@ int det_ctf_launch(const void* x, const float* tr, const void* wpk, const float*
 #define CTF2_CASE(CU_, CO_)                                                                                                                 \
     if (Cup == CU_ && Cout == CO_) {                                                                                                        \
         using CC = CtfCfg<CU_, CO_>;                                                                                                        \
-        static bool attr_set = false;                                                                                                       \
-        if (!attr_set) {                                                                                                                    \
+        static DevOnce attr_set;                                                                                                       \
+        if (attr_set.need()) {                                                                                                                    \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctf<CU_, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
                 hipSuccess)                                                                                                                 \
                 return OCRS_ERR_HIP;                                                                                                        \
-            attr_set = true;                                                                                                                \
+            attr_set.done();                                                                                                                \
         }                                                                                                                                   \
         hipLaunchKernelGGL((k_ctf<CU_, CO_>), dim3((int)g), dim3(512), CC::SMEM, st, (const bf16*)x, tr, wpk, bias, (bf16*)out, h, w, H, W, N); \
     }

@@ -223,12 +223,12 @@ int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
 #define DWF_CASE(CI_, CO_)                                                                                                                   \
     if (!done && Cin == CI_ && Cout == CO_) {                                                                                                \
         using CC = DwfCfg<CI_, CO_>;                                                                                                         \
-        static bool attr_set = false;                                                                                                        \
-        if (!attr_set) {                                                                                                                     \
+        static DevOnce attr_set;                                                                                                        \
+        if (attr_set.need()) {                                                                                                                     \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwf<CI_, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
                 hipSuccess)                                                                                                                  \
                 return OCRS_ERR_HIP;                                                                                                         \
-            attr_set = true;                                                                                                                 \
+            attr_set.done();                                                                                                                 \
         }                                                                                                                                    \
         const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);                                                                            \
         long g = tg.ntiles;                                                                                                                  \

@@ -222,12 +222,12 @@ int det_pw8_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
 #define PW8_CASE(CI_, CO_)                                                                                                                 \
     if (Cin == CI_ && Cout == CO_) {                                                                                                       \
         using CC = Pw8Cfg<CI_, CO_>;                                                                                                       \
-        static bool attr_set = false;                                                                                                      \
-        if (!attr_set) {                                                                                                                   \
+        static DevOnce attr_set;                                                                                                      \
+        if (attr_set.need()) {                                                                                                                   \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_bwd8<CI_, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != \
                 hipSuccess)                                                                                                                \
                 return OCRS_ERR_HIP;                                                                                                       \
-            attr_set = true;                                                                                                               \
+            attr_set.done();                                                                                                               \
         }                                                                                                                                  \
         OCRS_LAUNCH_T((k_pw_bwd8<CI_, CO_>), dim3(gx, CC::NBI * CC::NBO), dim3(512), CC::SMEM, st, x, tra, trb, wdw, gs, (const bf16*)z, bn, coef, \
                            wpk_d, (bf16*)du, dwpw, ws, tg);                                                                                \

@@ -436,12 +436,12 @@ int det_pwb_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
 #define PWB_LAUNCH(CI_, CO_, PP_, GG_)                                                                                                              \
     {                                                                                                                                               \
         using CC = PwbCfg<CI_, CO_>;                                                                                                                \
-        static bool attr_set = false;                                                                                                               \
-        if (!attr_set) {                                                                                                                            \
+        static DevOnce attr_set;                                                                                                               \
+        if (attr_set.need()) {                                                                                                                            \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pwb<CI_, CO_, PP_, GG_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
                 hipSuccess)                                                                                                                         \
                 return OCRS_ERR_HIP;                                                                                                                \
-            attr_set = true;                                                                                                                        \
+            attr_set.done();                                                                                                                        \
         }                                                                                                                                           \
         OCRS_LAUNCH_T((k_pwb<CI_, CO_, PP_, GG_>), dim3(gx, ny), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, \
                       bn, coef, wpk_d, (bf16*)du, ws, tg, fin);                                                                                          \

@@ -1508,14 +1508,14 @@ int ocrs_wgrad_gather(const void* A, int ldA, int CA, const float* trA, const vo
     long gx;
     int gy;
     wgrad_gather_grid(CA, CB, KH * KW, P, dtype, gx, gy);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
                 hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_gather<bf16, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) !=
                 hipSuccess)
             return OCRS_ERR_HIP;
-        attr_set = true;
+        attr_set.done();
     }
     if (dtype == 1 && ws && wgrad_gather_tr_on(dtype)) {
         int g, gy2, ta, cpb;
@@ -1719,14 +1719,14 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
     OCRS_CHECK_ARG(dz && x && dW && Cout % 8 == 0 && Cout <= 128 && Cin % 32 == 0);
     const int gy = Cin / 32;
     const long gx = wgrad3x3_gx(Cin, N, H, W);  // few flushing blocks: each loops over many tiles
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) !=
                 hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_wgrad<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) !=
                 hipSuccess)
             return OCRS_ERR_HIP;
-        attr_set = true;
+        attr_set.done();
     }
     static const int use_tr = env_int("OCRS_WGRAD3X3_TR", 1);
     if (dtype == 1 && use_tr) {

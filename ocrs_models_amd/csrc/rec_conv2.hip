@@ -244,12 +244,12 @@ int conv3x3_c128_launch(const void* x, int ldx, const void* wpk, void* out, int 
     const bool two = H < 16;  // two images x 8 rows per tile
     const int TH = two ? 8 : 16, NI = two ? 2 : 1;
     const long ntiles = (long)((N + NI - 1) / NI) * ((W + C2_TW - 1) / C2_TW) * ((H + TH - 1) / TH);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DevOnce attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c128<16>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_SMEM) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c128<8>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_SMEM) != hipSuccess)
             return OCRS_ERR_HIP;
-        attr_set = true;
+        attr_set.done();
     }
     const int grid = persistent_grid(ntiles, 2);
     if (two)
