@@ -25,7 +25,7 @@
 #define OCRS_MM_TH_8_8 12  // 12 rows: 476 of 512 threads hold a (z, g) item instead of 340 -- more bytes in flight from the same registers (650 -> 621 us)
 #endif
 #ifndef OCRS_MM_TH_16_8
-#define OCRS_MM_TH_16_8 OCRS_MM_TH
+#define OCRS_MM_TH_16_8 12  // (round 3, after the index-arithmetic diet freed registers: 890 -> 840 us, no spills in the FULL instantiations)
 #endif
 #ifndef OCRS_MM_TH_8_16
 #define OCRS_MM_TH_8_16 12  // (946 -> 881 us; needs the single-buffered dgrad to fit 128 registers)
@@ -34,7 +34,7 @@
 #define OCRS_MM_TH_16_16 OCRS_MM_TH
 #endif
 #ifndef OCRS_MM_TH_16_16_P
-#define OCRS_MM_TH_16_16_P 8   // pooled gradient (the level-0 16 -> 16 block): 8 rows (1112 us) beat 12 (1151 us: 20 B of spills even with the two register diets)
+#define OCRS_MM_TH_16_16_P 12  // pooled gradient (the level-0 16 -> 16 block): round 2: 8 rows (1112 us) beat 12 (1151 us, 20 B of spills); round 3 (no spills after the index diet): 12 rows 1209 vs 1250 us
 #endif
 #define OCRS_MM_TH_OF(ci, co) ((ci) == 8 ? ((co) == 8 ? OCRS_MM_TH_8_8 : OCRS_MM_TH_8_16) : ((co) == 8 ? OCRS_MM_TH_16_8 : OCRS_MM_TH_16_16))
 #ifndef OCRS_MM_SW
@@ -65,6 +65,15 @@
 #ifndef OCRS_MF_TH16
 #define OCRS_MF_TH16 8     // forward tile rows, Cin = 16 (16 spills)
 #endif
+#ifndef OCRS_MF_TH16_32
+#define OCRS_MF_TH16_32 8  // forward tile rows, Cin = 16 -> Cout = 32
+#endif
+#ifndef OCRS_MF_TH32
+#define OCRS_MF_TH32 8     // forward tile rows, Cin = 32
+#endif
+// forward tile rows must be a multiple of 8: the 8 waves share TH (row pair, column half) units (a 12-row build silently computes 8 rows --
+// MfCfg asserts it)
+#define OCRS_MF_TH_OF(ci, co, nst) ((nst) == 2 ? 8 : ((ci) == 32 ? OCRS_MF_TH32 : ((co) == 32 ? OCRS_MF_TH16_32 : ((ci) == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16))))
 #ifndef OCRS_MF_BPC16_8
 #define OCRS_MF_BPC16_8 3  // forward blocks per CU, Cin = 16 -> Cout = 8 (80 registers: 490 -> 438 us at level 0; every other Cin = 16 shape spills at 85)
 #endif
@@ -100,7 +109,7 @@ struct MmCfg {
     static constexpr int TW = 32;
     static constexpr int TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : ((PPOOL && CIN == 16 && COUT == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(CIN, COUT));
     static constexpr int TP = TW * TH;
-    static constexpr bool T12P = PPOOL && CIN == 16 && COUT == 16 && TH == 12;  // 12-row pooled tile: needs the two register diets below to fit 128
+    static constexpr bool T12P = CIN == 16 && COUT == 16 && TH == 12;  // 12-row 16 -> 16 tile (pooled or direct gradient): needs the two register diets below to fit 128
     static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3;  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
@@ -921,7 +930,7 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
     const long ntiles = (long)N * ((W + pooled + 31) / 32) * ((H + pooled + th - 1) / th);
     return persistent_grid(ntiles, bpc);
 }
-static int mm_th(int Cin, int Cout) { return (Cin == 32 || Cout == 32) ? 8 : (Cin == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16); }  // forward tiles
+static int mm_th(int Cin, int Cout, int nst) { return OCRS_MF_TH_OF(Cin, Cout, nst); }  // forward tiles
 static int mm_bwd_bpc(int Cin, int Cout, int pooled = 0) {
     if (Cin == 32 && Cout == 32) return OCRS_MM_C32_BPC;
     return (OCRS_MM_B3_16_8 && Cin == 16 && Cout == 8 && !pooled) ? 3 : 2;
@@ -1061,12 +1070,13 @@ namespace {
 template <int CINB, int NST, int COUT>
 struct MfCfg {
     static constexpr int NT = 512, NW = 8;
-    static constexpr int TW = 32, TH = (CINB == 32 || COUT == 32) ? 8 : (CINB == 8 ? OCRS_MF_TH8 : OCRS_MF_TH16), TP = TW * TH;
+    static constexpr int TW = 32, TH = OCRS_MF_TH_OF(CINB, COUT, NST), TP = TW * TH;
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;
     static constexpr int CGB = CINB / 8;
     static constexpr int PX = MmPitch<CINB>::V;
     static constexpr int MT = (COUT + 15) / 16;
     static constexpr int KC = (9 * CINB + 31) / 32;
+    static_assert(TH % 8 == 0, "forward tiles: TH (row pair, column half) units over 8 waves");
     static constexpr int UPW = TH / 8, NPW = 2 * UPW;                  // (row pair, column half) units per wave; 16-pixel N tiles per wave
     static constexpr int NXI = (DP * CGB + NT - 1) / NT;               // x items per thread and stage
     static constexpr int OFF_X = 0;
@@ -1466,7 +1476,7 @@ long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
 // number of per-block statistics partials ocrs_mm_fwd writes (ws = that many x 2 * Cout floats)
 long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int cinb = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
-    const int th = mm_th(cinb, Cout);
+    const int th = mm_th(cinb, Cout, (Ca == 32 && Cb == 32) ? 2 : 1);
     return mm_grid(th, N, H, W, 0, cinb == 8 ? OCRS_MF_BPC8 : ((cinb == 16 && Cout == 8) ? OCRS_MF_BPC16_8 : 2));
 }
 
