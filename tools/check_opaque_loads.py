@@ -34,6 +34,16 @@ def main():
                "--cuda-device-only", SRC, "-o", out]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         txt = open(out).read().splitlines()
+    bad, nk = check(txt)
+    for b in bad:
+        print("VIOLATION", b)
+    print(f"check_opaque_loads: {nk} kernels with opaque prefetch loads, {len(bad)} violations")
+    return 1 if bad else 0
+
+
+def check(txt):
+    """txt: lines of a `hipcc -S` dump.  Returns (violations, number of kernels with opaque loads); tests/test_isa_checker.py feeds it
+    hand-written snippets."""
     labels = {}
     for i, line in enumerate(txt):
         m = re.match(r"^(\.LBB\w+):", line)
@@ -221,11 +231,7 @@ def main():
     unseen = {kernel_of[x] for x in asm_load_lines} - kernels
     for k in sorted(unseen):
         bad.append((k, 0, "the walk never reached this kernel's opaque loads (checker blind spot)", []))
-    nk = len(kernels)
-    for b in bad:
-        print("VIOLATION", b)
-    print(f"check_opaque_loads: {nk} kernels with opaque prefetch loads, {len(bad)} violations")
-    return 1 if bad else 0
+    return bad, len(kernels)
 
 
 if __name__ == "__main__":
