@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_log_softmax_bwd(const float* __restrict
 // alpha rows are written to the global workspace (needed by the backward), the rolling row lives in LDS.
 //   lp      [T][N][C] fp32 log-probs;  targets [N][Lpad] int32 (padded with anything);  in_len/tg_len [N] int64
 //   alpha   [N][T][Smax] fp32 workspace;  nll [N] fp32
-static constexpr int CTC_SPT = 3;  // states per thread: supports S <= 768 (L <= 383)
+// states per thread SPT (template parameter): 3 -> S <= 768 (L <= 383: every lattice the CRNN's own widths can need), 8 -> 2048, 16 -> 4096 (L <= 2047)
+static constexpr int CTC_SPT_MAX = 16;
 
 // H16 (the separately-toleranced "fp16 alpha/beta" variant of BASELINE configs[4]): the alpha lattice kept for the backward is stored as
 // fp16 of (alpha[t][s] - max_s alpha[t][s]) plus one fp32 row maximum per time step -- half the lattice bytes; the states that carry
@@ -72,11 +73,11 @@ __device__ __forceinline__ float block_max256(float v, float* s_red /*[4]*/) {
     __syncthreads();
     return m;
 }
-template <bool H16>
+template <bool H16, int SPT>
 __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
                                                    const long long* __restrict__ tg_len, void* __restrict__ alpha_v, float* __restrict__ rowmax,
                                                    float* __restrict__ nll, int T, int N, int C, int Lpad, int Smax) {
-    __shared__ float row[2][256 * CTC_SPT + 2];
+    __shared__ float row[2][256 * SPT + 2];
     __shared__ float s_red[4];
     float* alpha = reinterpret_cast<float*>(alpha_v);
     _Float16* alpha16 = reinterpret_cast<_Float16*>(alpha_v);
@@ -91,30 +92,30 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
     const int* tg = targets + (long)n * Lpad;
     float* al = alpha + (long)n * T * Smax;
     _Float16* al16 = alpha16 + (long)n * T * Smax;
-    int ext[CTC_SPT];
-    bool skip[CTC_SPT];
+    int ext[SPT];
+    bool skip[SPT];
 #pragma unroll
-    for (int j = 0; j < CTC_SPT; ++j) {
+    for (int j = 0; j < SPT; ++j) {
         const int s = threadIdx.x + j * 256;
         ext[j] = (s < S && (s & 1)) ? tg[s >> 1] : 0;
         skip[j] = s < S && (s & 1) && s >= 2 && tg[s >> 1] != tg[(s >> 1) - 1];
     }
     // store one lattice row: fp32 as is, or fp16 relative to the row maximum (a block reduction per time step)
-    auto store_row = [&](int t, const float (&a)[CTC_SPT]) {
+    auto store_row = [&](int t, const float (&a)[SPT]) {
         if constexpr (!H16) {
 #pragma unroll
-            for (int j = 0; j < CTC_SPT; ++j) {
+            for (int j = 0; j < SPT; ++j) {
                 const int s = threadIdx.x + j * 256;
                 if (s < S) al[(long)t * Smax + s] = a[j];
             }
         } else {
             float m = NEG_INF;
 #pragma unroll
-            for (int j = 0; j < CTC_SPT; ++j) m = fmaxf(m, a[j]);
+            for (int j = 0; j < SPT; ++j) m = fmaxf(m, a[j]);
             m = block_max256(m, s_red);
             if (threadIdx.x == 0) rowmax[(long)n * T + t] = m;
 #pragma unroll
-            for (int j = 0; j < CTC_SPT; ++j) {
+            for (int j = 0; j < SPT; ++j) {
                 const int s = threadIdx.x + j * 256;
                 if (s < S) al16[(long)t * Smax + s] = (_Float16)((a[j] == NEG_INF || m == NEG_INF) ? -65504.f : fmaxf(a[j] - m, -65504.f));
             }
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
     // t = 0
     // rolling rows: state s lives at index s + 2; indices 0,1 are -inf pad slots (written below)
     {
-        float a0v[CTC_SPT];
+        float a0v[SPT];
 #pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             const int s = threadIdx.x + j * 256;
             float a = NEG_INF;
             if (s < S && s < 2) a = lp[(long)n * C + ext[j]];
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256) void k_ctc_alpha(const float* __restrict__ lp,
     int cur = 0;
     for (int t = 1; t < Ti; ++t) {
         const float* lpt = lp + ((long)t * N + n) * C;
-        float av[CTC_SPT];
+        float av[SPT];
 #pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             const int s = threadIdx.x + j * 256;
             av[j] = NEG_INF;
             if (s < S) {
@@ -182,12 +183,12 @@ __global__ __launch_bounds__(256) void k_ctc_reduce(const float* __restrict__ nl
 }
 
 // CTC backward: beta recursion + gradient, one block per sample.  grad [T][N][C] is fully written (zeros for t >= T_n).
-template <bool H16>
+template <bool H16, int SPT>
 __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
                                                        const long long* __restrict__ tg_len, const void* __restrict__ alpha_v,
                                                        const float* __restrict__ rowmax, const float* __restrict__ nll,
                                                        const float* __restrict__ gout, float* __restrict__ grad, int T, int N, int C, int Lpad, int Smax) {
-    __shared__ float row[2][256 * CTC_SPT + 2];
+    __shared__ float row[2][256 * SPT + 2];
     extern __shared__ unsigned s_occ[];  // [C] state-occupancy sums per class in 2^-30 fixed point (see below)
     const int n = blockIdx.x;
     // device-side lengths are clamped to the tensor extents (torch raises for input_lengths > T / target_lengths > Lpad on host lengths --
@@ -202,10 +203,10 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
     const _Float16* al16 = reinterpret_cast<const _Float16*>(alpha_v) + (long)n * T * Smax;
     const float nl = nll[n];
     const float scale = gout[0] / ((float)N * (float)(L > 1 ? L : 1));
-    int ext[CTC_SPT];
-    bool skip[CTC_SPT];  // transition s -> s+2 allowed
+    int ext[SPT];
+    bool skip[SPT];  // transition s -> s+2 allowed
 #pragma unroll
-    for (int j = 0; j < CTC_SPT; ++j) {
+    for (int j = 0; j < SPT; ++j) {
         const int s = threadIdx.x + j * 256;
         ext[j] = (s < S && (s & 1)) ? tg[s >> 1] : 0;
         skip[j] = (s & 1) && s + 2 < S && tg[s >> 1] != tg[(s >> 1) + 1];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
         for (int c = threadIdx.x; c < C; c += 256) grad[((long)t * N + n) * C + c] = 0.f;
     if (Ti <= 0) return;
     // row layout: state s at index s, two NEG_INF pad slots behind S
-    for (int i = threadIdx.x; i < 256 * CTC_SPT + 2; i += 256) row[0][i] = row[1][i] = NEG_INF;
+    for (int i = threadIdx.x; i < 256 * SPT + 2; i += 256) row[0][i] = row[1][i] = NEG_INF;
     __syncthreads();
     int cur = 0;
     for (int t = Ti - 1; t >= 0; --t) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
         if constexpr (H16) rm = rowmax[(long)n * T + t];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < CTC_SPT; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             const int s = threadIdx.x + j * 256;
             if (s < S) {
                 float b;
@@ -337,8 +338,14 @@ int ocrs_log_softmax_bwd(const float* lp, const float* g, void* dlogits, long ro
 int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, float* alpha, float* nll, float* loss,
                  int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && nll && loss && T > 0 && N > 0 && C > 0);
-    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT && Smax >= 1);
-    hipLaunchKernelGGL(k_ctc_alpha<false>, dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT_MAX && Smax >= 1);
+    if (Smax <= 256 * 3) {
+        hipLaunchKernelGGL((k_ctc_alpha<false, 3>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
+    } else if (Smax <= 256 * 8) {
+        hipLaunchKernelGGL((k_ctc_alpha<false, 8>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
+    } else {
+        hipLaunchKernelGGL((k_ctc_alpha<false, 16>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
+    }
     hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -348,8 +355,14 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
 int ocrs_ctc_fwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, void* alpha16, float* rowmax, float* nll,
                      float* loss, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha16 && rowmax && nll && loss && T > 0 && N > 0 && C > 0);
-    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT && Smax >= 1);
-    hipLaunchKernelGGL(k_ctc_alpha<true>, dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, T, N, C, Lpad, Smax);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT_MAX && Smax >= 1);
+    if (Smax <= 256 * 3) {
+        hipLaunchKernelGGL((k_ctc_alpha<true, 3>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, T, N, C, Lpad, Smax);
+    } else if (Smax <= 256 * 8) {
+        hipLaunchKernelGGL((k_ctc_alpha<true, 8>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, T, N, C, Lpad, Smax);
+    } else {
+        hipLaunchKernelGGL((k_ctc_alpha<true, 16>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, T, N, C, Lpad, Smax);
+    }
     hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -359,16 +372,28 @@ int ocrs_ctc_fwd_h16(const float* lp, const int* targets, const long long* in_le
 int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
                  const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && nll && gout && grad);
-    hipLaunchKernelGGL(k_ctc_beta_grad<false>, dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, (const void*)alpha,
-                       (const float*)nullptr, nll, gout, grad, T, N, C, Lpad, Smax);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT_MAX && Smax >= 1);
+    if (Smax <= 256 * 3) {
+        hipLaunchKernelGGL((k_ctc_beta_grad<false, 3>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, (const void*)alpha, (const float*)nullptr, nll, gout, grad, T, N, C, Lpad, Smax);
+    } else if (Smax <= 256 * 8) {
+        hipLaunchKernelGGL((k_ctc_beta_grad<false, 8>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, (const void*)alpha, (const float*)nullptr, nll, gout, grad, T, N, C, Lpad, Smax);
+    } else {
+        hipLaunchKernelGGL((k_ctc_beta_grad<false, 16>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, (const void*)alpha, (const float*)nullptr, nll, gout, grad, T, N, C, Lpad, Smax);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 int ocrs_ctc_bwd_h16(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const void* alpha16, const float* rowmax,
                      const float* nll, const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
     OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha16 && rowmax && nll && gout && grad);
-    hipLaunchKernelGGL(k_ctc_beta_grad<true>, dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, gout, grad, T,
-                       N, C, Lpad, Smax);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT_MAX && Smax >= 1);
+    if (Smax <= 256 * 3) {
+        hipLaunchKernelGGL((k_ctc_beta_grad<true, 3>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, gout, grad, T, N, C, Lpad, Smax);
+    } else if (Smax <= 256 * 8) {
+        hipLaunchKernelGGL((k_ctc_beta_grad<true, 8>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, gout, grad, T, N, C, Lpad, Smax);
+    } else {
+        hipLaunchKernelGGL((k_ctc_beta_grad<true, 16>), dim3(N), dim3(256), C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha16, rowmax, nll, gout, grad, T, N, C, Lpad, Smax);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -49,7 +49,7 @@ def balanced_cross_entropy_loss(pred: torch.Tensor, target: torch.Tensor) -> tor
     return _BalancedBCE.apply(pred, target)
 
 
-MAX_CTC_STATES = 768  # csrc/rec_seq.hip: CTC_SPT (3) states per thread x 256 threads
+MAX_CTC_STATES = 4096  # csrc/rec_seq.hip: up to 16 states per thread x 256 threads (labels of up to 2047 symbols)
 
 
 class _CTC(torch.autograd.Function):

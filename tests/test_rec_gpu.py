@@ -509,6 +509,39 @@ def test_split_bf16_gemm(dev, P, K, M, km, kw):
     assert float((out[:, M4:] - 7.0).abs().max()) == 0.0  # columns beyond that untouched
 
 
+@pytest.mark.parametrize("T,Lmax,h16", [(1100, 500, False), (2600, 1250, False), (4200, 2047, False), (1100, 500, True)])
+def test_ctc_long_targets_match_torch(dev, T, Lmax, h16):
+    """The reference's CTCLoss has no target-length limit (train_rec.py:110-113 passes whatever the batch holds): lattices of up to 4096
+    states (8 / 16 states per thread) against torch.nn.functional.ctc_loss on the CPU -- loss, and the gradient w.r.t. the log-probs."""
+    import ocrs_models_amd as oa
+
+    g = torch.Generator().manual_seed(T + Lmax)
+    N, C = 3, 23
+    lp = torch.log_softmax(1.5 * torch.randn(T, N, C, generator=g), -1)
+    tl = torch.tensor([Lmax, Lmax // 3, 1])
+    il = torch.tensor([T, T - 7, T // 2])
+    tg = torch.randint(1, C, (N, Lmax), generator=g, dtype=torch.int32)
+    tg[0, 5:9] = tg[0, 5]  # repeated labels
+    ref_in = lp.clone().requires_grad_(True)
+    ref = torch.nn.functional.ctc_loss(ref_in, tg.long(), il, tl)
+    ref.backward()
+    x = lp.to(dev).requires_grad_(True)
+    loss = oa.CTCLoss(lattice_dtype=torch.float16 if h16 else torch.float32)(x, tg.to(dev), il, tl)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * abs(ref.item()), (loss.item(), ref.item())
+    e = rel(x.grad, ref_in.grad)
+    print(f"CTC T={T} L<={Lmax} ({'fp16' if h16 else 'fp32'} lattice): loss {loss.item():.4f} vs {ref.item():.4f}, gradient relL2 {e:.2e}")
+    assert e < (5e-3 if h16 else 2e-4)
+
+
+def test_ctc_rejects_lattices_beyond_4096_states(dev):
+    import ocrs_models_amd as oa
+
+    lp = torch.log_softmax(torch.randn(10, 1, 5), -1).to(dev)
+    with pytest.raises(RuntimeError, match="4096"):
+        oa.CTCLoss()(lp, torch.ones(1, 2100, dtype=torch.int32), torch.tensor([10]), torch.tensor([2100]))
+
+
 def test_ctc_fp16_lattice_variant_and_determinism(dev):
     """BASELINE configs[4] "fp16 CTC alpha/beta" (a separately-toleranced variant): CTCLoss(lattice_dtype=float16) keeps the alpha
     lattice for the backward as fp16 relative to a per-time-step maximum.  Stated tolerance: loss bit-identical to the fp32 variant (the
