@@ -56,14 +56,18 @@ def get_metric_means(metrics_dicts: list[dict[str, float]]) -> dict[str, float]:
     return {k: mean([md.get(k, 0.0) for md in metrics_dicts]) for k in keys}
 
 
-def test(device, dataloader, model, loss_fn=balanced_cross_entropy_loss, metrics_fn=None) -> tuple[float, dict[str, float]]:
+def test(device, dataloader, model, loss_fn=balanced_cross_entropy_loss, metrics_fn="default") -> tuple[float, dict[str, float]]:
     """Validation loop with the reference's return value: (mean pixel-level loss, mean word-level metrics).
 
     The forward and the loss run on the GPU in eval mode under ``torch.inference_mode()``; the loss is accumulated on the device (one
-    host sync per epoch).  The reference's word-level metrics come from cv2 connected components + shapely IoU on the CPU
-    (postprocess.py:11-36,102-187, both libraries absent here): pass ``metrics_fn(bin_pred_mask_cpu, bin_target_mask_cpu) -> dict`` to
-    compute them per image exactly where the reference does; without it the metrics dict is empty.
+    host sync per epoch).  The word-level metrics (precision / recall / merged_frac / split_frac per image, averaged) are computed on
+    the CPU per image exactly where the reference does (train_detection.py:177-184) by ``postprocess.mask_metrics`` -- a numpy
+    restatement of the reference's cv2 + shapely post-processing (postprocess.py:11-36, 102-187; neither library is installed here, so
+    its parity is unpinned: see ocrs_models_amd/postprocess.py).  ``metrics_fn(bin_pred_mask_cpu, bin_target_mask_cpu) -> dict`` replaces
+    it (e.g. the reference's own functions); ``metrics_fn=None`` skips the metrics (empty dict).
     """
+    if metrics_fn == "default":
+        from .postprocess import mask_metrics as metrics_fn
     model.eval()
     n_batches = 0
     metrics = []

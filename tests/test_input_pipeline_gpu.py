@@ -173,8 +173,21 @@ def test_detection_validation_loop_matches_oracle(dev):
     assert not m.training
     assert abs(loss - want) < 2e-4 * abs(want), (loss, want)
     assert len(calls) == 3 and metrics["precision"] == 0.5 and abs(metrics["recall"] - 2.0) < 1e-12
-    loss2, metrics2 = td.test(dev, batches, m)
+    loss2, metrics2 = td.test(dev, batches, m, metrics_fn=None)
     assert loss2 == loss and metrics2 == {}
+    # default: the word-level metrics of the reference's loop (postprocess.py restated in ocrs_models_amd/postprocess.py), the mean over the
+    # images of what mask_metrics gives for the binarised prediction and target of each
+    from ocrs_models_amd.postprocess import mask_metrics
+    loss3, metrics3 = td.test(dev, batches, m)
+    assert loss3 == loss and set(metrics3) == {"precision", "recall", "merged_frac", "split_frac"}
+    per_image = []
+    with torch.inference_mode():
+        for bt in batches:
+            pr = m(bt["image"].to(dev))
+            for i in range(pr.shape[0]):
+                per_image.append(mask_metrics(td.binarize_mask(pr[i]).cpu(), td.binarize_mask(bt["text_mask"][i])))
+    for k in metrics3:
+        assert abs(metrics3[k] - sum(d[k] for d in per_image) / len(per_image)) < 1e-12
 
 
 def test_recognition_validation_loop_matches_oracle(dev, capsys):
