@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Train-step throughput of the detection hot path on MI355X (BASELINE.json configs[1]):
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns the N ranks itself, self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 step = forward + balanced BCE + zero_grad + backward (+ RCCL gradient all-reduce, overlapped) + Adam on a batch of
@@ -18,7 +18,7 @@ Objects in the line besides the contract fields (all byte / flop models are SURV
   fp32_exact   -- the same step in the fp32 parity mode (a few steps).
   crnn         -- line-crops/s of the CRNN recognition train step (configs[2], at the legal crop height 64) with its own roofline
                   (conv MFMA TF/s vs the 2.5 PF dense bf16 peak; GRU us per time step vs the 1.45 us kernel-boundary floor) and the
-                  exact-fp32 GRU number; `crnn_config5`: the width-bucketed variable-width workload of configs[4] (N > 1 or --rec-config5).
+                  exact-fp32 GRU number; `crnn.config5`: the width-bucketed variable-width workload of configs[4] (every N).
   cpu_baseline -- oracle/ (CPU restatement of the reference, stock ATen CPU ops) on this host, N=1 only, 8(d) protocol.
 """
 from __future__ import annotations
@@ -432,7 +432,7 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         os.environ["OCRS_GRU_X3"] = "1" if x3 else "0"
         out["other_gru_mode"] = {"gru_projection_gemms": "exact fp32 MFMA (OCRS_GRU_X3=0)" if x3 else "split-bf16 x3", "value": round(n2 / dt2, 1),
                                  "ms_per_step": round(dt2 / max(3, args.steps // 2) * 1e3, 3)}
-    if args.rec_config5 or world > 1:
+    if not args.no_rec_config5:
         nb = max(8, args.steps)
         batches = config5_batches(B, rank, world, nb, dev)
         dt5, n5, _ = timed(batches, min(4, len(batches)), len(batches))
@@ -442,6 +442,68 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
                           "bucket_widths": {str(k): widths.count(k) for k in sorted(set(widths))}, "crops_per_gpu_per_step": B, "n_gpus": world,
                           "ctc_alpha_beta": "fp32 in LDS"}
     return out
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (the driver's command line): re-exec this script under torch.distributed.run with N ranks
+    on a free local port.  The ranks' stdout is passed through (rank 0 prints the one JSON line); the exit code is the launcher's."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing(args, world, rank):
+    """OCRS_BENCH_PLUMBING=1: the launch / rendezvous / timing / one-JSON-line contract of this script WITHOUT a GPU (gloo, CPU tensors) -- the
+    step is the gradient bucketer's reduce of the real flat gradient buffers (622 122 floats detection, 2 426 913 recognition) reported in
+    backward-completion order.  Used by tests/test_host_side.py to drive `python bench.py --gpus 2` on a CPU-only box; never a bench figure."""
+    import torch.distributed as dist
+
+    from ocrs_models_amd.ddp import GradBucketer
+
+    dist.init_process_group("gloo")
+    sizes = {"detection": 622122, "recognition": 2426913}
+    res = {}
+    for name, n in sizes.items():
+        flat = torch.full((n,), float(rank + 1))
+        b = GradBucketer()
+        cuts = [0, n // 50, n // 3, n]
+
+        def step():
+            flat.fill_(float(rank + 1))
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                b.ready(flat, lo, hi)
+            return b.finish(flat)
+
+        for _ in range(args.warmup):
+            step()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ranges = step()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        want = sum(range(1, world + 1)) / world
+        res[name] = {"floats": n, "buckets": len(ranges), "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3),
+                     "mean_of_ranks_ok": bool(torch.allclose(flat, torch.full_like(flat, want)))}
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU): bucketed gradient all-reduce on gloo", "value": None, "unit": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "plumbing": True, "ddp": {"rccl_ranks": 0, "gloo_ranks": world, **res}}), flush=True)
+    dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------------------------ detection
@@ -463,8 +525,14 @@ def main():
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1-sized (B=2 x 512^2) eager vs hipGraph step")
     ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
     ap.add_argument("--rec-width", type=int, default=400)
-    ap.add_argument("--rec-config5", action="store_true", help="also time the width-bucketed variable-width CRNN workload (default at N > 1)")
+    ap.add_argument("--rec-config5", action="store_true", help="(default since round 4) time the width-bucketed variable-width CRNN workload")
+    ap.add_argument("--no-rec-config5", action="store_true", help="skip the width-bucketed variable-width CRNN workload (BASELINE configs[4] per-rank share)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: spawn the N ranks ourselves
+        raise SystemExit(self_launch(args.gpus))
+    if os.environ.get("OCRS_BENCH_PLUMBING") == "1":
+        return plumbing(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
 
     import torch.distributed as dist
 
@@ -476,8 +544,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running with {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1 or "RANK" in os.environ  # under torch.distributed.run, also with one rank

@@ -9,6 +9,9 @@ pool, the loss's top-k selection and Adam's step count run on the device) and re
     step = GraphedTrainStep(model, optimizer, loss_fn, example_input, example_target)   # optimizer: optim.Adam(..., capturable=True)
     loss = step(x, target)          # device scalar (static buffer: read it before the next call or clone it)
 
+The constructor's `warmup` eager iterations are REAL optimizer steps on the example batch (they size the allocator pools and build the
+pointer tables): pass a batch you want trained on, or snapshot / restore the model and optimizer state around the construction.
+
 Restrictions of a capture: fixed input shapes; the optimizer must be capturable; the learning rate is baked at capture time (re-capture
 after a scheduler step); no gradient bucketer (single GPU).
 """
@@ -39,6 +42,13 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()
+            # the capture ran Adam.step()'s HOST bookkeeping (state["step"] += 1) but no kernel: take that count back so the host mirror
+            # equals the device-side step count (checkpoints store the mirror; a resumed capturable run seeds the device count from it)
+            for group in self.opt.param_groups:
+                for p in group["params"]:
+                    st = self.opt.state.get(p)
+                    if st:
+                        st["step"] -= 1
         finally:
             if prev is None:
                 os.environ.pop("OCRS_OVERLAP", None)

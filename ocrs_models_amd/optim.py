@@ -29,11 +29,23 @@ class _Table:
         # into a hipGraph finds its source bytes again at every replay.
         if reuse is not None and reuse._host[0].shape == (len(rows), 5) and reuse._host[1].shape == (len(chunks), 2):
             self._host, self.table, self.chunks = reuse._host, reuse.table, reuse.chunks
+            # The previous rebuild's asynchronous H2D copies read these same pinned bytes: they must have EXECUTED before the bytes are
+            # rewritten, or a step whose copy is still queued would pick up this step's pointers (the caching host allocator's event
+            # tracking protected the old fresh-pin_memory() path; here the event is ours).  While a stream is capturing nothing has been
+            # enqueued to wait for (and event synchronisation is not permitted): the recorded copy reads the bytes at replay time.
+            capturing = torch.cuda.is_current_stream_capturing()
+            if reuse._copied is not None and not capturing:
+                reuse._copied.synchronize()
             self._host[0].copy_(torch.tensor(rows, dtype=torch.int64))
             self._host[1].copy_(torch.tensor(chunks, dtype=torch.int32))
             self.table.copy_(self._host[0], non_blocking=True)
             self.chunks.copy_(self._host[1], non_blocking=True)
+            self._copied = None
+            if not capturing:
+                self._copied = torch.cuda.Event()
+                self._copied.record()
         else:
+            self._copied = None  # (fresh pinned tensors: the caching host allocator keeps them alive until the copy has run)
             self._host = (torch.tensor(rows, dtype=torch.int64).pin_memory(), torch.tensor(chunks, dtype=torch.int32).pin_memory())
             self.table = self._host[0].to(dev, non_blocking=True)
             self.chunks = self._host[1].to(dev, non_blocking=True)

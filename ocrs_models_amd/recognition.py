@@ -419,7 +419,10 @@ def _gru_err_reset(dev):
     """A timeout was observed: clear the word (device and host copy) and route this process to the per-step kernels (rec_gru.hip) -- a
     transient stall (another process or stream holding the CUs the resident grid needs) must not end the training process."""
     ent = _gru_err_entry(dev)
+    # every poll copy queued so far (e.g. the failed step's backward poll) must have landed before the host word is cleared, or it would
+    # set the word again and the next forward would report the same failure twice; the device word is cleared in stream order first
     ent[0].zero_()
+    torch.cuda.current_stream(dev).synchronize()
     ent[1].zero_()
     _GRU_SEQ_OFF[dev] = True
 
@@ -434,7 +437,8 @@ def _gru_err(dev):
     if int(ent[1][0]) != 0:
         _gru_err_reset(dev)
         raise RuntimeError("a persistent GRU launch (ocrs_gru_seq_fwd/_bwd) timed out waiting for its peer workgroups: the results of the previous "
-                           "step are incomplete -- discard or repeat it.  The error word was cleared and this process now uses the per-step GRU "
+                           "step are incomplete and the optimizer step that followed it has ALREADY been applied -- restore the last checkpoint (or accept one step "
+                           "taken with incomplete gradients) before continuing.  The error word was cleared and this process now uses the per-step GRU "
                            "kernels (csrc/rec_gru.hip); later steps are not affected")
     return ent[0]
 

@@ -189,3 +189,26 @@ def test_bucketer_single_process_is_identity():
     with pytest.raises(RuntimeError):
         b.ready(flat, 0, 10)
         b.ready(flat, 20, 30)
+
+
+def test_bench_self_launches_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command line) must spawn the two ranks itself and print
+    ONE JSON line on rank 0.  CPU stand-in (OCRS_BENCH_PLUMBING=1: gloo, the bucketer over the real flat gradient sizes) -- the launch,
+    rendezvous, barrier / max-over-ranks timing and output contract are the ones the GPU run uses."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OCRS_BENCH_PLUMBING="1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["plumbing"] is True
+    for leg in ("detection", "recognition"):
+        assert d["ddp"][leg]["mean_of_ranks_ok"] and d["ddp"][leg]["buckets"] >= 1
+    assert d["ddp"]["detection"]["floats"] == 622122 and d["ddp"]["recognition"]["floats"] == 2426913

@@ -37,6 +37,10 @@ def test_graphed_train_step_equals_eager(dev, dtype):
     o2 = oa.optim.Adam(m2.parameters(), capturable=True)
     sd = {k: v.clone() for k, v in m2.state_dict().items()}
     step = oa.graph.GraphedTrainStep(m2, o2, oa.balanced_cross_entropy_loss, xs[0], ts[0])
+    # after construction the host mirror of the step count equals the device-side count (the capture itself executes no Adam kernel)
+    torch.cuda.synchronize()
+    for ds in o2._dev_step.values():
+        assert all(st["step"] == int(ds.item()) for st in o2.state.values()), ([st["step"] for st in o2.state.values()][:3], float(ds.item()))
     m2.load_state_dict(sd)  # (in place: the recorded pointers stay valid)
     for st in o2.state.values():
         st["exp_avg"].zero_()

@@ -6,7 +6,7 @@ OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 # 1. un-profiled default bench line (what the driver runs)
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 # 2. kernel stats of the same command (detection + CRNN), CPU baseline off
-rm -rf gpurun_out/ks; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 --no-gru-exact --no-ref-style --no-ddp-probe --no-config1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/ks.err
+rm -rf gpurun_out/ks; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-fp32 --no-gru-exact --no-rec-config5 --no-ref-style --no-ddp-probe --no-config1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/ks.err
 cp $(find gpurun_out/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 # 3. per-launch trace of one detection step
 bash tools/run_trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step.txt $OUT/${TAG}_step_trace.txt
