@@ -56,8 +56,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if any(os.path.basename(s) == "det_mm.hip" for s, _ in jobs):
         # the hand-waited prefetch loads of det_mm.hip are only valid if hipcc left their destination registers alone until the wait
         chk = os.path.join(os.path.dirname(HERE), "tools", "check_opaque_loads.py")
-        if os.path.exists(chk):
-            r = subprocess.run([sys.executable, chk], capture_output=True, text=True)
+        if not os.path.exists(chk):
+            print("WARNING: tools/check_opaque_loads.py not found -- det_mm.hip's hand-waited prefetch loads were NOT verified against this "
+                  "compiler's register allocation (build from the repository tree, or run with OCRS_MM_FULL=0 to use the compiler-waited kernels)",
+                  file=sys.stderr, flush=True)
+        else:
+            r = subprocess.run([sys.executable, chk], capture_output=True, text=True,
+                               env={**os.environ, "OCRS_CHECK_HIPCC": hipcc, "OCRS_CHECK_FLAGS": " ".join(FLAGS)})
             if verbose:
                 print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr, flush=True)
             if r.returncode != 0:

@@ -1,0 +1,405 @@
+// 3x3 convolution of the CRNN's wide layers (ocrs_models/models.py:189-236: conv.6 / 8 / 12 / 15 forward and the dgrads of 8 / 12 / 15) as an
+// implicit GEMM with ONE workgroup per CU that owns whole image rows (gfx950, bf16).  Same contract as k_conv_igemm (rec_conv.hip).
+//
+// Why another form (round 4).  k_conv3x3_c128 (rec_conv2.hip: 128 x 256 block tiles, two 4-wave blocks per CU) sits at 30-34 % MFMA-busy:
+// every K = 32 step re-stages 8 KB of weights through registers and ds_write, waits for 12 fragments at the top of the step, and ends in a
+// barrier; its 16-pixel-wide tiles waste 12 % of a 100-pixel row and its tile count (1792 / 896 over 512 slots) leaves a partial last round.
+// At the benchmarked sizes a layer is exactly ONE image per CU (B = 256 crops, 256 CUs), so here:
+//   * a PASS = R whole rows of one image (R x W <= 832 pixels; 8 x 100 for the 128-channel layers), flattened to N tiles of 16 pixels that may
+//     straddle rows (a lane's halo position is a per-lane LDS address, the tap is a wave-uniform offset): no column waste, no partial round;
+//   * 4 waves, one per SIMD, as WM (channel groups) x WN (pixel groups): a wave holds MH x NTW accumulator tiles -- 4 x 13 = 208 registers, all
+//     AGPRs, for the 128-channel layers (64 channels x 208 pixels: 4 A + 13 B fragments feed 52 MFMAs per K = 32 step, 0.33 KB of LDS per MFMA;
+//     the 64 x 128 wave tiles of rec_conv2 need 0.375) -- and the VGPR half of the register file is free for deep fragment prefetch.
+//     (8 x 13 tiles per wave = 416 accumulator registers was tried first: hipcc shuffles accumulators between the AGPR and VGPR halves around
+//     every MFMA once more than 256 are live -- 328 v_accvgpr moves per 80 MFMAs -- so the accumulators must fit the AGPR half);
+//   * both operands reach LDS by LDS-DMA (global_load_lds_dwordx4, inline asm so that hipcc's waitcnt bookkeeping does not drain it): packed
+//     weight fragments are lane-linear as they lie in memory; the input halo is staged PLANAR -- [8-channel group][staged pixel][16 B], plane
+//     stride = 0 mod 256 B -- so a B fragment read (16 consecutive pixels x 4 channel groups) is conflict-free at every tap shift, and one
+//     DMA instruction fills 64 consecutive staged pixels of a plane (padding lanes read a zero line): no VGPR, no ds_write, no VALU per byte;
+//   * weights live in a ring of 3 step slots filled two steps ahead, the next 32-channel chunk's halo is filled during taps 1..4 of the
+//     current chunk (also across passes); B fragments stream through a 4-deep register ring three tiles ahead of their MFMAs, the next
+//     step's A fragments replace the current ones behind the last tile's MFMAs; ONE barrier per step (1664 MFMA cycles), placed three
+//     tiles before the end so that the DMA waits sit under MFMA work:  step s: [DMA issue] tiles 0..9 | vmcnt + s_barrier | tiles 10..12.
+#include "det_common.h"
+
+#ifndef R3_ABL
+#define R3_ABL 0  // ablation mask (measurement builds only): 1 no halo DMA, 2 no weight DMA, 4 no barrier / vmcnt wait, 8 no MFMA, 16 no B fragment reads
+#endif
+#ifndef R3_DBG
+#define R3_DBG 0  // 1: per-phase cycle counters of every wave of block 0 (measurement builds; read with ocrs_conv_rows_dbg)
+#endif
+#if R3_DBG
+__device__ long long g_r3dbg[8][8];
+#define R3_T() __builtin_readcyclecounter()
+#endif
+namespace {
+constexpr int R3_RING = 4;       // weight step slots (filled three steps ahead)
+constexpr int R3_HPMAX = 1024;   // staged halo pixels per plane (<= 64 KB per 32-channel chunk, two chunks)
+__device__ uint4 g_zero64[4];    // 64 zero bytes: source of the padding lanes' DMA (four channel groups)
+
+// LDS-DMA of 16 bytes per lane: lane i's bytes land at LDS byte `lds_dst` + 16 i (lds_dst wave-uniform).  Invisible to hipcc's s_waitcnt
+// bookkeeping (the point: a counted vmcnt below instead of vmcnt(0) in front of the next ds_read).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// the same with a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: nothing per-lane for the compiler to pre-compute per step
+__device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+// hide a wave-uniform value from loop-invariant code motion (hipcc otherwise pre-computes every step's address set of the 18-step body
+// outside the chunk loop -- ~150 registers -- and spills it; a spill reload inside the loop is a VMEM load hipcc waits vmcnt(0) for)
+__device__ __forceinline__ unsigned opaque_s(unsigned v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ int opaque_v(int v) {  // the per-lane counterpart (a value derived from it cannot be kept in a register across the loop)
+    asm volatile("" : "+v"(v));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+}  // namespace
+
+template <int MH /* 16-channel output tiles per wave */, int WM /* waves along the channels: Cout = 16 MH WM */, int NTW /* N tiles of 16 pixels per wave */,
+          int UPS /* halo DMA units per wave and step (taps 1..5): 1 for <= 640 staged pixels, 2 up to 1280 */>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict__ x, int ldx, const uint4* __restrict__ wpk, bf16* __restrict__ out, int ldo,
+                                                         const float* __restrict__ bias, int relu, double* __restrict__ gstat, int Cin, int N, int H, int W,
+                                                         int R, int hppad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int MTB = MH * WM, WN = 8 / WM, NU = 5 * UPS;
+    const int wm = wave % WM, wn = wave / WM;  // waves w and w + 4 share a SIMD: pixel groups (0, 2) and (1, 3) -> 13 / 13 / 12 / 12 tiles of a 25-tile pass
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int HWp = W + 2;
+    const unsigned PLANE = (unsigned)hppad * 16u;
+    const unsigned XB = 8u * PLANE;                    // weight ring
+    constexpr unsigned WSLOT = MTB * 1024u;
+    const unsigned DB = XB + R3_RING * WSLOT;          // 1 KB nobody reads: target of the padding DMA instructions
+    const unsigned SB = DB + 1024u;                    // statistics slots [WN pixel groups][2][MTB * 16] floats
+    const unsigned TB = SB + WN * 2 * MTB * 16 * 4;    // halo DMA unit table [NU][512] int2
+    const int ncc = Cin / 32, nsteps = ncc * 9;        // ncc even (launch condition): chunk q of a pass lives in input buffer q & 1
+    const int ppi = (H + R - 1) / R, total = N * ppi;
+    const int ppb = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int p_first = blockIdx.x * ppb, p_end = p_first + ppb < total ? p_first + ppb : total;
+    if (p_first >= p_end) return;
+    const int npx = R * W;
+    float* s_stat = reinterpret_cast<float*>(smem + SB);
+    if (gstat) {
+        for (int i = tid; i < WN * 2 * MTB * 16; i += 512) s_stat[i] = 0.f;
+    }
+#if R3_DBG
+    long long t_start = R3_T(), t_bar = 0, t_epi = 0, t_pro = 0, t_x = 0;
+#endif
+
+    // ---- per-lane constants.  B fragment of N tile j (tile index j * WN + wn, pixel p = tile * 16 + l15 of the pass): LDS byte offset of
+    // the pixel's halo position (tap (0, 0)) in plane kq
+    unsigned baddr[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        int p = (j * WN + wn) * 16 + l15;
+        p = p < npx ? p : npx - 1;
+        const int row = p / W, col = p - row * W;
+        baddr[j] = kq * PLANE + (unsigned)(row * HWp + col) * 16u;
+    }
+    // input DMA units: unit u = (group u >> 2 of 64 staged pixels, plane u & 3), hppad / 16 of them per chunk; wave w issues units w + 8 i, UPS
+    // per step at taps 1 .. 5 (a unit is a 64-lane gather -- every lane another pixel's line, ~64 cycles of the CU's address path -- and a
+    // chunk's halo must have landed two barriers before tap 8 starts reading it).  Units past the staged pixels
+    // and lanes outside the image read the zero line (padding units go to the dump slot): every wave issues the same number of DMAs per step,
+    // so the counted waits are compile-time constants.
+    const char* zsrc = reinterpret_cast<const char*>(g_zero64);
+    const int nunits = hppad / 16;
+    // Per (unit, lane) table in LDS, filled once: byte offset of the source relative to the pass's first pixel, and the staged row (the only
+    // part of the bounds test that depends on the pass; 1 << 24 = never valid) -- the issue path is a ds_read_b64, a compare and a select.
+    int2* s_xt = reinterpret_cast<int2*>(smem + TB);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int u = i * 8 + wave, grp = u >> 2, kg = u & 3;
+        const int sp = grp * 64 + lane, hy = sp / HWp, hx = sp - hy * HWp, w = hx - 1;
+        const bool colok = u < nunits && hy < R + 2 && (unsigned)w < (unsigned)W;
+        s_xt[i * 512 + tid] = make_int2((((hy - 1) * W + w) * ldx + kg * 8) * 2, colok ? hy : (1 << 24));
+    }
+    // unit i (run-time, wave-uniform) of the chunk at `xc` (first pixel of its pass + the chunk's channel offset; r0 = first row of the pass)
+    auto issue_x = [&](int i, const char* xc, int r0, int buf) {
+        const int u = i * 8 + wave, grp = u >> 2, kg = u & 3;
+        const int2 e = s_xt[i * 512 + tid];
+        const bool ok = (unsigned)(r0 - 1 + e.y) < (unsigned)H;
+        const char* src = ok ? xc + e.x : zsrc;
+        const unsigned dst = (unsigned)(buf * 4 + kg) * PLANE + (unsigned)grp * 1024u;
+        dma16(src, __builtin_amdgcn_readfirstlane(u < nunits ? dst : DB));
+    };
+    // weights: this wave's share of the MTB fragments of a step, from a wave-uniform step pointer
+    static_assert(MTB % 8 == 0, "every wave stages MTB / 8 weight fragments per step");
+    constexpr int WPW = MTB / 8;
+    const unsigned wlane = (unsigned)(wave * WPW * 64 + lane) * 16u;
+    auto issue_w = [&](const char* wstep, int slot) {
+#pragma unroll
+        for (int a = 0; a < WPW; ++a)
+            dma16_s(wstep + a * 1024, wlane, __builtin_amdgcn_readfirstlane(XB + (unsigned)slot * WSLOT + (unsigned)(wave * WPW + a) * 1024u));
+    };
+    auto lds16 = [&](unsigned off) -> uint4 { return *reinterpret_cast<const uint4*>(smem + off); };
+    auto pass_ptr = [&](int ps, int& r0) -> const char* {
+        const int n = ps / ppi;
+        r0 = (ps - n * ppi) * R;
+        return reinterpret_cast<const char*>(x + ((long)n * H + r0) * W * ldx);
+    };
+    const char* wbase = reinterpret_cast<const char*>(wpk);
+    const long tapstride = (long)ncc * (MTB * 1024);  // bytes between the fragments of consecutive taps of one chunk
+
+    // ---- prologue: chunk 0 of the first pass, weights of steps 0, 1 and 2
+    int r0c;
+    const char* xpc = pass_ptr(p_first, r0c);
+    __syncthreads();  // (unit table)
+#pragma unroll
+    for (int i = 0; i < NU; ++i) issue_x(i, xpc, r0c, 0);
+    issue_w(wbase, 0);
+    issue_w(wbase + tapstride, 1);
+    issue_w(wbase + 2 * tapstride, 2);
+    wait_vm<0>();
+    __syncthreads();
+
+    f32x4 acc[MH][NTW];
+    uint4 afA[MH], afB[MH], bq[NTW];
+#pragma unroll
+    for (int a = 0; a < MH; ++a) afA[a] = lds16(XB + (unsigned)(wm * MH + a) * 1024u + lane * 16u);
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) bq[b] = lds16(baddr[b]);
+#if R3_DBG
+    t_pro = R3_T() - t_start;
+#endif
+
+    // run-time step state, kept to a few scalar instructions per step (the first version's (tap, chunk, pass) state machine with its
+    // divisions and 64-bit address arithmetic cost ~200 scalar + ~100 vector instructions per step -- as much issue time as the 28 MFMAs)
+    int tap = 0, kx = 0;                 // current step's tap, its column
+    int cc = 0;                          // current chunk
+    int slot = 0;                        // ring slot of the current step
+    unsigned tapoff = 0;                 // LDS byte offset of the current step's tap (incl. the input buffer)
+    unsigned xbuf = 0;                   // input buffer of the current chunk (0 / 1)
+    int tap3 = 3, cc3 = 0;               // (tap, chunk) of step + 3
+    const char* wp3 = wbase + 3 * tapstride;
+    bool wx_prev = false;
+    const char* xnc = xpc;               // source of the halo units issued during the current chunk: first pixel of the NEXT chunk's pass + its channels
+    int rnc = r0c;
+    const char* xnx = xpc;               // the same for the chunk after the pass's last one: chunk 0 of the next pass
+    int rnx = 0;
+    const unsigned rowjump = (unsigned)(HWp - 2) * 16u;
+
+    // One K = 32 step: MFMAs of the NTW tiles from af / bq (loaded one step ago); behind tile b's MFMAs bq[b] is refilled with the next step's
+    // tile b (a full step of distance), behind the barrier afn -- the other A register set -- receives the next step's A fragments.  DMA at
+    // the top: weights of step + 3, and at taps 1..5 UPS halo units of the next chunk; the barrier waits for everything issued before the
+    // PREVIOUS step's top (two steps of flight time).
+    auto step = [&](auto first_tag, const uint4 (&af)[MH], uint4 (&afn)[MH]) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (!(R3_ABL & 2)) issue_w(wp3, (slot + 3) & (R3_RING - 1));
+        const bool with_x = !(R3_ABL & 1) && (unsigned)(tap - 1) < 5u;
+        if (with_x) {
+#pragma unroll
+            for (int q = 0; q < UPS; ++q) issue_x((tap - 1) * UPS + q, xnc, rnc, (int)(xbuf ^ 1u));
+        }
+        // next step's tap offset: one pixel right, or to the start of the next row, or (after tap 8) tap 0 of the other input buffer
+        unsigned ntapoff = tapoff + (kx == 2 ? rowjump : 16u);
+        if (tap == 8) ntapoff = (xbuf ^ 1u) * 4u * PLANE;
+        const int nslot = (slot + 1) & (R3_RING - 1);
+        const unsigned abase = XB + (unsigned)nslot * WSLOT + (unsigned)(wm * MH) * 1024u + lane * 16u;
+        constexpr int W0 = (R3_ABL & 2) ? 0 : 2 * WPW;
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            if (b == 1 && !(R3_ABL & 4)) {  // this wave's DMAs of two and more steps ago have landed; then every wave's
+#if R3_DBG
+                const long long tb0 = R3_T();
+#endif
+                if (with_x) {
+                    if (wx_prev) wait_vm<W0 + 2 * UPS>();
+                    else wait_vm<W0 + UPS>();
+                } else {
+                    if (wx_prev) wait_vm<W0 + UPS>();
+                    else wait_vm<W0>();
+                }
+#if R3_DBG
+                const long long tb1 = R3_T();
+                t_x += tb1 - tb0;
+#endif
+                __builtin_amdgcn_s_barrier();
+#if R3_DBG
+                t_bar += R3_T() - tb1;
+#endif
+            }
+#pragma unroll
+            for (int a = 0; a < MH; ++a) {
+                const f32x4 c = FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[a][b];
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bq[b]), c, 0, 0, 0);
+            }
+            if (!(R3_ABL & 16)) bq[b] = lds16(baddr[b] + ntapoff);
+            if (b >= 1 && b < 1 + MH) afn[b - 1] = lds16(abase + (unsigned)(b - 1) * 1024u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- advance (scalar)
+        wx_prev = with_x;
+        slot = nslot;
+        tapoff = ntapoff;
+        kx = kx == 2 ? 0 : kx + 1;
+        wp3 += tapstride;
+        if (++tap3 == 9) {  // step + 3 enters the next chunk (after a pass's last chunk: chunk 0 again, same weights)
+            tap3 = 0;
+            cc3 = cc3 + 1 == ncc ? 0 : cc3 + 1;
+            wp3 = wbase + (long)cc3 * (MTB * 1024);
+        }
+        if (++tap == 9) {  // next chunk; the halo units issued during it belong to the chunk after it
+            tap = 0;
+            xbuf ^= 1u;
+            ++cc;
+            const bool lastc = cc + 1 >= ncc;
+            xnc = lastc ? xnx : xpc + (cc + 1) * 64;
+            rnc = lastc ? rnx : r0c;
+        }
+    };
+
+    for (int ps = p_first; ps < p_end; ++ps) {
+        // successor of the pass's last chunk: chunk 0 of the next pass (none: every lane reads the zero line, nobody reads the buffer)
+        rnx = -(1 << 20);
+        xnx = xpc;
+        if (ps + 1 < p_end) xnx = pass_ptr(ps + 1, rnx);
+        cc = 0;
+        xnc = ncc == 1 ? xnx : xpc + 64;
+        rnc = ncc == 1 ? rnx : r0c;
+        step(std::true_type{}, afA, afB);
+        step(std::false_type{}, afB, afA);
+#pragma clang loop unroll(disable)
+        for (int sidx = 2; sidx < nsteps; sidx += 2) {  // (nsteps = 9 ncc is even: ncc % 2 == 0 is a launch condition)
+            step(std::false_type{}, afA, afB);
+            step(std::false_type{}, afB, afA);
+        }
+#if R3_DBG
+        const long long te0 = R3_T();
+#endif
+        // ---- epilogue of the pass: bias, ReLU, store, per-channel sums of the stored values
+        const int n = ps / ppi, r0 = r0c;
+        const int lim = (H - r0) * W < npx ? (H - r0) * W : npx;
+        const int lane_e = opaque_v(lane), l15 = lane_e & 15, kq = lane_e >> 4;  // (shadowing: nothing of the epilogue's addressing lives in registers across the K loop)
+        bf16* obase = out + ((long)n * H + r0) * W * ldo + wm * MH * 16 + kq * 4;
+#pragma unroll
+        for (int a = 0; a < MH; ++a) {
+            float bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bs[r] = bias[(wm * MH + a) * 16 + kq * 4 + r];
+            }
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int p = (j * WN + wn) * 16 + l15;
+                if (p < lim && !((R3_ABL & 32) && acc[a][j][0] != 123.f)) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[a][j][r] + bs[r];
+                        if (relu) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    store4(obase + (long)p * ldo + a * 16, v[0], v[1], v[2], v[3]);
+                    if (gstat) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float q = Elem<bf16>::round(v[r]);
+                            s1[r] += q;
+                            s2[r] = fmaf(q, q, s2[r]);
+                        }
+                    }
+                }
+            }
+            if (gstat) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
+                    if (l15 == 0) {  // (wave, channel) has exactly one owner lane: plain adds in program order -> run-to-run bit-stable
+                        s_stat[wn * 2 * MTB * 16 + (wm * MH + a) * 16 + kq * 4 + r] += a1;
+                        s_stat[wn * 2 * MTB * 16 + MTB * 16 + (wm * MH + a) * 16 + kq * 4 + r] += a2;
+                    }
+                }
+            }
+        }
+#if R3_DBG
+        t_epi += R3_T() - te0;
+#endif
+        xpc = xnx;
+        r0c = rnx;
+    }
+#if R3_DBG
+    if (blockIdx.x == 0 && lane == 0) {
+        g_r3dbg[wave][0] = R3_T() - t_start;
+        g_r3dbg[wave][1] = t_pro;
+        g_r3dbg[wave][2] = t_x;
+        g_r3dbg[wave][3] = t_bar;
+        g_r3dbg[wave][4] = t_epi;
+    }
+#endif
+    wait_vm<0>();  // (the wrapped-around weight loads of the last steps: no LDS-DMA may be in flight when the workgroup's LDS is released)
+    if (gstat) {
+        __syncthreads();
+        constexpr int M = MTB * 16;
+        for (int i = tid; i < 2 * M; i += 512) {
+            float t = s_stat[i];  // pixel groups in a fixed order
+#pragma unroll
+            for (int q = 1; q < WN; ++q) t += s_stat[q * 2 * M + i];
+            atomicAdd(&gstat[i], (double)t);  // fp64 sums of fp32 partials: exact, order-independent
+        }
+    }
+}
+
+// pass geometry: rows per pass (0: the shape does not fit this kernel); cap = N tiles a pass can hold (WN * NTW)
+static int conv3x3_rows_geometry(int H, int W, int cap, int* hppad) {
+    int best = 0;
+    double best_cost = 1e30;
+    for (int R = 1; R <= H; ++R) {
+        const int nt = (R * W + 15) / 16, hp = (R + 2) * (W + 2);
+        if (nt > cap || hp > 640) break;  // (UPS = 1: five halo units per wave and chunk)
+        const double cost = (double)((H + R - 1) / R);  // every pass costs NTW tile times per step whatever it fills
+        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && R > best)) {
+            best_cost = cost;
+            best = R;
+        }
+    }
+    if (best) *hppad = (((best + 2) * (W + 2)) + 63) / 64 * 64;
+    return best;
+}
+
+bool conv3x3_rows_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype) {
+    const int on = env_int("OCRS_CONV_ROWS", 1);
+    int hp;
+    return on && dtype == 1 && M == 128 && Cin % 64 == 0 && KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi && ldx % 8 == 0 &&
+           ldo % 4 == 0 && conv3x3_rows_geometry(Hi, Wi, 28, &hp) > 0 && (long)Hi * Wi * ldx < (1L << 30);
+}
+
+int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int H, int W,
+                        hipStream_t st) {
+    int hppad = 0;
+    const int R = conv3x3_rows_geometry(H, W, 28, &hppad);
+    const int total = N * ((H + R - 1) / R);
+    const int smem = 8 * hppad * 16 + R3_RING * 8 * 1024 + 1024 + 4 * 2 * 128 * 4 + 5 * 512 * 8;
+    static DevOnce attr_set;
+    if (attr_set.need()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_rows<4, 2, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return OCRS_ERR_HIP;
+        attr_set.done();
+    }
+    // whole passes per block, as evenly as the pass count allows (two / four passes = one image per CU at B = 256)
+    int grid = total < kNumCU ? total : kNumCU;
+    const int ppb = (total + grid - 1) / grid;
+    grid = (total + ppb - 1) / ppb;
+    hipLaunchKernelGGL((k_conv3x3_rows<4, 2, 7, 1>), dim3(grid), dim3(512), smem, st, (const bf16*)x, ldx, (const uint4*)wpk, (bf16*)out, ldo, bias, relu, gstat, Cin,
+                       N, H, W, R, hppad);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+#if R3_DBG
+extern "C" int ocrs_conv_rows_dbg(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_r3dbg), sizeof(long long) * 64) == hipSuccess ? 0 : 2; }
+#endif

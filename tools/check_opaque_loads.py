@@ -30,8 +30,10 @@ def regs(tok):
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "det_mm.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-Wno-unused-result", *sys.argv[1:], "-S",
-               "--cuda-device-only", SRC, "-o", out]
+        # the build passes ITS compiler and flag list (OCRS_CHECK_HIPCC / OCRS_CHECK_FLAGS) so that the text checked here is the code it built
+        hipcc = os.environ.get("OCRS_CHECK_HIPCC", "/opt/rocm/bin/hipcc")
+        flags = os.environ.get("OCRS_CHECK_FLAGS", "--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -Wno-unused-result").split()
+        cmd = [hipcc, *flags, *sys.argv[1:], "-S", "--cuda-device-only", SRC, "-o", out]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         txt = open(out).read().splitlines()
     bad, nk = check(txt)
