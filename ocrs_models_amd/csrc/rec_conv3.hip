@@ -25,6 +25,9 @@
 #ifndef R3_ABL
 #define R3_ABL 0  // ablation mask (measurement builds only): 1 no halo DMA, 2 no weight DMA, 4 no barrier / vmcnt wait, 8 no MFMA, 16 no B fragment reads
 #endif
+#ifndef R3_STAGGER
+#define R3_STAGGER 0  // 1: stagger (measured: 89 -> 146 us, the older wave of a SIMD then waits for the younger at every barrier); 0: both waves of a SIMD take the step barrier at tile 1
+#endif
 #ifndef R3_DBG
 #define R3_DBG 0  // 1: per-phase cycle counters of every wave of block 0 (measurement builds; read with ocrs_conv_rows_dbg)
 #endif
@@ -33,7 +36,6 @@ __device__ long long g_r3dbg[8][8];
 #define R3_T() __builtin_readcyclecounter()
 #endif
 namespace {
-constexpr int R3_RING = 4;       // weight step slots (filled three steps ahead)
 constexpr int R3_HPMAX = 1024;   // staged halo pixels per plane (<= 64 KB per 32-channel chunk, two chunks)
 __device__ uint4 g_zero64[4];    // 64 zero bytes: source of the padding lanes' DMA (four channel groups)
 
@@ -64,6 +66,17 @@ __device__ __forceinline__ int opaque_v(int v) {  // the per-lane counterpart (a
     asm volatile("" : "+v"(v));
     return v;
 }
+// A fragment straight from global memory / L2 into registers, hidden from hipcc's waitcnt bookkeeping like the DMAs (all VMEM operations of the
+// K loop are counted by hand: mixing kinds makes hipcc over-wait by the number of hidden operations).  The destination is only valid behind
+// wait_a() (the statement ties the registers, so no consumer is scheduled above it); tools/check_opaque_loads.py-style audit: no spills and no
+// compiler copies of the fragment registers between load and wait (kernel-resource-usage: 0 spills; the loop's only v_mov are scalar moves).
+typedef unsigned r3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_a(r3_u32x4& d, unsigned voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wait_a4(r3_u32x4& a, r3_u32x4& b, r3_u32x4& c, r3_u32x4& d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -82,11 +95,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     const int l15 = lane & 15, kq = lane >> 4;
     const int HWp = W + 2;
     const unsigned PLANE = (unsigned)hppad * 16u;
-    const unsigned XB = 8u * PLANE;                    // weight ring
-    constexpr unsigned WSLOT = MTB * 1024u;
-    const unsigned DB = XB + R3_RING * WSLOT;          // 1 KB nobody reads: target of the padding DMA instructions
+    const unsigned DB = 8u * PLANE;                    // 1 KB nobody reads: target of the padding DMA instructions
     const unsigned SB = DB + 1024u;                    // statistics slots [WN pixel groups][2][MTB * 16] floats
     const unsigned TB = SB + WN * 2 * MTB * 16 * 4;    // halo DMA unit table [NU][512] int2
+    const unsigned EB = TB + NU * 512 * 8;             // epilogue staging: 2 KB per wave
     const int ncc = Cin / 32, nsteps = ncc * 9;        // ncc even (launch condition): chunk q of a pass lives in input buffer q & 1
     const int ppi = (H + R - 1) / R, total = N * ppi;
     const int ppb = (total + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -137,14 +149,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
         const unsigned dst = (unsigned)(buf * 4 + kg) * PLANE + (unsigned)grp * 1024u;
         dma16(src, __builtin_amdgcn_readfirstlane(u < nunits ? dst : DB));
     };
-    // weights: this wave's share of the MTB fragments of a step, from a wave-uniform step pointer
-    static_assert(MTB % 8 == 0, "every wave stages MTB / 8 weight fragments per step");
-    constexpr int WPW = MTB / 8;
-    const unsigned wlane = (unsigned)(wave * WPW * 64 + lane) * 16u;
-    auto issue_w = [&](const char* wstep, int slot) {
+    // weights: the wave's MH fragments of a step straight from the packed array (wave-uniform step pointer + this per-lane offset): the 295 KB
+    // of a layer's weights stay in L2 / L1 (four waves read the same fragments), and without a shared LDS ring there is nothing to
+    // synchronise per step
+    const unsigned wlane = (unsigned)((wm * MH) * 64 + lane) * 16u;
+    auto load_af = [&](r3_u32x4 (&dst)[MH], const char* wstep) {
 #pragma unroll
-        for (int a = 0; a < WPW; ++a)
-            dma16_s(wstep + a * 1024, wlane, __builtin_amdgcn_readfirstlane(XB + (unsigned)slot * WSLOT + (unsigned)(wave * WPW + a) * 1024u));
+        for (int a = 0; a < MH; ++a) load_a(dst[a], wlane, wstep + a * 1024);
     };
     auto lds16 = [&](unsigned off) -> uint4 { return *reinterpret_cast<const uint4*>(smem + off); };
     auto pass_ptr = [&](int ps, int& r0) -> const char* {
@@ -161,16 +172,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     __syncthreads();  // (unit table)
 #pragma unroll
     for (int i = 0; i < NU; ++i) issue_x(i, xpc, r0c, 0);
-    issue_w(wbase, 0);
-    issue_w(wbase + tapstride, 1);
-    issue_w(wbase + 2 * tapstride, 2);
-    wait_vm<0>();
-    __syncthreads();
-
     f32x4 acc[MH][NTW];
-    uint4 afA[MH], afB[MH], bq[NTW];
-#pragma unroll
-    for (int a = 0; a < MH; ++a) afA[a] = lds16(XB + (unsigned)(wm * MH + a) * 1024u + lane * 16u);
+    r3_u32x4 afA[MH], afB[MH];
+    uint4 bq[NTW];
+    load_af(afA, wbase);
+    wait_a4(afA[0], afA[1], afA[2], afA[3]);
+    __syncthreads();
+    load_af(afB, wbase + tapstride);  // step 1
 #pragma unroll
     for (int b = 0; b < NTW; ++b) bq[b] = lds16(baddr[b]);
 #if R3_DBG
@@ -181,77 +189,71 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     // divisions and 64-bit address arithmetic cost ~200 scalar + ~100 vector instructions per step -- as much issue time as the 28 MFMAs)
     int tap = 0, kx = 0;                 // current step's tap, its column
     int cc = 0;                          // current chunk
-    int slot = 0;                        // ring slot of the current step
     unsigned tapoff = 0;                 // LDS byte offset of the current step's tap (incl. the input buffer)
     unsigned xbuf = 0;                   // input buffer of the current chunk (0 / 1)
-    int tap3 = 3, cc3 = 0;               // (tap, chunk) of step + 3
-    const char* wp3 = wbase + 3 * tapstride;
-    bool wx_prev = false;
+    int tap2 = 2, cc2 = 0;               // (tap, chunk) of step + 2
+    const char* wp2 = wbase + 2 * tapstride;
     const char* xnc = xpc;               // source of the halo units issued during the current chunk: first pixel of the NEXT chunk's pass + its channels
     int rnc = r0c;
     const char* xnx = xpc;               // the same for the chunk after the pass's last one: chunk 0 of the next pass
     int rnx = 0;
     const unsigned rowjump = (unsigned)(HWp - 2) * 16u;
 
-    // One K = 32 step: MFMAs of the NTW tiles from af / bq (loaded one step ago); behind tile b's MFMAs bq[b] is refilled with the next step's
-    // tile b (a full step of distance), behind the barrier afn -- the other A register set -- receives the next step's A fragments.  DMA at
-    // the top: weights of step + 3, and at taps 1..5 UPS halo units of the next chunk; the barrier waits for everything issued before the
-    // PREVIOUS step's top (two steps of flight time).
-    auto step = [&](auto first_tag, const uint4 (&af)[MH], uint4 (&afn)[MH]) {
+    // One K = 32 step: MFMAs of the NTW tiles from af / bq (B fragments loaded one step ago); behind tile b's MFMAs bq[b] is refilled with the
+    // next step's tile b (a full step of distance).  afp -- the A register set the PREVIOUS step used -- receives the fragments of step + 1 at
+    // the top, one step ahead of their use.  DMA: at taps 1..5 UPS halo units of the next chunk.  The top-of-step wait (this step's A
+    // fragments; VMEM returns in order, so also every DMA this wave issued before them) is the only per-step synchronisation; the ONE barrier
+    // per chunk sits at tap 8, whose fragment refills are the first reads of the next chunk's buffer.
+    auto step = [&](auto first_tag, r3_u32x4 (&af)[MH], r3_u32x4 (&afp)[MH], bool peel) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        if (!(R3_ABL & 2)) issue_w(wp3, (slot + 3) & (R3_RING - 1));
+        if (!peel) {
+#if R3_DBG
+            const long long tb0 = R3_T();
+#endif
+            wait_a4(af[0], af[1], af[2], af[3]);
+#if R3_DBG
+            t_x += R3_T() - tb0;
+#endif
+            if (!(R3_ABL & 2)) load_af(afp, wp2);
+        }
         const bool with_x = !(R3_ABL & 1) && (unsigned)(tap - 1) < 5u;
         if (with_x) {
 #pragma unroll
             for (int q = 0; q < UPS; ++q) issue_x((tap - 1) * UPS + q, xnc, rnc, (int)(xbuf ^ 1u));
         }
+        if (tap == 8 && !(R3_ABL & 4)) {  // every wave's halo units of the next chunk have landed (issued at taps <= 5, waited for at the top of tap 7)
+#if R3_DBG
+            const long long tb1 = R3_T();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (and this wave's reads of the buffer the chunk after next will be staged into)
+            __builtin_amdgcn_s_barrier();
+#if R3_DBG
+            t_bar += R3_T() - tb1;
+#endif
+        }
         // next step's tap offset: one pixel right, or to the start of the next row, or (after tap 8) tap 0 of the other input buffer
         unsigned ntapoff = tapoff + (kx == 2 ? rowjump : 16u);
         if (tap == 8) ntapoff = (xbuf ^ 1u) * 4u * PLANE;
-        const int nslot = (slot + 1) & (R3_RING - 1);
-        const unsigned abase = XB + (unsigned)nslot * WSLOT + (unsigned)(wm * MH) * 1024u + lane * 16u;
-        constexpr int W0 = (R3_ABL & 2) ? 0 : 2 * WPW;
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
-            if (b == 1 && !(R3_ABL & 4)) {  // this wave's DMAs of two and more steps ago have landed; then every wave's
-#if R3_DBG
-                const long long tb0 = R3_T();
-#endif
-                if (with_x) {
-                    if (wx_prev) wait_vm<W0 + 2 * UPS>();
-                    else wait_vm<W0 + UPS>();
-                } else {
-                    if (wx_prev) wait_vm<W0 + UPS>();
-                    else wait_vm<W0>();
-                }
-#if R3_DBG
-                const long long tb1 = R3_T();
-                t_x += tb1 - tb0;
-#endif
-                __builtin_amdgcn_s_barrier();
-#if R3_DBG
-                t_bar += R3_T() - tb1;
-#endif
-            }
 #pragma unroll
             for (int a = 0; a < MH; ++a) {
                 const f32x4 c = FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[a][b];
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bq[b]), c, 0, 0, 0);
             }
             if (!(R3_ABL & 16)) bq[b] = lds16(baddr[b] + ntapoff);
-            if (b >= 1 && b < 1 + MH) afn[b - 1] = lds16(abase + (unsigned)(b - 1) * 1024u);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- advance (scalar)
-        wx_prev = with_x;
-        slot = nslot;
         tapoff = ntapoff;
         kx = kx == 2 ? 0 : kx + 1;
-        wp3 += tapstride;
-        if (++tap3 == 9) {  // step + 3 enters the next chunk (after a pass's last chunk: chunk 0 again, same weights)
-            tap3 = 0;
-            cc3 = cc3 + 1 == ncc ? 0 : cc3 + 1;
-            wp3 = wbase + (long)cc3 * (MTB * 1024);
+        if (!peel) {
+            wp2 += tapstride;
+            if (++tap2 == 9) {  // step + 2 enters the next chunk (after a pass's last chunk: chunk 0 again, same weights)
+                tap2 = 0;
+                cc2 = cc2 + 1 == ncc ? 0 : cc2 + 1;
+                wp2 = wbase + (long)cc2 * (MTB * 1024);
+            }
         }
         if (++tap == 9) {  // next chunk; the halo units issued during it belong to the chunk after it
             tap = 0;
@@ -271,60 +273,74 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
         cc = 0;
         xnc = ncc == 1 ? xnx : xpc + 64;
         rnc = ncc == 1 ? rnx : r0c;
-        step(std::true_type{}, afA, afB);
-        step(std::false_type{}, afB, afA);
+        step(std::true_type{}, afA, afB, ps == p_first);
+        step(std::false_type{}, afB, afA, false);
 #pragma clang loop unroll(disable)
         for (int sidx = 2; sidx < nsteps; sidx += 2) {  // (nsteps = 9 ncc is even: ncc % 2 == 0 is a launch condition)
-            step(std::false_type{}, afA, afB);
-            step(std::false_type{}, afB, afA);
+            step(std::false_type{}, afA, afB, false);
+            step(std::false_type{}, afB, afA, false);
         }
 #if R3_DBG
         const long long te0 = R3_T();
 #endif
-        // ---- epilogue of the pass: bias, ReLU, store, per-channel sums of the stored values
+        // ---- epilogue of the pass: bias, ReLU, per-channel sums of the stored values, store.  A lane holds 4 consecutive channels of one pixel
+        // per accumulator tile; stored directly that is 8-byte pieces of four different instructions per 32 bytes -- and every CU of the chip
+        // reaches its epilogue at the same time, so the layer's output is written in bursts at the HBM write rate that partial lines allow.
+        // Each wave therefore regroups one N tile at a time through 2 KB of LDS of its own ([16 pixels][64 channels], 16-byte chunks XOR-ed
+        // with the pixel index): the stores are 16 bytes per lane, eight lanes per 128-byte line of a pixel's channel half.
         const int n = ps / ppi, r0 = r0c;
         const int lim = (H - r0) * W < npx ? (H - r0) * W : npx;
         const int lane_e = opaque_v(lane), l15 = lane_e & 15, kq = lane_e >> 4;  // (shadowing: nothing of the epilogue's addressing lives in registers across the K loop)
-        bf16* obase = out + ((long)n * H + r0) * W * ldo + wm * MH * 16 + kq * 4;
+        char* stg = smem + EB + wave * 2048;
+        char* obase = reinterpret_cast<char*>(out + ((long)n * H + r0) * W * ldo + wm * MH * 16);
+        float bs[MH][4], s1[MH][4], s2[MH][4];
 #pragma unroll
-        for (int a = 0; a < MH; ++a) {
-            float bs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
+        for (int a = 0; a < MH; ++a)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bs[r] = bias[(wm * MH + a) * 16 + kq * 4 + r];
+            for (int r = 0; r < 4; ++r) {
+                bs[a][r] = bias ? bias[(wm * MH + a) * 16 + kq * 4 + r] : 0.f;
+                s1[a][r] = s2[a][r] = 0.f;
             }
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int p = (j * WN + wn) * 16 + l15;
-                if (p < lim && !((R3_ABL & 32) && acc[a][j][0] != 123.f)) {
-                    float v[4];
+        for (int j = 0; j < NTW; ++j) {
+            const int pj = (j * WN + wn) * 16;
+            if (pj >= lim || ((R3_ABL & 32) && acc[0][j][0] != 123.f)) continue;  // (wave-uniform)
+            const bool mine = pj + l15 < lim;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[a][j][r] + bs[r];
-                        if (relu) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    store4(obase + (long)p * ldo + a * 16, v[0], v[1], v[2], v[3]);
-                    if (gstat) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float q = Elem<bf16>::round(v[r]);
-                            s1[r] += q;
-                            s2[r] = fmaf(q, q, s2[r]);
-                        }
-                    }
-                }
-            }
-            if (gstat) {
+            for (int a = 0; a < MH; ++a) {
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a1 = quad16_sum(s1[r]), a2 = quad16_sum(s2[r]);
-                    if (l15 == 0) {  // (wave, channel) has exactly one owner lane: plain adds in program order -> run-to-run bit-stable
+                    v[r] = acc[a][j][r] + bs[a][r];
+                    if (relu) v[r] = fmaxf(v[r], 0.f);
+                }
+                const uint2 pk = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                if (gstat && mine) {
+                    const float q0 = __uint_as_float(pk.x << 16), q1 = __uint_as_float(pk.x & 0xffff0000u), q2 = __uint_as_float(pk.y << 16),
+                                q3 = __uint_as_float(pk.y & 0xffff0000u);
+                    s1[a][0] += q0; s1[a][1] += q1; s1[a][2] += q2; s1[a][3] += q3;
+                    s2[a][0] = fmaf(q0, q0, s2[a][0]); s2[a][1] = fmaf(q1, q1, s2[a][1]); s2[a][2] = fmaf(q2, q2, s2[a][2]); s2[a][3] = fmaf(q3, q3, s2[a][3]);
+                }
+                *reinterpret_cast<uint2*>(stg + l15 * 128 + (((a * 2 + (kq >> 1)) ^ (l15 & 7)) << 4) + (kq & 1) * 8) = pk;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ci = lane_e + 64 * h, px = ci >> 3, c16 = ci & 7;
+                const uint4 q = *reinterpret_cast<const uint4*>(stg + px * 128 + ((c16 ^ (px & 7)) << 4));
+                if (pj + px < lim) *reinterpret_cast<uint4*>(obase + (long)(pj + px) * ldo * 2 + c16 * 16) = q;
+            }
+        }
+        if (gstat) {
+#pragma unroll
+            for (int a = 0; a < MH; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = quad16_sum(s1[a][r]), a2 = quad16_sum(s2[a][r]);
+                    if (l15 == 0) {  // (pixel group, channel) has exactly one owner lane: plain adds in program order -> run-to-run bit-stable
                         s_stat[wn * 2 * MTB * 16 + (wm * MH + a) * 16 + kq * 4 + r] += a1;
                         s_stat[wn * 2 * MTB * 16 + MTB * 16 + (wm * MH + a) * 16 + kq * 4 + r] += a2;
                     }
                 }
-            }
         }
 #if R3_DBG
         t_epi += R3_T() - te0;
@@ -375,7 +391,7 @@ bool conv3x3_rows_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, in
     const int on = env_int("OCRS_CONV_ROWS", 1);
     int hp;
     return on && dtype == 1 && M == 128 && Cin % 64 == 0 && KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi && ldx % 8 == 0 &&
-           ldo % 4 == 0 && conv3x3_rows_geometry(Hi, Wi, 28, &hp) > 0 && (long)Hi * Wi * ldx < (1L << 30);
+           ldo % 8 == 0 && conv3x3_rows_geometry(Hi, Wi, 28, &hp) > 0 && (long)Hi * Wi * ldx < (1L << 30);
 }
 
 int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int H, int W,
@@ -383,7 +399,7 @@ int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int 
     int hppad = 0;
     const int R = conv3x3_rows_geometry(H, W, 28, &hppad);
     const int total = N * ((H + R - 1) / R);
-    const int smem = 8 * hppad * 16 + R3_RING * 8 * 1024 + 1024 + 4 * 2 * 128 * 4 + 5 * 512 * 8;
+    const int smem = 8 * hppad * 16 + 1024 + 4 * 2 * 128 * 4 + 5 * 512 * 8 + 8 * 2048;
     static DevOnce attr_set;
     if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_rows<4, 2, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
