@@ -370,50 +370,83 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     }
 }
 
-// pass geometry: rows per pass (0: the shape does not fit this kernel); cap = N tiles a pass can hold (WN * NTW)
-static int conv3x3_rows_geometry(int H, int W, int cap, int* hppad) {
-    int best = 0;
-    double best_cost = 1e30;
+// ---- launch side: instantiations and pass geometry -------------------------------------------------------------------------------------
+namespace {
+struct R3Variant {
+    int M, ntw, ups, cap;  // output channels, N tiles per wave, halo units per step, N tiles per pass (WN * NTW)
+};
+// 128 output channels: 2 channel groups x 4 pixel groups; 64: 1 x 8.  NTW = 7 fits a 4 x 100 pass (25 tiles as 7 / 6 / 6 / 6), NTW = 8 power-of-two widths.
+constexpr R3Variant R3_VARIANTS[] = {{128, 7, 1, 28}, {128, 8, 1, 32}, {128, 8, 2, 32}, {64, 4, 1, 32}, {64, 4, 2, 32}};
+constexpr int R3_NVAR = sizeof(R3_VARIANTS) / sizeof(R3_VARIANTS[0]);
+constexpr int R3_LDS_FIXED = 1024 + 4 * 2 * 128 * 4 + 8 * 2048;  // dump slot, statistics, epilogue staging
+
+struct R3Plan {
+    int var, R, hppad, smem;
+    double cost;
+};
+// rows per pass for one variant: fewest passes per image (a pass costs NTW tile times per step whatever it fills), then the tallest pass
+R3Plan r3_plan_variant(int vi, int H, int W) {
+    const R3Variant& v = R3_VARIANTS[vi];
+    R3Plan best{vi, 0, 0, 0, 1e30};
     for (int R = 1; R <= H; ++R) {
-        const int nt = (R * W + 15) / 16, hp = (R + 2) * (W + 2);
-        if (nt > cap || hp > 640) break;  // (UPS = 1: five halo units per wave and chunk)
-        const double cost = (double)((H + R - 1) / R);  // every pass costs NTW tile times per step whatever it fills
-        if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && R > best)) {
-            best_cost = cost;
-            best = R;
-        }
+        const int nt = (R * W + 15) / 16, hp = ((R + 2) * (W + 2) + 63) / 64 * 64;
+        const int smem = 8 * hp * 16 + R3_LDS_FIXED + 5 * v.ups * 512 * 8;
+        if (nt > v.cap || hp > 640 * v.ups || smem > 160 * 1024) break;
+        const double cost = (double)((H + R - 1) / R) * v.ntw;
+        if (cost <= best.cost) best = R3Plan{vi, R, hp, smem, cost};
     }
-    if (best) *hppad = (((best + 2) * (W + 2)) + 63) / 64 * 64;
     return best;
 }
+R3Plan r3_plan(int M, int H, int W) {
+    R3Plan best{-1, 0, 0, 0, 1e30};
+    for (int vi = 0; vi < R3_NVAR; ++vi) {
+        if (R3_VARIANTS[vi].M != M) continue;
+        const R3Plan p = r3_plan_variant(vi, H, W);
+        if (p.R > 0 && p.cost < best.cost) best = p;
+    }
+    return best;
+}
+template <int MH, int WM, int NTW, int UPS>
+int r3_launch(const R3Plan& pl, const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int N, int H, int W,
+              hipStream_t st) {
+    static DevOnce attr_set;
+    auto kern = &k_conv3x3_rows<MH, WM, NTW, UPS>;
+    if (attr_set.need()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OCRS_ERR_HIP;
+        attr_set.done();
+    }
+    // whole passes per block, as evenly as the pass count allows (two / four passes = one image per CU at B = 256)
+    const int total = N * ((H + pl.R - 1) / pl.R);
+    int grid = total < kNumCU ? total : kNumCU;
+    const int ppb = (total + grid - 1) / grid;
+    grid = (total + ppb - 1) / ppb;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.smem, st, (const bf16*)x, ldx, (const uint4*)wpk, (bf16*)out, ldo, bias, relu, gstat, Cin, N, H, W, pl.R,
+                       pl.hppad);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+}  // namespace
 
 bool conv3x3_rows_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype) {
-    const int on = env_int("OCRS_CONV_ROWS", 1);
-    int hp;
-    return on && dtype == 1 && M == 128 && Cin % 64 == 0 && KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi && ldx % 8 == 0 &&
-           ldo % 8 == 0 && conv3x3_rows_geometry(Hi, Wi, 28, &hp) > 0 && (long)Hi * Wi * ldx < (1L << 30);
+    const int on = env_int("OCRS_CONV_ROWS", 1);  // 2: every shape the kernel can run (tests / measurements)
+    // measured (tools/experiments/r4_conv_time.py, B = 256): ahead of k_conv3x3_c128 / k_conv_igemm by 10-30 % where a row is not a whole number
+    // of 16-pixel tiles (100, 37, ...) or short (<= 64); behind at 128 / 192 pixels per row (568 / 425 vs 729 / 696 TF/s) -- those stay there
+    if (on == 1 && !(Wi % 16 != 0 || Wi <= 64)) return false;
+    return on && dtype == 1 && (M == 128 || M == 64) && Cin % 64 == 0 && KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi && ldx % 8 == 0 &&
+           ldo % 8 == 0 && (long)Hi * Wi * ldx < (1L << 30) && r3_plan(M, Hi, Wi).var >= 0;
 }
 
 int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int H, int W,
                         hipStream_t st) {
-    int hppad = 0;
-    const int R = conv3x3_rows_geometry(H, W, 28, &hppad);
-    const int total = N * ((H + R - 1) / R);
-    const int smem = 8 * hppad * 16 + 1024 + 4 * 2 * 128 * 4 + 5 * 512 * 8 + 8 * 2048;
-    static DevOnce attr_set;
-    if (attr_set.need()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_rows<4, 2, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return OCRS_ERR_HIP;
-        attr_set.done();
+    const R3Plan pl = r3_plan(M, H, W);
+    switch (pl.var) {
+        case 0: return r3_launch<4, 2, 7, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
+        case 1: return r3_launch<4, 2, 8, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
+        case 2: return r3_launch<4, 2, 8, 2>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
+        case 3: return r3_launch<4, 1, 4, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
+        case 4: return r3_launch<4, 1, 4, 2>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
     }
-    // whole passes per block, as evenly as the pass count allows (two / four passes = one image per CU at B = 256)
-    int grid = total < kNumCU ? total : kNumCU;
-    const int ppb = (total + grid - 1) / grid;
-    grid = (total + ppb - 1) / ppb;
-    hipLaunchKernelGGL((k_conv3x3_rows<4, 2, 7, 1>), dim3(grid), dim3(512), smem, st, (const bf16*)x, ldx, (const uint4*)wpk, (bf16*)out, ldo, bias, relu, gstat, Cin,
-                       N, H, W, R, hppad);
-    OCRS_LAUNCH_CHECK();
-    return OCRS_OK;
+    return OCRS_ERR_ARG;
 }
 
 #if R3_DBG

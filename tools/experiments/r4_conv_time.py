@@ -13,7 +13,7 @@ from tests.test_rec_gpu import _run, nchw, nhwc, rel  # noqa: E402
 
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-SHAPES = [(128, 128, 8, 100), (128, 128, 16, 100), (64, 128, 16, 100), (128, 128, 16, 64), (128, 128, 16, 128), (128, 128, 8, 192), (128, 128, 7, 37)]
+SHAPES = [(128, 128, 8, 100), (128, 128, 16, 100), (64, 128, 16, 100), (128, 64, 16, 100), (128, 64, 9, 37), (128, 128, 16, 64), (128, 128, 16, 128), (128, 128, 8, 192), (128, 128, 7, 37)]
 dtype = torch.bfloat16
 for ci, co, H, W in SHAPES[: int(os.environ.get("R4_SHAPES", len(SHAPES)))]:
     g = torch.Generator().manual_seed(ci + co + H)
