@@ -74,8 +74,11 @@ typedef unsigned r3_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load_a(r3_u32x4& d, unsigned voff, const void* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void wait_a4(r3_u32x4& a, r3_u32x4& b, r3_u32x4& c, r3_u32x4& d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+__device__ __forceinline__ void wait_a(r3_u32x4 (&f)[4]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+__device__ __forceinline__ void wait_a(r3_u32x4 (&f)[2]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(f[0]), "+v"(f[1])::"memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     r3_u32x4 afA[MH], afB[MH];
     uint4 bq[NTW];
     load_af(afA, wbase);
-    wait_a4(afA[0], afA[1], afA[2], afA[3]);
+    wait_a(afA);
     __syncthreads();
     load_af(afB, wbase + tapstride);  // step 1
 #pragma unroll
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
 #if R3_DBG
             const long long tb0 = R3_T();
 #endif
-            wait_a4(af[0], af[1], af[2], af[3]);
+            wait_a(af);
 #if R3_DBG
             t_x += R3_T() - tb0;
 #endif
@@ -291,6 +294,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
         const int n = ps / ppi, r0 = r0c;
         const int lim = (H - r0) * W < npx ? (H - r0) * W : npx;
         const int lane_e = opaque_v(lane), l15 = lane_e & 15, kq = lane_e >> 4;  // (shadowing: nothing of the epilogue's addressing lives in registers across the K loop)
+        constexpr int CPP = MH * 2;  // 16-byte chunks per pixel of the wave's channel group
+        static_assert(MH == 4 || MH == 2, "epilogue staging layout");
         char* stg = smem + EB + wave * 2048;
         char* obase = reinterpret_cast<char*>(out + ((long)n * H + r0) * W * ldo + wm * MH * 16);
         float bs[MH][4], s1[MH][4], s2[MH][4];
@@ -321,12 +326,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
                     s1[a][0] += q0; s1[a][1] += q1; s1[a][2] += q2; s1[a][3] += q3;
                     s2[a][0] = fmaf(q0, q0, s2[a][0]); s2[a][1] = fmaf(q1, q1, s2[a][1]); s2[a][2] = fmaf(q2, q2, s2[a][2]); s2[a][3] = fmaf(q3, q3, s2[a][3]);
                 }
-                *reinterpret_cast<uint2*>(stg + l15 * 128 + (((a * 2 + (kq >> 1)) ^ (l15 & 7)) << 4) + (kq & 1) * 8) = pk;
+                *reinterpret_cast<uint2*>(stg + l15 * (CPP * 16) + (((a * 2 + (kq >> 1)) ^ (l15 & (CPP - 1))) << 4) + (kq & 1) * 8) = pk;
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ci = lane_e + 64 * h, px = ci >> 3, c16 = ci & 7;
-                const uint4 q = *reinterpret_cast<const uint4*>(stg + px * 128 + ((c16 ^ (px & 7)) << 4));
+            for (int h = 0; h < MH / 2; ++h) {
+                const int ci = lane_e + 64 * h, px = ci / CPP, c16 = ci % CPP;
+                const uint4 q = *reinterpret_cast<const uint4*>(stg + px * (CPP * 16) + ((c16 ^ (px & (CPP - 1))) << 4));
                 if (pj + px < lim) *reinterpret_cast<uint4*>(obase + (long)(pj + px) * ldo * 2 + c16 * 16) = q;
             }
         }
@@ -376,7 +381,7 @@ struct R3Variant {
     int M, ntw, ups, cap;  // output channels, N tiles per wave, halo units per step, N tiles per pass (WN * NTW)
 };
 // 128 output channels: 2 channel groups x 4 pixel groups; 64: 1 x 8.  NTW = 7 fits a 4 x 100 pass (25 tiles as 7 / 6 / 6 / 6), NTW = 8 power-of-two widths.
-constexpr R3Variant R3_VARIANTS[] = {{128, 7, 1, 28}, {128, 8, 1, 32}, {128, 8, 2, 32}, {64, 4, 1, 32}, {64, 4, 2, 32}};
+constexpr R3Variant R3_VARIANTS[] = {{128, 7, 1, 28}, {128, 8, 1, 32}, {128, 8, 2, 32}, {64, 4, 1, 32}, {64, 4, 2, 32}};  // (32 output channels x 4 tiles = 8 MFMAs per wave and step was measured: the per-step costs dominate, 324 vs 193 us for k_conv_igemm at 64 -> 32, 32 x 200)
 constexpr int R3_NVAR = sizeof(R3_VARIANTS) / sizeof(R3_VARIANTS[0]);
 constexpr int R3_LDS_FIXED = 1024 + 4 * 2 * 128 * 4 + 8 * 2048;  // dump slot, statistics, epilogue staging
 
