@@ -213,6 +213,14 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
                  int T, int N, int C, int Lpad, int Smax, hipStream_t st);
 int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
                  const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+/* torch.nn.CTCLoss() forward AND gradient in one launch (train_rec.py:104,121 + the backward of train_rec.py:140), lattice and log-probabilities
+ * in LDS.  ocrs_ctc_fused_lds_bytes: LDS bytes a sample needs, 0 = shape not covered (use ocrs_ctc_fwd / ocrs_ctc_bwd).
+ * grad_pre [T][N][C] (nullable: loss only) = dloss/dlog_probs for an upstream gradient of 1. */
+long ocrs_ctc_fused_lds_bytes(int T, int C, int Smax);
+int ocrs_ctc_fused(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, float* nll, float* loss, float* grad_pre, int T,
+                   int N, int C, int Lpad, int Smax, hipStream_t st);
+/* out[i] = in[i] * g[0], g a device scalar: the upstream gradient of loss.backward() applied to grad_pre. */
+int ocrs_scale_by_dev(const float* in, const float* g, float* out, long n, hipStream_t st);
 /* The same with the alpha lattice kept for the backward in fp16 (BASELINE configs[4] "fp16 CTC alpha/beta"; SURVEY D5: a separately-toleranced
  * variant): alpha16 [N][T][Smax] fp16 = alpha - rowmax, rowmax [N][T] fp32 (row maximum per time step).  The recursion and the loss stay fp32
  * (identical loss bits); the gradient sees the fp16 rounding of the lattice (~1e-3 relative). */

@@ -64,6 +64,15 @@ class _CTC(torch.autograd.Function):
         dev = lp.device
         nll = torch.empty(N, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
+        ctx.fused = False
+        if not h16 and L.ctc_fused_lds_bytes(T, C, Smax) > 0:
+            # fused wave-level form (csrc/rec_seq.hip k_ctc_fused_w): loss AND the gradient for an upstream gradient of 1 in one launch
+            need_grad = log_probs.requires_grad
+            gpre = torch.empty_like(lp) if need_grad else None
+            L.ctc_fused(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(nll), ptr(loss), ptr(gpre), T, N, C, Lpad, Smax)
+            ctx.fused = True
+            ctx.save_for_backward(gpre)
+            return loss
         if h16:
             alpha = torch.empty(N, T, Smax, dtype=torch.float16, device=dev)
             rowmax = torch.empty(N, T, dtype=torch.float32, device=dev)
@@ -78,6 +87,11 @@ class _CTC(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.fused:
+            (gpre,) = ctx.saved_tensors
+            g = gout.contiguous().float().reshape(1)
+            lib().scale_by_dev(ptr(gpre), ptr(g), ptr(gpre), gpre.numel())  # (in place: the buffer belongs to this node)
+            return gpre, None, None, None, None, None
         lp, tg, in_len, tg_len, alpha, nll, rowmax = ctx.saved_tensors
         T, N, C = lp.shape
         grad = torch.empty_like(lp)

@@ -590,3 +590,30 @@ def test_gemm_partial_last_m_tile_reads_no_weights_past_the_pack(dev):
     torch.cuda.synchronize()
     assert rel(out[:, :M], x @ w.t() + b) < 1e-5
     assert float(out[:, M:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("knob", ["OCRS_CTC_WAVE", "OCRS_CTC_FUSED"])
+def test_ctc_wave_level_forms_are_bit_identical_to_the_block_kernels(dev, knob, monkeypatch):
+    """csrc/rec_seq.hip k_ctc_alpha_w / k_ctc_beta_grad_w (one wave per sample, DPP wave shifts for the neighbour states) and k_ctc_fused_w
+    (lattice + log-probabilities in LDS, loss and gradient in one launch): same lse3, same association, integer occupancy sums -> the loss
+    and the gradient must equal the default block kernels' bit for bit (2 and 4 states per lane, ragged lengths, repeated labels, L = 0)."""
+    import ocrs_models_amd as oa
+
+    g = torch.Generator().manual_seed(11)
+    for T, N, C, Lmax in [(101, 37, 97, 40), (65, 9, 97, 20), (120, 5, 23, 100)]:
+        lp = torch.log_softmax(3 * torch.randn(T, N, C, generator=g), -1).to(dev)
+        tl = torch.randint(0, Lmax + 1, (N,), generator=g)
+        tl[0] = Lmax
+        tg = torch.randint(1, C, (N, Lmax), generator=g).int()
+        tg[0, 2:5] = tg[0, 2]
+        il = torch.randint(T // 2, T + 1, (N,), generator=g)
+        il[0] = T
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv(knob, mode)
+            x = lp.clone().requires_grad_(True)
+            loss = oa.CTCLoss()(x, tg, il, tl)
+            loss.backward()
+            out[mode] = (loss.detach().clone(), x.grad.clone())
+        assert torch.equal(out["0"][0], out["1"][0]) or (torch.isinf(out["0"][0]) and torch.isinf(out["1"][0])), (T, N, Lmax)
+        assert torch.equal(torch.nan_to_num(out["0"][1]), torch.nan_to_num(out["1"][1])), (T, N, Lmax)
