@@ -38,16 +38,24 @@ def _run(dev, dtype, N, H=64, W=64):
     return r
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("ci,co,k,pad,H,W", [(32, 64, 3, 1, 12, 20), (64, 128, 3, 1, 9, 17), (128, 128, 3, 1, 8, 33), (128, 128, 2, 1, 4, 19),
-                                             # the 128-output-channel 3x3 layers at their real sizes (csrc/rec_conv2.hip: one image x 16 rows and two images
-                                             # x 8 rows per tile, odd batch, partial tiles in both directions)
-                                             (64, 128, 3, 1, 16, 100), (128, 128, 3, 1, 16, 37), (128, 128, 3, 1, 8, 100), (128, 128, 3, 1, 21, 16)])
-def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W):
-    from ocrs_models_amd._lib import ptr
+CONV_CASES = [(32, 64, 3, 1, 12, 20, 3), (64, 128, 3, 1, 9, 17, 3), (128, 128, 3, 1, 8, 33, 3), (128, 128, 2, 1, 4, 19, 3),
+              # the 128-output-channel 3x3 layers at their real sizes (csrc/rec_conv3.hip whole-row passes / rec_conv2.hip tiles: odd batch,
+              # partial passes and tiles in both directions)
+              (64, 128, 3, 1, 16, 100, 3), (128, 128, 3, 1, 16, 37, 3), (128, 128, 3, 1, 8, 100, 3), (128, 128, 3, 1, 21, 16, 3),
+              # BASELINE configs[2] itself: B = 256 crops (one image per CU in rec_conv3.hip), and the 64-output-channel dgrad shape
+              (128, 128, 3, 1, 8, 100, 256), (128, 64, 3, 1, 16, 100, 64)]
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ci,co,k,pad,H,W,N", CONV_CASES)
+def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W, N):
+    """nn.Conv2d forward / dgrad / wgrad through the C ABI against conv2d autograd on the CPU.  bf16: the reference is ROUNDING-MATCHED -- the
+    same bf16-rounded input, weight and upstream gradient, fp32 accumulation, the output rounded where the kernel stores bf16 -- so what is
+    left is the kernels' own fp32 summation order: measured <= 3.6e-5 (output), <= 4.0e-5 (dgrad), <= 6.2e-7 (wgrad, fp32 output) over these
+    cases; the bounds are ~5x that (round 3 compared against the unrounded reference at 0.1)."""
+    if N > 3 and dtype == torch.float32:
+        pytest.skip("full-batch cases: throughput (bf16) mode only")
     g = torch.Generator().manual_seed(ci + co + k)
-    N = 3
     Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
     x = torch.randn(N, ci, H, W, generator=g).to(dev)
     w = (torch.randn(co, ci, k, k, generator=g) / math.sqrt(ci * k * k)).to(dev)
@@ -57,20 +65,21 @@ def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W):
     r.G = {"w": torch.zeros_like(w)}
     xs = nhwc(x, dtype)
     out, gstat = r.conv(xs, w, b, True, True, H, W, pad, Ho, Wo)
-    xr = nchw(xs).requires_grad_(True)
-    wr = w.clone().requires_grad_(True)
-    ref = torch.relu(F.conv2d(xr, wr, b, padding=pad))
-    tol = TOL[dtype]
-    assert rel(nchw(out), ref) < tol
-    q = ref.detach().to(dtype).float()
-    assert rel(gstat[:co], q.sum((0, 2, 3))) < 10 * tol and rel(gstat[co:], (q * q).sum((0, 2, 3))) < 10 * tol
-    dz = nhwc(torch.randn(N, co, Ho, Wo, generator=g).to(dev), dtype)
+    bf = dtype == torch.bfloat16
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    xr = nchw(xs).cpu().requires_grad_(True)
+    wr = rnd(w).cpu().clone().requires_grad_(True)  # (the kernels pack the fp32 master weights to bf16 fragments)
     pre = F.conv2d(xr, wr, None, padding=pad)
-    pre.backward(nchw(dz))
+    ref = rnd(torch.relu(pre + b.cpu().view(1, -1, 1, 1))).detach()
+    t_out, t_dx, t_dw = (3e-4, 3e-4, 5e-6) if bf else (2e-5, 1e-4, 1e-4)
+    assert rel(nchw(out), ref) < t_out
+    assert rel(gstat[:co], ref.sum((0, 2, 3))) < 1e-4 and rel(gstat[co:], (ref * ref).sum((0, 2, 3))) < 1e-4
+    dz = nhwc(torch.randn(N, co, Ho, Wo, generator=g).to(dev), dtype)
+    pre.backward(nchw(dz).cpu())
     dx = r.conv_bwd("w", dz, xs, Ho, Wo, H, W, pad)
     torch.cuda.synchronize()
-    assert rel(nchw(dx), xr.grad) < 5 * tol, "dgrad"
-    assert rel(r.G["w"], wr.grad) < 5 * tol, "wgrad"
+    assert rel(nchw(dx), rnd(xr.grad)) < t_dx, "dgrad"
+    assert rel(r.G["w"], wr.grad) < t_dw, "wgrad"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -247,11 +256,13 @@ def test_recognition_bf16_autocast_mode(dev):
         errs.append(compare_to_golden(G, f"rec1/f32/grad/{k}", p.grad, 0, atol=1e-7))
         floors.append(golden_vs_golden(G, f"rec1/bf16/grad/{k}", f"rec1/f32/grad/{k}"))
     assert float(np.median(errs)) < 1.5 * float(np.median(floors)) + 1e-2, (float(np.median(errs)), float(np.median(floors)))
-    # the fp32 part of the net (GRU, Linear: exact-fp32 or split-bf16 GEMMs) must hold PER TENSOR, not only in the median: their error is
-    # what the bf16 conv stack feeds them, i.e. bounded by the reference's own bf16-vs-fp32 difference for that tensor
-    for (k, _), e_k, f_k in zip(m.named_parameters(), errs, floors):
-        if k.startswith(("gru.", "output.")):
-            assert e_k < 2.0 * f_k + 2e-2, (k, e_k, f_k)
+    # PER TENSOR, all 36 parameter gradients (round 4; round 3 bounded only the median of the conv stack): a tensor's distance from the
+    # reference's fp32 gradient may not exceed 1.6 x the reference's OWN bf16-autocast-vs-fp32 distance for that tensor (+ 5e-3).  Measured:
+    # ratio 0.24 ... 1.34 (worst: gru.weight_hh_l1 6.4e-3 vs 4.8e-3, conv.13.weight 6.7e-2 vs 5.1e-2) -- the HIP path's bf16 numerics
+    # are the reference's, tensor by tensor.  (Op level, the conv kernels are pinned against a rounding-matched reference at 3e-4 / 5e-6:
+    # test_conv_igemm_fwd_dgrad_wgrad.)
+    bad = {k: (e_k, f_k) for (k, _), e_k, f_k in zip(m.named_parameters(), errs, floors) if not e_k < 1.6 * f_k + 5e-3}
+    assert not bad, bad
 
 
 def test_recognition_bf16_step_is_bit_stable(dev):
