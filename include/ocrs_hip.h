@@ -174,11 +174,6 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
 int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
                    hipStream_t st);
-/* The same pair with the forward's window arg-max kept for the backward (training): amax [N][H/2][W/2][4] uint32, per output channel a
- * nibble = 0 (every candidate <= 0: ReLU) or 1 + (oy * 2 + ox) of the first maximum; amax == NULL = the calls above. */
-int ocrs_conv0_fwd_am(const float* img, const float* w, const float* bias, void* out, unsigned* amax, int N, int H, int W, int dtype, hipStream_t st);
-int ocrs_conv0_bwd_am(const float* img, const float* w, const float* bias, const void* g, const unsigned* amax, float* dW, float* db, int N, int H, int W,
-                      int dtype, hipStream_t st);
 /* BatchNorm2d + ReLU + MaxPool2d((2,2)|(2,1)) (models.py:197-199, 214-216, 231-233) forward and the pieces of its backward. */
 int ocrs_act_pool_fwd(const void* z, const float* tr, void* out, int C, int N, int H, int W, int PH, int PW, int dtype, hipStream_t st);
 int ocrs_rec_bn_reduce(const void* g, const void* z, const float* bn, const float* saved, double* gsum, int C, int N, int H, int W, int PH, int PW,

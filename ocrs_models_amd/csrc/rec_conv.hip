@@ -613,8 +613,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_wgrad_tr(const bf16* __restrict
 // first layer: Conv2d(1,32,3,pad 1,bias) + ReLU + MaxPool2d(2) (models.py:180-187).  One thread per (pooled pixel, 8 out channels).
 template <class T>
 __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img, const float* __restrict__ w /*[32][9]*/,
-                                                   const float* __restrict__ bias, T* __restrict__ out /*[N][H/2][W/2][32]*/,
-                                                   unsigned* __restrict__ amax /*[N][H/2][W/2][4] or null*/, int N, int H, int W) {
+                                                   const float* __restrict__ bias, T* __restrict__ out /*[N][H/2][W/2][32]*/, int N, int H, int W) {
     const int Hp = H >> 1, Wp = W >> 1;
     // a thread keeps its group of 8 output channels (the grid's thread count is a multiple of 4): their 72 weights + 8 biases live in registers
     // (re-loading them per pixel made 20 of the kernel's 37 load instructions per store)
@@ -641,11 +640,9 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img
                 patch[dy][dx] = ok ? v : 0.f;
             }
         float m[8];
-        unsigned am = 0u;  // per channel a nibble: 0 = every candidate <= 0 (ReLU kills the gradient), else 1 + index of the FIRST maximum
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float best = 0.f;  // ReLU floor: max(relu(a), relu(b), ...) = max(0, a, b, ...)
-            unsigned bo = 0u;
 #pragma unroll
             for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
@@ -653,24 +650,18 @@ __global__ __launch_bounds__(256) void k_conv0_fwd(const float* __restrict__ img
                     float s = bs[i];
 #pragma unroll
                     for (int k = 0; k < 9; ++k) s = fmaf(wk[i][k], patch[oy + k / 3][ox + k % 3], s);
-                    if (s > best) {
-                        best = s;
-                        bo = 1u + oy * 2 + ox;
-                    }
+                    best = fmaxf(best, s);
                 }
             m[i] = best;
-            am |= bo << (4 * i);
         }
         store8(out + pp * 32 + c0, m);
-        if (amax) amax[pp * 4 + (c0 >> 3)] = am;
     }
 }
 
 // backward of the fused first layer: dW [32][9], db [32] accumulated.  g = gradient w.r.t. the pooled output [N][H/2][W/2][32].
 template <class T>
 __global__ __launch_bounds__(256) void k_conv0_bwd(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                                                   const T* __restrict__ g, const unsigned* __restrict__ amax, float* __restrict__ dW,
-                                                   float* __restrict__ db, int N, int H, int W) {
+                                                   const T* __restrict__ g, float* __restrict__ dW, float* __restrict__ db, int N, int H, int W) {
     __shared__ float s_acc[32 * 10];
     for (int i = threadIdx.x; i < 320; i += 256) s_acc[i] = 0.f;
     __syncthreads();
@@ -700,25 +691,18 @@ __global__ __launch_bounds__(256) void k_conv0_bwd(const float* __restrict__ img
             }
         float gv[8];
         load8(g + pp * 32 + c0, gv);
-        // the forward's window arg-max (k_conv0_fwd: a nibble per channel), or -- amax == null -- the four candidates recomputed (rounds 1-3:
-        // 36 FMAs + 4 compares per channel, more than the gradient arithmetic itself)
-        const unsigned am = amax ? amax[pp * 4 + (c0 >> 3)] : 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            float best = 0.f;
             int bo = -1;  // -1: every candidate <= 0 -> ReLU kills the gradient
-            if (amax) {
-                bo = (int)((am >> (4 * i)) & 15u) - 1;
-            } else {
-                float best = 0.f;
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float s = bs[i];
+            for (int o = 0; o < 4; ++o) {
+                float s = bs[i];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) s = fmaf(wk[i][k], patch[(o >> 1) + k / 3][(o & 1) + k % 3], s);
-                    if (s > best) {
-                        best = s;
-                        bo = o;
-                    }
+                for (int k = 0; k < 9; ++k) s = fmaf(wk[i][k], patch[(o >> 1) + k / 3][(o & 1) + k % 3], s);
+                if (s > best) {
+                    best = s;
+                    bo = o;
                 }
             }
             const float gi = bo >= 0 ? gv[i] : 0.f;
@@ -1778,35 +1762,26 @@ int ocrs_conv3x3_wgrad(const void* dz, int Cout, const void* x, int Cin, float* 
 }
 
 // Conv2d(1,32,3,p1)+ReLU+MaxPool2d(2) fused (models.py:180-187): img fp32 (N,1,H,W) -> out [N][H/2][W/2][32].
-// amax (nullable; training): [N][H/2][W/2][4] uint32, per output channel a nibble = 0 (ReLU floor) or 1 + index (oy * 2 + ox) of the window's
-// first maximum -- what ocrs_conv0_bwd_am needs instead of recomputing the four candidates
-int ocrs_conv0_fwd_am(const float* img, const float* w, const float* bias, void* out, unsigned* amax, int N, int H, int W, int dtype, hipStream_t st) {
+int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(img && w && bias && out && H >= 2 && W >= 2);  // (odd sizes: floor-mode pooling, the last row / column is in no window)
     const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
     if (dtype == 1)
-        hipLaunchKernelGGL(k_conv0_fwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (bf16*)out, amax, N, H, W);
+        hipLaunchKernelGGL(k_conv0_fwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (bf16*)out, N, H, W);
     else
-        hipLaunchKernelGGL(k_conv0_fwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (float*)out, amax, N, H, W);
-    OCRS_LAUNCH_CHECK();
-    return OCRS_OK;
-}
-int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* out, int N, int H, int W, int dtype, hipStream_t st) {
-    return ocrs_conv0_fwd_am(img, w, bias, out, nullptr, N, H, W, dtype, st);
-}
-int ocrs_conv0_bwd_am(const float* img, const float* w, const float* bias, const void* g, const unsigned* amax, float* dW, float* db, int N, int H, int W,
-                      int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(img && w && bias && g && dW && db);
-    const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
-    if (dtype == 1)
-        hipLaunchKernelGGL(k_conv0_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (const bf16*)g, amax, dW, db, N, H, W);
-    else
-        hipLaunchKernelGGL(k_conv0_bwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (const float*)g, amax, dW, db, N, H, W);
+        hipLaunchKernelGGL(k_conv0_fwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (float*)out, N, H, W);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
                    hipStream_t st) {
-    return ocrs_conv0_bwd_am(img, w, bias, g, nullptr, dW, db, N, H, W, dtype, st);
+    OCRS_CHECK_ARG(img && w && bias && g && dW && db);
+    const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_conv0_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (const bf16*)g, dW, db, N, H, W);
+    else
+        hipLaunchKernelGGL(k_conv0_bwd<float>, dim3(grid), dim3(256), 0, st, img, w, bias, (const float*)g, dW, db, N, H, W);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
 }
 
 #define DT_DISPATCH(KERNEL, GRID, SMEM, ...)                                                     \

@@ -180,9 +180,7 @@ class _RecRun:
         S = self
         self.prepack()
         S.a0 = self.empty(N, 32, W // 2, 32)
-        # (training: keep the fused max-pool's arg-max -- 16 bytes per pooled pixel -- so that the backward does not recompute the four candidates)
-        S.am0 = torch.empty(N, 32, W // 2, 4, dtype=torch.int32, device=self.dev) if self.train else None
-        L.conv0_fwd_am(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(S.a0), ptr(S.am0), N, H, W, self.dt)
+        L.conv0_fwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(S.a0), N, H, W, self.dt)
         H1, W1 = 32, W // 2
         S.z3, gs = self.conv(S.a0, P["conv.3.weight"], None, False, True, H1, W1, 1)
         S.tr3, S.sv3 = self.bn("conv.4", gs, N * H1 * W1, 64, 0.0)
@@ -392,7 +390,7 @@ class _RecRun:
         dz3 = self.bn_pool_bwd("conv.4", g3, S.z3, S.tr3, S.sv3, 64, 32, W // 2, 2, 2)
         g0 = self.conv_bwd("conv.3.weight", dz3, S.a0, 32, W // 2, 32, W // 2, 1)
         stage_done("conv.3.")
-        L.conv0_bwd_am(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(g0), ptr(S.am0), ptr(G["conv.0.weight"]), ptr(G["conv.0.bias"]), N, self.H,
+        L.conv0_bwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(g0), ptr(G["conv.0.weight"]), ptr(G["conv.0.bias"]), N, self.H,
                     W, self.dt)
         stage_done("conv.0.")
         if bucketer is not None:
