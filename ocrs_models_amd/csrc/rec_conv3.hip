@@ -90,19 +90,23 @@ template <int MH /* 16-channel output tiles per wave */, int WM /* waves along t
           int UPS /* halo DMA units per wave and step (taps 1..5): 1 for <= 640 staged pixels, 2 up to 1280 */>
 __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict__ x, int ldx, const uint4* __restrict__ wpk, bf16* __restrict__ out, int ldo,
                                                          const float* __restrict__ bias, int relu, double* __restrict__ gstat, int Cin, int N, int H, int W,
-                                                         int R, int hppad) {
+                                                         int R, int hppad, int Hi, int Wi, int KW, int pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int MTB = MH * WM, WN = 8 / WM, NU = 5 * UPS;
+    constexpr int MTB = MH * WM, WN = 8 / WM;
+    // (H, W = OUTPUT size; Hi, Wi = input size; KW x KW taps, padding `pad`: 3 x 3 / pad 1 is Ho = Hi; the CRNN's last conv is 2 x 2 / pad 1, Ho = Hi + 1)
+    const int NT = KW * KW;                       // taps = steps per chunk
+    const int XT0 = NT == 9 ? 1 : 0, XTN = NT == 9 ? 5 : 2;  // halo units are issued at taps XT0 .. XT0 + XTN - 1 (landed two tops later: <= NT - 1)
+    const int NUW = XTN * UPS;                    // units per wave and chunk
     const int wm = wave % WM, wn = wave / WM;  // waves w and w + 4 share a SIMD: pixel groups (0, 2) and (1, 3) -> 13 / 13 / 12 / 12 tiles of a 25-tile pass
     const int l15 = lane & 15, kq = lane >> 4;
-    const int HWp = W + 2;
+    const int HWp = W + KW - 1;
     const unsigned PLANE = (unsigned)hppad * 16u;
     const unsigned DB = 8u * PLANE;                    // 1 KB nobody reads: target of the padding DMA instructions
     const unsigned SB = DB + 1024u;                    // statistics slots [WN pixel groups][2][MTB * 16] floats
-    const unsigned TB = SB + WN * 2 * MTB * 16 * 4;    // halo DMA unit table [NU][512] int2
-    const unsigned EB = TB + NU * 512 * 8;             // epilogue staging: 2 KB per wave
-    const int ncc = Cin / 32, nsteps = ncc * 9;        // ncc even (launch condition): chunk q of a pass lives in input buffer q & 1
+    const unsigned TB = SB + WN * 2 * MTB * 16 * 4;    // halo DMA unit table [NUW][512] int2
+    const unsigned EB = TB + (unsigned)NUW * 512 * 8;             // epilogue staging: 2 KB per wave
+    const int ncc = Cin / 32, nsteps = ncc * KW * KW;        // ncc even (launch condition): chunk q of a pass lives in input buffer q & 1
     const int ppi = (H + R - 1) / R, total = N * ppi;
     const int ppb = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int p_first = blockIdx.x * ppb, p_end = p_first + ppb < total ? p_first + ppb : total;
@@ -137,17 +141,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     // part of the bounds test that depends on the pass; 1 << 24 = never valid) -- the issue path is a ds_read_b64, a compare and a select.
     int2* s_xt = reinterpret_cast<int2*>(smem + TB);
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {
+    for (int i = 0; i < 6 * UPS; ++i) {
+        if (i >= NUW) break;
         const int u = i * 8 + wave, grp = u >> 2, kg = u & 3;
-        const int sp = grp * 64 + lane, hy = sp / HWp, hx = sp - hy * HWp, w = hx - 1;
-        const bool colok = u < nunits && hy < R + 2 && (unsigned)w < (unsigned)W;
-        s_xt[i * 512 + tid] = make_int2((((hy - 1) * W + w) * ldx + kg * 8) * 2, colok ? hy : (1 << 24));
+        const int sp = grp * 64 + lane, hy = sp / HWp, hx = sp - hy * HWp, w = hx - pad;
+        const bool colok = u < nunits && hy < R + KW - 1 && (unsigned)w < (unsigned)Wi;
+        s_xt[i * 512 + tid] = make_int2((((hy - pad) * Wi + w) * ldx + kg * 8) * 2, colok ? hy : (1 << 24));
     }
     // unit i (run-time, wave-uniform) of the chunk at `xc` (first pixel of its pass + the chunk's channel offset; r0 = first row of the pass)
     auto issue_x = [&](int i, const char* xc, int r0, int buf) {
         const int u = i * 8 + wave, grp = u >> 2, kg = u & 3;
         const int2 e = s_xt[i * 512 + tid];
-        const bool ok = (unsigned)(r0 - 1 + e.y) < (unsigned)H;
+        const bool ok = (unsigned)(r0 - pad + e.y) < (unsigned)Hi;
         const char* src = ok ? xc + e.x : zsrc;
         const unsigned dst = (unsigned)(buf * 4 + kg) * PLANE + (unsigned)grp * 1024u;
         dma16(src, __builtin_amdgcn_readfirstlane(u < nunits ? dst : DB));
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     auto pass_ptr = [&](int ps, int& r0) -> const char* {
         const int n = ps / ppi;
         r0 = (ps - n * ppi) * R;
-        return reinterpret_cast<const char*>(x + ((long)n * H + r0) * W * ldx);
+        return reinterpret_cast<const char*>(x + ((long)n * Hi + r0) * Wi * ldx);  // (row r0 of the INPUT: may lie past its last row -- only an address base)
     };
     const char* wbase = reinterpret_cast<const char*>(wpk);
     const long tapstride = (long)ncc * (MTB * 1024);  // bytes between the fragments of consecutive taps of one chunk
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     const char* xpc = pass_ptr(p_first, r0c);
     __syncthreads();  // (unit table)
 #pragma unroll
-    for (int i = 0; i < NU; ++i) issue_x(i, xpc, r0c, 0);
+    for (int i = 0; i < 6 * UPS; ++i)
+        if (i < NUW) issue_x(i, xpc, r0c, 0);
     f32x4 acc[MH][NTW];
     r3_u32x4 afA[MH], afB[MH];
     uint4 bq[NTW];
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
     int rnc = r0c;
     const char* xnx = xpc;               // the same for the chunk after the pass's last one: chunk 0 of the next pass
     int rnx = 0;
-    const unsigned rowjump = (unsigned)(HWp - 2) * 16u;
+    const unsigned rowjump = (unsigned)(HWp - (KW - 1)) * 16u;
 
     // One K = 32 step: MFMAs of the NTW tiles from af / bq (B fragments loaded one step ago); behind tile b's MFMAs bq[b] is refilled with the
     // next step's tile b (a full step of distance).  afp -- the A register set the PREVIOUS step used -- receives the fragments of step + 1 at
@@ -219,12 +225,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
 #endif
             if (!(R3_ABL & 2)) load_af(afp, wp2);
         }
-        const bool with_x = !(R3_ABL & 1) && (unsigned)(tap - 1) < 5u;
+        const bool with_x = !(R3_ABL & 1) && (unsigned)(tap - XT0) < (unsigned)XTN;
         if (with_x) {
 #pragma unroll
-            for (int q = 0; q < UPS; ++q) issue_x((tap - 1) * UPS + q, xnc, rnc, (int)(xbuf ^ 1u));
+            for (int q = 0; q < UPS; ++q) issue_x((tap - XT0) * UPS + q, xnc, rnc, (int)(xbuf ^ 1u));
         }
-        if (tap == 8 && !(R3_ABL & 4)) {  // every wave's halo units of the next chunk have landed (issued at taps <= 5, waited for at the top of tap 7)
+        if (tap == NT - 1 && !(R3_ABL & 4)) {  // every wave's halo units of the next chunk have landed (issued at taps <= 5, waited for at the top of tap 7)
 #if R3_DBG
             const long long tb1 = R3_T();
 #endif
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
 #endif
         }
         // next step's tap offset: one pixel right, or to the start of the next row, or (after tap 8) tap 0 of the other input buffer
-        unsigned ntapoff = tapoff + (kx == 2 ? rowjump : 16u);
-        if (tap == 8) ntapoff = (xbuf ^ 1u) * 4u * PLANE;
+        unsigned ntapoff = tapoff + (kx == KW - 1 ? rowjump : 16u);
+        if (tap == NT - 1) ntapoff = (xbuf ^ 1u) * 4u * PLANE;
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
 #pragma unroll
@@ -249,16 +255,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
         }
         // ---- advance (scalar)
         tapoff = ntapoff;
-        kx = kx == 2 ? 0 : kx + 1;
+        kx = kx == KW - 1 ? 0 : kx + 1;
         if (!peel) {
             wp2 += tapstride;
-            if (++tap2 == 9) {  // step + 2 enters the next chunk (after a pass's last chunk: chunk 0 again, same weights)
+            if (++tap2 == NT) {  // step + 2 enters the next chunk (after a pass's last chunk: chunk 0 again, same weights)
                 tap2 = 0;
                 cc2 = cc2 + 1 == ncc ? 0 : cc2 + 1;
                 wp2 = wbase + (long)cc2 * (MTB * 1024);
             }
         }
-        if (++tap == 9) {  // next chunk; the halo units issued during it belong to the chunk after it
+        if (++tap == NT) {  // next chunk; the halo units issued during it belong to the chunk after it
             tap = 0;
             xbuf ^= 1u;
             ++cc;
@@ -380,8 +386,9 @@ namespace {
 struct R3Variant {
     int M, ntw, ups, cap;  // output channels, N tiles per wave, halo units per step, N tiles per pass (WN * NTW)
 };
+// (KW = 2: a chunk has 4 steps and its halo units go out in 2 of them -- 3 per wave and step for <= 768 staged pixels)
 // 128 output channels: 2 channel groups x 4 pixel groups; 64: 1 x 8.  NTW = 7 fits a 4 x 100 pass (25 tiles as 7 / 6 / 6 / 6), NTW = 8 power-of-two widths.
-constexpr R3Variant R3_VARIANTS[] = {{128, 7, 1, 28}, {128, 8, 1, 32}, {128, 8, 2, 32}, {64, 4, 1, 32}, {64, 4, 2, 32}};  // (32 output channels x 4 tiles = 8 MFMAs per wave and step was measured: the per-step costs dominate, 324 vs 193 us for k_conv_igemm at 64 -> 32, 32 x 200)
+constexpr R3Variant R3_VARIANTS[] = {{128, 7, 1, 28}, {128, 8, 1, 32}, {128, 8, 2, 32}, {64, 4, 1, 32}, {64, 4, 2, 32}, {128, 7, 3, 28}, {128, 8, 3, 32}};  // (32 output channels x 4 tiles = 8 MFMAs per wave and step was measured: the per-step costs dominate, 324 vs 193 us for k_conv_igemm at 64 -> 32, 32 x 200)
 constexpr int R3_NVAR = sizeof(R3_VARIANTS) / sizeof(R3_VARIANTS[0]);
 constexpr int R3_LDS_FIXED = 1024 + 4 * 2 * 128 * 4 + 8 * 2048;  // dump slot, statistics, epilogue staging
 
@@ -390,30 +397,32 @@ struct R3Plan {
     double cost;
 };
 // rows per pass for one variant: fewest passes per image (a pass costs NTW tile times per step whatever it fills), then the tallest pass
-R3Plan r3_plan_variant(int vi, int H, int W) {
+R3Plan r3_plan_variant(int vi, int H, int W, int KW) {  // H, W: OUTPUT size
     const R3Variant& v = R3_VARIANTS[vi];
     R3Plan best{vi, 0, 0, 0, 1e30};
+    const int xtn = KW == 3 ? 5 : 2;  // steps of a chunk that carry halo units
+    if ((KW == 3) != (v.ups < 3)) return best;
     for (int R = 1; R <= H; ++R) {
-        const int nt = (R * W + 15) / 16, hp = ((R + 2) * (W + 2) + 63) / 64 * 64;
-        const int smem = 8 * hp * 16 + R3_LDS_FIXED + 5 * v.ups * 512 * 8;
-        if (nt > v.cap || hp > 640 * v.ups || smem > 160 * 1024) break;
+        const int nt = (R * W + 15) / 16, hp = ((R + KW - 1) * (W + KW - 1) + 63) / 64 * 64;
+        const int smem = 8 * hp * 16 + R3_LDS_FIXED + xtn * v.ups * 512 * 8;
+        if (nt > v.cap || hp / 16 > 8 * xtn * v.ups || smem > 160 * 1024) break;
         const double cost = (double)((H + R - 1) / R) * v.ntw;
         if (cost <= best.cost) best = R3Plan{vi, R, hp, smem, cost};
     }
     return best;
 }
-R3Plan r3_plan(int M, int H, int W) {
+R3Plan r3_plan(int M, int H, int W, int KW) {
     R3Plan best{-1, 0, 0, 0, 1e30};
     for (int vi = 0; vi < R3_NVAR; ++vi) {
         if (R3_VARIANTS[vi].M != M) continue;
-        const R3Plan p = r3_plan_variant(vi, H, W);
+        const R3Plan p = r3_plan_variant(vi, H, W, KW);
         if (p.R > 0 && p.cost < best.cost) best = p;
     }
     return best;
 }
 template <int MH, int WM, int NTW, int UPS>
 int r3_launch(const R3Plan& pl, const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int N, int H, int W,
-              hipStream_t st) {
+              int Hi, int Wi, int KW, int pad, hipStream_t st) {
     static DevOnce attr_set;
     auto kern = &k_conv3x3_rows<MH, WM, NTW, UPS>;
     if (attr_set.need()) {
@@ -426,7 +435,7 @@ int r3_launch(const R3Plan& pl, const void* x, int ldx, const void* wpk, void* o
     const int ppb = (total + grid - 1) / grid;
     grid = (total + ppb - 1) / ppb;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pl.smem, st, (const bf16*)x, ldx, (const uint4*)wpk, (bf16*)out, ldo, bias, relu, gstat, Cin, N, H, W, pl.R,
-                       pl.hppad);
+                       pl.hppad, Hi, Wi, KW, pad);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -436,21 +445,27 @@ bool conv3x3_rows_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, in
     const int on = env_int("OCRS_CONV_ROWS", 1);  // 2: every shape the kernel can run (tests / measurements)
     // measured (tools/experiments/r4_conv_time.py, B = 256): ahead of k_conv3x3_c128 / k_conv_igemm by 10-30 % where a row is not a whole number
     // of 16-pixel tiles (100, 37, ...) or short (<= 64); behind at 128 / 192 pixels per row (568 / 425 vs 729 / 696 TF/s) -- those stay there
-    if (on == 1 && !(Wi % 16 != 0 || Wi <= 64)) return false;
-    return on && dtype == 1 && (M == 128 || M == 64) && Cin % 64 == 0 && KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi && ldx % 8 == 0 &&
-           ldo % 8 == 0 && (long)Hi * Wi * ldx < (1L << 30) && r3_plan(M, Hi, Wi).var >= 0;
+    if (on == 1 && KW == 3 && !(Wi % 16 != 0 || Wi <= 64)) return false;
+    const bool k3 = KH == 3 && KW == 3 && padh == 1 && padw == 1 && Ho == Hi && Wo == Wi;
+    const bool k2 = KH == 2 && KW == 2 && padh == padw && (padh == 0 || padh == 1) && Ho == Hi + 2 * padh - 1 && Wo == Wi + 2 * padw - 1 && M == 128;
+    return on && dtype == 1 && (M == 128 || M == 64) && Cin % 64 == 0 && (k3 || k2) && ldx % 8 == 0 && ldo % 8 == 0 && (long)Hi * Wi * ldx < (1L << 30) &&
+           r3_plan(M, Ho, Wo, KW).var >= 0;
 }
 
-int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int H, int W,
-                        hipStream_t st) {
-    const R3Plan pl = r3_plan(M, H, W);
+int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int Hi, int Wi,
+                        int Ho, int Wo, int KW, int pad, hipStream_t st) {
+    const R3Plan pl = r3_plan(M, Ho, Wo, KW);
+#define R3_GO(MH_, WM_, NTW_, UPS_) return r3_launch<MH_, WM_, NTW_, UPS_>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, Ho, Wo, Hi, Wi, KW, pad, st)
     switch (pl.var) {
-        case 0: return r3_launch<4, 2, 7, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
-        case 1: return r3_launch<4, 2, 8, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
-        case 2: return r3_launch<4, 2, 8, 2>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
-        case 3: return r3_launch<4, 1, 4, 1>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
-        case 4: return r3_launch<4, 1, 4, 2>(pl, x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, N, H, W, st);
+        case 0: R3_GO(4, 2, 7, 1);
+        case 1: R3_GO(4, 2, 8, 1);
+        case 2: R3_GO(4, 2, 8, 2);
+        case 3: R3_GO(4, 1, 4, 1);
+        case 4: R3_GO(4, 1, 4, 2);
+        case 5: R3_GO(4, 2, 7, 3);
+        case 6: R3_GO(4, 2, 8, 3);
     }
+#undef R3_GO
     return OCRS_ERR_ARG;
 }
 
