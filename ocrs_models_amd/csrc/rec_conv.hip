@@ -1172,6 +1172,9 @@ static inline int ew_grid(long items) {
 bool conv3x3_rows_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype);  // rec_conv3.hip
 int conv3x3_rows_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int Hi, int Wi,
                         int Ho, int Wo, int KW, int pad, hipStream_t st);
+bool conv3x3_tile_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype);  // rec_conv4.hip
+int conv3x3_tile_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N, int H, int W,
+                        hipStream_t st);
 bool conv3x3_c128_supported(int ldx, int ldo, int Cin, int M, int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype);  // rec_conv2.hip
 int conv3x3_c128_launch(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int N, int H, int W,
                         hipStream_t st);
@@ -1332,6 +1335,8 @@ extern "C" {
 int ocrs_conv_igemm(const void* x, int ldx, const void* wpk, void* out, int ldo, const float* bias, int relu, double* gstat, int Cin, int M, int N,
                     int Hi, int Wi, int Ho, int Wo, int KH, int KW, int padh, int padw, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(x && wpk && out && Cin % 32 == 0 && ldx >= Cin && M > 0 && ldo >= M && ldo % 4 == 0 && KH >= 1 && KW >= 1 && KH * KW <= 9);
+    if (conv3x3_tile_supported(ldx, ldo, Cin, M, Hi, Wi, Ho, Wo, KH, KW, padh, padw, dtype))  // narrow layers, weights resident in LDS (rec_conv4.hip)
+        return conv3x3_tile_launch(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, st);
     if (conv3x3_rows_supported(ldx, ldo, Cin, M, Hi, Wi, Ho, Wo, KH, KW, padh, padw, dtype))  // whole-row passes, one workgroup per CU (rec_conv3.hip)
         return conv3x3_rows_launch(x, ldx, wpk, out, ldo, bias, relu, gstat, Cin, M, N, Hi, Wi, Ho, Wo, KW, padh, st);
     if (conv3x3_c128_supported(ldx, ldo, Cin, M, Hi, Wi, Ho, Wo, KH, KW, padh, padw, dtype))  // the 128-output-channel 3x3 layers: 128 x 256 block tiles (rec_conv2.hip)

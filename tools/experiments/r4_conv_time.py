@@ -13,7 +13,7 @@ from tests.test_rec_gpu import _run, nchw, nhwc, rel  # noqa: E402
 
 dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-SHAPES = [(128, 128, 4, 100, 2), (128, 128, 8, 100), (128, 128, 16, 100), (64, 128, 16, 100), (128, 64, 16, 100), (128, 64, 9, 37), (128, 128, 16, 64), (128, 128, 16, 128), (128, 128, 8, 192), (128, 128, 7, 37)]
+SHAPES = [(32, 64, 32, 200), (64, 32, 32, 200), (32, 64, 12, 37), (64, 32, 7, 20), (128, 128, 4, 100, 2), (128, 128, 8, 100), (128, 128, 16, 100), (64, 128, 16, 100), (128, 64, 16, 100), (128, 64, 9, 37), (128, 128, 16, 64), (128, 128, 16, 128), (128, 128, 8, 192), (128, 128, 7, 37)]
 dtype = torch.bfloat16
 for shp in SHAPES[: int(os.environ.get("R4_SHAPES", len(SHAPES)))]:
     ci, co, H, W = shp[:4]
@@ -29,6 +29,7 @@ for shp in SHAPES[: int(os.environ.get("R4_SHAPES", len(SHAPES)))]:
     res = {}
     for mode in ("1", "0"):
         os.environ["OCRS_CONV_ROWS"] = mode
+        os.environ["OCRS_CONV_TILE"] = mode
         out, gstat = r.conv(xs, w, b, True, True, H, W, 1, Ho, Wo)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
