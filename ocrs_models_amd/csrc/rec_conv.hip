@@ -1490,7 +1490,7 @@ static void wgrad_gather_grid(int CA, int CB, int ntaps, long P, int dtype, long
     const long ntiles = (P + TP - 1) / TP;
     const int CA8 = (CA + 7) & ~7;
     gy = ((CA8 + 127) / 128) * ((ntaps * CB + 127) / 128);
-    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);  // few flushing blocks, each loops over many tiles
+    static const int target = env_int("OCRS_WGRAD_BLOCKS", 512);  // two 4-wave blocks per CU (round 4: one wave per SIMD cannot keep the MFMA pipe busy -- tools/probes/mfma_issue_probe.hip; 256 -> 512: 0.563 -> 0.496 ms per step, 768: 0.59)  // few flushing blocks, each loops over many tiles
     gx = ntiles / 4;
     if (gx < 1) gx = 1;
     long cap = target / gy;
@@ -1659,7 +1659,7 @@ static void wgrad_x3_grid(int CA, int CB, long P, int& gx, int& gy, int& tiles_a
 static int wgrad3x3_gx(int Cin, int N, int H, int W) {
     const int ntiles = N * ((W + 15) / 16) * ((H + 7) / 8);
     const int gy = Cin / 32;
-    static const int target = env_int("OCRS_WGRAD_BLOCKS", 256);
+    static const int target = env_int("OCRS_WGRAD_BLOCKS", 512);  // two 4-wave blocks per CU (round 4: one wave per SIMD cannot keep the MFMA pipe busy -- tools/probes/mfma_issue_probe.hip; 256 -> 512: 0.563 -> 0.496 ms per step, 768: 0.59)
     long gx = ntiles / 4;
     if (gx < 1) gx = 1;
     long cap = target / gy;
