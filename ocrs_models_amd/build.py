@@ -53,21 +53,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    if any(os.path.basename(s) == "det_mm.hip" for s, _ in jobs):
-        # the hand-waited prefetch loads of det_mm.hip are only valid if hipcc left their destination registers alone until the wait
+    for asm_src in ("det_mm.hip", "rec_conv3.hip"):
+        if not any(os.path.basename(s) == asm_src for s, _ in jobs):
+            continue
+        # the hand-waited asm loads of det_mm.hip (tile prefetch) and rec_conv3.hip (A fragments) are only valid if hipcc left their
+        # destination registers alone until the wait
         chk = os.path.join(os.path.dirname(HERE), "tools", "check_opaque_loads.py")
         if not os.path.exists(chk):
-            print("WARNING: tools/check_opaque_loads.py not found -- det_mm.hip's hand-waited prefetch loads were NOT verified against this "
+            print(f"WARNING: tools/check_opaque_loads.py not found -- {asm_src}'s hand-waited asm loads were NOT verified against this "
                   "compiler's register allocation (build from the repository tree, or run with OCRS_MM_FULL=0 to use the compiler-waited kernels)",
                   file=sys.stderr, flush=True)
         else:
             r = subprocess.run([sys.executable, chk], capture_output=True, text=True,
-                               env={**os.environ, "OCRS_CHECK_HIPCC": hipcc, "OCRS_CHECK_FLAGS": " ".join(FLAGS)})
+                               env={**os.environ, "OCRS_CHECK_HIPCC": hipcc, "OCRS_CHECK_FLAGS": " ".join(FLAGS), "OCRS_CHECK_SRC": asm_src})
             if verbose:
                 print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr, flush=True)
             if r.returncode != 0:
-                os.remove(os.path.join(OBJ, "det_mm.hip.o"))
-                raise RuntimeError("tools/check_opaque_loads.py: hipcc touched an in-flight prefetch register in det_mm.hip:\n" + r.stdout[-3000:])
+                os.remove(os.path.join(OBJ, asm_src + ".o"))
+                raise RuntimeError(f"tools/check_opaque_loads.py: hipcc touched an in-flight asm-load register in {asm_src}:\n" + r.stdout[-3000:])
     objs = [os.path.join(OBJ, src + ".o") for src in sources()]
     if force or jobs or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -28,6 +28,10 @@ def regs(tok):
 
 
 def main():
+    # OCRS_CHECK_SRC: another source of csrc/ with hand-waited asm loads (rec_conv3.hip: the A fragments of k_conv3x3_rows); default det_mm.hip
+    global SRC
+    if os.environ.get("OCRS_CHECK_SRC"):
+        SRC = os.path.join(ROOT, "ocrs_models_amd", "csrc", os.environ["OCRS_CHECK_SRC"])
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "det_mm.s")
         # the build passes ITS compiler and flag list (OCRS_CHECK_HIPCC / OCRS_CHECK_FLAGS) so that the text checked here is the code it built
@@ -39,7 +43,7 @@ def main():
     bad, nk = check(txt)
     for b in bad:
         print("VIOLATION", b)
-    print(f"check_opaque_loads: {nk} kernels with opaque prefetch loads, {len(bad)} violations")
+    print(f"check_opaque_loads ({os.path.basename(SRC)}): {nk} kernels with opaque prefetch loads, {len(bad)} violations")
     return 1 if bad else 0
 
 
