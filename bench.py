@@ -407,7 +407,7 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         prow, psrc = crnn_pmc_profile()
         conv_traffic, hbm_kernels = None, None
         if prow:
-            is_conv = lambda k: k.startswith(("k_conv_igemm<bf16", "k_conv3x3_c128", "k_conv3x3_wgrad_tr"))  # noqa: E731
+            is_conv = lambda k: k.startswith(("k_conv_igemm<bf16", "k_conv3x3_c128", "k_conv3x3_rows", "k_conv3x3_tile", "k_conv3x3_wgrad_tr"))  # noqa: E731
             conv_traffic = round(sum((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9 for r in prow if is_conv(r["kernel"])))
             mem = ("k_dz_apply", "k_rec_bn_reduce", "k_act_pool_fwd", "k_conv0_", "k_ctc_", "k_avgpool", "k_log_softmax", "k_argmax", "k_col_sum", "k_multi_")
             hbm_kernels = {r["kernel"]: {"launches_per_step": float(r["launches_per_step"]), "hbm_MB_per_step": round((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e3, 2),
@@ -415,7 +415,7 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
                                          "frac_of_8TBps": round(float(r["achieved_GBps"]) / HBM_PEAK_GBS, 4)}
                            for r in prow if r["kernel"].startswith(mem)}
         out["roofline"] = {
-            "kernel": "k_conv_igemm (fwd+dgrad) + k_conv3x3_wgrad_tr", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
+            "kernel": "k_conv3x3_rows / k_conv3x3_tile / k_conv_igemm (fwd+dgrad) + k_conv3x3_wgrad_tr", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
             "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": conv_traffic, "traffic_source": psrc,
             "traffic_note": "HBM bytes per step of the conv kernels named in `kernel` (PMC FETCH_SIZE x2 + WRITE_SIZE)", "hbm_bound_kernels": hbm_kernels,
             "conv_fwd_dgrad": {"ms": round(conv_ms, 3), "gflop": round(conv_fl / 1e9, 1), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 1) if conv_ms else None},

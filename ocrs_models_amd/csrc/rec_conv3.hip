@@ -5,21 +5,27 @@
 // every K = 32 step re-stages 8 KB of weights through registers and ds_write, waits for 12 fragments at the top of the step, and ends in a
 // barrier; its 16-pixel-wide tiles waste 12 % of a 100-pixel row and its tile count (1792 / 896 over 512 slots) leaves a partial last round.
 // At the benchmarked sizes a layer is exactly ONE image per CU (B = 256 crops, 256 CUs), so here:
-//   * a PASS = R whole rows of one image (R x W <= 832 pixels; 8 x 100 for the 128-channel layers), flattened to N tiles of 16 pixels that may
+//   * a PASS = R whole rows of one image (R x W <= 448 pixels; 4 x 100 for the 128-channel layers), flattened to N tiles of 16 pixels that may
 //     straddle rows (a lane's halo position is a per-lane LDS address, the tap is a wave-uniform offset): no column waste, no partial round;
-//   * 4 waves, one per SIMD, as WM (channel groups) x WN (pixel groups): a wave holds MH x NTW accumulator tiles -- 4 x 13 = 208 registers, all
-//     AGPRs, for the 128-channel layers (64 channels x 208 pixels: 4 A + 13 B fragments feed 52 MFMAs per K = 32 step, 0.33 KB of LDS per MFMA;
-//     the 64 x 128 wave tiles of rec_conv2 need 0.375) -- and the VGPR half of the register file is free for deep fragment prefetch.
-//     (8 x 13 tiles per wave = 416 accumulator registers was tried first: hipcc shuffles accumulators between the AGPR and VGPR halves around
-//     every MFMA once more than 256 are live -- 328 v_accvgpr moves per 80 MFMAs -- so the accumulators must fit the AGPR half);
-//   * both operands reach LDS by LDS-DMA (global_load_lds_dwordx4, inline asm so that hipcc's waitcnt bookkeeping does not drain it): packed
-//     weight fragments are lane-linear as they lie in memory; the input halo is staged PLANAR -- [8-channel group][staged pixel][16 B], plane
-//     stride = 0 mod 256 B -- so a B fragment read (16 consecutive pixels x 4 channel groups) is conflict-free at every tap shift, and one
-//     DMA instruction fills 64 consecutive staged pixels of a plane (padding lanes read a zero line): no VGPR, no ds_write, no VALU per byte;
-//   * weights live in a ring of 3 step slots filled two steps ahead, the next 32-channel chunk's halo is filled during taps 1..4 of the
-//     current chunk (also across passes); B fragments stream through a 4-deep register ring three tiles ahead of their MFMAs, the next
-//     step's A fragments replace the current ones behind the last tile's MFMAs; ONE barrier per step (1664 MFMA cycles), placed three
-//     tiles before the end so that the DMA waits sit under MFMA work:  step s: [DMA issue] tiles 0..9 | vmcnt + s_barrier | tiles 10..12.
+//   * 8 waves (512 threads), TWO per SIMD, as WM (channel groups) x WN (pixel groups): a wave holds MH x NTW accumulator tiles (4 x 7 for the
+//     128-channel layers: 64 channels x 112 pixels).  Measured on the way (tools/probes/mfma_issue_probe.hip): one wave per SIMD issues
+//     v_mfma_f32_16x16x32_bf16 at 43-64 % of the peak however clean its loop, two reach 73-78 %; and a wave with more than 256 accumulator
+//     registers (8 x 13 tiles was the first form) makes hipcc shuffle accumulators between the AGPR and VGPR halves around every MFMA
+//     (328 v_accvgpr moves per 80 MFMAs);
+//   * the input halo reaches LDS by LDS-DMA (global_load_lds_dwordx4 in inline asm, so that hipcc's waitcnt bookkeeping does not drain it),
+//     staged PLANAR -- [8-channel group][staged pixel][16 B], plane stride = 0 mod 256 B -- so a B fragment read (16 consecutive pixels x 4
+//     channel groups) is conflict-free at every tap shift; one DMA unit fills 64 consecutive staged pixels of a plane (padding lanes read a
+//     zero line): no VGPR, no ds_write, no VALU per byte.  Two chunk buffers: the next 32-channel chunk's halo (also the next pass's first) is
+//     issued one unit per wave and step at taps 1..5 of the current chunk;
+//   * the A (weight) fragments come straight from the packed array in L2 / L1 into registers, one step ahead, by asm loads with a hand-written
+//     wait (two register sets, steps in pairs): no weight ring in LDS, hence nothing to synchronise per step -- ONE barrier per chunk (tap 8,
+//     whose fragment refills are the first reads of the next chunk's buffer).  With a shared weight ring and a barrier per step the older
+//     wave of every SIMD waited 22 % of the kernel for the younger one;
+//   * B fragments are refilled in place a full step ahead of their MFMAs; the step's scalar state is incremental (a few dozen SALU; the first
+//     version's (tap, chunk, pass) arithmetic was ~300 instructions per step next to 28 MFMAs);
+//   * the epilogue regroups an N tile through 2 KB of LDS per wave and stores 16 bytes per lane (the CUs reach their epilogues together: the
+//     layer's output is written in bursts, and 8-byte pieces of 32-byte segments made those bursts 40 % longer).
+// 2 x 2 kernels and padding 0 / 1 (the CRNN's last conv and its dgrad) run through the same code with 4 steps per chunk.
 #include "det_common.h"
 
 #ifndef R3_ABL
@@ -27,6 +33,9 @@
 #endif
 #ifndef R3_STAGGER
 #define R3_STAGGER 0  // 1: stagger (measured: 89 -> 146 us, the older wave of a SIMD then waits for the younger at every barrier); 0: both waves of a SIMD take the step barrier at tile 1
+#endif
+#ifndef R3_SETPRIO
+#define R3_SETPRIO 0  // s_setprio 1 around a step's MFMA / fragment-refill block
 #endif
 #ifndef R3_DBG
 #define R3_DBG 0  // 1: per-phase cycle counters of every wave of block 0 (measurement builds; read with ocrs_conv_rows_dbg)
@@ -243,6 +252,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
         // next step's tap offset: one pixel right, or to the start of the next row, or (after tap 8) tap 0 of the other input buffer
         unsigned ntapoff = tapoff + (kx == KW - 1 ? rowjump : 16u);
         if (tap == NT - 1) ntapoff = (xbuf ^ 1u) * 4u * PLANE;
+#if R3_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
 #pragma unroll
@@ -253,6 +265,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
             if (!(R3_ABL & 16)) bq[b] = lds16(baddr[b] + ntapoff);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if R3_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- advance (scalar)
         tapoff = ntapoff;
         kx = kx == KW - 1 ? 0 : kx + 1;
