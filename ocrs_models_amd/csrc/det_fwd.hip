@@ -13,6 +13,8 @@
 //   mode 0: element (k, m) at src[(k / K2) * s1 + (k % K2) * s2 + m * sm]
 //   mode 1: ConvTranspose2d forward "effective" weight (src = W[Cup][Cout][3][3], K2 = Cup, M = 4*Cout):
 //           k = d*Cup + c (d = dy*2+dx), m = q*Cout + o (q = py*2+px) -> W[c][o][py+2dy][px+2dx] or 0
+//   mode 2 (bf16 only): mode-0 addressing, SPLIT into hi = bf16(w), lo = bf16(w - hi): [kc][mt][plane = hi, lo][lane][8] (twice the bytes
+//           of a plain bf16 pack) -- the A operand of the split-bf16 GEMM k_gemm_x3w (rec_conv.hip)
 // ----------------------------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ void pack_frags_body(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out,
@@ -30,7 +32,7 @@ __device__ __forceinline__ void pack_frags_body(const float* __restrict__ src, i
         const int k = Elem<T>::is_bf16 ? kc * 32 + (lane >> 4) * 8 + j : kc * 32 + j * 4 + (lane >> 4);
         float x = 0.f;
         if (k < K && m < M) {
-            if (mode == 0) {
+            if (mode == 0 || mode == 2) {
                 x = src[(long)(k / K2) * s1 + (long)(k % K2) * s2 + (long)m * sm];
             } else {
                 const int Cup = K2, Cout = M / 4;
@@ -40,6 +42,20 @@ __device__ __forceinline__ void pack_frags_body(const float* __restrict__ src, i
             }
         }
         v[j] = x;
+    }
+    if constexpr (Elem<T>::is_bf16) {
+        if (mode == 2) {
+            float lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float h = Elem<bf16>::round(v[j]);
+                lo[j] = v[j] - h;
+                v[j] = h;
+            }
+            store8(out + ((frag * 2) * 64 + lane) * 8, v);
+            store8(out + ((frag * 2 + 1) * 64 + lane) * 8, lo);
+            return;
+        }
     }
     store8(out + idx * 8, v);
 }

@@ -44,6 +44,7 @@ class _RecRun:
         self.dtype = dtype
         self.dt = _DT[self.dtype]
         self.x3 = os.environ.get("OCRS_GRU_X3", "1") != "0"  # split-bf16 GEMMs for the fp32 GRU weight gradients in throughput mode
+        self.x3p = self.x3 and os.environ.get("OCRS_GEMM_X3P", "1") != "0"  # ... the projections on the pipelined kernel (rec_gemm.hip, round 4)
         # recurrence as one persistent launch per layer and pass (csrc/rec_gru_seq.hip) when all its workgroups can be resident; its matrix
         # products follow the projection GEMMs' arithmetic: exact fp32 MFMA in parity mode, split-bf16 x3 in throughput mode
         self.gru_seq = bool(self.L.gru_seq_supported(x.shape[0])) and not _GRU_SEQ_OFF.get(x.device, False)
@@ -98,7 +99,7 @@ class _RecRun:
         stays in place (same scheme as models.py::_Run.prepack)."""
         P = self.P
         cache = getattr(self.mod, "_pack_cache", None)
-        key = (self.dt, self.train, tuple(p.data_ptr() for p in P.values()))
+        key = (self.dt, self.train, self.x3p, tuple(p.data_ptr() for p in P.values()))
         if cache is None or cache[0] != key:
             rows = []  # (src tensor, dtype code, K, M, K2, s1, s2, sm, element offset)
             for name in self._CONVS:
@@ -112,7 +113,19 @@ class _RecRun:
                 rows.append((P["output.0.weight"], 0, 512, C, 512, 0, 1, 512, 0))
                 if self.train:
                     rows.append((P["output.0.weight"], 0, C, 512, C, 0, 512, 1, 0))
-            sizes = [self.L.pack_frags_bytes(r[2], r[3], r[1]) for r in rows]
+            elif self.x3p:
+                # throughput mode, pipelined split-bf16 GEMM (csrc/rec_gemm.hip): the GRU input-projection weights pre-split into hi / lo bf16
+                # fragment planes (pack mode 2), forward A[m][k] = W_ih[m][k] and -- training -- input-gradient A[m][k] = W_ih[k][m] layouts;
+                # the output layer's input gradient likewise (its forward has a ragged M = n_classes and stays on k_gemm_x3)
+                for layer, I in ((0, 128), (1, 512)):
+                    w_ih = self.mod._gru_stacked(layer, P)[0]
+                    rows.append((w_ih, 1, I, 1536, I, 0, 1, I, 0, 2))
+                    if self.train:
+                        rows.append((w_ih, 1, 1536, I, 1536, 0, I, 1, 0, 2))
+                if self.train:
+                    rows.append((P["output.0.weight"], 1, C, 512, C, 0, 512, 1, 0, 2))
+            rows = [r if len(r) == 10 else r + (0,) for r in rows]  # (last field: pack mode)
+            sizes = [self.L.pack_frags_bytes(r[2], r[3], r[1]) * (2 if r[9] == 2 else 1) for r in rows]
             offs = [0]
             for n in sizes:
                 offs.append(offs[-1] + ((n + 255) // 256) * 256)
@@ -120,11 +133,11 @@ class _RecRun:
             views, tables = {}, []
             for dt in sorted({r[1] for r in rows}):
                 sel = [(r, o) for r, o in zip(rows, offs) if r[1] == dt]
-                table = torch.tensor([[r[0].data_ptr() + 4 * r[8], buf.data_ptr() + o, 0, r[2], r[3], r[4], r[5], r[6], r[7]] for r, o in sel],
+                table = torch.tensor([[r[0].data_ptr() + 4 * r[8], buf.data_ptr() + o, r[9], r[2], r[3], r[4], r[5], r[6], r[7]] for r, o in sel],
                                      dtype=torch.int64).to(self.dev)
                 tables.append((table, len(sel), max(((r[2] + 31) // 32) * ((r[3] + 15) // 16) * 64 for r, _ in sel), dt))
             for r, o, n in zip(rows, offs, sizes):
-                views[(r[0].data_ptr() + 4 * r[8], r[1], r[2], r[3], r[5], r[6], r[7])] = buf[o:o + n]
+                views[(r[0].data_ptr() + 4 * r[8], r[1], r[2], r[3], r[5], r[6], r[7]) + ((r[9],) if r[9] else ())] = buf[o:o + n]
             cache = (key, tables, buf, views)
             self.mod._pack_cache = cache
         for table, n, maxthr, dt in cache[1]:
@@ -157,6 +170,13 @@ class _RecRun:
     def gemm_x3(self, x, ldx, K, w, ldw, km, bias, M, ldo, rows, kw=0):
         """Throughput-mode fp32 GEMM as split-bf16 (see csrc/rec_conv.hip::k_gemm_x3): W straight from the master layout."""
         out = self.empty(rows, ldo, dtype=torch.float32)
+        if self.x3p and M % 128 == 0:
+            # pre-split weights of this step's prepack (mode 2): A[m][k] = W[m][k] (km = 0: s2 = 1, sm = ldw) or W[k][m] (km = 1: s2 = ldw, sm = 1)
+            Kw = kw or K
+            wpk = self.packs.get((w.data_ptr(), 1, Kw, M, 0, ldw if km else 1, 1 if km else ldw, 2))
+            if wpk is not None and self.L.gemm_x3p_supported(ldx, K, ldo, M, rows):
+                self.L.gemm_x3p(ptr(x), ldx, K, ptr(wpk), ptr(bias), ptr(out), ldo, M, rows)
+                return out
         self.L.gemm_x3(ptr(x), ldx, K, ptr(w), ldw, km, ptr(bias), ptr(out), ldo, M, rows, kw)
         return out
 

@@ -520,6 +520,39 @@ def test_split_bf16_gemm(dev, P, K, M, km, kw):
     assert float((out[:, M4:] - 7.0).abs().max()) == 0.0  # columns beyond that untouched
 
 
+@pytest.mark.parametrize("P,K,M,km,kw,ntw", [(25856, 128, 1536, 0, 0, 0), (25856, 512, 1536, 0, 0, 0), (25856, 1536, 128, 1, 0, 0), (25856, 1536, 512, 1, 0, 0),
+                                             (777, 1536, 512, 1, 0, 4), (777, 64, 128, 0, 0, 2), (1, 32, 128, 0, 0, 2), (5000, 128, 512, 1, 97, 0),
+                                             (70001, 96, 256, 0, 0, 4), (4099, 512, 1536, 0, 0, 2)])
+def test_pipelined_split_bf16_gemm_is_bit_identical(dev, P, K, M, km, kw, ntw, monkeypatch):
+    """ocrs_gemm_x3p (csrc/rec_gemm.hip: producer waves + LDS-DMA ring + persistent tiles, weights pre-split by ocrs_pack_frags mode 2) computes
+    the same products in the same order as ocrs_gemm_x3: bit-identical outputs at the CRNN's four projection shapes (T N = 25856 rows), ragged row
+    counts (a partial last tile, fewer tiles than workgroups, a single row), both weight layouts, the zero-padded class columns of the output
+    layer's gradient (kw), both tile heights; columns past M are left untouched; against float64 within the split-bf16 bound."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    g = torch.Generator().manual_seed(P + K + M)
+    Kw = kw or K
+    X = torch.randn(P, K, generator=g).to(dev)
+    W = (torch.randn(Kw, M, generator=g) if km else torch.randn(M, Kw, generator=g)).to(dev)
+    bias = torch.randn(M, generator=g).to(dev)
+    ldo = M + 4
+    ref = torch.full((P, ldo), 7.0, device=dev)
+    L.gemm_x3(ptr(X), K, K, ptr(W), M if km else Kw, km, ptr(bias), ptr(ref), ldo, M, P, kw)
+    assert L.gemm_x3p_supported(K, K, ldo, M, P) == 1
+    wpk = torch.empty(2 * L.pack_frags_bytes(Kw, M, 1), dtype=torch.uint8, device=dev)
+    L.pack_frags(ptr(W), 2, Kw, M, Kw, 0, M if km else 1, 1 if km else Kw, ptr(wpk), 1)
+    out = torch.full((P, ldo), 7.0, device=dev)
+    L.gemm_x3p_tiles(ptr(X), K, K, ptr(wpk), ptr(bias), ptr(out), ldo, M, P, ntw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    Wkm = W.double() if km else W.double().T
+    exact = X[:, :Kw].double() @ Wkm + bias.double()
+    scale = X[:, :Kw].double().norm(dim=1)[:, None] * Wkm.norm(dim=0)[None, :]
+    assert ((out[:, :M].double() - exact).abs() / scale).max().item() < 5e-5
+    assert L.gemm_x3p_supported(K, K, ldo, M + 4, P) == 0  # (M % 128 != 0: the caller keeps ocrs_gemm_x3)
+
+
 @pytest.mark.parametrize("T,Lmax,h16", [(1100, 500, False), (2600, 1250, False), (4200, 2047, False), (1100, 500, True)])
 def test_ctc_long_targets_match_torch(dev, T, Lmax, h16):
     """The reference's CTCLoss has no target-length limit (train_rec.py:110-113 passes whatever the batch holds): lattices of up to 4096
