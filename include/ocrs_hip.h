@@ -164,11 +164,10 @@ int ocrs_wgrad_gemm_x3(const float* A, int ldA, int CA, const float* B, int ldB,
  * its input gradient, models.py:245-248): output columns [M, round_up(M, 4)) are written as 0. */
 int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int km, const float* bias, float* out, int ldo, int M, long P, int Kw,
                  hipStream_t st);
-/* The same GEMM with the weights pre-split and pre-packed once per step (ocrs_pack_frags mode 2, dtype 1, W as A[m][k]: K % 32 == 0,
- * 2 * ocrs_pack_frags_bytes(K, M, 1) bytes): A fragments straight from L2, only the row operand goes through LDS (round 4). */
-int ocrs_gemm_x3w(const float* X, int ldx, int K, const void* wpk, const float* bias, float* out, int ldo, int M, long P, hipStream_t st);
-/* The pipelined form (csrc/rec_gemm.hip: one workgroup per CU, both operands by LDS-DMA three chunks deep, persistent over tiles): K % 32 == 0,
- * M % 128 == 0, M <= 2048, P * ldx * 4 < 2^31 -- ocrs_gemm_x3p_supported() returns 1 for shapes it takes.  Bit-identical to ocrs_gemm_x3. */
+/* The pipelined form of the same GEMM (csrc/rec_gemm.hip, round 4: one workgroup per CU = 8 MFMA waves + 4 producer waves that move both
+ * operands by LDS-DMA through a three-stage ring, persistent over XCD-ordered tiles).  Weights pre-split and pre-packed once per step:
+ * wpk = ocrs_pack_frags(mode 2, dtype 1) of W as A[m][k], 2 * ocrs_pack_frags_bytes(K, M, 1) bytes.  K % 32 == 0, M % 128 == 0, M <= 2048,
+ * P * ldx * 4 < 2^31 -- ocrs_gemm_x3p_supported() returns 1 for shapes it takes.  Bit-identical to ocrs_gemm_x3. */
 long ocrs_gemm_x3p_supported(int ldx, int K, int ldo, int M, long P);
 int ocrs_gemm_x3p(const float* X, int ldx, int K, const void* wpk, const float* bias, float* out, int ldo, int M, long P, hipStream_t st);
 /* ... with the workgroup tile height chosen by the caller: ntw = 4 (256 rows), 2 (128 rows) or 0 (automatic, what ocrs_gemm_x3p does). */

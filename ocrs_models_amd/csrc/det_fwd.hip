@@ -14,7 +14,7 @@
 //   mode 1: ConvTranspose2d forward "effective" weight (src = W[Cup][Cout][3][3], K2 = Cup, M = 4*Cout):
 //           k = d*Cup + c (d = dy*2+dx), m = q*Cout + o (q = py*2+px) -> W[c][o][py+2dy][px+2dx] or 0
 //   mode 2 (bf16 only): mode-0 addressing, SPLIT into hi = bf16(w), lo = bf16(w - hi): [kc][mt][plane = hi, lo][lane][8] (twice the bytes
-//           of a plain bf16 pack) -- the A operand of the split-bf16 GEMM k_gemm_x3w (rec_conv.hip)
+//           of a plain bf16 pack) -- the A operand of the split-bf16 GEMM k_gemm_x3p (rec_gemm.hip)
 // ----------------------------------------------------------------------------------------------
 template <class T>
 __device__ __forceinline__ void pack_frags_body(const float* __restrict__ src, int mode, int K, int M, int K2, long s1, long s2, long sm, T* __restrict__ out,

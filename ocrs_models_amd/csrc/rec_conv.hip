@@ -1332,123 +1332,6 @@ __global__ __launch_bounds__(256) void k_gemm_x3(const float* __restrict__ X, in
 }
 
 
-// The same GEMM with the WEIGHT operand pre-split and pre-packed (ocrs_pack_frags mode 2: [kc][mt][hi, lo][lane] 16-byte MFMA A fragments):
-// every workgroup used to re-split the same weights (P / 128 = 202 times per launch) and to push them through LDS.  Here a wave loads its
-// eight A fragments of the next K chunk straight from L2 (1 KB per instruction, contiguous) while it multiplies the current one; LDS holds
-// only the pixel operand (half the LDS writes, half the fragment reads, half the split arithmetic of k_gemm_x3).
-__global__ __launch_bounds__(256) void k_gemm_x3w(const float* __restrict__ X, int ldx, const uint4* __restrict__ Wpk, const float* __restrict__ bias,
-                                                  float* __restrict__ out, int ldo, int K, int M, long P) {
-    constexpr int BP = 128, KC = 32, PK = KC + 8;
-    __shared__ __attribute__((aligned(16))) bf16 Xh[BP * PK];
-    __shared__ __attribute__((aligned(16))) bf16 Xl[BP * PK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long p0 = (long)blockIdx.x * BP;
-    const int m0 = blockIdx.y * 128;
-    const int MT = (M + 15) >> 4;
-    const int wm = wave & 1, wn = wave >> 1;  // 2 x 2 waves: 4 m-tiles x 4 pixel-tiles each
-    const int i16 = lane & 15, kg = lane >> 4;
-    float4 rx[4];
-    auto issue = [&](int kc) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + j * 256, px = f >> 3, k4 = (f & 7) * 4;
-#ifdef X3_SAMEROWS  // (measurement build: every workgroup reads the first 128 rows -- L2-resident operand)
-            rx[j] = p0 + px < P ? *reinterpret_cast<const float4*>(X + (long)px * ldx + kc * KC + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#else
-            rx[j] = p0 + px < P ? *reinterpret_cast<const float4*>(X + (p0 + px) * ldx + kc * KC + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-        }
-    };
-    const int mt0 = (m0 >> 4) + wm * 4;
-    auto load_w = [&](int kc, uint4 (&w)[8]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int mt = mt0 + i < MT ? mt0 + i : MT - 1;  // (tiles past M: any valid fragment -- their outputs are not stored)
-            const uint4* f = Wpk + (((long)kc * MT + mt) * 2) * 64 + lane;
-            w[i] = f[0];
-            w[4 + i] = f[64];
-        }
-    };
-    auto split_store = [&](const float4& v, int off) {
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        float h[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h[i] = Elem<bf16>::round(x[i]);
-            l[i] = x[i] - h[i];
-        }
-        *reinterpret_cast<uint2*>(Xh + off) = make_uint2(pack2bf(h[0], h[1]), pack2bf(h[2], h[3]));
-        *reinterpret_cast<uint2*>(Xl + off) = make_uint2(pack2bf(l[0], l[1]), pack2bf(l[2], l[3]));
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nkc = K / KC;
-    uint4 wc[8], wnx[8];
-    issue(0);
-    load_w(0, wc);
-    for (int kc = 0; kc < nkc; ++kc) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + j * 256;
-            split_store(rx[j], (f >> 3) * PK + (f & 7) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nkc) {
-            issue(kc + 1);
-            load_w(kc + 1, wnx);
-        }
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = ((wn * 4 + j) * 16 + i16) * PK + kg * 8;
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xh + o));
-            const bf16x8 xl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Xl + o));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, wc[i]), wl = __builtin_bit_cast(bf16x8, wc[4 + i]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[i][j], 0, 0, 0);
-#ifndef X3_ONEMFMA  // (measurement build: a third of the matrix work)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[i][j], 0, 0, 0);
-#else
-                asm volatile("" :: "v"(wl), "v"(xl));
-#endif
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wc[i] = wnx[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (wm * 4 + i) * 16 + kg * 4;
-        if (m >= M) continue;
-        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) {
-            if (m + 3 < M)
-                bs = *reinterpret_cast<const float4*>(bias + m);
-            else  // last, partial quad of a ragged M: columns [M, round_up(M, 4)) are written as 0 (their packed weights are zero)
-                bs = make_float4(bias[m], m + 1 < M ? bias[m + 1] : 0.f, m + 2 < M ? bias[m + 2] : 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long p = p0 + (wn * 4 + j) * 16 + i16;
-#ifdef X3_NOSTORE  // (measurement build: no output traffic)
-            if (p < P && K < 0) {
-#else
-            if (p < P) {
-#endif
-                const f32x4 v = acc[i][j];
-                *reinterpret_cast<float4*>(out + p * ldo + m) = make_float4(v[0] + bs.x, v[1] + bs.y, v[2] + bs.z, v[3] + bs.w);
-            }
-        }
-    }
-}
-
-
 extern "C" {
 
 // Implicit-GEMM convolution / GEMM:  out[n][ho][wo][m] = sum_{ky,kx,c} W[m][(ky,kx,c)] * x[n][ho+ky-padh][wo+kx-padw][c]  (+bias, ReLU)
@@ -1845,17 +1728,6 @@ int ocrs_gemm_x3(const float* X, int ldx, int K, const float* Wm, int ldw, int k
         hipLaunchKernelGGL(k_gemm_x3<true>, grid, dim3(256), (2 * 128 * 40 + 2 * 32 * 136) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P, Kw);
     else
         hipLaunchKernelGGL(k_gemm_x3<false>, grid, dim3(256), (4 * 128 * 40) * 2, st, X, ldx, Wm, ldw, bias, out, ldo, K, M, P, Kw);
-    OCRS_LAUNCH_CHECK();
-    return OCRS_OK;
-}
-
-// The same GEMM with pre-split, pre-packed weights:  wpk = ocrs_pack_frags(mode 2, dtype bf16) of W as A[m][k] (K % 32 == 0; the pack zero-fills
-// rows m >= M, so a ragged M is fine with ldo >= round_up(M, 4)); 2 * ocrs_pack_frags_bytes(K, M, 1) bytes.
-int ocrs_gemm_x3w(const float* X, int ldx, int K, const void* wpk, const float* bias, float* out, int ldo, int M, long P, hipStream_t st) {
-    OCRS_CHECK_ARG(X && wpk && out && P > 0 && K > 0 && K % 32 == 0 && M > 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= K && ldo >= ((M + 3) & ~3));
-    OCRS_CHECK_ARG(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(wpk) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0);
-    const dim3 grid((unsigned)((P + 127) / 128), (unsigned)((M + 127) / 128));
-    hipLaunchKernelGGL(k_gemm_x3w, grid, dim3(256), 0, st, X, ldx, reinterpret_cast<const uint4*>(wpk), bias, out, ldo, K, M, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

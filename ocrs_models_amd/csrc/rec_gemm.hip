@@ -8,20 +8,29 @@
 // row operand L2-resident -> still 112 of 201 us (K = 512, M = 1536): a 128 x 128 x 32 chunk costs ~3500 cycles whatever is in it, because
 // the chunk's loads are issued one chunk (0.3 us of matrix work) ahead and consumed behind a barrier, with two workgroups per CU to hide it.
 //
-// Here: one 512-thread workgroup per CU (8 waves = 2 along the 128 output columns x 4 along the rows, two waves per SIMD -- one wave per
-// SIMD cannot issue more than ~60 % of the MFMA peak, tools/probes/mfma_issue_probe.hip), persistent over (row block, column block) tiles;
-// both operands of a 32-deep K chunk arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write, no VALU) into a ring of
-// THREE stages, two chunks (~1.3 us of matrix work) ahead, across tile boundaries; one barrier per chunk; all vector-memory operations of
-// the loop are counted by hand (`s_waitcnt vmcnt(NL)`), which stays correct with output stores in flight: loads complete in order among
-// themselves, so "at most NL operations incomplete" cannot leave a load of the older chunk incomplete while the NL loads of the younger one
-// are (stores in flight only make the wait conservative).
+// Here (third form; the first two are in DESIGN.md's round-4 section): one 768-thread workgroup per CU, persistent over (row block, column
+// block) tiles of 256 (or 128) rows x 128 columns, with ROLES:
+//   * 4 PRODUCER waves issue every LDS-DMA of the workgroup (global_load_lds_dwordx4: no VGPR staging, no ds_write, no VALU) into a ring of
+//     THREE stages, two 32-deep K chunks ahead of the matrix work, across tile boundaries.  A wave gets one 1 KB DMA instruction out every
+//     ~90 cycles (measured: 24 instructions = 2200 cycles), a chunk needs 48 -- issued by the MFMA waves themselves (first form) every wave
+//     lost ~600 cycles per chunk in front of its MFMAs, and every CU-wide phase (issue, LDS reads, MFMA) ran in lock step;
+//   * 8 CONSUMER waves (2 along the columns x 4 along the rows, two per SIMD -- one wave per SIMD cannot issue more than ~60 % of the MFMA
+//     peak, tools/probes/mfma_issue_probe.hip) only read LDS, split and multiply.  They have NO vector-memory loads, so nothing they do
+//     waits for their output stores (in the first form the counted `s_waitcnt vmcnt` in front of every chunk also waited for the previous
+//     tile's stores: 20 us of 146).
+//   One s_barrier per chunk: producers arrive after "chunk g + 1 has landed" (their own counted vmcnt), consumers after "done reading chunk
+//   g": the stage of chunk g is then free for chunk g + 3.
 //   row operand X: raw fp32 rows, 8 rows x 128 B per DMA instruction (whole lines), XOR-swizzled by the source address each lane picks so
 //     that the fragment reads (two ds_read_b128 per lane = 8 consecutive k) are bank-conflict-free for ds_read_b128's lane groups; the
 //     hi / lo split happens in registers after the read (6 VALU per pair of values: v_cvt_pk_bf16_f32 + shift / and + 2 subs + cvt).
 //   weight operand: pre-split, pre-packed MFMA A fragments (ocrs_pack_frags mode 2: [kc][mt][hi, lo][lane]), 16 KB per chunk and column
-//     block, contiguous -> DMA as is, read back lane-linear.
+//     block, contiguous -> DMA as is, read back lane-linear.  (Second form: the A fragments straight from L2 into registers instead --
+//     half the LDS traffic but 96 KB instead of 48 KB per chunk through the CU's 64 B / clk vector-memory path: slower.)
 // XCD-aware tile order: workgroup b runs on XCD b % 8; XCD x owns the row blocks x, x + 8, ... and walks (row block, column block) with the
 // column block fastest, so the column blocks that share a row block's X rows meet in one L2.
+// Measured (T N = 25856 rows; k_gemm_x3 -> this kernel): K 128 -> M 1536: 71 -> 52 us; 512 -> 1536: 183 -> 137; 1536 -> 512: 195 -> 153;
+// 1536 -> 128: 67 -> 40.  What is left: the consumers' LDS traffic (16 KB of fragment reads per 48 MFMAs: a chunk takes ~2400 cycles of
+// which 1536 are MFMA issue) and the tile quantisation of M = 512 (404 tiles on 256 CUs).
 #include "det_common.h"
 #include <type_traits>
 
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(512 + 64 * G_NPROD) void k_gemm_x3p(const float* __
 #endif
 }
 
-// true when ocrs_gemm_x3p can take the shape (the caller falls back to ocrs_gemm_x3w / ocrs_gemm_x3 otherwise)
+// true when ocrs_gemm_x3p can take the shape (the caller falls back to ocrs_gemm_x3 otherwise)
 static bool gemm_x3p_ok(int ldx, int K, int ldo, int M, long P) {
     return K % 32 == 0 && M % 128 == 0 && M <= 2048 && ldx % 4 == 0 && ldo % 4 == 0 && P > 0 && (long)P * ldx * 4 < (1L << 31);
 }

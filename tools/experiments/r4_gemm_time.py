@@ -35,14 +35,9 @@ for name, K, M, km in [("gi0", 128, 1536, 0), ("gi1", 512, 1536, 0), ("dx1", 153
     t = timeit(lambda: L.gemm_x3(ptr(X), K, K, ptr(W), M if km else K, km, None, ptr(out), M, M, P, 0))
     ref = (X[:512].double() @ (W.double() if km else W.double().t())).float()
     err = float((out[:512] - ref).abs().max() / ref.abs().max())
-    if hasattr(L, "gemm_x3w"):
-        wpk = torch.empty(2 * L.pack_frags_bytes(K, M, 1), dtype=torch.uint8, device=dev)
-        # W(m, k): km = 0 -> W[m * K + k] (s2 = 1, sm = K); km = 1 -> W[k * M + m] (s2 = M, sm = 1)
-        L.pack_frags(ptr(W), 2, K, M, K, 0, M if km else 1, 1 if km else K, ptr(wpk), 1)
-        out2 = torch.empty(P, M, device=dev)
-        t2 = timeit(lambda: L.gemm_x3w(ptr(X), K, K, ptr(wpk), None, ptr(out2), M, M, P))
-        tp = timeit(lambda: L.pack_frags(ptr(W), 2, K, M, K, 0, M if km else 1, 1 if km else K, ptr(wpk), 1))
-        print(f"gemm_x3w {name}: {t2:7.1f} us (+ pack {tp:5.1f} us)  max |x3w - x3| {float((out2 - out).abs().max()):.2e}  bit-identical {bool((out2 == out).all())}", flush=True)
+    wpk = torch.empty(2 * L.pack_frags_bytes(K, M, 1), dtype=torch.uint8, device=dev)
+    # W(m, k): km = 0 -> W[m * K + k] (s2 = 1, sm = K); km = 1 -> W[k * M + m] (s2 = M, sm = 1)
+    L.pack_frags(ptr(W), 2, K, M, K, 0, M if km else 1, 1 if km else K, ptr(wpk), 1)
     if hasattr(L, "gemm_x3p") and L.gemm_x3p_supported(K, K, M, M, P):
         bias = torch.randn(M, generator=g).to(dev)
         out3 = torch.empty(P, M, device=dev)
