@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    for asm_src in ("det_mm.hip", "rec_conv3.hip", "rec_gemm.hip"):
+    for asm_src in ("det_mm.hip", "rec_conv3.hip"):
         if not any(os.path.basename(s) == asm_src for s, _ in jobs):
             continue
         # the hand-waited asm loads of det_mm.hip (tile prefetch) and rec_conv3.hip (A fragments) are only valid if hipcc left their

@@ -53,20 +53,6 @@ __device__ __forceinline__ void g_dma16(const void* sbase, unsigned voff, unsign
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
-// 16 bytes per lane from (wave-uniform base + per-lane byte offset + OFF) into registers, hidden from hipcc's waitcnt bookkeeping like the
-// DMAs; the destination is only valid behind g_wait_w (which ties the registers, so no consumer is scheduled above it)
-typedef unsigned g_u32x4 __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void g_load16(g_u32x4& d, unsigned voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void g_wait_w(g_u32x4 (&f)[8]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
-                 : "n"(N)
-                 : "memory");
-}
 template <int N>
 __device__ __forceinline__ void g_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

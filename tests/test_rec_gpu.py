@@ -466,11 +466,14 @@ def test_persistent_gru_timeout_is_recoverable(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,CA,ldA,CB,ldB", [(25856, 1536, 1536, 256, 256), (4001, 768, 1536, 256, 512), (77, 100, 128, 36, 40), (6000, 97, 128, 512, 512)])
+@pytest.mark.parametrize("P,CA,ldA,CB,ldB", [(25856, 1536, 1536, 256, 256), (4001, 768, 1536, 256, 512), (77, 100, 128, 36, 40), (6000, 97, 128, 512, 512),
+                                             (25856, 1536, 1536, 512, 512), (25600, 768, 1536, 256, 512), (25856, 1536, 1536, 128, 128), (65, 256, 256, 128, 128),
+                                             (1000, 512, 520, 128, 132), (6000, 768, 772, 128, 132), (2100, 768, 768, 256, 256), (2049, 1536, 1536, 512, 512)])
 def test_split_bf16_wgrad_gemm(dev, P, CA, ldA, CB, ldB):
     """ocrs_wgrad_gemm_x3 (bf16x3 emulation of the fp32 GRU weight-gradient GEMMs, throughput mode only) against a float64 matmul:
     products carry <= ~1.1e-5 relative error, fp32 accumulation -> the result must be within 5e-5 of the exact one relative to
-    ||A||.||B|| (column-wise), i.e. fp32-GEMM class; also checks accumulation into dW and ragged sizes / leading dimensions."""
+    ||A||.||B|| (column-wise), i.e. fp32-GEMM class; also checks accumulation into dW and ragged sizes / leading dimensions.
+    Includes the CRNN's five GRU weight-gradient shapes, last chunks of 1 row, leading dimensions != widths."""
     from ocrs_models_amd._lib import lib, ptr
 
     L = lib()
