@@ -17,7 +17,7 @@ bash tools/run_pmc_sq.sh "k_mm_bwd<8, 8, false, false, true, true>|k_mm_bwd<16, 
 # 6. CRNN: per-kernel time, and the MFMA-busy counter of the convolution kernels (separate PMC pass)
 bash tools/run_trace_crnn.sh > /dev/null 2>&1; cp gpurun_out/crnn_stats.txt $OUT/${TAG}_crnn_kernel_stats.txt
 rm -rf gpurun_out/pmc_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/prof_crnn.py --steps 2 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_mfma "k_conv_igemm<bf16|k_conv3x3_c128|k_conv3x3_rows|k_conv3x3_tile|k_conv3x3_wgrad_tr|k_gru_s" > $OUT/${TAG}_crnn_pmc_mfma.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_mfma "k_conv_igemm<bf16|k_conv3x3_c128|k_conv3x3_rows|k_conv3x3_tile|k_conv3x3_wgrad_tr|k_gemm_x3|k_wgrad_gemm_x3|k_gru_s" > $OUT/${TAG}_crnn_pmc_mfma.txt 2>&1
 # 7. per-launch trace of one CRNN step
 rm -rf gpurun_out/trace_crnn; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_crnn -- python tools/prof_crnn.py --steps 3 --warmup 2 > gpurun_out/trace_crnn.log 2>&1
 python tools/trace_step.py gpurun_out/trace_crnn k_conv0_fwd > $OUT/${TAG}_crnn_step_trace.txt 2>&1
