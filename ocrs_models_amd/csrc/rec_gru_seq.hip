@@ -26,6 +26,15 @@
 // accumulation: fp32-class, ~2^-17 relative per product, 5x fewer MFMA cycles) -- the same switch as the projection GEMMs (OCRS_GRU_X3).
 #include "common.h"
 
+#ifndef OCRS_GRU_FAST_ACT
+#define OCRS_GRU_FAST_ACT 1  // throughput mode: hardware exp2 / rcp in the gate activations (0: libm, as the exact-fp32 mode always uses)
+#endif
+#ifndef OCRS_GRU_WAIT_SLEEP
+#define OCRS_GRU_WAIT_SLEEP 1  // s_sleep between two polls of a group's arrival counter (x 64 clocks)
+#endif
+#ifndef OCRS_GRU_POLL_SLEEP
+#define OCRS_GRU_POLL_SLEEP 2  // ... between two polls of the tagged exchange words
+#endif
 namespace {
 constexpr int SH = 256, S3 = 768;  // hidden size, 3 gates
 constexpr int SNB = 32;            // batch columns per group
@@ -47,7 +56,19 @@ __device__ __forceinline__ void ld8_agent(const float* p, float (&v)[8]) {
         v[2 * q + 1] = __uint_as_float((unsigned)(x >> 32));
     }
 }
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// gate activations.  FAST (throughput mode, split-bf16 products): hardware exp2 / rcp (~1 ulp each, |error| ~ 2e-7 -- two orders below the
+// 2^-17 per-product error of that mode); the libm forms cost ~0.2 us of the 2.7 us a forward step takes (the whole step is one dependent
+// chain: CRNN step 4.93 -> 4.89 ms).  The exact-fp32 parity mode keeps libm.
+template <bool FAST>
+__device__ __forceinline__ float sigm(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+    else return 1.f / (1.f + expf(-x));
+}
+template <bool FAST>
+__device__ __forceinline__ float tanh_(float x) {
+    if constexpr (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+    else return tanhf(x);
+}
 
 // hi / lo bf16 split of 8 floats (one 16x16x32 operand each)
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
@@ -122,7 +143,7 @@ __device__ __forceinline__ bool seq_wait(unsigned* cnt, unsigned need, unsigned*
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(OCRS_GRU_WAIT_SLEEP);
     }
 }
 }  // namespace
@@ -190,7 +211,7 @@ __device__ __forceinline__ bool xpoll(float* xws, int group, int par, int kc0, i
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(OCRS_GRU_POLL_SLEEP);
     }
 }
 __device__ __forceinline__ void st_xw(bool fast, float* p, unsigned a, unsigned b) { st_x(fast, p, __uint_as_float(a), __uint_as_float(b)); }
@@ -255,6 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
         }
     };
     load_gi(d == 0 ? 0 : T - 1);
+    constexpr bool FASTACT = !EXACT && OCRS_GRU_FAST_ACT != 0;
 
 #ifdef OCRS_GRU_SEQ_PROF
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
@@ -317,10 +339,10 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                 gh[g] = (rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS]);
             }
         }
-        const float rv = sigm(gi_r + gh[0] + bh_r);
-        const float zv = sigm(gi_z + gh[1] + bh_z);
+        const float rv = sigm<FASTACT>(gi_r + gh[0] + bh_r);
+        const float zv = sigm<FASTACT>(gi_z + gh[1] + bh_z);
         const float hn = gh[2] + bh_n;
-        const float nv = tanhf(gi_n + rv * hn);
+        const float nv = tanh_<FASTACT>(gi_n + rv * hn);
         const float hv = bv ? (1.f - zv) * nv + zv * hp : 0.f;
         hp = hv;
         const float hv1 = __shfl_down(hv, 1);  // unit j + 1 of the same column (adjacent lane)
