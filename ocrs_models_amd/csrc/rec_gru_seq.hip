@@ -267,15 +267,39 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
     const int xkc = jt >> 1, xpos = (jt & 1) * 16 + jl, xlane = (bl & 15) + 16 * (xpos >> 3), xq = (xpos & 7) >> 1, xnt = bl >> 4;
     const float bh_r = bhh[d * S3 + j], bh_z = bhh[d * S3 + SH + j], bh_n = bhh[d * S3 + 2 * SH + j];
     float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, hp = 0.f;
-    auto load_gi = [&](int t) {
+    float gn_r = 0.f, gn_z = 0.f, gn_n = 0.f;  // the NEXT step's gi (loaded a whole step ahead)
+    auto load_gi = [&](int t, float& r, float& z, float& n) {
         if (bv) {
             const float* gir = gi + ((long)t * N + b) * (2 * S3) + d * S3 + j;
-            gi_r = gir[0];
-            gi_z = gir[SH];
-            gi_n = gir[2 * SH];
+            r = gir[0];
+            z = gir[SH];
+            n = gir[2 * SH];
         }
     };
-    load_gi(d == 0 ? 0 : T - 1);
+    load_gi(d == 0 ? 0 : T - 1, gi_r, gi_z, gi_n);
+    // Everything a step stores or loads besides the exchange -- out / saved of the step, gi of the next -- is issued right BEHIND the wait for the
+    // peers' h (deferred by one step), not in front of it: the price of a hand-off sits in the consumer CU's own memory queue
+    // (MI355X_MICROARCH.md, handoff-1to1: unloaded -> unloaded 1.1 us, -> loaded 2.5 us), and the polls used to queue behind these:
+    // 2.76 -> 2.50 us per step standalone.  (Issued behind the step's MFMAs instead: 2.58.  The same deferral in the backward kernel, whose
+    // publish drains vmcnt(0) in front of its arrival signal, makes every step wait for the deferred stores' acknowledgements: 4.0 -> 8 us.)
+    float p_rv = 0.f, p_zv = 0.f, p_nv = 0.f, p_hn = 0.f, p_hv = 0.f, p_hv1 = 0.f;
+    auto store_prev = [&](int s) {  // out / saved of step s - 1
+        if (s > 0 && bv) {
+            const int tp = d == 0 ? s - 1 : T - s;
+            if ((jl & 1) == 0) *reinterpret_cast<float2*>(out + ((long)tp * N + b) * 512 + d * SH + j) = make_float2(p_hv, p_hv1);
+            if (saved) {
+                float* sv = saved + (((long)tp * N + b) * 2 + d) * 4 * SH + j;
+                sv[0] = p_rv;
+                sv[SH] = p_zv;
+                sv[2 * SH] = p_nv;
+                sv[3 * SH] = p_hn;
+            }
+        }
+    };
+    auto after_wait = [&](int s) {  // tagged hand-off, s = the step that is starting: the previous step's stores, the next step's gi
+        store_prev(s);
+        if (s + 1 < T) load_gi(d == 0 ? s + 1 : T - 2 - s, gn_r, gn_z, gn_n);
+    };
     constexpr bool FASTACT = !EXACT && OCRS_GRU_FAST_ACT != 0;
 
 #ifdef OCRS_GRU_SEQ_PROF
@@ -287,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
         float gh[3] = {0.f, 0.f, 0.f};
+        if (!EXACT && s == 0) after_wait(0);
         if (s > 0) {
             f32x4 acc[3];
 #pragma unroll
@@ -310,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
                 unsigned w[2][8];
                 if (!xpoll<8, 2>(xws, group, (s - 1) & 1, 2 * kk, wnt, lane, (unsigned)((((s - 1) >> 1) & 1) ^ 1), err, w)) s_fail = 1;
                 PROF_MARK(0)
+                after_wait(s);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     bf16x8 hhi, hlo;
@@ -361,19 +387,16 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
             }
         }
         PROF_MARK(4)
-        if (bv) {
-            if ((jl & 1) == 0) *reinterpret_cast<float2*>(out + ((long)t * N + b) * 512 + d * SH + j) = make_float2(hv, hv1);
-            if (saved) {
-                float* sv = saved + (((long)t * N + b) * 2 + d) * 4 * SH + j;
-                sv[0] = rv;
-                sv[SH] = zv;
-                sv[2 * SH] = nv;
-                sv[3 * SH] = hn;
-            }
+        p_rv = rv; p_zv = zv; p_nv = nv; p_hn = hn; p_hv = hv; p_hv1 = hv1;
+        if constexpr (EXACT) {  // counter hand-off: its publish drains vmcnt(0) -- nothing may be pending in front of it, so no deferral
+            store_prev(s + 1);
+            if (s + 1 < T) load_gi(d == 0 ? s + 1 : T - 2 - s, gi_r, gi_z, gi_n);  // next step's operands: in flight during the wait
+        } else {
+            gi_r = gn_r; gi_z = gn_z; gi_n = gn_n;
         }
-        if (s + 1 < T) load_gi(d == 0 ? s + 1 : T - 2 - s);  // next step's operands: in flight during the wait
         PROF_MARK(5)
     }
+    if constexpr (!EXACT) after_wait(T);  // (the last step's out / saved)
 #ifdef OCRS_GRU_SEQ_PROF
     if (tid == 0 && jt == 0) {
         cnt[1] = fast ? 1u : 0u;
