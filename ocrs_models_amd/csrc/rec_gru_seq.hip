@@ -215,6 +215,25 @@ __device__ __forceinline__ bool xpoll(float* xws, int group, int par, int kc0, i
     }
 }
 __device__ __forceinline__ void st_xw(bool fast, float* p, unsigned a, unsigned b) { st_x(fast, p, __uint_as_float(a), __uint_as_float(b)); }
+// the same split without a tag (counter hand-offs: the backward kernel): hi = bf16(v), lo = bf16(v - hi), exactly what split8 computes --
+// done ONCE by the producer instead of by each of its 16 consumers (48 values x ~4 VALU per lane and step, on the step's critical chain)
+__device__ __forceinline__ unsigned pack_hilo_full(float v) {
+    const __bf16 h = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)h);
+    return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+// 8 packed words -> the hi and lo MFMA operands: one v_perm_b32 per pair and plane
+__device__ __forceinline__ void unpack_hilo_perm(const float (&w)[8], bf16x8& hi, bf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a = __float_as_uint(w[2 * i]), b = __float_as_uint(w[2 * i + 1]);
+        h[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);  // (a >> 16) | (b & 0xffff0000)
+        l[i] = __builtin_amdgcn_perm(b, a, 0x05040100u);  // (a & 0xffff) | (b << 16)
+    }
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
 
 // gi [T][N][2*768] (b_ih added), whh [2][768][256] fp32 master, bhh [2][768], out [T][N][512], saved [T][N][2][4][256] (nullable)
 // sync: per group SYNC_STRIDE words (zeroed before the launch); err: sticky error word (set when a wait times out); xws: exchange workspace.
@@ -469,12 +488,16 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
     };
     load_ep(d == 0 ? T - 1 : 0);
 
+#ifdef OCRS_GRU_SEQ_PROF
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         float dh = e_dout;
         if (s > 0) {
             if (tid == 0) s_ok = seq_wait(cnt, 16u * (unsigned)s, err) ? 1 : 0;
             __syncthreads();
+            PROF_MARK(0)
             if (!s_ok) return;
             f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -490,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
                         for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[cw][i], gb[c][i], acc, 0, 0, 0);
                     } else {
                         bf16x8 ghi, glo;
-                        split8(gb[c], ghi, glo);
+                        unpack_hilo_perm(gb[c], ghi, glo);  // (the producers published hi | lo words)
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[cw], ghi, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[cw], glo, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[cw], ghi, acc, 0, 0, 0);
@@ -499,7 +522,9 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[kk][wnt][kq * 4 + r][l15] = acc[r];
+            PROF_MARK(1)
             __syncthreads();
+            PROF_MARK(2)
             const float* rp = &red[0][bl >> 4][jl][bl & 15];
             constexpr int WS = 2 * 16 * 17;
             dh += carry + ((rp[0] + rp[WS]) + (rp[2 * WS] + rp[3 * WS]));
@@ -515,16 +540,28 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
         sb_nr += dnr;
         carry = dh * e_z;
         const float dr1 = __shfl_down(dr, 1), dz1 = __shfl_down(dz, 1), dnr1 = __shfl_down(dnr, 1);
+        PROF_MARK(3)
         if (s + 1 < T) {
-            if ((jl & 1) == 0) {
-                st_x(fast, xslot<24>(xws, group, s & 1, xkc, xnt, xq, xlane), dr, dr1);
-                st_x(fast, xslot<24>(xws, group, s & 1, 8 + xkc, xnt, xq, xlane), dz, dz1);
-                st_x(fast, xslot<24>(xws, group, s & 1, 16 + xkc, xnt, xq, xlane), dnr, dnr1);
+            if constexpr (EXACT) {
+                if ((jl & 1) == 0) {
+                    st_x(fast, xslot<24>(xws, group, s & 1, xkc, xnt, xq, xlane), dr, dr1);
+                    st_x(fast, xslot<24>(xws, group, s & 1, 8 + xkc, xnt, xq, xlane), dz, dz1);
+                    st_x(fast, xslot<24>(xws, group, s & 1, 16 + xkc, xnt, xq, xlane), dnr, dnr1);
+                }
+            } else {
+                const unsigned wr = pack_hilo_full(dr), wz = pack_hilo_full(dz), wn = pack_hilo_full(dnr);
+                const unsigned wr1 = __shfl_down(wr, 1), wz1 = __shfl_down(wz, 1), wn1 = __shfl_down(wn, 1);
+                if ((jl & 1) == 0) {
+                    st_xw(fast, xslot<24>(xws, group, s & 1, xkc, xnt, xq, xlane), wr, wr1);
+                    st_xw(fast, xslot<24>(xws, group, s & 1, 8 + xkc, xnt, xq, xlane), wz, wz1);
+                    st_xw(fast, xslot<24>(xws, group, s & 1, 16 + xkc, xnt, xq, xlane), wn, wn1);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) seq_signal(fast, cnt);
         }
+        PROF_MARK(4)
         if (bv) {
             float* gi_ = dgi + ((long)t * N + b) * (2 * S3) + d * S3 + j;
             gi_[0] = dr;
@@ -538,7 +575,14 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
             }
         }
         if (s + 1 < T) load_ep(d == 0 ? T - 2 - s : s + 1);
+        PROF_MARK(5)
     }
+#ifdef OCRS_GRU_SEQ_PROF
+    if (tid == 0 && jt == 0) {
+        cnt[1] = fast ? 1u : 0u;
+        for (int i = 0; i < 6; ++i) cnt[2 + i] = (unsigned)(pt[i] / (unsigned long long)T);
+    }
+#endif
     // bias gradients (nullable): db_ih = column sums of dgi, db_hh = column sums of dgh over (t, n) -- the two 159-MB re-reads of dgi / dgh by
     // k_col_sum4 (0.17 ms per CRNN step) are not needed.  Lanes -> the wave's four batch columns (lanes 16 apart), waves through LDS in a fixed
     // order, then one fp32 atomic per (group, unit, gate) -- 8 groups per direction at N = 256 (like k_col_sum4's per-block atomics).

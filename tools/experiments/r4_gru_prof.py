@@ -21,3 +21,15 @@ e1.record(); torch.cuda.synchronize()
 w = buf[:nsync].cpu()
 print(f"k_gru_seq_fwd {e0.elapsed_time(e1) / 5 * 1e3:.1f} us per launch, {e0.elapsed_time(e1) / 5 / T * 1e3:.2f} us per step; fast path {int(w[1])}")
 print("cycles per step [poll wait, -, MFMA + partials + barrier, reduce + gates, exchange store, out / saved stores + next gi]:", [int(w[2 + i]) for i in range(6)], "sum", int(w[2:8].sum()))
+
+dout = torch.randn(T, N, 512, generator=g).to(dev); dgi = torch.empty(T, N, 1536, device=dev); dgh = torch.empty(T, N, 1536, device=dev)
+dbi = torch.zeros(1536, device=dev); dbh = torch.zeros(1536, device=dev)
+def bwd():
+    L.gru_seq_bwd(ptr(dout), ptr(saved), ptr(out), ptr(whh), ptr(dgi), ptr(dgh), T, N, ptr(buf[:nsync]), ptr(err), ptr(buf[nsync:]), 0, ptr(dbi), ptr(dbh))
+for _ in range(3): bwd()
+torch.cuda.synchronize(); e0.record()
+for _ in range(5): bwd()
+e1.record(); torch.cuda.synchronize()
+w = buf[:nsync].cpu()
+print(f"k_gru_seq_bwd {e0.elapsed_time(e1) / 5 * 1e3:.1f} us per launch, {e0.elapsed_time(e1) / 5 / T * 1e3:.2f} us per step; fast path {int(w[1])}")
+print("cycles per step [counter wait + barrier, fragment loads + MFMA + partials, barrier, reduce + gates, exchange stores + drain + barrier + signal, dgi / dgh stores + next operands]:", [int(w[2 + i]) for i in range(6)], "sum", int(w[2:8].sum()))
