@@ -29,6 +29,9 @@
 #ifndef OCRS_GRU_FAST_ACT
 #define OCRS_GRU_FAST_ACT 1  // throughput mode: hardware exp2 / rcp in the gate activations (0: libm, as the exact-fp32 mode always uses)
 #endif
+#ifndef OCRS_GRU_NT_OUT
+#define OCRS_GRU_NT_OUT 1  // forward recurrence: non-temporal stores for out / saved
+#endif
 #ifndef OCRS_GRU_WAIT_SLEEP
 #define OCRS_GRU_WAIT_SLEEP 1  // s_sleep between two polls of a group's arrival counter (x 64 clocks)
 #endif
@@ -214,6 +217,24 @@ __device__ __forceinline__ bool xpoll(float* xws, int group, int par, int kc0, i
         __builtin_amdgcn_s_sleep(OCRS_GRU_POLL_SLEEP);
     }
 }
+// The forward's bulk outputs of a step (out, saved: 265 MB per launch) as NON-TEMPORAL stores: plain stores stream them through the L2 the
+// exchange workspace lives in -- 2.50 -> 2.00 us per step.  (Measured and not used: the same for the backward's dgi / dgh stores (4.14 -> 4.17-4.29),
+// non-temporal loads of gi (2.01 -> 2.55) and of the backward's operands (no change).)
+__device__ __forceinline__ void nt_store(float* p, float v) {
+#if OCRS_GRU_NT_OUT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void nt_store2(float* p, float a, float b) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+#if OCRS_GRU_NT_OUT
+    __builtin_nontemporal_store((f2v){a, b}, reinterpret_cast<f2v*>(p));
+#else
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+#endif
+}
 __device__ __forceinline__ void st_xw(bool fast, float* p, unsigned a, unsigned b) { st_x(fast, p, __uint_as_float(a), __uint_as_float(b)); }
 // the same split without a tag (counter hand-offs: the backward kernel): hi = bf16(v), lo = bf16(v - hi), exactly what split8 computes --
 // done ONCE by the producer instead of by each of its 16 consumers (48 values x ~4 VALU per lane and step, on the step's critical chain)
@@ -305,13 +326,13 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_fwd(const float* __restrict_
     auto store_prev = [&](int s) {  // out / saved of step s - 1
         if (s > 0 && bv) {
             const int tp = d == 0 ? s - 1 : T - s;
-            if ((jl & 1) == 0) *reinterpret_cast<float2*>(out + ((long)tp * N + b) * 512 + d * SH + j) = make_float2(p_hv, p_hv1);
+            if ((jl & 1) == 0) nt_store2(out + ((long)tp * N + b) * 512 + d * SH + j, p_hv, p_hv1);
             if (saved) {
                 float* sv = saved + (((long)tp * N + b) * 2 + d) * 4 * SH + j;
-                sv[0] = p_rv;
-                sv[SH] = p_zv;
-                sv[2 * SH] = p_nv;
-                sv[3 * SH] = p_hn;
+                nt_store(sv, p_rv);
+                nt_store(sv + SH, p_zv);
+                nt_store(sv + 2 * SH, p_nv);
+                nt_store(sv + 3 * SH, p_hn);
             }
         }
     };
