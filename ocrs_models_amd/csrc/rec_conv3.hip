@@ -37,6 +37,10 @@
 #ifndef R3_SETPRIO
 #define R3_SETPRIO 0  // s_setprio 1 around a step's MFMA / fragment-refill block
 #endif
+#ifndef R3_NT_OUT
+#define R3_NT_OUT 1  // non-temporal output stores: the kernel 3-4 % faster (77.9 -> 75.1, 145 -> 139 us), CRNN step 4.92 -> 4.88 ms in A/B runs (the
+                     // same in k_conv3x3_tile: no further change; in k_gemm_x3p, whose output the persistent GRU reads next: slower)
+#endif
 #ifndef R3_DBG
 #define R3_DBG 0  // 1: per-phase cycle counters of every wave of block 0 (measurement builds; read with ocrs_conv_rows_dbg)
 #endif
@@ -353,7 +357,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3_rows(const bf16* __restrict_
             for (int h = 0; h < MH / 2; ++h) {
                 const int ci = lane_e + 64 * h, px = ci / CPP, c16 = ci % CPP;
                 const uint4 q = *reinterpret_cast<const uint4*>(stg + px * (CPP * 16) + ((c16 ^ (px & (CPP - 1))) << 4));
+#if R3_NT_OUT
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                if (pj + px < lim) __builtin_nontemporal_store((u4v){q.x, q.y, q.z, q.w}, reinterpret_cast<u4v*>(obase + (long)(pj + px) * ldo * 2 + c16 * 16));
+#else
                 if (pj + px < lim) *reinterpret_cast<uint4*>(obase + (long)(pj + px) * ldo * 2 + c16 * 16) = q;
+#endif
             }
         }
         if (gstat) {
