@@ -1661,7 +1661,8 @@ static void wgrad_x3_grid(int CA, int CB, long P, int& gx, int& gy, int& tiles_a
     tiles_a = (CA + 127) / 128;
     gy = tiles_a * ((CB + 127) / 128);
     const long nchunks = (P + 31) / 32;
-    long g = 512 / gy;
+    static const int target = env_int("OCRS_WGRAD_X3_BLOCKS", 512);  // (two resident 4-wave workgroups per CU; 384 / 768 / 1024 measured: no better)
+    long g = target / gy;
     if (g < 1) g = 1;
     if (g > nchunks) g = nchunks;
     cpb = (int)((nchunks + g - 1) / g);
