@@ -221,6 +221,13 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
                  int T, int N, int C, int Lpad, int Smax, hipStream_t st);
 int ocrs_ctc_bwd(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* nll,
                  const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+/* The same loss with the beta lattice computed by the same launch (alpha and beta recursions side by side, two workgroups per sample) and a
+ * backward that is parallel over (sample, time step) -- round 4; loss and gradient bit-identical to ocrs_ctc_fwd + ocrs_ctc_bwd.
+ * alpha, beta: workspaces [N][T][Smax] fp32. */
+int ocrs_ctc_fwd_ab(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, float* alpha, float* beta, float* nll,
+                    float* loss, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
+int ocrs_ctc_grad_ab(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* beta,
+                     const float* nll, const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st);
 /* torch.nn.CTCLoss() forward AND gradient in one launch (train_rec.py:104,121 + the backward of train_rec.py:140), lattice and log-probabilities
  * in LDS.  ocrs_ctc_fused_lds_bytes: LDS bytes a sample needs, 0 = shape not covered (use ocrs_ctc_fwd / ocrs_ctc_bwd).
  * grad_pre [T][N][C] (nullable: loss only) = dloss/dlog_probs for an upstream gradient of 1. */

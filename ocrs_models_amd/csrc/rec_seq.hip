@@ -275,6 +275,146 @@ __global__ __launch_bounds__(256) void k_ctc_beta_grad(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// CTC with the two recursions side by side (round 4).  k_ctc_beta_grad runs T dependent steps of [three barriers, the
+// alpha row from global memory, an LDS-atomic occupancy sum and a gradient-row store]: 121 us against the alpha recursion's 50.  But beta does
+// not depend on alpha, and the gradient of a time step depends on nothing else once both lattices exist:
+//   k_ctc_ab    grid (N, 2): blockIdx.y = 0 runs the alpha recursion (exactly k_ctc_alpha), 1 the beta recursion of the same sample, storing
+//               its lattice -- both at once, two workgroups per CU;
+//   k_ctc_grad  one WAVE per (sample, time step): occupancy sums with the same 2^-30 fixed-point integer atomics, then the gradient row.
+// Same lse3, same association, integer sums: loss and gradient are bit-identical to k_ctc_alpha + k_ctc_beta_grad.
+template <int SPT>
+__global__ __launch_bounds__(256) void k_ctc_ab(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
+                                                const long long* __restrict__ tg_len, float* __restrict__ alpha, float* __restrict__ beta,
+                                                float* __restrict__ nll, int T, int N, int C, int Lpad, int Smax) {
+    __shared__ float row[2][256 * SPT + 2];
+    const int n = blockIdx.x;
+    int Ti = (int)in_len[n], L = (int)tg_len[n];
+    Ti = Ti > T ? T : Ti;
+    L = L < 0 ? 0 : (L > Lpad ? Lpad : L);
+    L = 2 * L + 1 > Smax ? (Smax - 1) / 2 : L;
+    const int S = 2 * L + 1;
+    const int* tg = targets + (long)n * Lpad;
+    if (blockIdx.y == 0) {  // ---- alpha (the code of k_ctc_alpha<false, SPT>)
+        float* al = alpha + (long)n * T * Smax;
+        int ext[SPT];
+        bool skip[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int s = threadIdx.x + j * 256;
+            ext[j] = (s < S && (s & 1)) ? tg[s >> 1] : 0;
+            skip[j] = s < S && (s & 1) && s >= 2 && tg[s >> 1] != tg[(s >> 1) - 1];
+        }
+        if (Ti <= 0) {
+            if (threadIdx.x == 0) nll[n] = (L == 0) ? 0.f : -NEG_INF;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int s = threadIdx.x + j * 256;
+            float a = NEG_INF;
+            if (s < S && s < 2) a = lp[(long)n * C + ext[j]];
+            row[0][s + 2] = a;
+            if (s < S) al[s] = a;
+        }
+        if (threadIdx.x < 2) row[0][threadIdx.x] = row[1][threadIdx.x] = NEG_INF;
+        __syncthreads();
+        int cur = 0;
+        for (int t = 1; t < Ti; ++t) {
+            const float* lpt = lp + ((long)t * N + n) * C;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int s = threadIdx.x + j * 256;
+                if (s < S) {
+                    const float a0 = row[cur][s + 2], a1 = row[cur][s + 1], a2 = skip[j] ? row[cur][s] : NEG_INF;
+                    const float a = lse3(a0, a1, a2) + lpt[ext[j]];
+                    row[cur ^ 1][s + 2] = a;
+                    al[(long)t * Smax + s] = a;
+                }
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float l1 = row[cur][S - 1 + 2];
+            const float l2 = S > 1 ? row[cur][S - 2 + 2] : NEG_INF;
+            nll[n] = -lse2(l1, l2);
+        }
+    } else {  // ---- beta (the recursion of k_ctc_beta_grad<false, SPT>, its rows stored)
+        float* be = beta + (long)n * T * Smax;
+        int ext[SPT];
+        bool skip[SPT];  // transition s -> s+2 allowed
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int s = threadIdx.x + j * 256;
+            ext[j] = (s < S && (s & 1)) ? tg[s >> 1] : 0;
+            skip[j] = (s & 1) && s + 2 < S && tg[s >> 1] != tg[(s >> 1) + 1];
+        }
+        if (Ti <= 0) return;
+        for (int i = threadIdx.x; i < 256 * SPT + 2; i += 256) row[0][i] = row[1][i] = NEG_INF;
+        __syncthreads();
+        int cur = 0;
+        for (int t = Ti - 1; t >= 0; --t) {
+            const float* lpt = lp + ((long)t * N + n) * C;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int s = threadIdx.x + j * 256;
+                if (s < S) {
+                    float b;
+                    if (t == Ti - 1) {
+                        b = (s >= S - 2) ? lpt[ext[j]] : NEG_INF;
+                    } else {
+                        const float b0 = row[cur][s], b1 = row[cur][s + 1], b2 = skip[j] ? row[cur][s + 2] : NEG_INF;
+                        b = lse3(b0, b1, b2) + lpt[ext[j]];
+                    }
+                    row[cur ^ 1][s] = b;
+                    be[(long)t * Smax + s] = b;
+                }
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+}
+// gradient rows from the two lattices: workgroup = 4 waves = 4 time steps of one sample; grad [T][N][C] fully written (zeros for t >= T_n)
+__global__ __launch_bounds__(256) void k_ctc_grad(const float* __restrict__ lp, const int* __restrict__ targets, const long long* __restrict__ in_len,
+                                                  const long long* __restrict__ tg_len, const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                  const float* __restrict__ nll, const float* __restrict__ gout, float* __restrict__ grad, int T, int N,
+                                                  int C, int Lpad, int Smax) {
+    extern __shared__ unsigned s_occ[];  // [4 waves][C]
+    const int n = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, t = blockIdx.x * 4 + w;
+    int Ti = (int)in_len[n], L = (int)tg_len[n];
+    Ti = Ti > T ? T : Ti;
+    L = L < 0 ? 0 : (L > Lpad ? Lpad : L);
+    L = 2 * L + 1 > Smax ? (Smax - 1) / 2 : L;
+    const int S = 2 * L + 1;
+    const int* tg = targets + (long)n * Lpad;
+    unsigned* occ = s_occ + w * C;
+    for (int c = lane; c < C; c += 64) occ[c] = 0u;
+    __syncthreads();
+    const bool live = t < T && t < Ti;
+    const float nl = nll[n];
+    const float scale = gout[0] / ((float)N * (float)(L > 1 ? L : 1));
+    const float* lpt = lp + ((long)(t < T ? t : 0) * N + n) * C;
+    if (live) {
+        const float* al = alpha + ((long)n * T + t) * Smax;
+        const float* be = beta + ((long)n * T + t) * Smax;
+        for (int s = lane; s < S; s += 64) {
+            const int e = (s & 1) ? tg[s >> 1] : 0;
+            const float ab = al[s] + be[s];
+            if (ab != NEG_INF) {
+                const float g = fminf(expf(ab + nl - lpt[e]), 2.f);
+                atomicAdd(&occ[e], (unsigned)(g * 1073741824.f + 0.5f));
+            }
+        }
+    }
+    __syncthreads();
+    if (t < T) {
+        float* gr = grad + ((long)t * N + n) * C;
+        for (int c = lane; c < C; c += 64) gr[c] = live ? (expf(lpt[c]) - (float)occ[c] * (1.f / 1073741824.f)) * scale : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Wave-level CTC (round 4; BASELINE north_star "wavefront shuffles for the CTC alpha / beta reductions").  The block kernels above give a
 // sample a whole 256-thread block: one LDS round trip + one __syncthreads() per time step and a dependent global gather lp[t][ext[s]] inside
 // the serial loop, with at most S = 2 L + 1 (81 at BASELINE configs[2]) of the 256 threads holding a state: 59 + 136 us per step.  Here a
@@ -787,6 +927,32 @@ int ocrs_ctc_fwd(const float* lp, const int* targets, const long long* in_len, c
         hipLaunchKernelGGL((k_ctc_alpha<false, 16>), dim3(N), dim3(256), 0, st, lp, targets, in_len, tg_len, (void*)alpha, (float*)nullptr, nll, T, N, C, Lpad, Smax);
     }
     hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+// ocrs_ctc_fwd with the beta lattice computed by the same launch (for a backward by ocrs_ctc_grad_ab): alpha, beta [N][T][Smax] fp32.
+// Loss and (with ocrs_ctc_grad_ab) gradient bit-identical to ocrs_ctc_fwd + ocrs_ctc_bwd.
+int ocrs_ctc_fwd_ab(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, float* alpha, float* beta, float* nll,
+                    float* loss, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
+    OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && beta && nll && loss && T > 0 && N > 0 && C > 0);
+    OCRS_CHECK_ARG(Smax <= 256 * CTC_SPT_MAX && Smax >= 1);
+    const dim3 grid(N, 2);
+    if (Smax <= 256 * 3)
+        hipLaunchKernelGGL((k_ctc_ab<3>), grid, dim3(256), 0, st, lp, targets, in_len, tg_len, alpha, beta, nll, T, N, C, Lpad, Smax);
+    else if (Smax <= 256 * 8)
+        hipLaunchKernelGGL((k_ctc_ab<8>), grid, dim3(256), 0, st, lp, targets, in_len, tg_len, alpha, beta, nll, T, N, C, Lpad, Smax);
+    else
+        hipLaunchKernelGGL((k_ctc_ab<16>), grid, dim3(256), 0, st, lp, targets, in_len, tg_len, alpha, beta, nll, T, N, C, Lpad, Smax);
+    hipLaunchKernelGGL(k_ctc_reduce, dim3(1), dim3(256), 0, st, nll, tg_len, loss, N);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+// backward of ocrs_ctc_fwd_ab: grad [T][N][C] written; gout = upstream scalar gradient (device fp32 [1])
+int ocrs_ctc_grad_ab(const float* lp, const int* targets, const long long* in_len, const long long* tg_len, const float* alpha, const float* beta,
+                     const float* nll, const float* gout, float* grad, int T, int N, int C, int Lpad, int Smax, hipStream_t st) {
+    OCRS_CHECK_ARG(lp && targets && in_len && tg_len && alpha && beta && nll && gout && grad && T > 0 && N > 0 && C > 0 && C <= 4096);
+    hipLaunchKernelGGL(k_ctc_grad, dim3((T + 3) / 4, N), dim3(256), 4 * C * sizeof(unsigned), st, lp, targets, in_len, tg_len, alpha, beta, nll, gout, grad,
+                       T, N, C, Lpad, Smax);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

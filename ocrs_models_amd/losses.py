@@ -5,6 +5,8 @@
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ._lib import lib, ptr
@@ -52,6 +54,9 @@ def balanced_cross_entropy_loss(pred: torch.Tensor, target: torch.Tensor) -> tor
 MAX_CTC_STATES = 4096  # csrc/rec_seq.hip: up to 16 states per thread x 256 threads (labels of up to 2047 symbols)
 
 
+_CTC_AB = os.environ.get("OCRS_CTC_AB", "1") != "0"  # alpha and beta recursions in one launch + a parallel gradient kernel (round 4)
+
+
 class _CTC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_probs, targets, in_len, tg_len, smax=None, h16=False):
@@ -65,6 +70,7 @@ class _CTC(torch.autograd.Function):
         nll = torch.empty(N, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ctx.fused = False
+        ctx.ab = False
         if not h16 and L.ctc_fused_lds_bytes(T, C, Smax) > 0:
             # fused wave-level form (csrc/rec_seq.hip k_ctc_fused_w): loss AND the gradient for an upstream gradient of 1 in one launch
             need_grad = log_probs.requires_grad
@@ -80,7 +86,14 @@ class _CTC(torch.autograd.Function):
         else:
             alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
             rowmax = nll  # (unused)
-            L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
+            if log_probs.requires_grad and _CTC_AB:
+                # a backward will follow: the beta recursion runs NEXT TO the alpha recursion in the same launch, the backward is then parallel
+                # over (sample, time step) -- bit-identical to ctc_fwd + ctc_bwd (csrc/rec_seq.hip: k_ctc_ab / k_ctc_grad)
+                rowmax = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)  # (the beta lattice travels in the rowmax slot)
+                L.ctc_fwd_ab(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(rowmax), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
+                ctx.ab = True
+            else:
+                L.ctc_fwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(loss), T, N, C, Lpad, Smax)
         ctx.save_for_backward(lp, tg, in_len, tg_len, alpha, nll, rowmax)
         ctx.smax, ctx.h16 = Smax, h16
         return loss
@@ -96,7 +109,9 @@ class _CTC(torch.autograd.Function):
         T, N, C = lp.shape
         grad = torch.empty_like(lp)
         g = gout.contiguous().float().reshape(1)
-        if ctx.h16:
+        if ctx.ab:
+            lib().ctc_grad_ab(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(rowmax), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
+        elif ctx.h16:
             lib().ctc_bwd_h16(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(rowmax), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)
         else:
             lib().ctc_bwd(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(alpha), ptr(nll), ptr(g), ptr(grad), T, N, C, tg.shape[1], ctx.smax)

@@ -664,3 +664,31 @@ def test_ctc_wave_level_forms_are_bit_identical_to_the_block_kernels(dev, knob, 
             out[mode] = (loss.detach().clone(), x.grad.clone())
         assert torch.equal(out["0"][0], out["1"][0]) or (torch.isinf(out["0"][0]) and torch.isinf(out["1"][0])), (T, N, Lmax)
         assert torch.equal(torch.nan_to_num(out["0"][1]), torch.nan_to_num(out["1"][1])), (T, N, Lmax)
+
+
+def test_ctc_side_by_side_recursions_are_bit_identical(dev, monkeypatch):
+    """csrc/rec_seq.hip k_ctc_ab (alpha and beta recursions of a sample in two workgroups of ONE launch) + k_ctc_grad (one wave per (sample, time
+    step)): the default when a backward follows.  Same lse3, same association, integer occupancy sums -> loss and gradient equal
+    k_ctc_alpha + k_ctc_beta_grad bit for bit (ragged lengths incl. T_n < T, repeated labels, L = 0, more than 768 lattice states)."""
+    import ocrs_models_amd as oa
+    from ocrs_models_amd import losses
+
+    g = torch.Generator().manual_seed(12)
+    for T, N, C, Lmax in [(101, 37, 97, 40), (65, 9, 97, 20), (120, 5, 23, 100), (1100, 3, 23, 500)]:
+        lp = torch.log_softmax(3 * torch.randn(T, N, C, generator=g), -1).to(dev)
+        tl = torch.randint(0, Lmax + 1, (N,), generator=g)
+        tl[0] = Lmax
+        tl[1] = 0
+        tg = torch.randint(1, C, (N, Lmax), generator=g).int()
+        tg[0, 2:5] = tg[0, 2]
+        il = torch.randint(T // 2, T + 1, (N,), generator=g)
+        il[0] = T
+        out = {}
+        for mode in (False, True):
+            monkeypatch.setattr(losses, "_CTC_AB", mode)
+            x = lp.clone().requires_grad_(True)
+            loss = oa.CTCLoss()(x, tg, il, tl)
+            (2.5 * loss).backward()
+            out[mode] = (loss.detach().clone(), x.grad.clone())
+        assert torch.equal(out[False][0], out[True][0]) or (torch.isinf(out[False][0]) and torch.isinf(out[True][0])), (T, N, Lmax)
+        assert torch.equal(torch.nan_to_num(out[False][1]), torch.nan_to_num(out[True][1])), (T, N, Lmax)
