@@ -263,11 +263,25 @@ class _RecRun:
         """dz: gradient w.r.t. the conv output [N][Hz][Wz][Cout]; accumulates dW, returns dx [N][Hx][Wx][Cin]."""
         L, w = self.L, self.P[name]
         co, ci, kh, kw = w.shape
-        if kh == 3 and kw == 3 and pad == 1 and co <= 128:
-            ws = self.empty(L.conv3x3_wgrad_ws_floats(co, ci, self.N, Hz, Wz), dtype=torch.float32)
-            L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), ptr(ws), self.N, Hz, Wz, self.dt)
-        else:
+
+        def wgrad_now():
+            if kh == 3 and kw == 3 and pad == 1 and co <= 128:
+                ws = self.empty(L.conv3x3_wgrad_ws_floats(co, ci, self.N, Hz, Wz), dtype=torch.float32)
+                L.conv3x3_wgrad(ptr(dz), co, ptr(xin), ci, ptr(self.G[name]), ptr(ws), self.N, Hz, Wz, self.dt)
+                return ws
             self.wgrad(dz, co, co, xin, ci, ci, self.G[name], self.N, Hz, Wz, Hx, Wx, pad, pad, kh, kw, self.dt)
+            return None
+        side = getattr(self, "_side", None)
+        if side is not None and need_dx:
+            # The weight gradient hangs off dz and nothing downstream in the backward reads it: it runs on a side stream next to the dgrad and the
+            # HBM-bound BatchNorm / pooling backward kernels of the next layer (matrix-core work next to streaming work).  Its operands stay
+            # referenced until the main stream has waited for the side stream (end of the backward, or the DDP stage report).
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ws = wgrad_now()
+            self._keep.extend((dz, xin, ws))
+        else:
+            wgrad_now()
         if not need_dx:
             return None
         dx = self.empty(self.N, Hx, Wx, ci)
@@ -337,8 +351,18 @@ class _RecRun:
         bucketer = getattr(self.mod, "_grad_bucketer", None)
         done = [0]
 
+        main = torch.cuda.current_stream()
+        self._side = _rec_side_stream(self.dev) if _REC_OVERLAP else None
+        self._keep = []
+
+        def join_side():
+            if self._side is not None and self._keep:
+                main.wait_stream(self._side)
+                self._keep.clear()
+
         def stage_done(stage):
             if bucketer is not None and stage_end[stage] > done[0]:
+                join_side()  # (DDP: a stage's gradients are final when they are reported)
                 bucketer.ready(flat, done[0], stage_end[stage])
             done[0] = max(done[0], stage_end[stage])
 
@@ -373,10 +397,21 @@ class _RecRun:
             sfx = [f"_l{layer}", f"_l{layer}_reverse"]
             # stacked views: [w_ih, w_ih_reverse] etc. are adjacent in the flat buffer (see `order`)
             gw_ih = G["gru.weight_ih" + sfx[0]]
-            self.wgrad(dgi, 1536, 1536, gl["x"], I, I, gw_ih, 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
-            for d in (0, 1):
-                self.wgrad(dgh.data_ptr() + 4 * d * 768, 1536, 768, gl["out"].data_ptr() + 4 * d * 256, 512, 256, G["gru.weight_hh" + sfx[d]], 1,
-                           T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
+
+            def gru_wgrads():
+                self.wgrad(dgi, 1536, 1536, gl["x"], I, I, gw_ih, 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
+                for d in (0, 1):
+                    self.wgrad(dgh.data_ptr() + 4 * d * 768, 1536, 768, gl["out"].data_ptr() + 4 * d * 256, 512, 256, G["gru.weight_hh" + sfx[d]], 1,
+                               T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
+            if layer == 0 and self._side is not None and _REC_OVERLAP_GRU:
+                # layer 0's weight gradients next to the conv backward that follows (layer 1's would run under layer 0's persistent recurrence,
+                # whose hand-offs suffer from streaming neighbours: measured slower in round 2)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    gru_wgrads()
+                self._keep.extend((dgi, dgh, gl["x"], gl["out"]))
+            else:
+                gru_wgrads()
             if not self.gru_seq:  # (the persistent launch accumulates the bias gradients itself)
                 L.col_sum(ptr(dgi), 1536, 1536, ptr(G["gru.bias_ih" + sfx[0]]), rows, 0)
                 L.col_sum(ptr(dgh), 1536, 1536, ptr(G["gru.bias_hh" + sfx[0]]), rows, 0)
@@ -412,6 +447,8 @@ class _RecRun:
         stage_done("conv.3.")
         L.conv0_bwd(ptr(self.x), ptr(P["conv.0.weight"]), ptr(P["conv.0.bias"]), ptr(g0), ptr(G["conv.0.weight"]), ptr(G["conv.0.bias"]), N, self.H,
                     W, self.dt)
+        join_side()
+        self._side = None
         stage_done("conv.0.")
         if bucketer is not None:
             bucketer.finish(flat)
@@ -488,6 +525,18 @@ class _RecFn(torch.autograd.Function):
         _gru_err_poll(ctx.run.dev)
         ctx.run = None  # free the saved activations (and break the output -> grad_fn -> ctx -> run cycle)
         return (None, None, None, None, *grads)
+
+
+_REC_OVERLAP = os.environ.get("OCRS_REC_OVERLAP", "1") != "0"  # conv weight gradients of the backward on a side stream
+_REC_OVERLAP_GRU = os.environ.get("OCRS_REC_OVERLAP_GRU", "1") != "0"  # ... and the GRU layer-0 weight gradients
+_REC_SIDE = {}
+
+
+def _rec_side_stream(dev):
+    st = _REC_SIDE.get(dev)
+    if st is None:
+        st = _REC_SIDE[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 class RecognitionModel(nn.Module):
