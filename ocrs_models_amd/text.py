@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import string
 
+import os
+
 import torch
 
 from ._lib import lib, ptr
@@ -64,6 +66,17 @@ class _Decode:
         return [row[:n] for row, n in zip(labels_h, lens_h)]
 
 
+_DECODE_SIDE = os.environ.get("OCRS_DECODE_SIDE", "1") != "0"
+_DECODE_STREAMS = {}
+
+
+def _decode_stream(dev):
+    st = _DECODE_STREAMS.get(dev)
+    if st is None:
+        st = _DECODE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def greedy_decode_batch_async(log_probs: torch.Tensor, input_lengths) -> _Decode:
     """(T,N,C) log-probs on the GPU -> handle; arg-max + collapse run on the device, ONE non-blocking copy brings labels | lengths to the
     host.  A caller that queues more GPU work (the backward pass) before asking for ``result()`` overlaps the host-side part with it."""
@@ -73,13 +86,22 @@ def greedy_decode_batch_async(log_probs: torch.Tensor, input_lengths) -> _Decode
     il = torch.as_tensor(input_lengths, dtype=torch.int64)
     if not il.is_cuda:
         il = il.pin_memory().to(dev, non_blocking=True)
-    amax = torch.empty(N, T, dtype=torch.int32, device=dev)
-    buf = torch.zeros(N * T + N, dtype=torch.int32, device=dev)  # labels | lens
-    lib().ctc_greedy_decode(ptr(lp), ptr(il), ptr(amax), ptr(buf), buf.data_ptr() + 4 * N * T, T, N, C)
-    host = torch.empty(N * T + N, dtype=torch.int32, pin_memory=True)
-    host.copy_(buf, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
+    # The decode depends on the log-probs only: on a side stream it runs next to the CTC loss / the start of the backward instead of in front
+    # of them (arg-max + collapse + copies are ~40 us of small launches).  result() waits for the event recorded on that stream.
+    main = torch.cuda.current_stream(dev)
+    side = _decode_stream(dev) if _DECODE_SIDE and not torch.cuda.is_current_stream_capturing() else main
+    if side is not main:
+        side.wait_stream(main)
+        lp.record_stream(side)
+        il.record_stream(side)
+    with torch.cuda.stream(side):
+        amax = torch.empty(N, T, dtype=torch.int32, device=dev)
+        buf = torch.zeros(N * T + N, dtype=torch.int32, device=dev)  # labels | lens
+        lib().ctc_greedy_decode(ptr(lp), ptr(il), ptr(amax), ptr(buf), buf.data_ptr() + 4 * N * T, T, N, C)
+        host = torch.empty(N * T + N, dtype=torch.int32, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
     return _Decode(host, ev, amax, N, T)
 
 
