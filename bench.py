@@ -384,8 +384,13 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         L = lib()
         fams = ["conv_igemm", "conv3x3_wgrad", "gru_layer_fwd", "gru_layer_bwd", "gru_seq_fwd", "gru_seq_bwd"]
         L.timing = {k: [] for k in fams}
+        # (per-launch durations: this one step runs with the backward's side stream off -- concurrent launches would stretch each other's
+        #  event intervals; the timed steps above ran with it on)
+        import ocrs_models_amd.recognition as _rec
+        _ov, _rec._REC_OVERLAP = _rec._REC_OVERLAP, False
         step(batch)
         torch.cuda.synchronize()
+        _rec._REC_OVERLAP = _ov
         tm, L.timing = L.timing, None
         conv_ms = conv_fl = 0.0
         for e0, e1, a in tm["conv_igemm"]:

@@ -1,4 +1,7 @@
 """CRNN train steps only (for rocprofv3 runs)."""
+import os
+os.environ.setdefault("OCRS_REC_OVERLAP", "0")  # per-kernel profiles: one stream (concurrent launches stretch each other's durations)
+os.environ.setdefault("OCRS_DECODE_SIDE", "0")
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse, torch
