@@ -379,6 +379,7 @@ class _RecRun:
             dout = self.gemm(dlog, S.ldl, S.ldl, self.pack(P["output.0.weight"], C, 512, C, 0, 512, 1, dt=0), None, 512, 512, rows)
         stage_done("output.")
         dhz = self.empty(2, 2, N, 256, dtype=torch.float32)
+        deferred_l1 = None
         for layer in (1, 0):
             gl = S.gru[layer]
             I = gl["I"]
@@ -398,16 +399,22 @@ class _RecRun:
             # stacked views: [w_ih, w_ih_reverse] etc. are adjacent in the flat buffer (see `order`)
             gw_ih = G["gru.weight_ih" + sfx[0]]
 
-            def gru_wgrads():
+            def gru_wgrads(dgi=dgi, dgh=dgh, gl=gl, I=I, gw_ih=gw_ih, sfx=sfx):  # (bound now: layer 1's call may run during layer 0's iteration)
                 self.wgrad(dgi, 1536, 1536, gl["x"], I, I, gw_ih, 1, 1, rows, 1, rows, 0, 0, 1, 1, 0)
                 for d in (0, 1):
                     self.wgrad(dgh.data_ptr() + 4 * d * 768, 1536, 768, gl["out"].data_ptr() + 4 * d * 256, 512, 256, G["gru.weight_hh" + sfx[d]], 1,
                                T, N, T, N, 1 if d == 0 else -1, 0, 1, 1, 0)
-            if layer == 0 and self._side is not None and _REC_OVERLAP_GRU:
-                # layer 0's weight gradients next to the conv backward that follows (layer 1's would run under layer 0's persistent recurrence,
-                # whose hand-offs suffer from streaming neighbours: measured slower in round 2)
+            if self._side is not None and _REC_OVERLAP_GRU and layer == 1 and _REC_OVERLAP_GRU1 and bucketer is None:
+                # layer 1's weight gradients must not run under layer 0's persistent recurrence (its hand-offs suffer from streaming neighbours:
+                # measured slower in round 2): they are queued on the side stream BEHIND that recurrence, together with layer 0's
+                deferred_l1 = gru_wgrads
+                self._keep.extend((dgi, dgh, gl["x"], gl["out"]))
+            elif layer == 0 and self._side is not None and _REC_OVERLAP_GRU:
+                # layer 0's weight gradients next to the conv backward that follows
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
+                    if deferred_l1 is not None:
+                        deferred_l1()
                     gru_wgrads()
                 self._keep.extend((dgi, dgh, gl["x"], gl["out"]))
             else:
@@ -529,6 +536,7 @@ class _RecFn(torch.autograd.Function):
 
 _REC_OVERLAP = os.environ.get("OCRS_REC_OVERLAP", "1") != "0"  # conv weight gradients of the backward on a side stream
 _REC_OVERLAP_GRU = os.environ.get("OCRS_REC_OVERLAP_GRU", "1") != "0"  # ... and the GRU layer-0 weight gradients
+_REC_OVERLAP_GRU1 = os.environ.get("OCRS_REC_OVERLAP_GRU1", "1") != "0"  # ... and layer 1's, queued behind layer 0's recurrence (single-GPU runs)
 _REC_SIDE = {}
 
 
