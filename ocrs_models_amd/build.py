@@ -53,15 +53,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
-    for asm_src in ("det_mm.hip", "rec_conv3.hip"):
+    for asm_src in ("det_mm.hip", "rec_conv3.hip", "det_rs.hip"):
         if not any(os.path.basename(s) == asm_src for s, _ in jobs):
             continue
         # the hand-waited asm loads of det_mm.hip (tile prefetch) and rec_conv3.hip (A fragments) are only valid if hipcc left their
         # destination registers alone until the wait
-        chk = os.path.join(os.path.dirname(HERE), "tools", "check_opaque_loads.py")
+        chk = os.path.join(os.path.dirname(HERE), "tools", "check_rs_loads.py" if asm_src == "det_rs.hip" else "check_opaque_loads.py")
         if not os.path.exists(chk):
-            print(f"WARNING: tools/check_opaque_loads.py not found -- {asm_src}'s hand-waited asm loads were NOT verified against this "
-                  "compiler's register allocation (build from the repository tree, or run with OCRS_MM_FULL=0 to use the compiler-waited kernels)",
+            knob = {"det_mm.hip": "OCRS_MM_FULL=0", "rec_conv3.hip": "OCRS_CONV_ROWS=0", "det_rs.hip": "OCRS_RS=0"}[asm_src]
+            print(f"WARNING: {os.path.basename(chk)} not found -- {asm_src}'s hand-waited asm loads were NOT verified against this "
+                  f"compiler's register allocation (build from the repository tree, or run with {knob} to use the compiler-waited kernels)",
                   file=sys.stderr, flush=True)
         else:
             r = subprocess.run([sys.executable, chk], capture_output=True, text=True,
@@ -70,7 +71,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr, flush=True)
             if r.returncode != 0:
                 os.remove(os.path.join(OBJ, asm_src + ".o"))
-                raise RuntimeError(f"tools/check_opaque_loads.py: hipcc touched an in-flight asm-load register in {asm_src}:\n" + r.stdout[-3000:])
+                raise RuntimeError(f"{os.path.basename(chk)}: hipcc touched an in-flight asm-load register in {asm_src}:\n" + r.stdout[-3000:])
     objs = [os.path.join(OBJ, src + ".o") for src in sources()]
     if force or jobs or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

@@ -15,6 +15,7 @@
 // HBM bytes per pixel: x (Cin) + z, g (Cout, 1.1-1.3x with the ring, mostly L2 hits) in, dx~ (Cin) out -- the 2 (Cin + Cout) of
 // SURVEY.md 8(d); du is never formed.  All flushes are per-block partials reduced by ONE deterministic kernel (no atomics).
 #include "det_common.h"
+#include "det_rs.h"
 #include <type_traits>
 
 // ---- tile-shape / residency knobs (measurement builds: tools/build_variant.sh; the defaults are the measured optimum, profiles/README.md)
@@ -991,7 +992,9 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout, 0)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout, 1));
-    return (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin + 1024);  // per block: its partials + 4 KB of scratch lines (stores of rows below the image)
+    const long tiled = (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin + 1024);  // per block: its partials + 4 KB of scratch lines (stores of rows below the image)
+    const long rs = rs_bwd_supported(Ca, Cb, Cout, 0, N, H, W) ? (long)rs_bwd_blocks(Cin, Cout, N, H, W, 0) * (Cout * Cin + 11 * Cin) : 0;  // row-streaming form (det_rs.hip)
+    return tiled > rs ? tiled : rs;
 }
 
 // Backward of one DepthwiseConv block on the matrix cores (replaces ocrs_pw_bwd + ocrs_dw_bwd [+ ocrs_bn_bwd_reduce of the producers]):
@@ -1022,11 +1025,14 @@ static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
         const float* svB = split ? nullptr : saved_b;
         double* gsB = split ? nullptr : gsum_b;
         const bool stats = gsA || gsB;
-        const int nb = mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout, pooled ? 1 : 0));
+        const bool rs = !split && rs_bwd_supported(Ca, Cb, Cout, pooled, N, H, W);  // the row-streaming kernel (det_rs.hip) covers this launch
+        const int nb = rs ? rs_bwd_blocks(Cin, Cout, N, H, W, g2 != nullptr)
+                          : mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout, pooled ? 1 : 0));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
+        if (rs) rs_bwd_launch(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, coef, ga, gb, ws, stats, Cout, N, H, W, fin, st);
 #define MM_CASE(CI_, CO_)                                                                                                             \
-    if (Cin == CI_ && Cout == CO_)                                                                                                    \
+    if (!rs && Cin == CI_ && Cout == CO_)                                                                                             \
         mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, fin, st);
         MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
 #undef MM_CASE

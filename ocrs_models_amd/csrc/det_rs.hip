@@ -1,0 +1,669 @@
+// Row-streaming form of the "everything on the matrix cores" DepthwiseConv block backward (reference ocrs_models/models.py:7-28; same
+// mathematics as k_mm_bwd in det_mm.hip: Weff[o][(tap, c)] = Wpw[o][c] * Wdw[c][tap], dz = A * ghat + B * z + C,
+// dx~ = Weff^T (*) dz, G_tap[c][o] = sum_q x~[q][c] dz[q - off(tap)][o], dWpw / dWdw from G) with a different execution structure.
+//
+// k_mm_bwd stages 12 x 32-pixel tiles per 512-thread block: two barriers per tile, a 2-D tile decode per tile, 24 % ring re-reads, the
+// producers' BatchNorm-backward sums as a per-lane VALU epilogue.  Round 3 / 4 measured that its time is neither bytes nor any one
+// unit but the per-tile chain of dependent phases (4.8 VALU wave-instructions and 0.63 KB of LDS traffic per pixel for 8 -> 8 channels).  Here:
+//
+//   * ONE WAVE owns a strip of 30 output columns (32 input columns: one halo column each side) and marches down the image two rows per tick.
+//     Its dz rows live in a wave-private 6-row LDS ring, its x~ rows in a 2-slot tile: LDS operations of one wave execute in order, so there
+//     is NO workgroup barrier in the main loop and the 16 waves of a CU drift apart freely (their VALU / LDS / MFMA / memory phases interleave).
+//   * A lane is a (row of the pair, pixel) and holds ALL channels of its pixel: every per-channel BatchNorm / transform coefficient is
+//     wave-uniform, i.e. a scalar-register operand of v_pk_fma_f32 (one of the two non-data operands; the other one sits in a VGPR pair) --
+//     no LDS parameter reads (k_mm_bwd: 16 ds_read_b128 per tile and wave).
+//   * Rows are contiguous in HBM: a tick's loads are 512-byte runs at (scalar tick offset + constant lane offset) through buffer descriptors
+//     (out-of-range lanes read 0 / their stores are dropped by the hardware bounds check: no address selects, no divergent branches, so hipcc's
+//     vmcnt bookkeeping is exact), issued TWO ticks ahead.
+//   * Cin = 8: the 16-row MFMA M tile carries (row parity, channel): one MFMA set yields both rows of the pair from the 4 ring rows around them
+//     (K = 4 x 3 taps x Cout = 96 for Cout = 8: no K padding, half the MFMAs / B-fragment reads / stores of the one-row form).
+//   * The producers' BatchNorm-backward sums S1 = sum ghat', S2 = sum ghat' x~ (ghat' = dx~ [x~ > 0]) come out of the weight-gradient GEMM:
+//     S2[c] = sum_{tap,o} Weff[o][(tap,c)] G_tap[c][o]  (dx~ is linear in dz), and S1 likewise from a second set of M rows that holds the
+//     0/1 mask [x~ > 0] instead of x~ (for Cin = 8 those are rows 8..15 of the same M tile: free).  The per-lane epilogue (29 % of k_mm_bwd's
+//     VALU work) is gone.  The sums are those of the UNROUNDED dx~ (k_mm_bwd sums the stored bf16 values): an unbiased 2^-9 / sqrt(pixels) difference.
+//   * Work split: the (image, strip, row pair) steps are cut into equal contiguous ranges, one per wave (two warm-up ticks per range start /
+//     strip change): no tail, no tile scheduler.
+// HBM bytes per pixel: x (Cin) + z, g (Cout) in, dx~ (Cin) out = the 2 (Cin + Cout) of SURVEY.md 8(d), x 32/30 for the halo columns of the reads.
+#include "det_rs.h"
+#include <type_traits>
+
+#ifndef OCRS_RS_WPS
+#define OCRS_RS_WPS 4  // waves per SIMD the kernel is compiled for (register cap 512 / WPS)
+#endif
+#ifndef OCRS_RS_WPS_G2
+#define OCRS_RS_WPS_G2 3  // two gradient tensors: 8 more prefetch registers per set (139 VGPRs; at the 128 cap hipcc spills loop invariants, and a scratch reload is a vmcnt(0))
+#endif
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct RsArgs {
+    const bf16 *xa, *xb;
+    int Ca, Cb;
+    const float *tra, *trb, *wdw, *wpw;
+    int ldw;
+    const bf16 *g1, *g2, *z;
+    const float *bn, *coef;
+    bf16 *gxa, *gxb;
+    float* ws;
+    int N, H, W, NS, NP;
+    int NB, PB, njobs;  // row blocks per image, row pairs per block, jobs = N * NB * NS
+    BnFin fin;
+};
+
+template <int CIN, int COUT>
+struct RsCfg {
+    static constexpr int NW = 4, NT = 256;
+    static constexpr int SW = 30;                    // output columns per strip (the 32 staged columns minus one halo column each side)
+    static constexpr int PDB = COUT * 2;             // bytes per pixel of a ring row
+    static constexpr int ROWB = 34 * PDB;            // ring row: the 32 staged pixels at positions 1..32, positions 0 / 33 stay zero (the reads of the
+                                                     // discarded edge outputs land there)
+    static constexpr int RROWS = 6;                  // rows 2cp - 1 .. 2cp + 2 of the pair being computed + the pair being committed
+    static constexpr int RINGB = RROWS * ROWB + 64;  // (+ slack: a zero-weight K slot reads one position past the last row)
+    static constexpr int XPB = CIN * 2;              // x tile: bytes per pixel of one plane (plane 0: x~, plane 1: [x~ > 0] as 0 / 1)
+    static constexpr int XROWB = 32 * XPB, XPLANEB = 2 * XROWB, XSLOTB = 2 * XPLANEB, XB = 2 * XSLOTB;  // [slot 2][plane 2][row 2][32 px]
+    static constexpr bool DUAL = CIN == 8;           // M tile = (row parity, channel)
+    static constexpr int NPASS = DUAL ? 1 : 2;       // dgrad passes per tick (one per row of the pair when M = 16 channels)
+    static constexpr int NDY = DUAL ? 4 : 3;         // ring rows a dgrad pass reads
+    static constexpr int G8 = COUT / 8;              // 8-channel groups per dz pixel
+    static constexpr int TPC = 4 / G8;               // column offsets (dxi) per 32-deep K chunk: a chunk = ONE ring row (wave-uniform row base)
+    static constexpr int CPD = (3 + TPC - 1) / TPC;  // chunks per ring row (the K slots past dxi = 2 carry zero weights)
+    static constexpr int KC = NDY * CPD;
+    static constexpr int MTG = (2 * CIN) / 16;       // weight-gradient M tiles: [x~ | mask]
+    // weight-gradient N units of 16 (tap, o) columns, each inside ONE kernel row ky: Cout = 8: {kx 0 | kx 1}, {kx 2 | (dup)}; Cout = 16: one tap
+    static constexpr int UPK = COUT == 8 ? 2 : 3;    // units per kernel row
+    static constexpr int NU = 3 * UPK;
+    static constexpr int NZ = COUT / 8, NX = CIN / 8;  // 16-byte items per lane and tick
+    static constexpr int OFF_RING = 64;              // (+ 64: position -1 of wave 0's first row)
+    static constexpr int OFF_XT = OFF_RING + NW * RINGB;
+    static constexpr int STB = 2 * 32 * CIN * 2;     // dx~ staging of a row pair (the MFMA output layout regrouped to one pixel per lane: 16-byte stores)
+    static constexpr int OFF_ST = OFF_XT + NW * XB;
+    static constexpr int OFF_WF = OFF_ST + NW * STB;
+    static constexpr int OFF_PAR = OFF_WF + KC * 1024;
+    static constexpr int PAR_FLOATS = 6 * COUT + 3 * CIN + 9 * CIN + COUT * CIN;  // bn [3][COUT] | coef [3][COUT] | trx [3][CIN] | w9 [CIN][9] | wp [COUT][CIN]
+    static constexpr int SMEM_MAIN = OFF_PAR + PAR_FLOATS * 4;
+    static constexpr int SLOT_BYTES = NW * MTG * NU * 1024;  // flush: every wave's G accumulators
+    static constexpr int SMEM = SMEM_MAIN > SLOT_BYTES ? SMEM_MAIN : SLOT_BYTES;
+    static constexpr int PART = COUT * CIN + 9 * CIN + 2 * CIN;  // = MmCfg::PART (k_mm_bwd_reduce's element layout)
+};
+
+__device__ __forceinline__ f32x4 mfma_bf(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf(const bf16x8& a, const bf16x8& b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ f32x2 unpk(unsigned w) { return (f32x2){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ float usc(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }  // -> scalar register
+__device__ __forceinline__ f32x2 vreg(f32x2 v) {  // pin a (uniform) pair into vector registers: the second non-data operand of a v_pk_fma_f32
+    asm volatile("" : "+v"(v));
+    return v;
+}
+// ---- buffer descriptor as four scalar words (raw buffer, 32-bit offsets, hardware range check against `bytes`)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    i32x4 r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+// Prefetch loads the compiler does not see, with hand-written waits (see det_mm.hip: with stores pending in the same counter hipcc waits
+// vmcnt(0) in front of the first use of a loaded register, i.e. for the NEXT tick's loads and for the acknowledgement of the last stores).
+// tools/check_rs_loads.py verifies that hipcc leaves the destination registers alone between the load and its wait.
+__device__ __forceinline__ u32x4 bload16_opaque(const i32x4& rsrc, int voff) {
+    u32x4 r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4& r) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%1) ; releases %0" : "+v"(r) : "n"(N) : "memory");  // (the comment names the registers for tools/check_rs_loads.py)
+}
+__device__ __forceinline__ const bf16* lds_at(const char* smem, unsigned off) { return reinterpret_cast<const bf16*>(smem + off); }
+
+// one tick of a wave's program: commit row pair q of strip s of image n into the ring / x tile, then compute pair q - 1 (comp = 0: a warm-up
+// tick -- the same vector-memory instructions with the stores switched off, so that the hand-counted vmcnt waits hold on every path)
+struct RsTick {
+    int n, s, q, qm3, comp, valid;  // qm3 = q mod 3 (ring rows 2 qm3, 2 qm3 + 1)
+};
+// Work order.  A job = one strip x one block of PB row pairs; jobs are numbered (image, row block, strip) with the strip fastest and dealt
+// round-robin to the waves (wave v runs jobs v, v + nwaves, ...; v numbered XCD-major), so that at any time neighbouring waves -- of one
+// workgroup, then of one XCD -- walk NEIGHBOURING strips down the same rows: the 128-byte lines two strips share (a strip's 480 / 512-byte
+// row segments are not line-aligned) are fetched / completed once in the L2 they share.  tools/probes/bw_probe.hip measured the alternative
+// (a wave walking one strip top to bottom, its neighbours' rows far away in time): 3.65 TB/s instead of 5.2-5.5 for 3 reads + 1 write -- every
+// shared line goes to HBM twice and every partial line write back as a read-modify-write (the first form of this kernel: 680 us for 8 -> 8
+// channels at level 0 with its memory operations compiled out at 271).  The last, partial round of jobs costs little: the kernel is
+// bandwidth-bound, the waves that are left run faster.
+struct RsGen {  // (all wave-uniform: scalar registers)
+    int j, njobs, nw, NS, NB, PB, NP;
+    int n, s, p, pend, pm3, phase, have;
+    __device__ __forceinline__ void load_job() {
+        have = j < njobs;
+        if (!have) return;  // (n, s, p stay on the last valid position: the dead ticks re-load it)
+        const int per = NB * NS;
+        n = j / per;
+        const int r = j - n * per, rb = r / NS;
+        s = r - rb * NS;
+        p = rb * PB;
+        pend = p + PB < NP ? p + PB : NP;
+        pm3 = p % 3;
+        phase = 0;
+    }
+    __device__ __forceinline__ RsGen(int first, int njobs_, int nw_, int NS_, int NB_, int PB_, int NP_)
+        : j(first), njobs(njobs_), nw(nw_), NS(NS_), NB(NB_), PB(PB_), NP(NP_), n(0), s(0), p(0), pend(0), pm3(0), phase(0) {
+        load_job();
+    }
+    static __device__ __forceinline__ int wrap3(int v) { return v < 0 ? v + 3 : (v >= 3 ? v - 3 : v); }
+    __device__ __forceinline__ RsTick next() {
+        RsTick t;
+        t.n = n;
+        t.s = s;
+        t.valid = have;
+        t.comp = 0;
+        if (!have) {  // past the end: a harmless re-load of the last position (keeps the loop body free of conditional loads)
+            t.q = p < NP ? p : NP - 1;
+            t.qm3 = pm3;
+            return t;
+        }
+        if (phase == 0) {
+            t.q = p - 1;
+            t.qm3 = wrap3(pm3 - 1);
+            phase = 1;
+        } else if (phase == 1) {
+            t.q = p;
+            t.qm3 = pm3;
+            phase = 2;
+        } else {
+            t.q = p + 1;
+            t.qm3 = wrap3(pm3 + 1);
+            t.comp = 1;
+            ++p;
+            pm3 = wrap3(pm3 + 1);
+            if (p == pend) {
+                j += nw;
+                load_job();
+            }
+        }
+        return t;
+    }
+};
+
+}  // namespace
+
+template <int CIN, int COUT, bool G2, bool SPLIT>
+__global__ __launch_bounds__(256, (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS)) void k_rs_bwd(RsArgs A) {
+    using C = RsCfg<CIN, COUT>;
+    constexpr int PDB = C::PDB, ROWB = C::ROWB, RINGB = C::RINGB, XPB = C::XPB, KC = C::KC, NU = C::NU, MTG = C::MTG, NZ = C::NZ, NX = C::NX, SW = C::SW;
+    constexpr int G8 = C::G8, TPC = C::TPC, CPD = C::CPD, UPK = C::UPK;
+    constexpr bool DUAL = C::DUAL;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    uint4* s_wf = reinterpret_cast<uint4*>(smem + C::OFF_WF);
+    float* s_bn = reinterpret_cast<float*>(smem + C::OFF_PAR);  // [3][COUT]
+    float* s_cf = s_bn + 3 * COUT;                               // [3][COUT]
+    float* s_trx = s_cf + 3 * COUT;                              // [3][CIN] scale | shift | lo
+    float* s_w9 = s_trx + 3 * CIN;                               // [CIN][9]
+    float* s_wp = s_w9 + 9 * CIN;                                // [COUT][CIN]
+    const int H = A.H, W = A.W;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- prologue (block-wide): parameters, effective-weight A fragments, zeroed rings / x tiles (the pad positions stay zero)
+    for (int i = tid; i < 3 * COUT; i += C::NT) s_bn[i] = A.bn[i];
+    if (A.fin.gsum) {
+        bn_fin_coef(A.fin, COUT, s_cf, tid, C::NT, blockIdx.x == 0);
+    } else {
+        for (int i = tid; i < 3 * COUT; i += C::NT) s_cf[i] = A.coef[i];
+    }
+    for (int i = tid; i < 3 * CIN; i += C::NT) {
+        const int r = i / CIN, c = i - r * CIN;
+        s_trx[i] = c < A.Ca ? A.tra[r * A.Ca + c] : A.trb[r * A.Cb + (c - A.Ca)];
+    }
+    for (int i = tid; i < 9 * CIN; i += C::NT) s_w9[i] = A.wdw[i];
+    for (int i = tid; i < COUT * CIN; i += C::NT) s_wp[i] = A.wpw[(i / CIN) * A.ldw + (i % CIN)];
+    for (int i = tid; i < C::OFF_WF / 16; i += C::NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // A[m][k] of the dgrad GEMM.  Chunk kc = (ring row dy, part h); K slot (lane group kgl, j): column offset dxi = h * TPC + kgl / G8 (dz pixel =
+    // output pixel + dxi - 1), channel o = (kgl % G8) * 8 + j.  The dz pixel (dy, dxi) is conv tap (ky, kx) = (rp + 2 - dy, 2 - dxi) of the
+    // output row rp.  DUAL: m = (rp, c), dy in 0..3; otherwise m = c, and the fragment is that of rp = 0 (pass ps reads ring rows ps + dy).
+    for (int f = tid; f < KC * 64; f += C::NT) {
+        const int l = f & 63, kc = f >> 6, m = l & 15, kgl = l >> 4;
+        const int dy = kc / CPD, h = kc - dy * CPD;
+        const int rp = DUAL ? (m >> 3) : 0, c = DUAL ? (m & 7) : m;
+        const int dxi = h * TPC + kgl / G8, ky = rp + 2 - dy, kx = 2 - dxi;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = (kgl % G8) * 8 + j;
+            v[j] = (dxi <= 2 && ky >= 0 && ky <= 2) ? s_w9[c * 9 + ky * 3 + kx] * s_wp[o * CIN + c] : 0.f;
+        }
+        s_wf[f] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+    __syncthreads();
+
+    // ---- per-channel coefficients: one operand of every packed fma from scalar registers, the other one pinned into a VGPR pair
+    f32x2 bs2[COUT / 2], bt2[COUT / 2], ca2[COUT / 2], cb2[COUT / 2], cc2[COUT / 2], sc2[CIN / 2], sh2[CIN / 2];
+    float lo1[CIN];
+#pragma unroll
+    for (int i = 0; i < COUT / 2; ++i) {
+        bs2[i] = (f32x2){usc(s_bn[2 * i]), usc(s_bn[2 * i + 1])};
+        bt2[i] = vreg((f32x2){s_bn[COUT + 2 * i], s_bn[COUT + 2 * i + 1]});
+        ca2[i] = (f32x2){usc(s_cf[2 * i]), usc(s_cf[2 * i + 1])};
+        cb2[i] = (f32x2){usc(s_cf[COUT + 2 * i]), usc(s_cf[COUT + 2 * i + 1])};
+        cc2[i] = vreg((f32x2){s_cf[2 * COUT + 2 * i], s_cf[2 * COUT + 2 * i + 1]});
+    }
+#pragma unroll
+    for (int i = 0; i < CIN / 2; ++i) {
+        sc2[i] = (f32x2){usc(s_trx[2 * i]), usc(s_trx[2 * i + 1])};
+        sh2[i] = vreg((f32x2){s_trx[CIN + 2 * i], s_trx[CIN + 2 * i + 1]});
+    }
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
+
+    // ---- buffer descriptors (hardware bounds check: out-of-range loads return 0, out-of-range stores are dropped)
+    const unsigned npix = (unsigned)A.N * (unsigned)H * (unsigned)W;
+    const int Ca = A.Ca, Cb = A.Cb;
+    const i32x4 r_z = make_rsrc(A.z, npix * PDB), r_g1 = make_rsrc(A.g1, npix * PDB), r_g2 = make_rsrc(G2 ? A.g2 : A.g1, npix * PDB);
+    const i32x4 r_xa = make_rsrc(A.xa, npix * Ca * 2), r_xb = make_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 2);
+    const __amdgpu_buffer_rsrc_t w_a = __builtin_amdgcn_make_buffer_rsrc((void*)A.gxa, 0, npix * Ca * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_b = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? A.gxb : A.gxa), 0, npix * (SPLIT ? Cb : Ca) * 2, 0x00020000);
+
+    // ---- lane constants
+    const int rr = lane >> 5, px = lane & 31;                       // commit: this lane's (row of the pair, staged pixel)
+    const int lz = (rr * W + px) * PDB;                             // z / g byte offset from the tick's corner pixel
+    int lxo[NX];                                                    // x items: byte offset, source by item
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const bool in_a = !SPLIT || 8 * j < Ca;
+        lxo[j] = (rr * W + px) * (in_a ? Ca : Cb) * 2 + (in_a ? 8 * j : 8 * j - Ca) * 2;
+    }
+    const unsigned ring_w = C::OFF_RING + wave * RINGB, xt_w = C::OFF_XT + wave * C::XB;
+    const unsigned wl = ring_w + rr * ROWB + (px + 1) * PDB;       // ring write (+ the pair's row base)
+    const unsigned xl = xt_w + rr * C::XROWB + px * XPB;           // x tile write (+ slot)
+    // dgrad B fragments: output pixel l15 (+ 16 per N tile) reads position l15 + dxi, K slot kg -> (dxi = kg / G8 (+ h * TPC), 8-channel group kg % G8)
+    const unsigned lbl = (l15 + kg / G8) * PDB + (kg % G8) * 16;
+    // dgrad stores: this lane's 4 channels of pixel l15 (+ 16 per N tile)
+    const int st_rp = DUAL ? (kg >> 1) : 0;                          // (DUAL: M rows 8..15 are the second row of the pair)
+    const int st_ch = DUAL ? (kg & 1) * 4 : kg * 4;
+    const unsigned stw = C::OFF_ST + wave * C::STB + (st_rp * 32 + l15) * (CIN * 2) + st_ch * 2;  // staging write: this lane's 4 channels of (row st_rp [+ pass], pixel l15 [+ 16])
+    const unsigned str = C::OFF_ST + wave * C::STB + (rr * 32 + px) * (CIN * 2);                   // staging read: (row rr, pixel px), 16 bytes per item
+    // weight gradient: transpose-read geometry (see lds_tr4): K = pixels prow (+16), 4 consecutive M / N columns at quad cq
+    const int prow = 4 * kg + (l15 >> 2), cq = lane & 3;
+    const unsigned lxa = xt_w + prow * XPB + (DUAL ? (cq >> 1) * C::XPLANEB + (cq & 1) * 8 : cq * 8);  // A: x~ | mask (DUAL: mask = M rows 8..15)
+    // B, Cout = 8: unit type 0 = {kx 0 | kx 1} by column half, type 1 = {kx 2 | kx 2}; x pixel q pairs with dz pixel q + 1 - kx = position q + 2 - kx.
+    // Cout = 16: unit = one tap, the kx shift is an immediate
+    const unsigned lw0 = COUT == 8 ? (prow + 2 - (cq >> 1)) * PDB + (cq & 1) * 8 : (prow + 2) * PDB + cq * 8;
+    const unsigned lw1 = prow * PDB + (cq & 1) * 8;
+
+    f32x4 accG[MTG][NU];
+#pragma unroll
+    for (int a = 0; a < MTG; ++a)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) accG[a][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr bool WREG = false && KC <= 4;  // the A fragments stay in registers when they are few
+    u32x4 wfr[WREG ? KC : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const uint4 q = s_wf[kc * 64 + lane];
+            wfr[kc] = (u32x4){q.x, q.y, q.z, q.w};
+        }
+    }
+
+    // ---- this wave's jobs (workgroup b runs on XCD b % 8: number the waves XCD-major)
+    const int nblk = gridDim.x;
+    const int vblk = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    RsGen gen(vblk * C::NW + wave, A.njobs, nblk * C::NW, A.NS, A.NB, A.PB, A.NP);
+
+    u32x4 pz[2][NZ], pg[2][NZ], pg2[2][G2 ? NZ : 1], pxr[2][NX];
+    auto corner = [&](const RsTick& t) -> int {  // pixel index of (row 2q clamped into the image, column 30 s - 1): may be -1 / beyond a row end
+        const int qc = t.q < 0 ? 0 : (t.q >= A.NP ? A.NP - 1 : t.q);
+#ifdef OCRS_RS_NOLOAD  // (floor-measurement build: every tick re-reads the same lines)
+        return (wave * 2) * W;
+#endif
+        return (t.n * H + 2 * qc) * W + SW * t.s - 1;
+    };
+    auto issue = [&](auto ST, const RsTick& t) {
+        constexpr int S = decltype(ST)::value;
+        const int cp = corner(t);
+        const int oz = cp * PDB;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            pz[S][j] = bload16_opaque(r_z, oz + lz + 16 * j);
+            pg[S][j] = bload16_opaque(r_g1, oz + lz + 16 * j);
+            if constexpr (G2) pg2[S][j] = bload16_opaque(r_g2, oz + lz + 16 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const bool in_a = !SPLIT || 8 * j < Ca;
+            pxr[S][j] = bload16_opaque(in_a ? r_xa : r_xb, cp * ((in_a ? Ca : Cb) * 2) + lxo[j]);
+        }
+    };
+    // operations a tick issues: its loads (behind its commit), then its compute's stores
+#ifdef OCRS_RS_NOCOMPUTE
+    constexpr int NLOADS = NZ * (G2 ? 3 : 2) + NX, NSTORE = 0;
+#else
+    constexpr int NLOADS = NZ * (G2 ? 3 : 2) + NX, NSTORE = NX;
+#endif
+    auto commit = [&](auto ST, auto YOUNGER, const RsTick& t) {
+        constexpr int S = decltype(ST)::value;
+        {   // the hand-written wait: YOUNGER = operations issued after this set's last load (vector memory operations retire in order)
+#ifdef OCRS_RS_DRAIN  // (debug build: wait for everything)
+            constexpr int Y = 0;
+#else
+            constexpr int Y = decltype(YOUNGER)::value;
+#endif
+            wait_vm<Y>(pxr[S][NX - 1]);
+#pragma unroll
+            for (int j = 0; j < NZ; ++j) {
+                wait_vm<Y>(pz[S][j]);
+                wait_vm<Y>(pg[S][j]);
+                if constexpr (G2) wait_vm<Y>(pg2[S][j]);
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < NX; ++j) wait_vm<Y>(pxr[S][j]);
+        }
+        const int col = SW * t.s - 1 + px;
+        const int row = 2 * t.q + rr;
+        const bool ok = (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H;
+        const bool okx = ok && px >= 1 && px <= SW;
+        const unsigned wrow = (unsigned)(2 * t.qm3) * ROWB;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = 4 * j + k;  // channel pair
+                const f32x2 zv = unpk(pz[S][j][k]);
+                f32x2 gv = unpk(pg[S][j][k]);
+                if constexpr (G2) gv += unpk(pg2[S][j][k]);
+                const f32x2 y = __builtin_elementwise_fma(zv, bs2[ci], bt2[ci]);
+                f32x2 gh;
+                gh.x = y.x > 0.f ? gv.x : 0.f;
+                gh.y = y.y > 0.f ? gv.y : 0.f;
+                const f32x2 d = __builtin_elementwise_fma(ca2[ci], gh, __builtin_elementwise_fma(cb2[ci], zv, cc2[ci]));
+                const unsigned pk = cvt_pk(d.x, d.y);
+                w[k] = ok ? pk : 0u;
+            }
+            *reinterpret_cast<uint4*>(smem + wl + wrow + 16 * j) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned xs = (unsigned)(t.q & 1) * C::XSLOTB;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            unsigned w[4], mk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = 4 * j + k;
+                f32x2 v = __builtin_elementwise_fma(unpk(pxr[S][j][k]), sc2[ci], sh2[ci]);
+                asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * ci]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * ci + 1]));
+                const unsigned pk = cvt_pk(v.x, v.y);
+                w[k] = okx ? pk : 0u;
+                // [x~ > 0] per half word: x~ is a non-negative bf16 (ReLU producers: lo = +0 and v_max(-0, +0) = +0), so bits != 0 <=> x~ > 0
+                unsigned one;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(one) : "v"(w[k]), "v"(0x00010001u));
+                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(mk[k]) : "v"(one), "v"(0x3f803f80u));
+            }
+            *reinterpret_cast<uint4*>(smem + xl + xs + 16 * j) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(smem + xl + xs + C::XPLANEB + 16 * j) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](const RsTick& t) {
+        const int cp = t.q - 1;  // the pair computed: rows 2cp, 2cp + 1 from image rows 2cp - 1 .. 2cp + 2 = ring rows (2 qm3 + 3 + dy) mod 6
+        unsigned rbase[4];        // (scalar)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const int r = 2 * t.qm3 + 3 + dy;
+            rbase[dy] = ring_w + (unsigned)(r >= 6 ? r - 6 : r) * ROWB;
+        }
+        const int colbase = SW * t.s - 1;
+        const int pix0 = (t.n * H + 2 * cp) * W + colbase;
+#ifdef OCRS_RS_NOSTORE  // (floor-measurement build: every store is dropped by the range check)
+        const bool comp = false;
+#else
+        const bool comp = t.comp != 0;
+#endif
+        // ================= dx~ = Weff^T (*) dz =================
+        unsigned ra[4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) ra[dy] = rbase[dy] + lbl;
+#pragma unroll
+        for (int ps = 0; ps < C::NPASS; ++ps) {
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int dy = kc / CPD, h = kc - dy * CPD;
+                u32x4 wf;
+                if constexpr (WREG) {
+                    wf = wfr[kc];
+                } else {
+                    const uint4 q = s_wf[kc * 64 + lane];
+                    wf = (u32x4){q.x, q.y, q.z, q.w};
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(smem + ra[ps + dy] + (h * TPC + nt * 16) * PDB);
+                    acc[nt] = mfma_bf(wf, (u32x4){q.x, q.y, q.z, q.w}, acc[nt]);
+                }
+            }
+            // regroup through LDS: the accumulator layout (4 channels of a pixel per lane, 8-byte pieces interleaved over the lane groups) -> one
+            // pixel per lane.  (8-byte stores: half-filled 16-byte granules per lane group -- the memory side then ran far below what the same
+            // bytes reach as 16-byte-per-lane, line-contiguous stores: tools/probes/bw_probe2.hip vs the first form of this kernel.)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                // (compiler-visible converts: an asm statement that reads MFMA results is invisible to hipcc's hazard recogniser -- with the asm
+                //  v_cvt_pk of the commit phase here, one register allocation read accumulators before the matrix core had written them: sparse NaNs)
+                *reinterpret_cast<uint2*>(smem + stw + ((DUAL ? 0 : ps * 32) + nt * 16) * (CIN * 2)) =
+                    make_uint2(pack2bf(acc[nt][0], acc[nt][1]), pack2bf(acc[nt][2], acc[nt][3]));
+            }
+        }
+        {
+            const bool ok = comp && 2 * cp + rr < H && px >= 1 && px <= SW && colbase + px < W;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const uint4 q = *reinterpret_cast<const uint4*>(smem + str + 16 * j);
+                const bool in_a = !SPLIT || 8 * j < Ca;
+                const int off = pix0 * ((in_a ? Ca : Cb) * 2) + lxo[j];
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, in_a ? w_a : w_b, ok ? off : -1, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= G_tap[c][o] += x~^T dz(shifted), and the same with [x~ > 0] for the producers' BatchNorm-backward sums =================
+        // (warm-up ticks skip this part: it holds no vector-memory operation, so the branch does not disturb the hand-counted waits)
+        if (!comp) return;
+        const unsigned xa0 = lxa + (unsigned)(cp & 1) * C::XSLOTB;
+        unsigned rw0[4], rw1[COUT == 8 ? 4 : 1];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            rw0[dy] = rbase[dy] + lw0;
+            if constexpr (COUT == 8) rw1[dy] = rbase[dy] + lw1;
+        }
+        // a dz ring row dy serves kernel row ky = 2 - dy of the pair's first x row and ky = 3 - dy of its second one: each B fragment is read once
+        bf16x8 af[2][MTG];
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+            for (int a = 0; a < MTG; ++a) {
+                const unsigned p = xa0 + rp * C::XROWB + (DUAL ? 0 : a * C::XPLANEB);
+                af[rp][a] = lds_tr8(lds_at(smem, p), lds_at(smem, p + 16 * XPB));
+            }
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+#pragma unroll
+            for (int ut = 0; ut < UPK; ++ut) {
+                unsigned p;
+                if constexpr (COUT == 8) {
+                    p = ut == 0 ? rw0[dy] : rw1[dy];
+                } else {
+                    p = rw0[dy] - ut * PDB;  // kx = ut
+                }
+                const bf16x8 bfr = lds_tr8(lds_at(smem, p), lds_at(smem, p + 16 * PDB));
+#pragma unroll
+                for (int rp = 0; rp < 2; ++rp) {
+                    const int ky = rp + 2 - dy;
+                    if (ky >= 0 && ky <= 2) {
+#pragma unroll
+                        for (int a = 0; a < MTG; ++a) accG[a][ky * UPK + ut] = mfma_bf(af[rp][a], bfr, accG[a][ky * UPK + ut]);
+                    }
+                }
+            }
+            if (dy == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    RsTick t0 = gen.next(), t1 = gen.next();
+    issue(S0{}, t0);
+    issue(S1{}, t1);
+    auto tick = [&](auto ST, auto YOUNGER, RsTick& t) __attribute__((always_inline)) {
+        commit(ST, YOUNGER, t);
+        const RsTick tn = gen.next();
+        issue(ST, tn);
+#ifndef OCRS_RS_NOCOMPUTE  // (floor-measurement build: loads + commit only)
+        compute(t);
+#endif
+        t = tn;
+    };
+    // issue order: L0 L1 | [commit 0] L0' St | [commit 1] L1' St | ...: younger than a set's loads are the other set's loads and the stores of the
+    // one (second tick) or two (steady state) computes in between
+    if (t0.valid) {
+        tick(S0{}, std::integral_constant<int, NLOADS>{}, t0);
+        if (t1.valid) {
+            tick(S1{}, std::integral_constant<int, NLOADS + NSTORE>{}, t1);
+            while (t0.valid) {
+                tick(S0{}, std::integral_constant<int, NLOADS + 2 * NSTORE>{}, t0);
+                if (!t1.valid) break;
+                tick(S1{}, std::integral_constant<int, NLOADS + 2 * NSTORE>{}, t1);
+            }
+        }
+    }
+    // the dead ticks' loads are still in flight: keep every prefetch register allocated (a "+v" tie) up to the drain -- hipcc re-uses a register
+    // whose loaded value is never read the moment the asm statement ends, and the late load then overwrites the new contents (caught by
+    // tools/check_rs_loads.py)
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            wait_vm<0>(pz[S][j]);
+            wait_vm<0>(pg[S][j]);
+            if constexpr (G2) wait_vm<0>(pg2[S][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) wait_vm<0>(pxr[S][j]);
+    }
+
+    // ================= flush: G of the four waves -> dWpw / dWdw / producers' sums partial of this block =================
+    __syncthreads();
+    float* slots = reinterpret_cast<float*>(smem);  // [wave][MTG][NU][4][64]
+#pragma unroll
+    for (int a = 0; a < MTG; ++a)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slots[((wave * MTG + a) * NU + u) * 256 + r * 64 + lane] = accG[a][u][r];
+    __syncthreads();
+    // G (mrow, tap, o): mrow = c for the x~ rows, CIN + c for the mask rows; fixed summation order over the waves -> deterministic
+    auto Gv = [&](int mrow, int tap, int o) -> float {
+        const int a = mrow >> 4, m = mrow & 15;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int u = COUT == 8 ? ky * UPK + (kx >> 1) : tap, n = COUT == 8 ? ((kx & 1) * 8 + o) : o;
+        const int idx = (a * NU + u) * 256 + (m & 3) * 64 + (m >> 2) * 16 + n;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < C::NW; ++w) s += slots[w * MTG * NU * 256 + idx];
+        return s;
+    };
+    float* part = A.ws + (long)blockIdx.x * C::PART;
+    for (int e = tid; e < COUT * CIN; e += C::NT) {
+        const int o = e / CIN, c = e - o * CIN;
+        float s = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) s = fmaf(A.wdw[c * 9 + tap], Gv(c, tap, o), s);
+        part[e] = s;
+    }
+    for (int e = tid; e < 9 * CIN; e += C::NT) {
+        const int c = e / 9, tap = e - c * 9;
+        float s = 0.f;
+        for (int o = 0; o < COUT; ++o) s = fmaf(A.wpw[o * A.ldw + c], Gv(c, tap, o), s);
+        part[COUT * CIN + e] = s;
+    }
+    for (int e = tid; e < 2 * CIN; e += C::NT) {  // [CIN][S1 | S2] with the bf16 effective weights the dgrad used
+        const int c = e >> 1, which = e & 1;
+        float s = 0.f;
+        for (int tap = 0; tap < 9; ++tap)
+            for (int o = 0; o < COUT; ++o) {
+                const float we = bf2f(f2bf(A.wdw[c * 9 + tap] * A.wpw[o * A.ldw + c]));
+                s = fmaf(we, Gv(which ? c : CIN + c, tap, o), s);
+            }
+        part[COUT * CIN + 9 * CIN + e] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+static int rs_env() {
+    static const int v = env_int("OCRS_RS", 1);
+    return v;
+}
+bool rs_bwd_supported(int Ca, int Cb, int Cout, int pooled, int N, int H, int W) {
+    if (!rs_env() || pooled) return false;
+    const int Cin = Ca + Cb;
+    if (!((Cin == 8 && Cout == 8))) return false;
+    if (Cb != 0 && !(Ca == 8 && Cb == 8)) return false;
+    const long bytes = (long)N * H * W * (Cin > Cout ? Cin : Cout) * 2;
+    return bytes < (1L << 31) && H >= 2 && W >= 2;
+}
+static void rs_geometry(int N, int H, int W, int wps, int& NS, int& NP, int& NB, int& PB, int& njobs, int& nblocks) {
+    NS = (W + 29) / 30;
+    NP = (H + 1) / 2;
+    static const int rb_env = env_int("OCRS_RS_RB", 64);          // rows per job (two warm-up ticks per job: 64 rows = 6 %)
+    static const int blocks_env = env_int("OCRS_RS_BLOCKS", 0);  // (tests: a small grid makes every wave run several jobs)
+    PB = rb_env / 2 > 0 ? rb_env / 2 : 1;
+    NB = (NP + PB - 1) / PB;
+    njobs = N * NB * NS;
+    const int cap = blocks_env > 0 ? blocks_env : kNumCU * wps;  // resident blocks (4 waves each) at wps waves per SIMD
+    const int need = (njobs + 3) / 4;
+    nblocks = need < cap ? need : cap;
+    if (nblocks >= 8) nblocks &= ~7;
+}
+int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
+    int NS, NP, NB, PB, njobs, nb;
+    rs_geometry(N, H, W, g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS, NS, NP, NB, PB, njobs, nb);
+    return nb;
+}
+void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
+                   const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
+                   const BnFin& fin, hipStream_t st) {
+    RsArgs a;
+    a.xa = x.a; a.xb = x.b; a.Ca = x.Ca; a.Cb = x.Cb;
+    a.tra = tra; a.trb = trb; a.wdw = wdw; a.wpw = wpw; a.ldw = ldw;
+    a.g1 = g1; a.g2 = g2; a.z = z; a.bn = bn; a.coef = coef; a.gxa = gxa; a.gxb = gxb; a.ws = ws;
+    a.N = N; a.H = H; a.W = W;
+    int nb;
+    rs_geometry(N, H, W, g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS, a.NS, a.NP, a.NB, a.PB, a.njobs, nb);
+    a.fin = fin;
+    (void)stats;
+    const int Cin = x.Ca + x.Cb;
+#define RS_LAUNCH(CI_, CO_, G2_, SP_)                                                                                                        \
+    {                                                                                                                                        \
+        using CC = RsCfg<CI_, CO_>;                                                                                                          \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<CI_, CO_, G2_, SP_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
+        OCRS_LAUNCH_T((k_rs_bwd<CI_, CO_, G2_, SP_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                             \
+    }
+    if (Cin == 8 && Cout == 8) {
+        if (g2) RS_LAUNCH(8, 8, true, false) else RS_LAUNCH(8, 8, false, false)
+    }
+#undef RS_LAUNCH
+}
