@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
                 s1[i] += r;
                 s2[i] = fmaf(r, r, s2[i]);
             }
+#ifdef OCRS_INJECT_BATCH_BUG  // (test-of-the-tests build, tools/experiments/r5_inject_batch_bug.sh: neighbouring images swap their outputs)
+            store8(z + (((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
+#else
             store8(z + (((long)it.n * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
+#endif
         }
     };
     C1Img imA, imB;

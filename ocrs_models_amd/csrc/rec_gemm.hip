@@ -271,19 +271,19 @@ int ocrs_gemm_x3p_tiles(const float* X, int ldx, int K, const void* wpk, const f
     if (ntw == 4) {
         const int nrb = (int)((P + 255) / 256);
         const size_t lds = 3 * (256 * 128 + 16384) + (size_t)M * 4;
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr4;  // (per device and thread-safe, like r3_launch / r4_launch: ADVICE r04)
+        if (attr4.need()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3p<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OCRS_ERR_HIP;
-            attr = true;
+            attr4.done();
         }
         hipLaunchKernelGGL(k_gemm_x3p<4>, dim3(kNumCU), dim3(512 + 64 * G_NPROD), lds, st, X, ldx, reinterpret_cast<const uint4*>(wpk), bias, out, ldo, K, M, P, nrb, ncb);
     } else {
         const int nrb = (int)((P + 127) / 128);
         const size_t lds = 3 * (128 * 128 + 16384) + (size_t)M * 4;
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr2;
+        if (attr2.need()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3p<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return OCRS_ERR_HIP;
-            attr = true;
+            attr2.done();
         }
         hipLaunchKernelGGL(k_gemm_x3p<2>, dim3(kNumCU), dim3(512 + 64 * G_NPROD), lds, st, X, ldx, reinterpret_cast<const uint4*>(wpk), bias, out, ldo, K, M, P, nrb, ncb);
     }

@@ -73,7 +73,7 @@ class _CTC(torch.autograd.Function):
         ctx.ab = False
         if not h16 and L.ctc_fused_lds_bytes(T, C, Smax) > 0:
             # fused wave-level form (csrc/rec_seq.hip k_ctc_fused_w): loss AND the gradient for an upstream gradient of 1 in one launch
-            need_grad = log_probs.requires_grad
+            need_grad = ctx.needs_input_grad[0]  # (False under an outer no_grad(): requires_grad alone would compute the gradient needlessly)
             gpre = torch.empty_like(lp) if need_grad else None
             L.ctc_fused(ptr(lp), ptr(tg), ptr(in_len), ptr(tg_len), ptr(nll), ptr(loss), ptr(gpre), T, N, C, Lpad, Smax)
             ctx.fused = True
@@ -86,7 +86,7 @@ class _CTC(torch.autograd.Function):
         else:
             alpha = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)
             rowmax = nll  # (unused)
-            if log_probs.requires_grad and _CTC_AB:
+            if ctx.needs_input_grad[0] and _CTC_AB:
                 # a backward will follow: the beta recursion runs NEXT TO the alpha recursion in the same launch, the backward is then parallel
                 # over (sample, time step) -- bit-identical to ctc_fwd + ctc_bwd (csrc/rec_seq.hip: k_ctc_ab / k_ctc_grad)
                 rowmax = torch.empty(N, T, Smax, dtype=torch.float32, device=dev)  # (the beta lattice travels in the rowmax slot)
@@ -103,8 +103,9 @@ class _CTC(torch.autograd.Function):
         if ctx.fused:
             (gpre,) = ctx.saved_tensors
             g = gout.contiguous().float().reshape(1)
-            lib().scale_by_dev(ptr(gpre), ptr(g), ptr(gpre), gpre.numel())  # (in place: the buffer belongs to this node)
-            return gpre, None, None, None, None, None
+            out = torch.empty_like(gpre)  # (a fresh tensor: a second backward over a retained graph must see the unscaled saved gradient -- ADVICE r04)
+            lib().scale_by_dev(ptr(gpre), ptr(g), ptr(out), gpre.numel())
+            return out, None, None, None, None, None
         lp, tg, in_len, tg_len, alpha, nll, rowmax = ctx.saved_tensors
         T, N, C = lp.shape
         grad = torch.empty_like(lp)

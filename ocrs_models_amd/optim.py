@@ -45,10 +45,15 @@ class _Table:
                 self._copied = torch.cuda.Event()
                 self._copied.record()
         else:
-            self._copied = None  # (fresh pinned tensors: the caching host allocator keeps them alive until the copy has run)
             self._host = (torch.tensor(rows, dtype=torch.int64).pin_memory(), torch.tensor(chunks, dtype=torch.int32).pin_memory())
             self.table = self._host[0].to(dev, non_blocking=True)
             self.chunks = self._host[1].to(dev, non_blocking=True)
+            # the first `reuse` of these pinned bytes must also wait for THESE copies (a host loop that never synchronises can be a full step
+            # ahead of the stream): record the event here too
+            self._copied = None
+            if not torch.cuda.is_current_stream_capturing():
+                self._copied = torch.cuda.Event()
+                self._copied.record()
         self.nchunks = len(chunks)
         self.key = tuple(r[1] for r in rows)
 

@@ -39,20 +39,37 @@ def double_conv(P, Bf, prefix, x, train):
     return dwpw_block(P, Bf, f"{prefix}.seq.1", x, train)
 
 
-def forward(P, Bf, x, train=True):
-    """x: (B,1,H,W) in [-0.5,0.5] -> probabilities (B,1,H,W).  Updates BN buffers in ``Bf``."""
+TAIL_PARAMS = ("up.0.contract.seq.1.seq.0.weight", "up.0.contract.seq.1.seq.1.weight", "up.0.contract.seq.1.seq.2.weight",
+               "up.0.contract.seq.1.seq.2.bias", "out_conv.0.weight", "out_conv.0.bias")
+
+
+def forward(P, Bf, x, train=True, tail_grad_only=False):
+    """x: (B,1,H,W) in [-0.5,0.5] -> probabilities (B,1,H,W).  Updates BN buffers in ``Bf``.
+
+    tail_grad_only: the same arithmetic, but everything in front of the LAST DepthwiseConv block (up.0.contract.seq.1) runs under
+    ``no_grad`` so that autograd only records the tail (that block + out_conv): the full gradients of ``TAIL_PARAMS`` -- they reach the loss
+    through the tail alone -- at a memory cost a 32 x 1024^2 batch can afford on the host (tests/test_full_size_gpu.py)."""
+    import contextlib
+
     n_lvl = len(DEPTH_SCALE) - 1
-    x0 = double_conv(P, Bf, "in_conv", x, train)
-    skips = [x0]
-    cur = x0
-    for i in range(n_lvl):
-        cur = F.max_pool2d(double_conv(P, Bf, f"down.{i}.seq.0", cur, train), 2)
-        skips.append(cur)
-    up = skips[-1]
-    for i in reversed(range(n_lvl)):
-        skip = skips[i]
-        t = F.conv_transpose2d(up, P[f"up.{i}.up.weight"], P[f"up.{i}.up.bias"], stride=2)
+    with (torch.no_grad() if tail_grad_only else contextlib.nullcontext()):
+        x0 = double_conv(P, Bf, "in_conv", x, train)
+        skips = [x0]
+        cur = x0
+        for i in range(n_lvl):
+            cur = F.max_pool2d(double_conv(P, Bf, f"down.{i}.seq.0", cur, train), 2)
+            skips.append(cur)
+        up = skips[-1]
+        for i in reversed(range(1, n_lvl)):
+            skip = skips[i]
+            t = F.conv_transpose2d(up, P[f"up.{i}.up.weight"], P[f"up.{i}.up.bias"], stride=2)
+            t = t[:, :, : skip.shape[2], : skip.shape[3]]
+            up = double_conv(P, Bf, f"up.{i}.contract", torch.cat((t, skip), 1), train)
+        skip = skips[0]
+        t = F.conv_transpose2d(up, P["up.0.up.weight"], P["up.0.up.bias"], stride=2)
         t = t[:, :, : skip.shape[2], : skip.shape[3]]
-        up = double_conv(P, Bf, f"up.{i}.contract", torch.cat((t, skip), 1), train)
+        mid = dwpw_block(P, Bf, "up.0.contract.seq.0", torch.cat((t, skip), 1), train)
+        del skips, t, skip, cur, x0
+    up = dwpw_block(P, Bf, "up.0.contract.seq.1", mid, train)
     logit = F.conv2d(up, P["out_conv.0.weight"], P["out_conv.0.bias"])
     return torch.sigmoid(logit)

@@ -396,3 +396,104 @@ def test_recognition_config5_rank_share_bucketed_b256_fp16_lattice(dev):
     assert rel(lp2, lp_o) < 1e-4 and abs(loss2 - loss_o.item()) < 1e-4 * abs(loss_o.item())
     eo = [rel(g2[k], go) for k, go in zip(P2, grads_o)]
     assert max(eo) < 2e-2 and float(np.median(eo)) < 3e-4, (max(eo), float(np.median(eo)))
+
+
+def test_detection_b32_1024_distinct_tiles_fp32_matches_oracle_and_bf16_tracks_it(dev):
+    """BASELINE configs[1] on DISTINCT data: 32 different 1024^2 tiles in ONE launch.  A cross-sample indexing defect (image i
+    reading image j's rows, a batch stride error in a 32-bit index path) is invisible to the replicated-tile test above -- every sample is
+    the same there; here every image differs, so such a defect changes predictions, BatchNorm statistics and gradients.
+      (a) fp32 parity mode vs the CPU oracle on the whole batch: per-image prediction, loss, every BatchNorm running buffer (their batch
+          statistics are sums over all 32 images) and the gradients of the tail (last block + out_conv: the oracle records only the tail --
+          forward(tail_grad_only=True), pinned to the full autograd by tests/test_oracle_golden.py -- because a full 32 x 1024^2 autograd tape
+          does not fit a test's memory budget);
+      (b) the same batch in the benchmarked bf16 mode vs run (a): per-image prediction, loss, tail gradients, running statistics.
+    Deliberately broken builds fail it (checked once by hand, tools/experiments/r5_inject_batch_bug.sh: image index n -> n ^ 1 in the first block's
+    forward kernel: predictions of every image off by O(1))."""
+    from oracle import detection as odet
+    from oracle import losses as olosses
+
+    torch.set_num_threads(max(32, torch.get_num_threads()))
+    B = 32
+    m, P, Bf = _det(63, dev, torch.float32)
+    m.train()
+    x, mask = _tile(63, B=B)
+    pred_o = odet.forward(P, Bf, x, True, tail_grad_only=True)
+    loss_o = olosses.balanced_bce(pred_o, mask)
+    tail = list(odet.TAIL_PARAMS)
+    grads_o = dict(zip(tail, torch.autograd.grad(loss_o, [P[k] for k in tail])))
+    pred_o = pred_o.detach()
+    xd, md = x.to(dev), mask.to(dev)
+    pred, loss, g = _det_step(m, xd, md)
+    per_img = [rel(pred[i], pred_o[i]) for i in range(B)]
+    print(f"B=32 distinct fp32 vs oracle: pred worst image {max(per_img):.2e}, loss {abs(loss - loss_o.item()) / abs(loss_o.item()):.2e}")
+    assert max(per_img) < 1e-4, per_img
+    assert abs(loss - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    sd = m.state_dict()
+    for k, v in Bf.items():
+        if "running" in k:
+            assert rel(sd[k], v) < 1e-4, k
+    eg = {k: rel(g[k], grads_o[k]) for k in tail}
+    print("tail gradients vs oracle", {k: f"{v:.1e}" for k, v in eg.items()})
+    assert all(v < 2e-3 for v in eg.values()), eg
+    bufs_f = {k: v.clone() for k, v in sd.items() if "running" in k}
+    pred_f, loss_f, g_f = pred.clone(), loss, {k: g[k].clone() for k in tail}
+    del m, pred, g, sd
+    torch.cuda.empty_cache()
+    # ---- (b) the benchmarked mode on the same 32 distinct tiles
+    mb, _, _ = _det(63, dev, torch.bfloat16)
+    mb.train()
+    pred_b, loss_b, g_b = _det_step(mb, xd, md)
+    per_img_b = [rel(pred_b[i], pred_f[i]) for i in range(B)]
+    eb = {k: rel(g_b[k], g_f[k]) for k in ("out_conv.0.weight", "out_conv.0.bias", "up.0.contract.seq.1.seq.2.weight", "up.0.contract.seq.1.seq.2.bias")}
+    print(f"B=32 distinct bf16 vs fp32: pred worst image {max(per_img_b):.2e}, loss {abs(loss_b - loss_f) / abs(loss_f):.2e}, tail {eb}")
+    assert max(per_img_b) < 6e-2 and abs(loss_b - loss_f) < 5e-3 * abs(loss_f)
+    assert all(v < 5e-2 for v in eb.values()), eb
+    sdb = mb.state_dict()
+    worst_buf = max(rel(sdb[k], v) for k, v in bufs_f.items())
+    assert worst_buf < 2e-2, worst_buf
+
+
+def test_recognition_b256_distinct_crops_fp32_matches_oracle_and_bf16_tracks_it(dev):
+    """BASELINE configs[2] on DISTINCT data: 256 different 64 x 400 crops with different texts in one launch.
+      (a) fp32 parity mode vs the CPU oracle on the whole batch: log-probs <= 1e-4, loss, ALL 36 parameter gradients, and the greedy-decode arg-max
+          indices bit-exact for every crop;
+      (b) bf16-autocast (the benchmarked mode) vs run (a) with per-tensor bounds: a tensor may differ from the fp32 HIP gradient by at most
+          1.6 x the reference's own bf16-autocast-vs-fp32 distance for that tensor (golden G-rec-1, as in test_rec_gpu.py) + 2e-2.
+    A cross-sample indexing defect (crop i reading crop j's rows / time steps) is invisible to the 8-crops-x-32 replica test above."""
+    import ocrs_models_amd as oa
+    from tests.golden_util import golden_vs_golden, load_npz
+    from oracle import ctc as octc
+    from oracle import recognition as orec
+
+    torch.set_num_threads(max(32, torch.get_num_threads()))
+    B = 256
+    m, P, Bf = _rec(66, dev)
+    m.train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    img, text, tl, il = _rec_batch(66, B, 400, dev)
+    assert len({bytes(t.numpy().tobytes()) for t in text}) > 250  # the crops really differ
+    lp, loss, g = _rec_step(m, img, text, tl, il, False)
+    lp_o = orec.forward(P, Bf, img.cpu(), True)
+    loss_o = octc.ctc_loss_torch(lp_o, text, il.tolist(), tl.tolist())
+    grads_o = torch.autograd.grad(loss_o, list(P.values()))
+    per_crop = (lp.cpu().double() - lp_o.detach().double()).flatten(2).norm(dim=(0, 2)) / lp_o.detach().double().flatten(2).norm(dim=(0, 2))
+    print(f"B=256 distinct fp32 vs oracle: log-probs worst crop {float(per_crop.max()):.2e}, loss {abs(loss - loss_o.item()) / abs(loss_o.item()):.2e}")
+    assert float(per_crop.max()) < 1e-4
+    assert abs(loss - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    eo = {k: rel(g[k], go) for k, go in zip(P, grads_o)}
+    print(f"gradients vs oracle: median {np.median(list(eo.values())):.1e} worst {max(eo.values()):.1e}")
+    assert max(eo.values()) < 5e-3 and float(np.median(list(eo.values()))) < 3e-4, eo
+    _, amax = oa.text.greedy_decode_batch(lp, il.tolist())
+    assert torch.equal(amax.cpu().long(), lp_o.detach().argmax(-1).T)
+    # ---- (b) bf16 autocast on the same batch, per tensor
+    m.load_state_dict(sd0)
+    lp_b, loss_b, g_b = _rec_step(m, img, text, tl, il, True)
+    G = load_npz("rec.npz")
+    assert rel(lp_b, lp) < 2e-2 and abs(loss_b - loss) < 2e-2 * abs(loss)
+    bad = {}
+    for k in g:
+        floor = golden_vs_golden(G, f"rec1/bf16/grad/{k}", f"rec1/f32/grad/{k}")
+        e = rel(g_b[k], g[k])
+        if not e < 1.6 * floor + 2e-2:
+            bad[k] = (e, floor)
+    assert not bad, bad

@@ -265,3 +265,26 @@ def test_aten_step_forms_agree_with_explicit_oracle():
     loss = A.rec_train_step(P3, B3, ooptim.Adam(P3.values()), x, tg, il, tl, False)
     assert abs(loss - float(l2)) < 1e-5 * abs(float(l2))
     assert all(float((P3[k] - P2[k]).abs().max()) > 0 for k in ("conv.0.weight", "gru.weight_hh_l1", "output.0.bias"))  # it stepped
+
+
+def test_oracle_tail_only_autograd_equals_full_autograd():
+    """oracle.detection.forward(tail_grad_only=True) -- what the B = 32 x 1024^2 distinct-data test uses on the host -- records only the last
+    block + out_conv: prediction, BatchNorm buffers and the gradients of TAIL_PARAMS must equal the fully recorded run's."""
+    from oracle import detection as odet
+    from oracle import losses as olosses
+    from oracle.params import detection_specs, make_state
+
+    r = np.random.RandomState(3)
+    x = torch.from_numpy(r.uniform(-0.5, 0.5, (3, 1, 64, 96)).astype(np.float32))
+    mask = torch.from_numpy((r.uniform(0, 1, (3, 1, 64, 96)) > 0.8).astype(np.float32))
+    P, Bf = make_state(detection_specs(), 5)
+    P2, Bf2 = make_state(detection_specs(), 5)
+    pred = odet.forward(P, Bf, x, True)
+    g = dict(zip(P, torch.autograd.grad(olosses.balanced_bce(pred, mask), list(P.values()))))
+    pred2 = odet.forward(P2, Bf2, x, True, tail_grad_only=True)
+    g2 = torch.autograd.grad(olosses.balanced_bce(pred2, mask), [P2[k] for k in odet.TAIL_PARAMS])
+    assert torch.equal(pred, pred2)
+    for k in Bf:
+        assert torch.equal(Bf[k], Bf2[k]), k
+    for k, v in zip(odet.TAIL_PARAMS, g2):
+        assert torch.allclose(v, g[k], rtol=1e-5, atol=1e-8), k

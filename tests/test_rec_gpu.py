@@ -43,7 +43,11 @@ CONV_CASES = [(32, 64, 3, 1, 12, 20, 3), (64, 128, 3, 1, 9, 17, 3), (128, 128, 3
               # partial passes and tiles in both directions)
               (64, 128, 3, 1, 16, 100, 3), (128, 128, 3, 1, 16, 37, 3), (128, 128, 3, 1, 8, 100, 3), (128, 128, 3, 1, 21, 16, 3),
               # BASELINE configs[2] itself: B = 256 crops (one image per CU in rec_conv3.hip), and the 64-output-channel dgrad shape
-              (128, 128, 3, 1, 8, 100, 256), (128, 64, 3, 1, 16, 100, 64)]
+              (128, 128, 3, 1, 8, 100, 256), (128, 64, 3, 1, 16, 100, 64),
+              # conv.3 (32 -> 64 at 32 x 200) and its dgrad (64 -> 32) at the production geometry -- k_conv3x3_tile (csrc/rec_conv4.hip): several
+              # passes per workgroup (the cross-pass prefetch and the wrapped weight loads) and column-split tiles; and a ragged width that
+              # forces a cut last column tile with left / right halos
+              (32, 64, 3, 1, 32, 200, 256), (32, 64, 3, 1, 32, 77, 40)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
