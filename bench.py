@@ -115,7 +115,7 @@ PASSES = {
     "maxpool_fwd": ("maxpool_fwd",),
 }
 PASS_KERNELS = {  # rocprof kernel-name prefixes per pass (PMC traffic lookup)
-    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_pwb<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<"),
+    "block_bwd": ("k_pw_bwd<", "k_pw_bwd2<", "k_pw_bwd8<", "k_pwb<", "k_dw_bwd<", "k_bn_bwd_reduce<", "k_mm_bwd<", "k_rs_bwd<"),
     "block_fwd": ("k_mm_fwd<", "k_dwpw_fwd<", "k_dwf<"),
     "convt_fwd": ("k_convt_fwd<", "k_convt_fwd_tile<", "k_ctf<"),
     "convt_bwd": ("k_convt_wgrad_tr<", "k_convt_dgrad<", "k_ctd<", "k_wgrad_gather<", "k_channel_sum<"),
@@ -160,6 +160,53 @@ def pmc_profile():
         if r["kernel"] != "TOTAL":
             rows[r["kernel"]] = ((float(r["fetch_GB_per_step_x2_corrected"]) + float(r["write_GB_per_step"])) * 1e9, float(r["launches_per_step"]))
     return rows, os.path.basename(files[-1])
+
+
+def pmc_live(args):
+    """FETCH_SIZE / WRITE_SIZE of THIS box's run: two separate `rocprofv3 --kernel-trace --pmc <counter>` passes (the guide's
+    rule: one counter set per pass, no other trace domains) over a 2-step, detection-only child of this script; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read).  Returns (rows, source) like pmc_profile(), or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not on this box"
+    nsteps = 2
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--size", str(args.size), "--dtype", args.dtype,
+             "--no-crnn", "--no-cpu-baseline", "--no-roofline", "--no-fp32", "--no-ref-style", "--no-ddp-probe", "--no-config1", "--no-pmc"]
+    acc = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            env = {**os.environ, "TMPDIR": "/tmp", "OCRS_BENCH_CHILD": "1"}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(d, counter)
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=240)
+                files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+                if r.returncode != 0 or not files:
+                    return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+                tot, n = collections.defaultdict(float), collections.defaultdict(set)
+                for f in files:
+                    for row in csv.DictReader(open(f)):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
+                        tot[name] += float(row["Counter_Value"])
+                        n[name].add(row["Dispatch_Id"])
+                acc[counter] = (tot, {k: len(v) for k, v in n.items()})
+    except Exception as e:  # noqa: BLE001
+        return None, f"live PMC pass failed: {e!r}"[:200]
+    (fa, fn), (wa, wn) = acc["FETCH_SIZE"], acc["WRITE_SIZE"]
+    rows = {}
+    for k in set(fa) | set(wa):
+        rows[k] = ((2 * fa.get(k, 0.0) + wa.get(k, 0.0)) * 1024 / nsteps, fn.get(k, wn.get(k, 0)) / nsteps)  # (counters are in KB)
+    return rows, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run's box (2 detection steps each, FETCH_SIZE x2)"
 
 
 def crnn_pmc_profile():
@@ -265,8 +312,12 @@ def cpu_baseline():
         torch.set_num_threads(phys)
         allc = {"torch_threads": torch.get_num_threads(), "det_config1_B2_512": det(2, 512, 2, 5), "det_B4_1024": det(4, 1024, 1, 3)}
         torch.set_num_threads(nthreads)
-    return {"value": d1024["images_per_s"], "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": d1024["sample"] + " (oracle/aten_step.py: stock ATen CPU ops, the operators the reference dispatches to)",
+    # n = the host's physical cores -> `value` / `cores` are the all-core figures; the 32-thread run, which is
+    # FASTER on these small convolutions, stays beside it (`threads_32`: the figures of rounds 1-4)
+    head, cores = (allc["det_B4_1024"], allc["torch_threads"]) if allc else (d1024, nthreads)
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": head["sample"] + " (oracle/aten_step.py: stock ATen CPU ops, the operators the reference dispatches to)",
+            "threads_32": {"value": d1024["images_per_s"], "cores": nthreads, "note": "the same step on 32 threads: faster than all cores on this host"},
             "det_config1_B2_512": d512, "det_B4_1024": d1024, "rec_B64_fp32": r32, "rec_B64_bf16_autocast": rbf, "all_physical_cores": allc, **info}
 
 
@@ -348,9 +399,13 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         loss, gn = train_rec.train_step(net, opt, batch, dev, decode_only, loss_fn, check_nan=False)
         return loss
 
+    ddp_stats = {}
+
     def timed(batches, warm, steps):
         for i in range(warm):
             loss = step(batches[i % len(batches)])
+        if distributed:
+            net.bucketer.timing = []  # events around the bucketer's final waits on the compute stream: the EXPOSED all-reduce time
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -364,7 +419,23 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        ddp_stats.clear()
+        if distributed:
+            ex = net.bucketer.exposed_ms()
+            net.bucketer.timing = None
+            ranges = getattr(net.bucketer, "last_ranges", [])
+            ddp_stats.update({"rccl_ranks": world, "collectives_issued": bool(world > 1 or net.bucketer.force), "buckets_per_step": len(ranges),
+                              "grad_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 3),
+                              "exposed_allreduce_ms_per_step": round(sum(ex) / len(ex), 4) if ex else None,
+                              "exposed_allreduce_ms_max": round(max(ex), 4) if ex else None})
         if world > 1:
+            ex_local = (sum(ex) / len(ex)) if (distributed and ex) else 0.0
+            mine = torch.tensor([dt / steps * 1e3, ex_local], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per, exr = [float(a[0]) for a in allr], [float(a[1]) for a in allr]
+            ddp_stats.update({"per_rank_ms_per_step": {"min": round(min(per), 3), "max": round(max(per), 3), "all": [round(v, 3) for v in per]},
+                              "exposed_allreduce_ms_per_step_per_rank": {"min": round(min(exr), 4), "max": round(max(exr), 4), "all": [round(v, 4) for v in exr]}})
             t = torch.tensor([dt, float(n)], dtype=torch.float64, device=dev)
             dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
             dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
@@ -379,6 +450,8 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
            "gru_projection_gemms": "split-bf16 x3 (fp32-class, OCRS_GRU_X3=1)" if x3 else "exact fp32 MFMA (OCRS_GRU_X3=0)",
            "config": {"workload": f"CRNN train step (fwd+CTC+bwd+clip+Adam, greedy decode for stats), {B}x1x64x{W} crops per GPU, T={W // 4 + 1}",
                       "global_batch": B * world, "final_loss": round(float(loss.item()), 4)}}
+    if ddp_stats:
+        out["ddp"] = dict(ddp_stats)
     if rank == 0 and not args.no_roofline:
         # one extra step with every conv / GRU launch bracketed by HIP events on the launch stream
         L = lib()
@@ -446,6 +519,8 @@ def bench_crnn(args, world, rank, dev, dist, distributed=False):
                           "unit": "crops/s", "ms_per_step": round(dt5 / len(batches) * 1e3, 3), "steps": len(batches),
                           "bucket_widths": {str(k): widths.count(k) for k in sorted(set(widths))}, "crops_per_gpu_per_step": B, "n_gpus": world,
                           "ctc_alpha_beta": "fp32 in LDS"}
+        if ddp_stats:
+            out["config5"]["ddp"] = dict(ddp_stats)
     return out
 
 
@@ -500,10 +575,15 @@ def plumbing(args, world, rank):
         for _ in range(args.steps):
             ranges = step()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        mine = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)  # (the same per-rank table the GPU path emits: ddp.per_rank_ms_per_step)
+        per = [float(a[0]) for a in allr]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         want = sum(range(1, world + 1)) / world
-        res[name] = {"floats": n, "buckets": len(ranges), "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3),
+        res[name] = {"floats": n, "buckets": len(ranges), "ms_per_step": round(float(t.item()), 3),
+                     "per_rank_ms_per_step": {"min": round(min(per), 3), "max": round(max(per), 3), "all": [round(v, 3) for v in per]},
                      "mean_of_ranks_ok": bool(torch.allclose(flat, torch.full_like(flat, want)))}
     if rank == 0:
         print(json.dumps({"metric": "plumbing only (no GPU): bucketed gradient all-reduce on gloo", "value": None, "unit": None, "n_gpus": world,
@@ -527,6 +607,7 @@ def main():
     ap.add_argument("--no-gru-exact", action="store_true", help="skip the second CRNN timing with the other GRU GEMM mode")
     ap.add_argument("--no-ref-style", action="store_true", help="skip the reference-style step (H2D copy + loss.item() inside the step)")
     ap.add_argument("--no-ddp-probe", action="store_true", help="skip the 1-rank RCCL probe of the gradient bucketer at N = 1")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two live rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic")
     ap.add_argument("--no-config1", action="store_true", help="skip the config-1-sized (B=2 x 512^2) eager vs hipGraph step")
     ap.add_argument("--rec-batch", type=int, default=256, help="line crops per GPU")
     ap.add_argument("--rec-width", type=int, default=400)
@@ -658,6 +739,15 @@ def main():
                              "exposed_allreduce_ms_per_step": round(sum(ex) / len(ex), 4) if ex else None,
                              "exposed_allreduce_ms_max": round(max(ex), 4) if ex else None, "ms_per_step": round(dt / steps * 1e3, 3)})
         if world > 1:
+            # every rank's own clock and exposed all-reduce wait (one driver run yields the whole 1 -> 8 table: VERDICT r04 item 6c)
+            ex_local = sum(ex) / len(ex) if (use_ddp and ex) else 0.0
+            mine = torch.tensor([dt / steps * 1e3, ex_local], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per = [float(a[0]) for a in allr]
+            exr = [float(a[1]) for a in allr]
+            ddp_info.update({"per_rank_ms_per_step": {"min": round(min(per), 3), "max": round(max(per), 3), "all": [round(v, 3) for v in per]},
+                             "exposed_allreduce_ms_per_step_per_rank": {"min": round(min(exr), 4), "max": round(max(exr), 4), "all": [round(v, 4) for v in exr]}})
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -693,7 +783,11 @@ def main():
             return {"ms_per_step": round(ms_tot / nsteps, 3), "alg_GB_per_step": round(b_tot / nsteps / 1e9, 3), "achieved_GBps": round(ach, 1),
                     "frac": round(ach / HBM_PEAK_GBS, 4), "launches_per_step": nlaunch // nsteps, "units_per_step": nblocks // nsteps}
 
-        rows, src = pmc_profile()
+        rows, src = (None, "--no-pmc") if args.no_pmc else pmc_live(args)
+        live_note = src
+        if rows is None:  # fall back to the committed profile of an earlier run (and say so)
+            rows, src = pmc_profile()
+            src = f"{src} (committed profile; live pass unavailable: {live_note})" if src else None
         dom = next(p for p, fams in PASSES.items() if set(fams) == set(timing))
         st = pass_stats(timing, dom, min(PROF_STEPS, args.steps))
         if st:

@@ -279,6 +279,10 @@ int ocrs_fill_f32(float* p, float v, long n, hipStream_t st);
 int ocrs_prof_enable(int on);
 long ocrs_prof_count(void);
 int ocrs_prof_read(float* ms, long first, long n, hipStream_t st);
+/* Test support for the data-parallel path (reference: none -- train_detection.py:375-376 is single-process): `blocks` 256-thread
+   workgroups that stay resident for `micros` microseconds on stream st, the CU footprint of a collective's channel kernels.  The persistent
+   GRU launches must survive next to it (tests/test_train_loop_gpu.py::test_persistent_gru_under_rccl_allreduce_load). */
+int ocrs_cu_hog(int blocks, int micros, hipStream_t st);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,15 @@
 #include "common.h"
 
 static OcrsProf g_prof = {0, 0, 0, nullptr};
+
+// Stand-in for a collective's resident channel kernels: `blocks` workgroups that each hold a workgroup slot for `micros` microseconds
+// (wall clock, s_memrealtime at 100 MHz) and do nothing else.  tests/test_train_loop_gpu.py runs the persistent, spin-waiting GRU launches next to
+// it: a 1-rank RCCL all-reduce moves no data and may launch no kernel at all, so on a single-GPU box it cannot show what 64 resident RCCL
+// channels do to a launch that needs its whole grid co-resident.
+__global__ __launch_bounds__(256) void k_cu_hog(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 OcrsProf& ocrs_prof() { return g_prof; }
 
 extern "C" {
@@ -32,6 +41,14 @@ int ocrs_prof_read(float* ms, long first, long n, hipStream_t st) {
     if (hipStreamSynchronize(st) != hipSuccess) return OCRS_ERR_HIP;
     for (long i = 0; i < n; ++i)
         if (hipEventElapsedTime(&ms[i], g_prof.ev[2 * (first + i)], g_prof.ev[2 * (first + i) + 1]) != hipSuccess) return OCRS_ERR_HIP;
+    return OCRS_OK;
+}
+
+// measurement / test support: `blocks` x 256-thread workgroups resident for `micros` microseconds on stream st (see k_cu_hog)
+int ocrs_cu_hog(int blocks, int micros, hipStream_t st) {
+    OCRS_CHECK_ARG(blocks > 0 && blocks <= 4096 && micros >= 0 && micros <= 1000000);
+    hipLaunchKernelGGL(k_cu_hog, dim3(blocks), dim3(256), 0, st, (unsigned long long)micros * 100ull);
+    OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
 

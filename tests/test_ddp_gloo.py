@@ -211,4 +211,6 @@ def test_bench_self_launches_n_ranks_without_a_launcher():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["plumbing"] is True
     for leg in ("detection", "recognition"):
         assert d["ddp"][leg]["mean_of_ranks_ok"] and d["ddp"][leg]["buckets"] >= 1
+        pr = d["ddp"][leg]["per_rank_ms_per_step"]  # the per-rank min / max / all table of both models
+        assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ddp"][leg]["ms_per_step"]) < 1e-6
     assert d["ddp"]["detection"]["floats"] == 622122 and d["ddp"]["recognition"]["floats"] == 2426913
