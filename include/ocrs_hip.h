@@ -54,6 +54,13 @@ long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype); /* 1 / 0 */
 long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W);
 int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z,
                 float* ws, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_mm_fwd with ocrs_bn_finalize_parts folded into the same launch (models.py:11-24: conv + BatchNorm2d training statistics; the last workgroup to
+   finish reduces the per-block partials in the association order of ocrs_bn_finalize_parts: bit-identical tr / saved / running statistics).
+   counter: one zeroed 32-bit word (left zero); bn_w / bn_b: the block's BatchNorm weight / bias; count, eps, momentum, tr, saved, run_mean,
+   run_var, nbt, lo: as ocrs_bn_finalize_parts. */
+int ocrs_mm_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
+                    const float* gamma, void* pooled, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps, float momentum, float* tr,
+                    float* saved, float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_bn_finalize_parts(const float* parts, int nparts, long count, int C, const float* gamma, const float* beta, float eps, float momentum,
                            float* tr, float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st);
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */

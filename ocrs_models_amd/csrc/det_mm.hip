@@ -1093,6 +1093,58 @@ struct MfCfg {
 };
 }  // namespace
 
+// BatchNorm statistics finalisation folded into the forward launch ("last workgroup done", round 5): every workgroup publishes its [COUT][sum | sum^2]
+// partial with agent-scope (sc1, write-through) stores, drains them, takes a ticket from an agent-scope counter; the workgroup that draws the last
+// ticket reads all partials with agent-scope loads (they may sit behind another XCD's L2) and does what k_bn_finalize_parts does, in the same
+// association order (bit-identical results) -- one ~6 us launch less per block on the forward's critical path.  counter: one zeroed word per launch.
+struct FwdFin {
+    unsigned* counter;  // null: plain partials, the caller runs ocrs_bn_finalize_parts
+    long count;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *tr, *saved, *run_mean, *run_var;
+    long long* nbt;
+    float lo;
+};
+// the arithmetic of k_bn_finalize_parts for element column `col` (0..31) of 32-element window `win`, chain `chain` (0..7); red: [windows][8][32] doubles
+template <bool AGENT>
+__device__ __forceinline__ double bn_parts_chain_sum(const float* __restrict__ parts, int nparts, int C, int e, int chain) {
+    double s = 0.0;
+    if (e < 2 * C) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight loads in flight per chain, fixed association order
+        auto ld = [&](long i) -> double {
+            if constexpr (AGENT) return (double)__hip_atomic_load(parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else return (double)parts[i];
+        };
+        int b = chain;
+        for (; b + 56 < nparts; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ld((long)(b + 8 * u) * 2 * C + e);
+        }
+        for (int u = 0; b < nparts; b += 8, ++u) a[u & 7] += ld((long)b * 2 * C + e);
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    return s;
+}
+__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, long count, int c, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                                    float* tr, float* saved, float* run_mean, float* run_var, float lo) {
+    const double mean = sum / (double)count;
+    double var = sumsq / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    tr[c] = sc;
+    tr[C + c] = beta[c] - (float)mean * sc;
+    tr[2 * C + c] = lo;
+    saved[c] = (float)mean;
+    saved[C + c] = rstd;
+    if (run_mean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
 // FULL (the launcher sets it when every tile lies inside the image: H % TH == 0, W % TW == 0, even sizes when pooling): every global store of
 // the tile loop is then UNCONDITIONAL for every lane (no divergent branch around a store) and the first tile is peeled out of the loop.
 // Why it matters: hipcc derives the `s_waitcnt vmcnt(N)` in front of the first use of a prefetched vector from the operations that are
@@ -1107,7 +1159,7 @@ template <int CINB, int NST, int COUT, bool POOL, bool FULL>
 __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
                                                    bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
-                                                   const float* __restrict__ gamma, bf16* __restrict__ pooled) {
+                                                   const float* __restrict__ gamma, bf16* __restrict__ pooled, FwdFin fin) {
     using C = MfCfg<CINB, NST, COUT>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, DW_ = C::DW_, DP = C::DP, CGB = C::CGB, PX = C::PX, MT = C::MT, KC = C::KC, NPW = C::NPW;
     constexpr int CIN = CINB * NST;
@@ -1399,8 +1451,35 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     for (int e = tid; e < 2 * COUT; e += NT) {
         float s = 0.f;
         for (int w = 0; w < C::NW; ++w) s += s_stat[w * MT * 32 + e];
-        ws[(long)blockIdx.x * (2 * COUT) + e] = s;
+        if (fin.counter) __hip_atomic_store(ws + (long)blockIdx.x * (2 * COUT) + e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sc1: visible across XCDs once drained)
+        else ws[(long)blockIdx.x * (2 * COUT) + e] = s;
     }
+    if (!fin.counter) return;
+    // ---- last workgroup done: finalise the statistics here (see FwdFin)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_flag = reinterpret_cast<int*>(smem);              // (the tiles are dead)
+    double* red = reinterpret_cast<double*>(smem + 64);      // [2 windows][8 chains][32 columns]
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (*s_flag == 0) return;
+    static_assert(2 * COUT <= 64 && NT == 512, "two 32-element windows x 8 chains x 32 columns = the 512 threads");
+    const int win = tid >> 8, t8 = tid & 255, col = t8 & 31, chain = t8 >> 5, e = win * 32 + col;
+    red[(win * 8 + chain) * 32 + col] = bn_parts_chain_sum<true>(ws, gridDim.x, COUT, e, chain);
+    __syncthreads();
+    if (chain == 0) {
+        const double* r = red + win * 256;
+        const double tot = ((r[col] + r[32 + col]) + (r[64 + col] + r[96 + col])) + ((r[128 + col] + r[160 + col]) + (r[192 + col] + r[224 + col]));
+        red[512 + win * 32 + col] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (fin.nbt) *fin.nbt += 1;
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for a replay of the same launch, e.g. a captured graph)
+    }
+    if (chain == 0 && e < 2 * COUT && !(e & 1))
+        bn_finalize_channel(red[512 + e], red[512 + e + 1], fin.count, e >> 1, COUT, fin.gamma, fin.beta, fin.eps, fin.momentum, fin.tr, fin.saved, fin.run_mean,
+                            fin.run_var, fin.lo);
 }
 
 // BatchNorm2d training statistics from per-block partials [nparts][C][sum | sum of squares] (fp32 partials, fp64 total, fixed summation order:
@@ -1412,18 +1491,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_parts(const float* __restri
     __shared__ double red[8][32];
     const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + col;  // element of [C][2]
-    double s = 0.0;
-    if (e < 2 * C) {
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // eight loads in flight per chain, fixed association order
-        int b = chain;
-        for (; b + 56 < nparts; b += 64) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += (double)parts[(long)(b + 8 * u) * 2 * C + e];
-        }
-        for (int u = 0; b < nparts; b += 8, ++u) a[u & 7] += (double)parts[(long)b * 2 * C + e];
-        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    }
-    red[chain][col] = s;
+    red[chain][col] = bn_parts_chain_sum<false>(parts, nparts, C, e, chain);
     __syncthreads();
     if (chain != 0) return;
     const double tot = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
@@ -1431,27 +1499,12 @@ __global__ __launch_bounds__(256) void k_bn_finalize_parts(const float* __restri
     __syncthreads();  // (only chain 0 = one wave half reaches here: 32 lanes of the first wave)
     if (e == 0 && nbt) *nbt += 1;
     if (e >= 2 * C || (e & 1)) return;
-    const int c = e >> 1;
-    const double mean = tot / (double)count;
-    double var = red[0][col + 1] / (double)count - mean * mean;
-    if (var < 0) var = 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    tr[c] = sc;
-    tr[C + c] = beta[c] - (float)mean * sc;
-    tr[2 * C + c] = lo;
-    saved[c] = (float)mean;
-    saved[C + c] = rstd;
-    if (run_mean) {
-        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-    }
+    bn_finalize_channel(tot, red[0][col + 1], count, e >> 1, C, gamma, beta, eps, momentum, tr, saved, run_mean, run_var, lo);
 }
 
 template <int CINB, int NST, int COUT>
 static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, bf16* z, float* ws, const float* gamma,
-                          bf16* pooled, int N, int H, int W, int nb, hipStream_t st) {
+                          bf16* pooled, int N, int H, int W, int nb, const FwdFin& fin, hipStream_t st) {
     using CC = MfCfg<CINB, NST, COUT>;
     const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);
     // (set per call: the attribute is per device and this is called from any thread; it is a cheap host-side table update)
@@ -1460,7 +1513,7 @@ static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* tr
 #define MF_LAUNCH(PO_, FU_)                                                                                                                          \
     {                                                                                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, PO_, FU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
-        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled); \
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin); \
     }
     if (pooled) {
         if (full) MF_LAUNCH(true, true) else MF_LAUNCH(true, false)
@@ -1489,19 +1542,35 @@ long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
 // DepthwiseConv block forward on the matrix cores up to the pre-BatchNorm output (replaces ocrs_dwpw_fwd for bf16, Cin / Cout in {8, 16, 32}
 // and the 32 | 32 concat): wdw [Cin][9] / wpw [Cout][Cin] fp32 masters; z [P][Cout]; ws: ocrs_mm_fwd_nparts() x [Cout][sum | sum^2] fp32
 // per-block partials of the batch statistics (-> ocrs_bn_finalize_parts); gamma / pooled (nullable): as ocrs_dwpw_fwd.
-int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
-                const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+static int mm_fwd_impl(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
+                       const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, const FwdFin& fin, hipStream_t st) {
     OCRS_CHECK_ARG(xa && tra && wdw && wpw && z && ws && (Cb == 0 || (xb && trb)) && (!pooled || gamma));
     OCRS_CHECK_ARG(ocrs_mm_fwd_supported(Ca, Cb, Cout, dtype) && (long)N * (H + 2) * (W + 2) < (1L << 31));
     const int Cin = Ca + Cb;
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
     const int nb = (int)ocrs_mm_fwd_nparts(Ca, Cb, Cout, N, H, W);
 #define MF_CASE(CB_, NS_, CO_) \
-    if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, st);
+    if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, fin, st);
     MF_CASE(8, 1, 8) MF_CASE(8, 1, 16) MF_CASE(16, 1, 8) MF_CASE(16, 1, 16) MF_CASE(16, 1, 32) MF_CASE(32, 1, 16) MF_CASE(32, 1, 32) MF_CASE(32, 2, 32)
 #undef MF_CASE
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
+}
+
+int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
+                const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    const FwdFin fin{nullptr, 0, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f};
+    return mm_fwd_impl(xa, xb, Ca, Cb, tra, trb, wdw, wpw, z, ws, gamma, pooled, Cout, N, H, W, dtype, fin, st);
+}
+
+// ocrs_mm_fwd with ocrs_bn_finalize_parts folded into the launch (the last workgroup to finish finalises the statistics, bit-identical to the
+// separate call): bn_w / bn_b = the block's BatchNorm weight / bias, counter = ONE zeroed 32-bit word (left zero), the rest as ocrs_bn_finalize_parts.
+int ocrs_mm_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
+                    const float* gamma, void* pooled, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps, float momentum, float* tr,
+                    float* saved, float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(counter && count > 0 && bn_w && bn_b && tr && saved);
+    const FwdFin fin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo};
+    return mm_fwd_impl(xa, xb, Ca, Cb, tra, trb, wdw, wpw, z, ws, gamma, pooled, Cout, N, H, W, dtype, fin, st);
 }
 
 // nn.BatchNorm2d training statistics from ocrs_mm_fwd's per-block partials (models.py:23): see ocrs_bn_finalize.

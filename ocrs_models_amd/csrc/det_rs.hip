@@ -28,11 +28,32 @@
 #include <type_traits>
 
 #ifndef OCRS_RS_WPS
-#define OCRS_RS_WPS 4  // waves per SIMD the kernel is compiled for (register cap 512 / WPS)
+#define OCRS_RS_WPS 3  // waves per SIMD the kernel is compiled for (register cap 512 / WPS) = resident 4-wave workgroups per CU.  Measured in the step (8 -> 8
+                       // channels, level 0): 3 per CU 480-507 us, 4 per CU 546 us, 2 per CU 480 us -- the memory side prefers fewer, more coherent streams
+#endif
+#ifndef OCRS_RS_LD_NT
+#define OCRS_RS_LD_NT 0          // 1: non-temporal prefetch loads (measurement knob)
+#endif
+#if OCRS_RS_LD_NT
+#define OCRS_RS_LD_HINT " nt"
+#else
+#define OCRS_RS_LD_HINT ""
+#endif
+#ifndef OCRS_RS_ST_AUX
+#define OCRS_RS_ST_AUX 0         // aux bits of the dx~ stores (measurement knob: 2 = nt)
+#endif
+#ifndef OCRS_RS_TICK_BARRIER
+#define OCRS_RS_TICK_BARRIER 0   // 1: the four waves of a workgroup meet at every tick (measurement knob: keeps their four adjacent strips in step)
 #endif
 #ifndef OCRS_RS_WPS_G2
 #define OCRS_RS_WPS_G2 3  // two gradient tensors: 8 more prefetch registers per set (139 VGPRs; at the 128 cap hipcc spills loop invariants, and a scratch reload is a vmcnt(0))
 #endif
+#ifndef OCRS_RS_WPS_16
+#define OCRS_RS_WPS_16 2  // a 16-channel side: twice the prefetch registers / coefficient pairs / G accumulators (spills at the 168-register cap of 3)
+#endif
+template <int CIN, int COUT, bool G2>
+constexpr int rs_wps() { return (CIN == 8 && COUT == 8) ? (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : OCRS_RS_WPS_16; }
+static int rs_wps_rt(int Cin, int Cout, int g2) { return (Cin == 8 && Cout == 8) ? (g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : OCRS_RS_WPS_16; }
 
 namespace {
 
@@ -120,7 +141,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 // tools/check_rs_loads.py verifies that hipcc leaves the destination registers alone between the load and its wait.
 __device__ __forceinline__ u32x4 bload16_opaque(const i32x4& rsrc, int voff) {
     u32x4 r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
     return r;
 }
 template <int N>
@@ -200,7 +221,7 @@ struct RsGen {  // (all wave-uniform: scalar registers)
 }  // namespace
 
 template <int CIN, int COUT, bool G2, bool SPLIT>
-__global__ __launch_bounds__(256, (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS)) void k_rs_bwd(RsArgs A) {
+__global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArgs A) {
     using C = RsCfg<CIN, COUT>;
     constexpr int PDB = C::PDB, ROWB = C::ROWB, RINGB = C::RINGB, XPB = C::XPB, KC = C::KC, NU = C::NU, MTG = C::MTG, NZ = C::NZ, NX = C::NX, SW = C::SW;
     constexpr int G8 = C::G8, TPC = C::TPC, CPD = C::CPD, UPK = C::UPK;
@@ -308,7 +329,7 @@ __global__ __launch_bounds__(256, (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS)) void k_rs
     for (int a = 0; a < MTG; ++a)
 #pragma unroll
         for (int u = 0; u < NU; ++u) accG[a][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr bool WREG = false && KC <= 4;  // the A fragments stay in registers when they are few
+    constexpr bool WREG = KC <= 4 && rs_wps<CIN, COUT, G2>() <= 3;  // the A fragments stay in registers when they are few
     u32x4 wfr[WREG ? KC : 1];
     if constexpr (WREG) {
 #pragma unroll
@@ -476,7 +497,7 @@ __global__ __launch_bounds__(256, (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS)) void k_rs
                 const uint4 q = *reinterpret_cast<const uint4*>(smem + str + 16 * j);
                 const bool in_a = !SPLIT || 8 * j < Ca;
                 const int off = pix0 * ((in_a ? Ca : Cb) * 2) + lxo[j];
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, in_a ? w_a : w_b, ok ? off : -1, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, in_a ? w_a : w_b, ok ? off : -1, 0, OCRS_RS_ST_AUX);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -529,6 +550,9 @@ __global__ __launch_bounds__(256, (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS)) void k_rs
     issue(S0{}, t0);
     issue(S1{}, t1);
     auto tick = [&](auto ST, auto YOUNGER, RsTick& t) __attribute__((always_inline)) {
+#if OCRS_RS_TICK_BARRIER
+        __builtin_amdgcn_s_barrier();  // (only valid while all four waves run the same number of ticks: a measurement build for full-size launches)
+#endif
         commit(ST, YOUNGER, t);
         const RsTick tn = gen.next();
         issue(ST, tn);
@@ -620,7 +644,10 @@ static int rs_env() {
 bool rs_bwd_supported(int Ca, int Cb, int Cout, int pooled, int N, int H, int W) {
     if (!rs_env() || pooled) return false;
     const int Cin = Ca + Cb;
-    if (!((Cin == 8 && Cout == 8))) return false;
+    // (the kernel is written for Cin / Cout in {8, 16}, but only 8 -> 8 is instantiated: with 16 channels on either side the per-channel coefficients
+    //  no longer fit the scalar register file next to the descriptors -- hipcc spills SGPRs to scratch inside the tick loop, 256 VGPRs + 40-88 B of
+    //  scratch -- and a scratch reload in that loop is a vmcnt(0); those shapes need LDS-resident coefficients first)
+    if (!(Cin == 8 && Cout == 8)) return false;
     if (Cb != 0 && !(Ca == 8 && Cb == 8)) return false;
     const long bytes = (long)N * H * W * (Cin > Cout ? Cin : Cout) * 2;
     return bytes < (1L << 31) && H >= 2 && W >= 2;
@@ -640,7 +667,7 @@ static void rs_geometry(int N, int H, int W, int wps, int& NS, int& NP, int& NB,
 }
 int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
     int NS, NP, NB, PB, njobs, nb;
-    rs_geometry(N, H, W, g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS, NS, NP, NB, PB, njobs, nb);
+    rs_geometry(N, H, W, rs_wps_rt(Cin, Cout, g2), NS, NP, NB, PB, njobs, nb);
     return nb;
 }
 void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
@@ -652,7 +679,7 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
     a.g1 = g1; a.g2 = g2; a.z = z; a.bn = bn; a.coef = coef; a.gxa = gxa; a.gxb = gxb; a.ws = ws;
     a.N = N; a.H = H; a.W = W;
     int nb;
-    rs_geometry(N, H, W, g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS, a.NS, a.NP, a.NB, a.PB, a.njobs, nb);
+    rs_geometry(N, H, W, rs_wps_rt(x.Ca + x.Cb, Cout, g2 != nullptr), a.NS, a.NP, a.NB, a.PB, a.njobs, nb);
     a.fin = fin;
     (void)stats;
     const int Cin = x.Ca + x.Cb;
@@ -662,8 +689,16 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<CI_, CO_, G2_, SP_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
         OCRS_LAUNCH_T((k_rs_bwd<CI_, CO_, G2_, SP_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                             \
     }
-    if (Cin == 8 && Cout == 8) {
-        if (g2) RS_LAUNCH(8, 8, true, false) else RS_LAUNCH(8, 8, false, false)
+    const bool sp = x.Cb > 0;
+#define RS_CASE(CI_, CO_)                                                                 \
+    if (Cin == CI_ && Cout == CO_) {                                                      \
+        if (g2) {                                                                         \
+            if (sp) RS_LAUNCH(CI_, CO_, true, (CI_ > 8)) else RS_LAUNCH(CI_, CO_, true, false)   \
+        } else {                                                                          \
+            if (sp) RS_LAUNCH(CI_, CO_, false, (CI_ > 8)) else RS_LAUNCH(CI_, CO_, false, false) \
+        }                                                                                 \
     }
+    RS_CASE(8, 8)
+#undef RS_CASE
 #undef RS_LAUNCH
 }

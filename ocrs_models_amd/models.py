@@ -119,6 +119,7 @@ class _DetRun:
         self.overlap = os.environ.get("OCRS_OVERLAP", "1") != "0"
         # BatchNorm-backward finalisation in the prologue of the matrix-core block backward instead of its own launch
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
+        self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
         self.x = x
         # test tap (tests/test_det_bf16_layerwise_gpu.py): when the module carries a dict ``_capture`` every backward stage records the gradient
@@ -220,9 +221,19 @@ class _DetRun:
             self.pooled_by_block = pooled
             nparts = L.mm_fwd_nparts(a.C, Cb, Cout, N, H, W)
             parts = self.empty(nparts * 2 * Cout, dtype=torch.float32)
-            L.mm_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
-                     ptr(z), ptr(parts), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
-            tr, saved = self.bn_tr(f"{prefix}.seq.2", parts, N * H * W, Cout, nparts=nparts)
+            bnp = f"{prefix}.seq.2"
+            if self.train and self.fold_fwd_fin:
+                # the BatchNorm statistics are finalised by the last workgroup of the same launch (bit-identical to ocrs_bn_finalize_parts)
+                tr, saved = self.empty(3, Cout, dtype=torch.float32), self.empty(2, Cout, dtype=torch.float32)
+                Bf = self.Bf
+                L.mm_fwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, a.C, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                             ptr(z), ptr(parts), ptr(gamma), ptr(pooled), ptr(self.zeros64(1)), N * H * W, ptr(P[f"{bnp}.weight"]), ptr(P[f"{bnp}.bias"]),
+                             1e-5, 0.1, ptr(tr), ptr(saved), ptr(Bf[f"{bnp}.running_mean"]), ptr(Bf[f"{bnp}.running_var"]),
+                             ptr(Bf[f"{bnp}.num_batches_tracked"]), 0.0, Cout, N, H, W, self.dt)
+            else:
+                L.mm_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
+                         ptr(z), ptr(parts), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
+                tr, saved = self.bn_tr(bnp, parts, N * H * W, Cout, nparts=nparts)
             r = _BlockRec()
             r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
             self.recs[prefix] = r

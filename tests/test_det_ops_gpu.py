@@ -30,7 +30,7 @@ def make_run(dev, dtype, N, P, Bf):
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
     r.fused, r.fuse_bn_bwd, r.fuse_pool, r.pooled_by_block = {}, True, True, None
-    r.use_mm, r.fold_fin, r.overlap = True, True, False
+    r.use_mm, r.fold_fin, r.overlap, r.fold_fwd_fin = True, True, False, True
     return r
 
 
@@ -268,6 +268,41 @@ def test_matrix_core_block_forward(dev, Ca, Cb, Cout, pool, shape):
     out2 = run.block(pfx, _Act(xa_s, tra, Ca, H, W), _Act(xb_s, trb, Cb, H, W) if Cb else None, Cout, pool=pool)
     torch.cuda.synchronize()
     assert torch.equal(out2.t, outs[True][0].t) and torch.equal(out2.tr, outs[True][0].tr)
+
+
+@pytest.mark.parametrize("Ca,Cb,Cout", [(8, 0, 8), (16, 0, 8), (8, 8, 16), (16, 0, 32), (32, 32, 32)])
+def test_forward_statistics_finalised_in_the_launch_are_bit_identical(dev, Ca, Cb, Cout):
+    """ocrs_mm_fwd_fin (the last workgroup of the forward launch finalises the BatchNorm statistics; round 5) against ocrs_mm_fwd +
+    ocrs_bn_finalize_parts: load transform, saved mean / rstd, running statistics and num_batches_tracked must be identical bit for bit
+    (same association order), on a many-workgroup shape and on a single-tile one, and again on a second call (the ticket word is left zero)."""
+    from ocrs_models_amd.models import _Act
+
+    dtype = torch.bfloat16
+    for (N, H, W) in [(3, 96, 160), (1, 8, 32)]:
+        g = torch.Generator().manual_seed(3 + Ca + Cout)
+        P, Bf = {}, {}
+        cin = Ca + Cb
+        P["C.seq.0.weight"] = (torch.randn(cin, 1, 3, 3, generator=g) / 3).to(dev)
+        P["C.seq.1.weight"] = (torch.randn(Cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(dev)
+        P["C.seq.2.weight"] = (1 + 0.1 * torch.randn(Cout, generator=g)).to(dev)
+        P["C.seq.2.bias"] = (0.1 * torch.randn(Cout, generator=g)).to(dev)
+        xa = _Act(nhwc(torch.randn(N, Ca, H, W, generator=g).to(dev), dtype), rand_tr(Ca, dev, g), Ca, H, W)
+        xb = _Act(nhwc(torch.randn(N, Cb, H, W, generator=g).to(dev), dtype), rand_tr(Cb, dev, g), Cb, H, W) if Cb else None
+        res = []
+        for fold in (True, False, True):
+            Bfi = {"C.seq.2.running_mean": torch.full((Cout,), 0.25, device=dev), "C.seq.2.running_var": torch.full((Cout,), 2.0, device=dev),
+                   "C.seq.2.num_batches_tracked": torch.full((), 7, dtype=torch.int64, device=dev)}
+            run = make_run(dev, dtype, N, P, Bfi)
+            run.fold_fwd_fin = fold
+            out = run.block("C", xa, xb, Cout)
+            out2 = run.block("C", xa, xb, Cout)  # a second launch through the same zero pool
+            torch.cuda.synchronize()
+            res.append((out.tr.clone(), run.recs["C"].saved.clone(), out2.tr.clone(), {k: v.clone() for k, v in Bfi.items()}))
+        for r in res[1:]:
+            assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+            for k in r[3]:
+                assert torch.equal(r[3][k], res[0][3][k]), k
+        assert int(res[0][3]["C.seq.2.num_batches_tracked"]) == 9
 
 
 MM_CASES = [(8, 8, 8, 8), (8, 8, 0, 16), (8, 16, 0, 8), (8, 16, 0, 16), (8, 8, 8, 16), (16, 16, 16, 16), (8, 16, 0, 32), (16, 32, 0, 32), (16, 32, 32, 32),
