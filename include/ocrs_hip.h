@@ -122,6 +122,13 @@ int ocrs_mm_bwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float*
                     const void* g2, int pooled, const void* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma,
                     float* dbeta, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b,
                     double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_mm_bwd_fin for the block in front of out_conv (models.py:143 reads up.0.contract's output): the gradient w.r.t. the block output is
+   not read from memory but formed as round(gl[p] * whead[c]) from ocrs_head_bwd_gl's 4-byte-per-pixel gl.  ocrs_mm_bwd_head_supported: 1 if this
+   launch is covered (the row-streaming backward: bf16, 8 -> 8 channels, one source). */
+long ocrs_mm_bwd_head_supported(int Ca, int Cb, int Cout, int N, int H, int W, int dtype);
+int ocrs_mm_bwd_fin_head(const void* xa, int Ca, const float* tra, const float* wdw, const float* wpw, const float* gl, const float* whead, const void* z,
+                         const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, void* gxa, float* dwpw,
+                         float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* acc64 [17] fp64 = dWpw [8] | dWdw [9], ACCUMULATED (caller-zeroed; the caller adds it to the fp32 gradients): fp64 sums of the per-block
  * fp32 partials are exact, hence independent of the order the blocks finish in (float atomics into the fp32 gradients were not). */
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
@@ -143,6 +150,10 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
 /* acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients; see ocrs_dwpw_c1_bwd). */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,
                   const float* saved, double* gsum, long P, int dtype, hipStream_t st);
+/* The same (models.py:127-130, 143: out_conv + Sigmoid backward) with a compact output: gl [P] fp32 = dL/dlogit instead of the 8-channel gradient gy
+   (gy[p][c] = gl[p] * w[c] is formed by the consumer, ocrs_mm_bwd_fin_head). */
+int ocrs_head_bwd_gl(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, float* gl, double* acc64,
+                     const float* saved, double* gsum, long P, int dtype, hipStream_t st);
 
 /* ------------------------------------------------------------------ detection loss ---------- */
 /* balanced_cross_entropy_loss (ocrs_models/train_detection.py:225-263), forward and backward. */

@@ -1186,7 +1186,10 @@ template <class T>
 __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
                                                   const float* __restrict__ pred, const float* __restrict__ gpred, T* __restrict__ gy,
                                                   double* __restrict__ acc64 /*[9]: dw[8] | db*/, const float* __restrict__ saved /*[2][8] or null*/,
-                                                  double* __restrict__ gsum /*[2][8] or null*/, long P) {
+                                                  double* __restrict__ gsum /*[2][8] or null*/, long P, float* __restrict__ gl_out /*[P] or null*/) {
+    // gl_out != null (round 5): instead of the 8-channel gradient gy (16 B per pixel in bf16) only gl = dL/dlogit is written (4 B); the block
+    // backward that consumes it (k_rs_bwd<..., HEAD>) forms gy = round(gl * w[c]) on the fly -- the same values: 12 B per pixel less written here
+    // and 12 B less read there
     // gsum != null: also the BatchNorm-backward sums (sum ghat, sum ghat*zhat) of the block that produced z -- this kernel is that
     // block's only consumer and already reads z, so its k_bn_bwd_reduce pass (0.24 ms at 32x1024^2) is not needed
     __shared__ float s_slots[4 * 25];
@@ -1216,7 +1219,8 @@ __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const
             st2[i] = fmaf(gh, v[i] - mu[i], st2[i]);
         }
         acc[8] += gl;
-        store8(gy + p * 8, o);
+        if (gl_out) gl_out[p] = gl;
+        else store8(gy + p * 8, o);
     }
     // deterministic block sums (no LDS float atomics), fp64 accumulation across blocks
     float all[25];
@@ -1653,17 +1657,28 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
 
 // Head backward: gy [P][8] written (dtype T); acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients).  saved / gsum (nullable): also accumulate the BatchNorm-backward
 // sums [2][8] (fp64, caller-zeroed) of the block that produced z (saved = its [mean | rstd]) -- replaces that block's ocrs_bn_bwd_reduce.
-int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,
-                  const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(z && tr && w && pred && gpred && gy && acc64 && P > 0 && (!gsum || saved));
+static int head_bwd_impl(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, float* gl, double* acc64,
+                         const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && w && pred && gpred && (gy || gl) && acc64 && P > 0 && (!gsum || saved));
     int grid = ew_grid(P);
     if (grid > 1024) grid = 1024;  // streaming kernel ending in same-address atomics: 4 blocks per CU are plenty
     if (dtype == 1)
-        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, acc64, saved, gsum, P);
+        hipLaunchKernelGGL(k_head_bwd<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, gpred, (bf16*)gy, acc64, saved, gsum, P, gl);
     else
-        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, acc64, saved, gsum, P);
+        hipLaunchKernelGGL(k_head_bwd<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, gpred, (float*)gy, acc64, saved, gsum, P, gl);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
+}
+int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,
+                  const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(gy);
+    return head_bwd_impl(z, tr, w, pred, gpred, gy, nullptr, acc64, saved, gsum, P, dtype, st);
+}
+// ocrs_head_bwd that writes gl [P] fp32 = dL/dlogit instead of the 8-channel gradient gy: for ocrs_mm_bwd_fin_head, which forms gy on the fly
+int ocrs_head_bwd_gl(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, float* gl, double* acc64,
+                     const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(gl);
+    return head_bwd_impl(z, tr, w, pred, gpred, nullptr, gl, acc64, saved, gsum, P, dtype, st);
 }
 
 }  // extern "C"

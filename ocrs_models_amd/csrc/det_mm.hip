@@ -1044,6 +1044,27 @@ static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
     return OCRS_OK;
 }
 
+long ocrs_mm_bwd_head_supported(int Ca, int Cb, int Cout, int N, int H, int W, int dtype) {
+    return dtype == 1 && Ca == 8 && Cb == 0 && Cout == 8 && rs_bwd_supported(Ca, Cb, Cout, 0, N, H, W) ? 1 : 0;
+}
+// ocrs_mm_bwd_fin with the gradient w.r.t. the block output formed on the fly from out_conv's backward (gl [N H W] fp32, whead [8]): see k_rs_bwd<..., HEAD>
+int ocrs_mm_bwd_fin_head(const void* xa, int Ca, const float* tra, const float* wdw, const float* wpw, const float* gl, const float* whead, const void* z,
+                         const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, void* gxa, float* dwpw,
+                         float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xa && tra && wdw && wpw && gl && whead && z && bn && gsum && gamma && saved && dgamma && dbeta && gxa && dwpw && dwdw && ws);
+    OCRS_CHECK_ARG(ocrs_mm_bwd_head_supported(Ca, 0, Cout, N, H, W, dtype) && (!gsum_a || saved_a));
+    const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
+    Src2<bf16> x{(const bf16*)xa, nullptr, Ca, 0};
+    const int nb = rs_bwd_blocks(Ca, Cout, N, H, W, 0);
+    rs_bwd_launch(x, tra, nullptr, wdw, wpw, Ca, nullptr, nullptr, (const bf16*)z, bn, nullptr, (bf16*)gxa, nullptr, ws, gsum_a != nullptr, Cout, N, H, W, fin, st, gl,
+                  whead);
+    const int ne = Cout * Ca + 11 * Ca;
+    OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Ca, Cout, Ca, dwpw, Ca, dwdw, gsum_a, (double*)nullptr, saved_a, (const float*)nullptr,
+                  tra, (const float*)nullptr);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
 int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
                 const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {

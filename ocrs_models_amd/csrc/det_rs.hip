@@ -66,6 +66,7 @@ struct RsArgs {
     const float *tra, *trb, *wdw, *wpw;
     int ldw;
     const bf16 *g1, *g2, *z;
+    const float *gl, *whead;  // HEAD: dL/dlogit [N H W] fp32 and out_conv's weight [8] instead of g1 / g2
     const float *bn, *coef;
     bf16 *gxa, *gxb;
     float* ws;
@@ -144,6 +145,16 @@ __device__ __forceinline__ u32x4 bload16_opaque(const i32x4& rsrc, int voff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
     return r;
 }
+__device__ __forceinline__ unsigned bload4_opaque(const i32x4& rsrc, int voff) {
+    unsigned r;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(unsigned& r) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%1) ; releases %0" : "+v"(r) : "n"(N) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm(u32x4& r) {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -220,8 +231,10 @@ struct RsGen {  // (all wave-uniform: scalar registers)
 
 }  // namespace
 
-template <int CIN, int COUT, bool G2, bool SPLIT>
+// HEAD: the block in front of out_conv -- dL/dy[p][c] = round(gl[p] * whead[c]) formed here from ocrs_head_bwd_gl's 4-byte-per-pixel gl (see there)
+template <int CIN, int COUT, bool G2, bool SPLIT, bool HEAD = false>
 __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArgs A) {
+    static_assert(!HEAD || (!G2 && COUT == 8), "head gradient: one 8-channel source");
     using C = RsCfg<CIN, COUT>;
     constexpr int PDB = C::PDB, ROWB = C::ROWB, RINGB = C::RINGB, XPB = C::XPB, KC = C::KC, NU = C::NU, MTG = C::MTG, NZ = C::NZ, NX = C::NX, SW = C::SW;
     constexpr int G8 = C::G8, TPC = C::TPC, CPD = C::CPD, UPK = C::UPK;
@@ -289,10 +302,16 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
     for (int i = 0; i < CIN; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
 
+    float wh[HEAD ? 8 : 1];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wh[i] = usc(A.whead[i]);
+    }
     // ---- buffer descriptors (hardware bounds check: out-of-range loads return 0, out-of-range stores are dropped)
     const unsigned npix = (unsigned)A.N * (unsigned)H * (unsigned)W;
     const int Ca = A.Ca, Cb = A.Cb;
-    const i32x4 r_z = make_rsrc(A.z, npix * PDB), r_g1 = make_rsrc(A.g1, npix * PDB), r_g2 = make_rsrc(G2 ? A.g2 : A.g1, npix * PDB);
+    const i32x4 r_z = make_rsrc(A.z, npix * PDB), r_g1 = HEAD ? make_rsrc(A.gl, npix * 4) : make_rsrc(A.g1, npix * PDB),
+                r_g2 = make_rsrc(G2 ? A.g2 : A.g1, npix * PDB);
     const i32x4 r_xa = make_rsrc(A.xa, npix * Ca * 2), r_xb = make_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 2);
     const __amdgpu_buffer_rsrc_t w_a = __builtin_amdgcn_make_buffer_rsrc((void*)A.gxa, 0, npix * Ca * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_b = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? A.gxb : A.gxa), 0, npix * (SPLIT ? Cb : Ca) * 2, 0x00020000);
@@ -344,7 +363,8 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     const int vblk = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     RsGen gen(vblk * C::NW + wave, A.njobs, nblk * C::NW, A.NS, A.NB, A.PB, A.NP);
 
-    u32x4 pz[2][NZ], pg[2][NZ], pg2[2][G2 ? NZ : 1], pxr[2][NX];
+    u32x4 pz[2][NZ], pg[2][HEAD ? 1 : NZ], pg2[2][G2 ? NZ : 1], pxr[2][NX];
+    unsigned pgl[2] = {0u, 0u};  // HEAD: this lane's gl
     auto corner = [&](const RsTick& t) -> int {  // pixel index of (row 2q clamped into the image, column 30 s - 1): may be -1 / beyond a row end
         const int qc = t.q < 0 ? 0 : (t.q >= A.NP ? A.NP - 1 : t.q);
 #ifdef OCRS_RS_NOLOAD  // (floor-measurement build: every tick re-reads the same lines)
@@ -359,9 +379,10 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
             pz[S][j] = bload16_opaque(r_z, oz + lz + 16 * j);
-            pg[S][j] = bload16_opaque(r_g1, oz + lz + 16 * j);
+            if constexpr (!HEAD) pg[S][j] = bload16_opaque(r_g1, oz + lz + 16 * j);
             if constexpr (G2) pg2[S][j] = bload16_opaque(r_g2, oz + lz + 16 * j);
         }
+        if constexpr (HEAD) pgl[S] = bload4_opaque(r_g1, (cp + rr * W + px) * 4);
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const bool in_a = !SPLIT || 8 * j < Ca;
@@ -370,9 +391,9 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     };
     // operations a tick issues: its loads (behind its commit), then its compute's stores
 #ifdef OCRS_RS_NOCOMPUTE
-    constexpr int NLOADS = NZ * (G2 ? 3 : 2) + NX, NSTORE = 0;
+    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX, NSTORE = 0;
 #else
-    constexpr int NLOADS = NZ * (G2 ? 3 : 2) + NX, NSTORE = NX;
+    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX, NSTORE = NX;
 #endif
     auto commit = [&](auto ST, auto YOUNGER, const RsTick& t) {
         constexpr int S = decltype(ST)::value;
@@ -386,9 +407,10 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
             for (int j = 0; j < NZ; ++j) {
                 wait_vm<Y>(pz[S][j]);
-                wait_vm<Y>(pg[S][j]);
+                if constexpr (!HEAD) wait_vm<Y>(pg[S][j]);
                 if constexpr (G2) wait_vm<Y>(pg2[S][j]);
             }
+            if constexpr (HEAD) wait_vm<Y>(pgl[S]);
 #pragma unroll
             for (int j = 0; j + 1 < NX; ++j) wait_vm<Y>(pxr[S][j]);
         }
@@ -404,7 +426,13 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             for (int k = 0; k < 4; ++k) {
                 const int ci = 4 * j + k;  // channel pair
                 const f32x2 zv = unpk(pz[S][j][k]);
-                f32x2 gv = unpk(pg[S][j][k]);
+                f32x2 gv;
+                if constexpr (HEAD) {  // the stored gradient of the separate path: gl * w[c] rounded to bf16
+                    const float glv = __uint_as_float(pgl[S]);
+                    gv = unpk(cvt_pk(glv * wh[2 * ci], glv * wh[2 * ci + 1]));
+                } else {
+                    gv = unpk(pg[S][j][k]);
+                }
                 if constexpr (G2) gv += unpk(pg2[S][j][k]);
                 const f32x2 y = __builtin_elementwise_fma(zv, bs2[ci], bt2[ci]);
                 f32x2 gh;
@@ -582,9 +610,10 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
             wait_vm<0>(pz[S][j]);
-            wait_vm<0>(pg[S][j]);
+            if constexpr (!HEAD) wait_vm<0>(pg[S][j]);
             if constexpr (G2) wait_vm<0>(pg2[S][j]);
         }
+        if constexpr (HEAD) wait_vm<0>(pgl[S]);
 #pragma unroll
         for (int j = 0; j < NX; ++j) wait_vm<0>(pxr[S][j]);
     }
@@ -672,8 +701,10 @@ int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
 }
 void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                    const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
-                   const BnFin& fin, hipStream_t st) {
+                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead) {
     RsArgs a;
+    a.gl = gl;
+    a.whead = whead;
     a.xa = x.a; a.xb = x.b; a.Ca = x.Ca; a.Cb = x.Cb;
     a.tra = tra; a.trb = trb; a.wdw = wdw; a.wpw = wpw; a.ldw = ldw;
     a.g1 = g1; a.g2 = g2; a.z = z; a.bn = bn; a.coef = coef; a.gxa = gxa; a.gxb = gxb; a.ws = ws;
@@ -688,6 +719,12 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
         using CC = RsCfg<CI_, CO_>;                                                                                                          \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<CI_, CO_, G2_, SP_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
         OCRS_LAUNCH_T((k_rs_bwd<CI_, CO_, G2_, SP_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                             \
+    }
+    if (gl) {  // the block in front of out_conv (8 -> 8 channels, one source, one gradient)
+        using CC = RsCfg<8, 8>;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+        OCRS_LAUNCH_T((k_rs_bwd<8, 8, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);
+        return;
     }
     const bool sp = x.Cb > 0;
 #define RS_CASE(CI_, CO_)                                                                 \

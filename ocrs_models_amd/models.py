@@ -119,7 +119,8 @@ class _DetRun:
         self.overlap = os.environ.get("OCRS_OVERLAP", "1") != "0"
         # BatchNorm-backward finalisation in the prologue of the matrix-core block backward instead of its own launch
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
-        self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"  # BatchNorm statistics finalised inside the matrix-core forward launch
+        self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"
+        self.head_gl = os.environ.get("OCRS_HEAD_GL", "1") != "0"  # out_conv's backward hands the last block gl (4 B / pixel) instead of its 8-channel gradient  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
         self.x = x
         # test tap (tests/test_det_bf16_layerwise_gpu.py): when the module carries a dict ``_capture`` every backward stage records the gradient
@@ -362,6 +363,13 @@ class _DetRun:
             sva, gsa = stat_target(a)
             svb, gsb = stat_target(b)
             ws = self.empty(L.mm_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
+            gl = getattr(self, "_head_gl", None)
+            if gl is not None and g1 is gl:  # the block in front of out_conv: its output gradient is formed from gl inside the launch
+                self._head_gl = None
+                L.mm_bwd_fin_head(ptr(a.t), Ca, ptr(a.tr), ptr(wdw), ptr(wpw), ptr(gl), ptr(P["out_conv.0.weight"]), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam),
+                                  ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]),
+                                  ptr(ws), ptr(sva), ptr(gsa), C, N, H, W, self.dt)
+                return gxa, gxb
             if fold:
                 L.mm_bwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),
                              ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(gxb),
@@ -431,14 +439,25 @@ class _DetRun:
                 keep.clear()
         gpred = gpred.contiguous().float()
         up = self.head_in
-        g = self.empty(N, H, W, 8)
         sv = gs_head = None
         if self.fuse_bn_bwd and up.src is not None:  # the head is this block's only consumer and reads its z anyway
             sv, gs_head = self.recs[up.src].saved, self.zeros64(16)
             self.fused[up.src] = gs_head
         acc = self.zeros64(9)
-        L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
-                   N * H * W, self.dt)
+        # out_conv's backward hands the last block either its 8-channel gradient g (16 B per pixel) or -- when that block's backward can form
+        # g = round(gl * w[c]) itself (ocrs_mm_bwd_fin_head: the row-streaming kernel) -- only gl = dL/dlogit (4 B per pixel)
+        r_up = self.recs.get(up.src) if up.src is not None else None
+        head_gl = (self.head_gl and self.capture is None and gs_head is not None and r_up is not None and r_up.b is None and self.use_mm and self.fold_fin
+                   and L.mm_bwd_head_supported(r_up.a.C, 0, r_up.Cout, N, H, W, self.dt))
+        if head_gl:
+            g = self.empty(N, H, W, dtype=torch.float32)
+            L.head_bwd_gl(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
+                          N * H * W, self.dt)
+        else:
+            g = self.empty(N, H, W, 8)
+            L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
+                       N * H * W, self.dt)
+        self._head_gl = g if head_gl else None
         self.G["out_conv.0.weight"].view(-1).add_(acc[:8])
         self.G["out_conv.0.bias"].view(-1).add_(acc[8:9])
         if self.capture is not None:

@@ -668,3 +668,55 @@ def test_balanced_bce(dev, shape, ppos):
     go, gd = p_o.grad, p_d.grad.cpu()
     assert abs(float(gd.double().sum()) - float(go.double().sum())) < 1e-3 * float(go.double().abs().sum())
     assert rel(gd, go) < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 37), (3, 64, 96)], ids=lambda s: "x".join(map(str, s)))
+def test_last_block_backward_from_head_gl_is_bit_identical(dev, shape):
+    """ocrs_head_bwd_gl + ocrs_mm_bwd_fin_head (round 5: out_conv's backward writes only gl = dL/dlogit, 4 B per pixel, and the row-streaming
+    backward of the block in front of it forms the 8-channel gradient round(gl * w[c]) on the fly) against ocrs_head_bwd + ocrs_mm_bwd_fin on the
+    stored 8-channel gradient: dL/dx, dWdw, dWpw, dgamma, dbeta, the head's own gradients and both sets of fused BatchNorm-backward sums must be
+    identical bit for bit."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(17 + H)
+    P_ = N * H * W
+    x = nhwc(torch.randn(N, 8, H, W, generator=g).to(dev), torch.bfloat16)
+    tra = rand_tr(8, dev, g)
+    z = nhwc(torch.randn(N, 8, H, W, generator=g).to(dev), torch.bfloat16)
+    tr = rand_tr(8, dev, g)  # this block's BatchNorm load transform
+    wdw = (torch.randn(8, 9, generator=g) / 3).to(dev)
+    wpw = (torch.randn(8, 8, generator=g) / 3).to(dev)
+    gamma = (1 + 0.1 * torch.randn(8, generator=g)).to(dev)
+    saved = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)
+    saved_a = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)
+    whead = torch.randn(8, generator=g).to(dev)
+    pred = torch.rand(P_, generator=g).to(dev)
+    gpred = torch.randn(P_, generator=g).to(dev)
+    if not L.mm_bwd_head_supported(8, 0, 8, N, H, W, 1):
+        pytest.skip("row-streaming backward switched off (OCRS_RS=0)")
+    outs = []
+    for head in (False, True):
+        acc = torch.zeros(9, dtype=torch.float64, device=dev)
+        gs_blk = torch.zeros(16, dtype=torch.float64, device=dev)
+        gs_a = torch.zeros(16, dtype=torch.float64, device=dev)
+        gx = torch.zeros(N, H, W, 8, dtype=torch.bfloat16, device=dev)
+        dwpw, dwdw = torch.zeros(8, 8, device=dev), torch.zeros(8, 9, device=dev)
+        dgam, dbet = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+        ws = torch.empty(L.mm_bwd_ws_floats(8, 0, 8, N, H, W), device=dev)
+        if head:
+            gl = torch.empty(P_, device=dev)
+            L.head_bwd_gl(ptr(z), ptr(tr), ptr(whead), ptr(pred), ptr(gpred), ptr(gl), ptr(acc), ptr(saved), ptr(gs_blk), P_, 1)
+            L.mm_bwd_fin_head(ptr(x), 8, ptr(tra), ptr(wdw), ptr(wpw), ptr(gl), ptr(whead), ptr(z), ptr(tr), ptr(gs_blk), ptr(gamma), ptr(saved), ptr(dgam),
+                              ptr(dbet), ptr(gx), ptr(dwpw), ptr(dwdw), ptr(ws), ptr(saved_a), ptr(gs_a), 8, N, H, W, 1)
+        else:
+            gy = torch.empty(N, H, W, 8, dtype=torch.bfloat16, device=dev)
+            L.head_bwd(ptr(z), ptr(tr), ptr(whead), ptr(pred), ptr(gpred), ptr(gy), ptr(acc), ptr(saved), ptr(gs_blk), P_, 1)
+            L.mm_bwd_fin(ptr(x), None, 8, 0, ptr(tra), None, ptr(wdw), ptr(wpw), ptr(gy), None, 0, ptr(z), ptr(tr), ptr(gs_blk), ptr(gamma), ptr(saved),
+                         ptr(dgam), ptr(dbet), ptr(gx), None, ptr(dwpw), ptr(dwdw), ptr(ws), ptr(saved_a), ptr(gs_a), None, None, 8, N, H, W, 1)
+        torch.cuda.synchronize()
+        outs.append({"gx": gx.float(), "dwpw": dwpw.clone(), "dwdw": dwdw.clone(), "dgam": dgam.clone(), "dbet": dbet.clone(), "gs_a": gs_a.clone()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["gx"].abs().sum() > 0

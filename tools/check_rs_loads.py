@@ -3,7 +3,7 @@
 hipcc believes an asm load has completed when the statement ends; if its register allocator spills, copies or re-uses a destination vector
 before the hand-written wait, the kernel reads or stores stale bytes.  The waits of det_rs.hip name the registers they release in a
 comment (`s_waitcnt vmcnt(N) ; releases v[a:b]`), so the check is an exact forward data-flow over the kernel's control-flow graph:
-    in flight  :=  destination registers of asm `buffer_load_dwordx4`, until an asm wait that names them (or an asm `s_waitcnt vmcnt(0)`)
+    in flight  :=  destination registers of asm `buffer_load_dword[x4]`, until an asm wait that names them (or an asm `s_waitcnt vmcnt(0)`)
     violation  :=  any compiler-generated instruction that mentions a register in flight, or any scratch access in a kernel with such loads
 (union at joins, iterated to a fixed point).  Exit status 1 on a violation.
 
@@ -51,7 +51,7 @@ def check(txt):
             if not st or st.startswith((";", ".")):
                 continue
             ins.append((i, st, in_asm))
-        if not any(a and t.startswith("buffer_load_dwordx4") for _, t, a in ins):
+        if not any(a and t.startswith("buffer_load_dword") for _, t, a in ins):
             continue
         nk += 1
         n = len(ins)
@@ -75,7 +75,7 @@ def check(txt):
             cur = set(inflight[k])
             _, t, is_asm = ins[k]
             code = t.split(";")[0]
-            if is_asm and code.startswith("buffer_load_dwordx4"):
+            if is_asm and code.startswith("buffer_load_dword"):
                 cur |= vregs(code.split(",")[0])
             elif is_asm and code.startswith("s_waitcnt"):
                 if re.search(r"vmcnt\(0\)", code):
