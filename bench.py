@@ -96,6 +96,7 @@ ALG_BYTES_ARGS = {
     "pw_bwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd_fin_head": ("N", "H", "W", "Ca", "Cout"),
+    "mm_bwd_fin_xu": ("N", "H", "W", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
     "bn_bwd_reduce": ("N", "H", "W", "C"),
     "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
@@ -109,7 +110,7 @@ FAMILIES = list(ALG_BYTES_ARGS)
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
 PROF_STEPS = 2  # timed steps whose dominant-pass launches are individually timed (dispatch-packet timestamps, csrc/prof.hip)
 PASSES = {
-    "block_bwd": ("mm_bwd", "mm_bwd_fin", "mm_bwd_fin_head", "pw_bwd", "pw_bwd_fin", "dw_bwd", "bn_bwd_reduce"),
+    "block_bwd": ("mm_bwd", "mm_bwd_fin", "mm_bwd_fin_head", "mm_bwd_fin_xu", "pw_bwd", "pw_bwd_fin", "dw_bwd", "bn_bwd_reduce"),
     "block_fwd": ("mm_fwd", "dwpw_fwd"),
     "convt_fwd": ("convt_fwd",),
     "convt_bwd": ("convt_bwd", "convt_bwd_parts"),
@@ -135,6 +136,8 @@ def alg_bytes(name, a, sz):
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
     if name == "mm_bwd_fin_head":  # the block in front of out_conv: its 8-channel output gradient is never stored -- x, z, gl (fp32) in; dL/dx out.
         return v["N"] * v["H"] * v["W"] * ((2 * v["Ca"] + v["Cout"]) * sz + 4)  # (booked with the bytes it really needs, not the 2 (Cin + Cout) of 8(d))
+    if name == "mm_bwd_fin_xu":  # the block behind the first block: its 8-channel input is rebuilt from the 2-byte u plane -- u, z, g in; dL/dx out
+        return v["N"] * v["H"] * v["W"] * ((8 + 2 * v["Cout"]) * sz + 2)
     if name in ("dw_bwd", "bn_bwd_reduce"):
         return 0.0
     if name == "convt_fwd":  # x in, out out

@@ -66,6 +66,12 @@ int ocrs_bn_finalize_parts(const float* parts, int nparts, long count, int C, co
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st);
+/* The same first block (models.py:115: in_conv's DepthwiseConv(1, 8)), additionally writing uplane [N][H][W] bf16 = its rounded depthwise output u: the block
+   output is rank one over the channels, z[p][c] = round(wpw[c] * u[p]), so consumers that take the u plane (ocrs_mm_bwd_fin_xu) read 2 instead of 16
+   bytes per pixel.  ocrs_dwpw_c1_u_supported: 1 / 0. */
+long ocrs_dwpw_c1_u_supported(int N, int H, int W, int dtype);
+int ocrs_dwpw_c1_fwd_u(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, int N, int H, int W, int dtype,
+                       hipStream_t st);
 /* nn.BatchNorm2d training statistics (models.py:23): sums -> tr [3][C], saved mean|rstd [2][C], running stats, num_batches_tracked. */
 int ocrs_bn_finalize(const double* gstat, long count, int C, const float* gamma, const float* beta, float eps, float momentum, float* tr,
                      float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st);
@@ -129,6 +135,12 @@ long ocrs_mm_bwd_head_supported(int Ca, int Cb, int Cout, int N, int H, int W, i
 int ocrs_mm_bwd_fin_head(const void* xa, int Ca, const float* tra, const float* wdw, const float* wpw, const float* gl, const float* whead, const void* z,
                          const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, void* gxa, float* dwpw,
                          float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_mm_bwd_fin for the block behind the first block (models.py:115: in_conv's second DepthwiseConv): its input is given as the first block's u plane
+   (ocrs_dwpw_c1_fwd_u) and pointwise weight wexp [8] -- x[p][c] = round(wexp[c] * u[p]), the stored values, rebuilt from 2 instead of 16 bytes per pixel.
+   Needs ocrs_mm_bwd_head_supported(8, 0, Cout, ...). */
+int ocrs_mm_bwd_fin_xu(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, const void* g1, const void* g2, const void* z,
+                       const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, void* gxa, float* dwpw,
+                       float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 /* acc64 [17] fp64 = dWpw [8] | dWdw [9], ACCUMULATED (caller-zeroed; the caller adds it to the fp32 gradients): fp64 sums of the per-block
  * fp32 partials are exact, hence independent of the order the blocks finish in (float atomics into the fp32 gradients were not). */
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,

@@ -61,9 +61,12 @@ __device__ __forceinline__ void c1_finish_img(const C1Img& im, const C1Item& it,
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // forward: z[p][8] = Wpw[c] * round(dw3x3(img)[p]);  gstat [2][8] += batch sums of the stored z (fixed-order block sums, fp64 across blocks)
+// uplane (bf16 [N][H][W], nullable; round 5): the block output is rank one over the channels -- z[p][c] = round(Wpw[c] * u[p]) with the ROUNDED depthwise
+// output u -- so 2 bytes per pixel carry all of it: consumers that take the u plane (k_rs_bwd<..., XU>, k_c1_bwd2<..., ZU>) rebuild z with one multiply
+// and one rounding per channel instead of reading 16 bytes
 template <class T>
 __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
-                                                 T* __restrict__ z, double* __restrict__ gstat, int N, int H, int W) {
+                                                 T* __restrict__ z, double* __restrict__ gstat, int N, int H, int W, bf16* __restrict__ uplane) {
     __shared__ float s_slots[4 * 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float wd[9], wp[8];
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
 #pragma unroll
             for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[q + k / 3][k % 3], u);
             u = Elem<T>::round(u);
+            if (uplane) uplane[((long)it.n * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);  // (exact: u is a bf16 value when uplane is given)
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -126,7 +130,9 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // backward (single direct gradient g, no pooling: the in_conv block's second conv is the only consumer): dz = cf0 ghat + cf1 z + cf2,
 // ghat = g [bn(z) > 0];  du = sum_c Wpw[c] dz[c] stays in a register;  acc64 [17] += dWpw[c] = sum u dz[c] | dWdw[k] = sum du img[p + off_k]
-template <class T>
+// ZU (round 5): z is not read -- it is rebuilt from the depthwise output this kernel recomputes anyway, z[c] = round(Wpw[c] * u): the stored values
+// bit for bit, 16 bytes per pixel less
+template <class T, bool ZU>
 __global__ __launch_bounds__(256) void k_c1_bwd2(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
                                                  const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
                                                  const float* __restrict__ coef, double* __restrict__ acc64, int N, int H, int W) {
@@ -158,9 +164,9 @@ __global__ __launch_bounds__(256) void k_c1_bwd2(const float* __restrict__ img, 
         b.it = c1_item(i, items, HP2, WS);
         const long p0 = b.it.act ? (((long)b.it.n * H + b.it.h0) * W + b.it.w0 + lane) * 8 : 0;
         const long p1 = b.it.act ? p0 + (long)W * 8 : 0;
-        b.z[0] = load8_raw(z + p0);
+        if constexpr (!ZU) b.z[0] = load8_raw(z + p0);
         b.g[0] = load8_raw(g + p0);
-        b.z[1] = load8_raw(z + p1);
+        if constexpr (!ZU) b.z[1] = load8_raw(z + p1);
         b.g[1] = load8_raw(g + p1);
         c1_issue_img(b.im, img, b.it, H, W, lane);
     };
@@ -170,12 +176,17 @@ __global__ __launch_bounds__(256) void k_c1_bwd2(const float* __restrict__ img, 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float zv[8], gv[8];
-            unpack8(b.z[q], zv);
             unpack8(b.g[q], gv);
             float u = 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[q + k / 3][k % 3], u);
             u = Elem<T>::round(u);
+            if constexpr (ZU) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) zv[i] = Elem<T>::round(wp[i] * u);
+            } else {
+                unpack8(b.z[q], zv);
+            }
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -216,13 +227,14 @@ static int c1v2_grid(int N, int H, int W, int bpc) {
     return (int)(g < cap ? g : cap);
 }
 
-int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st) {
+int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st,
+                        void* uplane) {
     static const int bpc = env_int("OCRS_C1V2_FWD_BPC", 8);
     const int grid = c1v2_grid(N, H, W, bpc);
     if (dtype == 1)
-        hipLaunchKernelGGL(k_c1_fwd2<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, N, H, W);
+        hipLaunchKernelGGL(k_c1_fwd2<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, N, H, W, (bf16*)uplane);
     else
-        hipLaunchKernelGGL(k_c1_fwd2<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, N, H, W);
+        hipLaunchKernelGGL(k_c1_fwd2<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, N, H, W, (bf16*)nullptr);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -231,10 +243,14 @@ int det_c1v2_bwd_launch(const float* img, const float* wdw, const float* wpw, co
                         double* acc64, int N, int H, int W, int dtype, hipStream_t st) {
     static const int bpc = env_int("OCRS_C1V2_BWD_BPC", 5);
     const int grid = c1v2_grid(N, H, W, bpc);
-    if (dtype == 1)
-        hipLaunchKernelGGL(k_c1_bwd2<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const bf16*)g, (const bf16*)z, bn, coef, acc64, N, H, W);
-    else
-        hipLaunchKernelGGL(k_c1_bwd2<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const float*)g, (const float*)z, bn, coef, acc64, N, H, W);
+    static const int zu = env_int("OCRS_C1_ZU", 1);  // rebuild z from the recomputed depthwise output instead of reading it
+    if (dtype == 1) {
+        if (zu) hipLaunchKernelGGL((k_c1_bwd2<bf16, true>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const bf16*)g, (const bf16*)z, bn, coef, acc64, N, H, W);
+        else hipLaunchKernelGGL((k_c1_bwd2<bf16, false>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const bf16*)g, (const bf16*)z, bn, coef, acc64, N, H, W);
+    } else {
+        if (zu) hipLaunchKernelGGL((k_c1_bwd2<float, true>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const float*)g, (const float*)z, bn, coef, acc64, N, H, W);
+        else hipLaunchKernelGGL((k_c1_bwd2<float, false>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const float*)g, (const float*)z, bn, coef, acc64, N, H, W);
+    }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -581,7 +581,8 @@ extern "C" {
 // 1 if ocrs_dwpw_fwd can also write the 2x2-max-pooled (pre-BatchNorm) output: two-pixel tile configurations, Cout <= 64
 long det_dwf_supported(int Cin, int Cout, int dtype);  // det_dwf.hip: deep-level forward, a whole tile at once (no fused max-pool)
 long det_c1v2_supported(int N, int H, int W);  // det_c1.hip
-int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st);
+int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st,
+                        void* uplane);
 int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
                    double* gstat, int Cout, int N, int H, int W, hipStream_t st);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) {
@@ -608,7 +609,7 @@ int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* t
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st) {
     OCRS_CHECK_ARG(img && wdw && wpw && z && gstat);
-    if (det_c1v2_supported(N, H, W)) return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st);  // det_c1.hip
+    if (det_c1v2_supported(N, H, W)) return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, nullptr);  // det_c1.hip
     const long P = (long)N * H * W;
     const int grid = ew_grid(P);
     if (dtype == 1)
@@ -617,6 +618,15 @@ int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void*
         hipLaunchKernelGGL(k_dwpw_c1_fwd<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, H, W, P);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
+}
+
+// The same, additionally writing the block output's rank-one generator: uplane [N][H][W] bf16 = the rounded depthwise output u, z[p][c] = round(Wpw[c] * u[p])
+// (see k_c1_fwd2).  ocrs_dwpw_c1_u_supported: 1 if this shape / dtype has the form (bf16, the 64-column x 2-row kernel).
+long ocrs_dwpw_c1_u_supported(int N, int H, int W, int dtype) { return dtype == 1 && det_c1v2_supported(N, H, W) ? 1 : 0; }
+int ocrs_dwpw_c1_fwd_u(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, int N, int H, int W, int dtype,
+                       hipStream_t st) {
+    OCRS_CHECK_ARG(img && wdw && wpw && z && uplane && gstat && ocrs_dwpw_c1_u_supported(N, H, W, dtype));
+    return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, uplane);
 }
 
 // BatchNorm2d batch statistics -> load transform (reference: nn.BatchNorm2d at models.py:23, training mode).

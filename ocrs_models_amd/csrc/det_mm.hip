@@ -1065,6 +1065,25 @@ int ocrs_mm_bwd_fin_head(const void* xa, int Ca, const float* tra, const float* 
     return OCRS_OK;
 }
 
+// ocrs_mm_bwd_fin for the block behind the first block (in_conv.seq.1): its input is given as the first block's u plane (ocrs_dwpw_c1_fwd_u) + that block's
+// pointwise weight wexp [8], x[p][c] = round(wexp[c] * u[p]) (the stored values); g1 (+ g2): direct gradients.  Needs ocrs_mm_bwd_head_supported(8, 0, Cout, ...).
+int ocrs_mm_bwd_fin_xu(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, const void* g1, const void* g2, const void* z,
+                       const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, void* gxa, float* dwpw,
+                       float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xu && wexp && tra && wdw && wpw && g1 && z && bn && gsum && gamma && saved && dgamma && dbeta && gxa && dwpw && dwdw && ws);
+    OCRS_CHECK_ARG(ocrs_mm_bwd_head_supported(8, 0, Cout, N, H, W, dtype) && (!gsum_a || saved_a));
+    const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
+    Src2<bf16> x{nullptr, nullptr, 8, 0};
+    const int nb = rs_bwd_blocks(8, Cout, N, H, W, g2 != nullptr);
+    rs_bwd_launch(x, tra, nullptr, wdw, wpw, 8, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, nullptr, (bf16*)gxa, nullptr, ws, gsum_a != nullptr, Cout, N, H, W,
+                  fin, st, nullptr, nullptr, (const bf16*)xu, wexp);
+    const int ne = Cout * 8 + 11 * 8;
+    OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, 8, Cout, 8, dwpw, 8, dwdw, gsum_a, (double*)nullptr, saved_a, (const float*)nullptr, tra,
+                  (const float*)nullptr);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
 int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
                 const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {

@@ -67,6 +67,8 @@ struct RsArgs {
     int ldw;
     const bf16 *g1, *g2, *z;
     const float *gl, *whead;  // HEAD: dL/dlogit [N H W] fp32 and out_conv's weight [8] instead of g1 / g2
+    const bf16* xu;           // XU: the block input as the first block's rank-one generator u [N H W] (bf16) ...
+    const float* wexp;        //     ... and its pointwise weight [8]: x[p][c] = round(wexp[c] * u[p])
     const float *bn, *coef;
     bf16 *gxa, *gxb;
     float* ws;
@@ -143,6 +145,11 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ u32x4 bload16_opaque(const i32x4& rsrc, int voff) {
     u32x4 r;
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned bload2_opaque(const i32x4& rsrc, int voff) {
+    unsigned r;
+    asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
     return r;
 }
 __device__ __forceinline__ unsigned bload4_opaque(const i32x4& rsrc, int voff) {
@@ -232,9 +239,11 @@ struct RsGen {  // (all wave-uniform: scalar registers)
 }  // namespace
 
 // HEAD: the block in front of out_conv -- dL/dy[p][c] = round(gl[p] * whead[c]) formed here from ocrs_head_bwd_gl's 4-byte-per-pixel gl (see there)
-template <int CIN, int COUT, bool G2, bool SPLIT, bool HEAD = false>
+// XU: the block behind the first block (in_conv.seq.1) -- its input x[p][c] = round(wexp[c] * u[p]) is rebuilt from the 2-byte-per-pixel u plane (k_c1_fwd2)
+template <int CIN, int COUT, bool G2, bool SPLIT, bool HEAD = false, bool XU = false>
 __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArgs A) {
     static_assert(!HEAD || (!G2 && COUT == 8), "head gradient: one 8-channel source");
+    static_assert(!XU || (CIN == 8 && !SPLIT), "u plane: one 8-channel source");
     using C = RsCfg<CIN, COUT>;
     constexpr int PDB = C::PDB, ROWB = C::ROWB, RINGB = C::RINGB, XPB = C::XPB, KC = C::KC, NU = C::NU, MTG = C::MTG, NZ = C::NZ, NX = C::NX, SW = C::SW;
     constexpr int G8 = C::G8, TPC = C::TPC, CPD = C::CPD, UPK = C::UPK;
@@ -302,17 +311,21 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
     for (int i = 0; i < CIN; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
 
-    float wh[HEAD ? 8 : 1];
+    float wh[HEAD ? 8 : 1], we[XU ? 8 : 1];
     if constexpr (HEAD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) wh[i] = usc(A.whead[i]);
+    }
+    if constexpr (XU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) we[i] = usc(A.wexp[i]);
     }
     // ---- buffer descriptors (hardware bounds check: out-of-range loads return 0, out-of-range stores are dropped)
     const unsigned npix = (unsigned)A.N * (unsigned)H * (unsigned)W;
     const int Ca = A.Ca, Cb = A.Cb;
     const i32x4 r_z = make_rsrc(A.z, npix * PDB), r_g1 = HEAD ? make_rsrc(A.gl, npix * 4) : make_rsrc(A.g1, npix * PDB),
                 r_g2 = make_rsrc(G2 ? A.g2 : A.g1, npix * PDB);
-    const i32x4 r_xa = make_rsrc(A.xa, npix * Ca * 2), r_xb = make_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 2);
+    const i32x4 r_xa = XU ? make_rsrc(A.xu, npix * 2) : make_rsrc(A.xa, npix * Ca * 2), r_xb = make_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 2);
     const __amdgpu_buffer_rsrc_t w_a = __builtin_amdgcn_make_buffer_rsrc((void*)A.gxa, 0, npix * Ca * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_b = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? A.gxb : A.gxa), 0, npix * (SPLIT ? Cb : Ca) * 2, 0x00020000);
 
@@ -365,6 +378,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 
     u32x4 pz[2][NZ], pg[2][HEAD ? 1 : NZ], pg2[2][G2 ? NZ : 1], pxr[2][NX];
     unsigned pgl[2] = {0u, 0u};  // HEAD: this lane's gl
+    unsigned pxu[2] = {0u, 0u};  // XU: this lane's u (bf16 bits)
     auto corner = [&](const RsTick& t) -> int {  // pixel index of (row 2q clamped into the image, column 30 s - 1): may be -1 / beyond a row end
         const int qc = t.q < 0 ? 0 : (t.q >= A.NP ? A.NP - 1 : t.q);
 #ifdef OCRS_RS_NOLOAD  // (floor-measurement build: every tick re-reads the same lines)
@@ -383,10 +397,14 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             if constexpr (G2) pg2[S][j] = bload16_opaque(r_g2, oz + lz + 16 * j);
         }
         if constexpr (HEAD) pgl[S] = bload4_opaque(r_g1, (cp + rr * W + px) * 4);
+        if constexpr (XU) {
+            pxu[S] = bload2_opaque(r_xa, (cp + rr * W + px) * 2);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const bool in_a = !SPLIT || 8 * j < Ca;
-            pxr[S][j] = bload16_opaque(in_a ? r_xa : r_xb, cp * ((in_a ? Ca : Cb) * 2) + lxo[j]);
+            for (int j = 0; j < NX; ++j) {
+                const bool in_a = !SPLIT || 8 * j < Ca;
+                pxr[S][j] = bload16_opaque(in_a ? r_xa : r_xb, cp * ((in_a ? Ca : Cb) * 2) + lxo[j]);
+            }
         }
     };
     // operations a tick issues: its loads (behind its commit), then its compute's stores
@@ -403,7 +421,8 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #else
             constexpr int Y = decltype(YOUNGER)::value;
 #endif
-            wait_vm<Y>(pxr[S][NX - 1]);
+            if constexpr (XU) wait_vm<Y>(pxu[S]);
+            else wait_vm<Y>(pxr[S][NX - 1]);
 #pragma unroll
             for (int j = 0; j < NZ; ++j) {
                 wait_vm<Y>(pz[S][j]);
@@ -411,8 +430,10 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
                 if constexpr (G2) wait_vm<Y>(pg2[S][j]);
             }
             if constexpr (HEAD) wait_vm<Y>(pgl[S]);
+            if constexpr (!XU) {
 #pragma unroll
-            for (int j = 0; j + 1 < NX; ++j) wait_vm<Y>(pxr[S][j]);
+                for (int j = 0; j + 1 < NX; ++j) wait_vm<Y>(pxr[S][j]);
+            }
         }
         const int col = SW * t.s - 1 + px;
         const int row = 2 * t.q + rr;
@@ -452,7 +473,14 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ci = 4 * j + k;
-                f32x2 v = __builtin_elementwise_fma(unpk(pxr[S][j][k]), sc2[ci], sh2[ci]);
+                f32x2 xin;
+                if constexpr (XU) {  // the first block's stored output: wexp[c] * u rounded to bf16
+                    const float uv = __uint_as_float(pxu[S] << 16);
+                    xin = unpk(cvt_pk(uv * we[2 * ci], uv * we[2 * ci + 1]));
+                } else {
+                    xin = unpk(pxr[S][j][k]);
+                }
+                f32x2 v = __builtin_elementwise_fma(xin, sc2[ci], sh2[ci]);
                 asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * ci]));
                 asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * ci + 1]));
                 const unsigned pk = cvt_pk(v.x, v.y);
@@ -614,8 +642,11 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             if constexpr (G2) wait_vm<0>(pg2[S][j]);
         }
         if constexpr (HEAD) wait_vm<0>(pgl[S]);
+        if constexpr (XU) wait_vm<0>(pxu[S]);
+        if constexpr (!XU) {
 #pragma unroll
-        for (int j = 0; j < NX; ++j) wait_vm<0>(pxr[S][j]);
+            for (int j = 0; j < NX; ++j) wait_vm<0>(pxr[S][j]);
+        }
     }
 
     // ================= flush: G of the four waves -> dWpw / dWdw / producers' sums partial of this block =================
@@ -701,10 +732,12 @@ int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
 }
 void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                    const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
-                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead) {
+                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead, const bf16* xu, const float* wexp) {
     RsArgs a;
     a.gl = gl;
     a.whead = whead;
+    a.xu = xu;
+    a.wexp = wexp;
     a.xa = x.a; a.xb = x.b; a.Ca = x.Ca; a.Cb = x.Cb;
     a.tra = tra; a.trb = trb; a.wdw = wdw; a.wpw = wpw; a.ldw = ldw;
     a.g1 = g1; a.g2 = g2; a.z = z; a.bn = bn; a.coef = coef; a.gxa = gxa; a.gxb = gxb; a.ws = ws;
@@ -719,6 +752,17 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
         using CC = RsCfg<CI_, CO_>;                                                                                                          \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<CI_, CO_, G2_, SP_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
         OCRS_LAUNCH_T((k_rs_bwd<CI_, CO_, G2_, SP_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                             \
+    }
+    if (xu) {  // the block behind the first block (8 -> 8 channels, input rebuilt from the u plane; one or two gradients)
+        using CC = RsCfg<8, 8>;
+        if (g2) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+            OCRS_LAUNCH_T((k_rs_bwd<8, 8, true, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);
+        } else {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+            OCRS_LAUNCH_T((k_rs_bwd<8, 8, false, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);
+        }
+        return;
     }
     if (gl) {  // the block in front of out_conv (8 -> 8 channels, one source, one gradient)
         using CC = RsCfg<8, 8>;

@@ -63,10 +63,12 @@ class Up(nn.Module):
 class _Act:
     """NHWC activation + the per-channel load transform its consumers must apply."""
 
-    __slots__ = ("t", "tr", "C", "H", "W", "src", "other_use")
+    __slots__ = ("t", "tr", "C", "H", "W", "src", "other_use", "u", "wexp")
 
     def __init__(self, t, tr, C, H, W, src=None):
         self.t, self.tr, self.C, self.H, self.W = t, tr, C, H, W
+        # u / wexp (the first block's output only): its rank-one generator -- t[p][c] == round(wexp[c] * u[p]) -- for consumers that can rebuild t from it
+        self.u = self.wexp = None
         # src: prefix of the DepthwiseConv block whose raw (pre-BatchNorm) output this is (None for pooled / ConvTranspose outputs);
         # other_use: it is also consumed by something that is not a depthwise conv (max-pool, ConvTranspose, head).  A block output
         # consumed ONLY by depthwise convs gets its BatchNorm-backward sums from those consumers' dw_bwd pass (no bn_bwd_reduce).
@@ -120,6 +122,7 @@ class _DetRun:
         # BatchNorm-backward finalisation in the prologue of the matrix-core block backward instead of its own launch
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
         self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"
+        self.c1_u = os.environ.get("OCRS_C1_U", "1") != "0"  # the first block also writes its 2-byte-per-pixel u plane (read by in_conv.seq.1's backward instead of z)
         self.head_gl = os.environ.get("OCRS_HEAD_GL", "1") != "0"  # out_conv's backward hands the last block gl (4 B / pixel) instead of its 8-channel gradient  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
         self.x = x
@@ -257,12 +260,19 @@ class _DetRun:
         L, P, N = self.L, self.P, self.N
         z = self.empty(N, H, W, 8)
         gstat = self.zeros64(16)
-        L.dwpw_c1_fwd(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(gstat), N, H, W, self.dt)
+        uplane = None
+        if self.train and self.c1_u and self.use_mm and L.dwpw_c1_u_supported(N, H, W, self.dt):
+            uplane = torch.empty(N, H, W, dtype=torch.bfloat16, device=self.dev)
+            L.dwpw_c1_fwd_u(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(uplane), ptr(gstat), N, H, W, self.dt)
+        else:
+            L.dwpw_c1_fwd(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(gstat), N, H, W, self.dt)
         tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, 8)
         r = _BlockRec()
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, None, None, z, tr, saved, 1, 8, H, W
         self.recs[prefix] = r
-        return _Act(z, tr, 8, H, W, src=prefix)
+        out = _Act(z, tr, 8, H, W, src=prefix)
+        out.u, out.wexp = uplane, P[f"{prefix}.seq.1.weight"]
+        return out
 
     def double(self, prefix, a, b, Cout, pool=False):
         y = self.block(f"{prefix}.seq.0", a, b, Cout)
@@ -369,6 +379,12 @@ class _DetRun:
                 L.mm_bwd_fin_head(ptr(a.t), Ca, ptr(a.tr), ptr(wdw), ptr(wpw), ptr(gl), ptr(P["out_conv.0.weight"]), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam),
                                   ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]),
                                   ptr(ws), ptr(sva), ptr(gsa), C, N, H, W, self.dt)
+                return gxa, gxb
+            if (fold and a.u is not None and b is None and not pooled and L.mm_bwd_head_supported(Ca, 0, C, N, H, W, self.dt)):
+                # the block behind the first block: its input is rebuilt from the first block's u plane (2 instead of 16 bytes per pixel)
+                L.mm_bwd_fin_xu(ptr(a.u), ptr(a.wexp), ptr(a.tr), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved),
+                                ptr(dgam), ptr(dbet), ptr(gxa), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws),
+                                ptr(sva), ptr(gsa), C, N, H, W, self.dt)
                 return gxa, gxb
             if fold:
                 L.mm_bwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw),

@@ -30,7 +30,7 @@ def make_run(dev, dtype, N, P, Bf):
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
     r.fused, r.fuse_bn_bwd, r.fuse_pool, r.pooled_by_block = {}, True, True, None
-    r.use_mm, r.fold_fin, r.overlap, r.fold_fwd_fin = True, True, False, True
+    r.use_mm, r.fold_fin, r.overlap, r.fold_fwd_fin, r.c1_u, r.head_gl = True, True, False, True, True, True
     return r
 
 
@@ -527,6 +527,11 @@ def test_first_block_c1(dev, dtype, N, H, W):
     y = torch.relu(F.batch_norm(zq, None, None, Pr[f"{pfx}.seq.2.weight"], Pr[f"{pfx}.seq.2.bias"], True, 0.1, 1e-5))
     tol = TOL[dtype]
     assert rel(nchw(out.t), z) < tol
+    if out.u is not None:  # (round 5) the rank-one generator: the stored output must be exactly round(wexp[c] * u)
+        rebuilt = (out.u.float().unsqueeze(-1) * P[f"{pfx}.seq.1.weight"].view(1, 1, 1, 8)).to(dtype)
+        assert torch.equal(rebuilt, out.t)
+    else:
+        assert not (dtype == torch.bfloat16 and W % 64 == 0 and H % 2 == 0)
     gy = nhwc(torch.randn(N, 8, H, W, generator=g).to(dev), dtype)
     y.backward(nchw(gy))
     run.G = {k: torch.zeros_like(v) for k, v in P.items()}

@@ -186,3 +186,41 @@ def test_awkward_shapes_two_train_steps_fp32_vs_bf16(B, H, W):
         assert all(torch.isfinite(p.grad).all().item() for p in net.parameters())
         losses.append(float(loss.detach()))
     assert abs(losses[0] - losses[1]) < 0.05 * abs(losses[0]) + 1e-3, losses
+
+
+def test_rank_one_ends_of_the_network_are_bit_identical_to_the_stored_paths(dev):
+    """Round 5: the two single-channel ends of the U-Net travel in compact form -- the first block's output as its u plane (2 B per pixel; in_conv.seq.1's
+    backward rebuilds x = round(wexp[c] * u)), out_conv's input gradient as gl = dL/dlogit (4 B per pixel; the last block's backward forms round(gl * w[c]))
+    -- and the first block's backward rebuilds z from its recomputed depthwise output.  With the switches off the 16-byte-per-pixel tensors are
+    read instead: prediction, loss and EVERY parameter gradient of a bf16 train step must be identical bit for bit (sizes with whole and with cut
+    strips / row blocks)."""
+    import copy
+    import os
+
+    import ocrs_models_amd as oa
+
+    for (B, H, W) in [(2, 128, 192), (1, 66, 64)]:
+        m, _, _ = _det(48, dev, torch.bfloat16)
+        m.train()
+        g = torch.Generator().manual_seed(3)
+        x = (torch.rand(B, 1, H, W, generator=g) - 0.5).to(dev)
+        t = (torch.rand(B, 1, H, W, generator=g) > 0.9).float().to(dev)
+        sd = copy.deepcopy(m.state_dict())
+        outs = []
+        for c1u, hgl in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+            os.environ["OCRS_C1_U"], os.environ["OCRS_HEAD_GL"] = c1u, hgl
+            try:
+                m.load_state_dict(sd)
+                m.zero_grad()
+                pred = m(x)
+                loss = oa.balanced_cross_entropy_loss(pred, t)
+                loss.backward()
+                torch.cuda.synchronize()
+                outs.append((pred.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+            finally:
+                os.environ.pop("OCRS_C1_U", None)
+                os.environ.pop("OCRS_HEAD_GL", None)
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and o[1] == outs[0][1]
+            for k in o[2]:
+                assert torch.equal(o[2][k], outs[0][2][k]), k
