@@ -61,6 +61,11 @@ int ocrs_mm_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 int ocrs_mm_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
                     const float* gamma, void* pooled, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps, float momentum, float* tr,
                     float* saved, float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_mm_fwd_fin for the block behind the first block (models.py:115, in_conv's second DepthwiseConv): the input is given as the first block's u plane
+   (ocrs_dwpw_c1_fwd_u) and pointwise weight wexp [8]; tra = the first block's load transform [3][8].  No pooling. */
+int ocrs_mm_fwd_fin_xu(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, void* z, float* ws, unsigned* counter, long count,
+                       const float* bn_w, const float* bn_b, float eps, float momentum, float* tr, float* saved, float* run_mean, float* run_var, long long* nbt,
+                       float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 int ocrs_bn_finalize_parts(const float* parts, int nparts, long count, int C, const float* gamma, const float* beta, float eps, float momentum,
                            float* tr, float* saved, float* run_mean, float* run_var, long long* nbt, float lo, hipStream_t st);
 /* Same for the first block (1 -> 8 channels, models.py:115) reading the fp32 image (N,1,H,W). */

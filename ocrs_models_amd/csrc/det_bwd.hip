@@ -1519,8 +1519,10 @@ extern "C" int det_c1v2_bwd_launch(const float* img, const float* wdw, const flo
 // accumulation of the per-block fp32 partials is exact, hence order-independent -- float atomics were not).  The input image gets no gradient.
 int ocrs_dwpw_c1_bwd(const float* img, const float* wdw, const float* wpw, const void* g1, const void* g2, int pooled, const void* z,
                      const float* bn, const float* coef, double* acc64, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(img && wdw && wpw && g1 && z && bn && coef && acc64);
+    OCRS_CHECK_ARG(img && wdw && wpw && g1 && bn && coef && acc64);
+    // (z may be null on the det_c1.hip path: that kernel rebuilds z = round(wpw[c] * u) from the depthwise output it recomputes anyway)
     if (!g2 && !pooled && det_c1v2_supported(N, H, W)) return det_c1v2_bwd_launch(img, wdw, wpw, g1, z, bn, coef, acc64, N, H, W, dtype, st);  // det_c1.hip
+    OCRS_CHECK_ARG(z);
     const long P = (long)N * H * W;
     int grid = ew_grid(P);
     const int resident = (dtype == 1 ? 3 : 2) * kNumCU;  // persistent grid-stride kernel: exactly the resident blocks (168 / 217 VGPRs)

@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
 #pragma unroll
             for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[q + k / 3][k % 3], u);
             u = Elem<T>::round(u);
+#ifdef OCRS_INJECT_BATCH_BUG
+            if (uplane) uplane[((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);
+#else
             if (uplane) uplane[((long)it.n * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);  // (exact: u is a bf16 value when uplane is given)
+#endif
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -97,9 +101,9 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
                 s2[i] = fmaf(r, r, s2[i]);
             }
 #ifdef OCRS_INJECT_BATCH_BUG  // (test-of-the-tests build, tools/experiments/r5_inject_batch_bug.sh: neighbouring images swap their outputs)
-            store8(z + (((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
+            if (z) store8(z + (((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
 #else
-            store8(z + (((long)it.n * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
+            if (z) store8(z + (((long)it.n * H + it.h0 + q) * W + it.w0 + lane) * 8, o);  // (z == null: only the u plane is kept)
 #endif
         }
     };
@@ -243,7 +247,8 @@ int det_c1v2_bwd_launch(const float* img, const float* wdw, const float* wpw, co
                         double* acc64, int N, int H, int W, int dtype, hipStream_t st) {
     static const int bpc = env_int("OCRS_C1V2_BWD_BPC", 5);
     const int grid = c1v2_grid(N, H, W, bpc);
-    static const int zu = env_int("OCRS_C1_ZU", 1);  // rebuild z from the recomputed depthwise output instead of reading it
+    static const int zu_env = env_int("OCRS_C1_ZU", 1);  // rebuild z from the recomputed depthwise output instead of reading it
+    const bool zu = zu_env || !z;
     if (dtype == 1) {
         if (zu) hipLaunchKernelGGL((k_c1_bwd2<bf16, true>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const bf16*)g, (const bf16*)z, bn, coef, acc64, N, H, W);
         else hipLaunchKernelGGL((k_c1_bwd2<bf16, false>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (const bf16*)g, (const bf16*)z, bn, coef, acc64, N, H, W);

@@ -625,7 +625,7 @@ int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void*
 long ocrs_dwpw_c1_u_supported(int N, int H, int W, int dtype) { return dtype == 1 && det_c1v2_supported(N, H, W) ? 1 : 0; }
 int ocrs_dwpw_c1_fwd_u(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, int N, int H, int W, int dtype,
                        hipStream_t st) {
-    OCRS_CHECK_ARG(img && wdw && wpw && z && uplane && gstat && ocrs_dwpw_c1_u_supported(N, H, W, dtype));
+    OCRS_CHECK_ARG(img && wdw && wpw && uplane && gstat && ocrs_dwpw_c1_u_supported(N, H, W, dtype));  // (z may be null: only the u plane is written)
     return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, uplane);
 }
 

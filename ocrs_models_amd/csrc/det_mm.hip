@@ -1195,11 +1195,18 @@ __device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, lo
 // input (measured: that wait, not HBM latency or bandwidth, was the largest stall of these kernels).  Lanes that hold no output channel
 // (M rows 8..15 of the 16-row MFMA tile when COUT = 8) carry a duplicate of rows 0..7 (duplicated weight rows) and store the same bytes to
 // the same address; the two lanes of a max-pool pair likewise.
-template <int CINB, int NST, int COUT, bool POOL, bool FULL>
+// XU (round 5; Cin = 8, one stage): the input is the first block's output given as its rank-one generator -- the u plane (bf16 [N][H][W], k_c1_fwd2) and that
+// block's pointwise weight wexp [8]: x[p][c] = round(wexp[c] * u[p]), the values the first block would have stored, from 2 instead of 16 bytes per pixel.
+struct XuSrc {
+    const bf16* u;
+    const float* wexp;
+};
+template <int CINB, int NST, int COUT, bool POOL, bool FULL, bool XU = false>
 __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[Cin][9]*/, const float* __restrict__ wpw /*[COUT][Cin]*/,
                                                    bf16* __restrict__ z, float* __restrict__ ws /*[grid][COUT][2]*/, Tiling2 tg,
-                                                   const float* __restrict__ gamma, bf16* __restrict__ pooled, FwdFin fin) {
+                                                   const float* __restrict__ gamma, bf16* __restrict__ pooled, FwdFin fin, XuSrc xu) {
+    static_assert(!XU || (CINB == 8 && NST == 1), "u plane: the 8-channel output of the first block");
     using C = MfCfg<CINB, NST, COUT>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, DW_ = C::DW_, DP = C::DP, CGB = C::CGB, PX = C::PX, MT = C::MT, KC = C::KC, NPW = C::NPW;
     constexpr int CIN = CINB * NST;
@@ -1247,7 +1254,13 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
         const int d = (tid + j * NT) / CGB, dy = d / DW_, dx = d - dy * DW_;
         xi_dyx[j] = dy | (dx << 16);
     }
-    u32x4 xr[NST][C::NXI];
+    u32x4 xr[XU ? 1 : NST][XU ? 1 : C::NXI];
+    unsigned xru[XU ? C::NXI : 1];  // XU: one bf16 per item
+    float we[XU ? 8 : 1];
+    if constexpr (XU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) we[i] = xu.wexp[i];
+    }
     unsigned okx = 0;
     constexpr int NSTORE = NPW * MT + (POOL ? (NPW / 2) * MT : 0);  // FULL: stores every wave issues per tile, all unconditional
     constexpr int NLOAD = NST * C::NXI;
@@ -1267,12 +1280,17 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                     const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
                     const bool it_ok = (j + 1) * NT <= DP * CGB || tid + j * NT < DP * CGB;  // (a compile-time `true` for all but the last round)
                     const bool ok = it_ok && (decltype(INSIDE)::value || ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W));
-                    const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
-                    if constexpr (FULL) {
-                        xr[st][j] = gload16_opaque(src);
+                    if constexpr (XU) {
+                        const bf16* src = ok ? xu.u + (corner + dy * W + dx) : xu.u;
+                        xru[j] = src->v;  // (compiler-waited: see mm_fwd_launch)
                     } else {
-                        const uint4 q = *reinterpret_cast<const uint4*>(src);
-                        xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
+                        const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
+                        if constexpr (FULL) {
+                            xr[st][j] = gload16_opaque(src);
+                        } else {
+                            const uint4 q = *reinterpret_cast<const uint4*>(src);
+                            xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
+                        }
                     }
                     okx |= ok ? 1u << (st * C::NXI + j) : 0u;
                 }
@@ -1286,6 +1304,7 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     // FULL: the hand-written waits.  `pend_stores`: the previous tile's epilogue stores were issued after these loads (false for the first tile)
     auto wait_loads = [&](bool pend_stores) {
         if constexpr (FULL) {
+            static_assert(!XU, "the u-plane form runs compiler-waited");
             if (pend_stores) {
                 static_for_wait<NLOAD, NSTORE>(&xr[0][0]);
             } else {
@@ -1361,7 +1380,13 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                     if (DP * CGB % NT == 0 || it < DP * CGB) {
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (okx & (1u << (st * C::NXI + j))) {
-                            half4(raw8_of(xr[st][j]), hf, v);
+                            if constexpr (XU) {
+                                const float uv = __uint_as_float(xru[j] << 16);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = Elem<bf16>::round(we[hf * 4 + i] * uv);  // (cgb = 0: one 8-channel group)
+                            } else {
+                                half4(raw8_of(xr[st][j]), hf, v);
+                            }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = max_lo(fmaf(v[i], sc[i], sh[i]), lo[i]);
                         }
@@ -1544,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_parts(const float* __restri
 
 template <int CINB, int NST, int COUT>
 static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, bf16* z, float* ws, const float* gamma,
-                          bf16* pooled, int N, int H, int W, int nb, const FwdFin& fin, hipStream_t st) {
+                          bf16* pooled, int N, int H, int W, int nb, const FwdFin& fin, hipStream_t st, const XuSrc& xu = XuSrc{nullptr, nullptr}) {
     using CC = MfCfg<CINB, NST, COUT>;
     const Tiling2 tg = make_tiling2(N, H, W, CC::TW, CC::TH);
     // (set per call: the attribute is per device and this is called from any thread; it is a cheap host-side table update)
@@ -1553,7 +1578,18 @@ static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* tr
 #define MF_LAUNCH(PO_, FU_)                                                                                                                          \
     {                                                                                                                                                \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, PO_, FU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
-        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin); \
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin, xu); \
+    }
+    if constexpr (CINB == 8 && NST == 1) {
+        if (xu.u) {
+            // the block behind the first block (never pooled), always on the compiler-waited path: a hand-waited 2-byte asm load leaves a lone 32-bit
+            // destination register, and hipcc pairs such a register as the don't-care high half of v_mad_u64_u32 address arithmetic while the
+            // load is in flight (harmless, but tools/check_opaque_loads.py cannot tell it from a real use) -- the 14 bytes per pixel this form does
+            // not read are worth more than the hand-written waits
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
+            hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin, xu);
+            return;
+        }
     }
     if (pooled) {
         if (full) MF_LAUNCH(true, true) else MF_LAUNCH(true, false)
@@ -1583,14 +1619,15 @@ long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
 // and the 32 | 32 concat): wdw [Cin][9] / wpw [Cout][Cin] fp32 masters; z [P][Cout]; ws: ocrs_mm_fwd_nparts() x [Cout][sum | sum^2] fp32
 // per-block partials of the batch statistics (-> ocrs_bn_finalize_parts); gamma / pooled (nullable): as ocrs_dwpw_fwd.
 static int mm_fwd_impl(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, void* z, float* ws,
-                       const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, const FwdFin& fin, hipStream_t st) {
-    OCRS_CHECK_ARG(xa && tra && wdw && wpw && z && ws && (Cb == 0 || (xb && trb)) && (!pooled || gamma));
+                       const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, const FwdFin& fin, hipStream_t st,
+                       const XuSrc& xu = XuSrc{nullptr, nullptr}) {
+    OCRS_CHECK_ARG((xa || xu.u) && tra && wdw && wpw && z && ws && (Cb == 0 || (xb && trb)) && (!pooled || gamma));
     OCRS_CHECK_ARG(ocrs_mm_fwd_supported(Ca, Cb, Cout, dtype) && (long)N * (H + 2) * (W + 2) < (1L << 31));
     const int Cin = Ca + Cb;
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
     const int nb = (int)ocrs_mm_fwd_nparts(Ca, Cb, Cout, N, H, W);
 #define MF_CASE(CB_, NS_, CO_) \
-    if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, fin, st);
+    if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, fin, st, xu);
     MF_CASE(8, 1, 8) MF_CASE(8, 1, 16) MF_CASE(16, 1, 8) MF_CASE(16, 1, 16) MF_CASE(16, 1, 32) MF_CASE(32, 1, 16) MF_CASE(32, 1, 32) MF_CASE(32, 2, 32)
 #undef MF_CASE
     OCRS_LAUNCH_CHECK();
@@ -1611,6 +1648,16 @@ int ocrs_mm_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float*
     OCRS_CHECK_ARG(counter && count > 0 && bn_w && bn_b && tr && saved);
     const FwdFin fin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo};
     return mm_fwd_impl(xa, xb, Ca, Cb, tra, trb, wdw, wpw, z, ws, gamma, pooled, Cout, N, H, W, dtype, fin, st);
+}
+
+// ocrs_mm_fwd_fin for the block behind the first block: the input is the first block's u plane + pointwise weight wexp [8] (see k_mm_fwd<..., XU>), tra its
+// load transform [3][8]; no pooling.
+int ocrs_mm_fwd_fin_xu(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, void* z, float* ws, unsigned* counter, long count,
+                       const float* bn_w, const float* bn_b, float eps, float momentum, float* tr, float* saved, float* run_mean, float* run_var, long long* nbt,
+                       float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    OCRS_CHECK_ARG(xu && wexp && counter && count > 0 && bn_w && bn_b && tr && saved && (Cout == 8 || Cout == 16));
+    const FwdFin fin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo};
+    return mm_fwd_impl(nullptr, nullptr, 8, 0, tra, nullptr, wdw, wpw, z, ws, nullptr, nullptr, Cout, N, H, W, dtype, fin, st, XuSrc{(const bf16*)xu, wexp});
 }
 
 // nn.BatchNorm2d training statistics from ocrs_mm_fwd's per-block partials (models.py:23): see ocrs_bn_finalize.

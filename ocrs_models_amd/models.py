@@ -122,6 +122,7 @@ class _DetRun:
         # BatchNorm-backward finalisation in the prologue of the matrix-core block backward instead of its own launch
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
         self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"
+        self.c1_noz = os.environ.get("OCRS_C1_NOZ", "1") != "0"  # ... and does not store its 8-channel output at all when every consumer takes the u plane
         self.c1_u = os.environ.get("OCRS_C1_U", "1") != "0"  # the first block also writes its 2-byte-per-pixel u plane (read by in_conv.seq.1's backward instead of z)
         self.head_gl = os.environ.get("OCRS_HEAD_GL", "1") != "0"  # out_conv's backward hands the last block gl (4 B / pixel) instead of its 8-channel gradient  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
@@ -226,7 +227,14 @@ class _DetRun:
             nparts = L.mm_fwd_nparts(a.C, Cb, Cout, N, H, W)
             parts = self.empty(nparts * 2 * Cout, dtype=torch.float32)
             bnp = f"{prefix}.seq.2"
-            if self.train and self.fold_fwd_fin:
+            if self.train and self.fold_fwd_fin and a.u is not None and b is None and pooled is None and Cout in (8, 16):
+                # the block behind the first block: its input is rebuilt from the first block's u plane (2 instead of 16 bytes per pixel)
+                tr, saved = self.empty(3, Cout, dtype=torch.float32), self.empty(2, Cout, dtype=torch.float32)
+                Bf = self.Bf
+                L.mm_fwd_fin_xu(ptr(a.u), ptr(a.wexp), ptr(a.tr), ptr(wdw), ptr(wpw), ptr(z), ptr(parts), ptr(self.zeros64(1)), N * H * W, ptr(P[f"{bnp}.weight"]),
+                                ptr(P[f"{bnp}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved), ptr(Bf[f"{bnp}.running_mean"]), ptr(Bf[f"{bnp}.running_var"]),
+                                ptr(Bf[f"{bnp}.num_batches_tracked"]), 0.0, Cout, N, H, W, self.dt)
+            elif self.train and self.fold_fwd_fin:
                 # the BatchNorm statistics are finalised by the last workgroup of the same launch (bit-identical to ocrs_bn_finalize_parts)
                 tr, saved = self.empty(3, Cout, dtype=torch.float32), self.empty(2, Cout, dtype=torch.float32)
                 Bf = self.Bf
@@ -263,6 +271,11 @@ class _DetRun:
         uplane = None
         if self.train and self.c1_u and self.use_mm and L.dwpw_c1_u_supported(N, H, W, self.dt):
             uplane = torch.empty(N, H, W, dtype=torch.bfloat16, device=self.dev)
+            # when every consumer of this block's output takes the u plane -- in_conv.seq.1's forward (ocrs_mm_fwd_fin_xu) and backward
+            # (ocrs_mm_bwd_fin_xu), this block's own backward (rebuilds z) -- the 8-channel tensor is never written at all
+            if (self.c1_noz and self.capture is None and self.fold_fwd_fin and self.fold_fin and self.fuse_bn_bwd and L.mm_fwd_supported(8, 0, 8, self.dt)
+                    and L.mm_bwd_head_supported(8, 0, 8, N, H, W, self.dt)):
+                z = None
             L.dwpw_c1_fwd_u(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(uplane), ptr(gstat), N, H, W, self.dt)
         else:
             L.dwpw_c1_fwd(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(gstat), N, H, W, self.dt)

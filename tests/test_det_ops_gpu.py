@@ -30,7 +30,7 @@ def make_run(dev, dtype, N, P, Bf):
     r = _DetRun.__new__(_DetRun)
     r.L, r.P, r.Bf, r.names, r.train, r.dev, r.dtype, r.dt, r.N, r.recs = lib(), P, Bf, list(P), True, dev, dtype, _DT[dtype], N, {}
     r.fused, r.fuse_bn_bwd, r.fuse_pool, r.pooled_by_block = {}, True, True, None
-    r.use_mm, r.fold_fin, r.overlap, r.fold_fwd_fin, r.c1_u, r.head_gl = True, True, False, True, True, True
+    r.use_mm, r.fold_fin, r.overlap, r.fold_fwd_fin, r.c1_u, r.head_gl, r.c1_noz, r.capture = True, True, False, True, True, True, False, None
     return r
 
 

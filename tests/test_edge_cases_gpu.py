@@ -207,8 +207,9 @@ def test_rank_one_ends_of_the_network_are_bit_identical_to_the_stored_paths(dev)
         t = (torch.rand(B, 1, H, W, generator=g) > 0.9).float().to(dev)
         sd = copy.deepcopy(m.state_dict())
         outs = []
-        for c1u, hgl in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
-            os.environ["OCRS_C1_U"], os.environ["OCRS_HEAD_GL"] = c1u, hgl
+        for c1u, noz, hgl in (("1", "1", "1"), ("0", "0", "0"), ("1", "0", "0"), ("0", "0", "1"), ("1", "1", "0")):
+            # (OCRS_C1_NOZ: the first block does not store its 8-channel output at all -- in_conv.seq.1's forward reads the u plane too)
+            os.environ["OCRS_C1_U"], os.environ["OCRS_C1_NOZ"], os.environ["OCRS_HEAD_GL"] = c1u, noz, hgl
             try:
                 m.load_state_dict(sd)
                 m.zero_grad()
@@ -219,6 +220,7 @@ def test_rank_one_ends_of_the_network_are_bit_identical_to_the_stored_paths(dev)
                 outs.append((pred.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()}))
             finally:
                 os.environ.pop("OCRS_C1_U", None)
+                os.environ.pop("OCRS_C1_NOZ", None)
                 os.environ.pop("OCRS_HEAD_GL", None)
         for o in outs[1:]:
             assert torch.equal(o[0], outs[0][0]) and o[1] == outs[0][1]
