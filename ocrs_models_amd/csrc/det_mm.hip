@@ -57,6 +57,17 @@
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
 #endif
+#ifndef OCRS_MM_C32_N256
+#define OCRS_MM_C32_N256 1  // backward, Cin = 32 AND Cout = 32: TWO independent 256-thread workgroups per CU (256 registers each, 8-row tiles) instead of one
+                            // 512-thread workgroup -- the same two waves per SIMD, but the barrier waits / commit / epilogue of one workgroup (35-40 % of a
+                            // tile at one workgroup per CU: tools/runs/mm_prof.sh) run under the MFMA phases of the other
+#endif
+#ifndef OCRS_MM_C32_MERGE
+#define OCRS_MM_C32_MERGE 1  // ... and both M tiles of the dgrad in ONE pass over the B fragments (the LDS reads of that phase halve: 16 more accumulator registers)
+#endif
+#ifndef OCRS_MM_C32_MERGE_BDB
+#define OCRS_MM_C32_MERGE_BDB 0  // ... with the B fragments single-buffered (double-buffered, the merged pass spills 12-36 B per lane)
+#endif
 #ifndef OCRS_MM_BDB
 #define OCRS_MM_BDB 1      // backward dgrad: double-buffer the B fragments across K chunks
 #endif
@@ -102,16 +113,18 @@ struct MmPitch {  // bf16 elements per pixel of an LDS tile: 16 / 32-byte rows a
 
 template <int CIN, int COUT, bool PPOOL = false>
 struct MmCfg {
-    static constexpr int NT = 512, NW = NT / 64;                       // 8 waves
+    static constexpr bool N256 = OCRS_MM_C32_N256 && CIN == 32 && COUT == 32;  // two 256-thread workgroups per CU with the full register file each
+    static constexpr int NT = N256 ? 256 : 512, NW = NT / 64;          // 8 (4) waves
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
     static constexpr bool T3 = OCRS_MM_B3_16_8 && CIN == 16 && COUT == 8 && !PPOOL;
-    static constexpr int BPC = (CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : (T3 ? 3 : 2);  // resident blocks per CU (= launch bound 2 * BPC waves per SIMD)
+    static constexpr int BPC = N256 ? 2 : ((CIN == 32 && COUT == 32) ? OCRS_MM_C32_BPC : (T3 ? 3 : 2));  // resident blocks per CU (launch bound: BPC * NW / 4 waves per SIMD)
     static constexpr int TW = 32;
-    static constexpr int TH = (CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : ((PPOOL && CIN == 16 && COUT == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(CIN, COUT));
+    static constexpr int TH = N256 ? 8 : ((CIN == 32 || COUT == 32) ? (BPC == 1 ? 16 : 8) : ((PPOOL && CIN == 16 && COUT == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(CIN, COUT)));
+    static constexpr bool MERGE = N256 && OCRS_MM_C32_MERGE;            // dgrad: both M tiles per pass
     static constexpr int TP = TW * TH;
     static constexpr bool T12P = CIN == 16 && COUT == 16 && TH == 12;  // 12-row 16 -> 16 tile (pooled or direct gradient): needs the two register diets below to fit 128
-    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3;  // dgrad B fragments double-buffered across K chunks
+    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3 && !(OCRS_MM_C32_N256 && OCRS_MM_C32_MERGE && !OCRS_MM_C32_MERGE_BDB && CIN == 32 && COUT == 32);  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -120,6 +133,7 @@ struct MmCfg {
     static constexpr int NPW = TP / 16 / NW;                           // dgrad N tiles (16 pixels) per wave
     static constexpr int KS = TP / 32;                                 // 32-pixel k-steps of the weight-gradient GEMM (one tile row each)
     static constexpr int TAPU = (COUT == 8) ? 5 : 9;                   // B-operand units: a tap, or a PAIR of taps when Cout = 8 (16 columns)
+    static constexpr int NOWN = (TAPU == 9) ? 8 / NW : 1;              // weight-gradient units a wave owns (units 0..7; the ninth is shared)
     static constexpr int NGI = (DP * CGO + NT - 1) / NT;               // (z, g) items per thread
     static constexpr int NXI = (TP * CGI + NT - 1) / NT;               // x items per thread
     static constexpr int NWIN = (DH_ / 2) * (DW_ / 2);                 // 2x2 windows of the (window-aligned) domain
@@ -132,7 +146,7 @@ struct MmCfg {
     static constexpr int OFF_PAR = OFF_WF + MT * KC * 64 * 16;
     static constexpr int PAR_FLOATS = 3 * CIN + 6 * COUT + 9 * CIN + COUT * CIN + NW * 2 * MT * 16;  // trx | bn | coef | wdw [c][9] | wpw [o][c] | stats slots
     static constexpr int TILE_BYTES = OFF_PAR + PAR_FLOATS * 4;
-    static constexpr int SLOT_FLOATS = NW * (MT * NTO + 1) * 256 + NW * 2 * MT * 16;  // flush: G slots (own unit | shared sub-tile) + stats slots
+    static constexpr int SLOT_FLOATS = (NW * NOWN * MT * NTO + NW) * 256 + NW * 2 * MT * 16;  // flush: G slots (own units | shared sub-tile) + stats slots
     static constexpr int SMEM = TILE_BYTES > SLOT_FLOATS * 4 ? TILE_BYTES : SLOT_FLOATS * 4;
     static constexpr int PART = COUT * CIN + 9 * CIN + 2 * CIN;        // floats per block partial: dWpw [COUT][CIN] | dWdw [CIN][9] | sums [2][CIN]
 };
@@ -195,7 +209,7 @@ __device__ __forceinline__ Raw8<bf16> raw8_of(const u32x4& v) {
 template <int CINB, int COUT>
 constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : ((CINB == 16 && COUT == 8) ? 2 * OCRS_MF_BPC16_8 : 4); }
 template <int CIN, int COUT, bool PPOOL>
-constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
+constexpr int mm_bwd_lb() { return MmCfg<CIN, COUT, PPOOL>::BPC * MmCfg<CIN, COUT, PPOOL>::NW / 4; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------------------------------------
@@ -204,7 +218,7 @@ constexpr int mm_bwd_lb() { return 2 * MmCfg<CIN, COUT, PPOOL>::BPC; }  // minim
 // FULL: see k_mm_fwd (every tile inside the image, direct gradient: unconditional stores, opaque prefetch loads with hand-written waits,
 // first tile peeled).
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS, bool FULL = false>
-__global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
+__global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb,
                                                    const float* __restrict__ wdw /*[.][9], already offset to this launch's first channel*/,
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
@@ -418,12 +432,18 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
     const int u_own = (C::TAPU == 9) ? wave : (wave & 3);
     const int ks_own0 = (C::TAPU == 9) ? 0 : (wave >> 2) * (KS / 2), ks_own1 = (C::TAPU == 9) ? KS : ks_own0 + KS / 2;
     const int sh_a = (wave % NSUB) % MT, sh_b = (wave % NSUB) / MT, sh_k0 = (wave / NSUB) * KS / NKR, sh_k1 = (wave / NSUB + 1) * KS / NKR;
-    const int off_own = unit_off(u_own), off_sh = unit_off(C::TAPU - 1) + sh_b * 16;
-    f32x4 accO[MT][NTO], accS = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NOWN = C::NOWN;  // own units of this wave: u_own, u_own + NW, ...
+    int off_own[NOWN];
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int j = 0; j < NOWN; ++j) off_own[j] = unit_off(u_own + j * C::NW);
+    const int off_sh = unit_off(C::TAPU - 1) + sh_b * 16;
+    f32x4 accO[NOWN][MT][NTO], accS = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < NTO; ++b) accO[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NOWN; ++j)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NTO; ++b) accO[j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // producers' BatchNorm-backward sums: per-lane register accumulators (one M tile), or -- with two M tiles, where 16 more live registers
     // spill -- per-tile sums added to this wave's own LDS slots (single writer, fixed order: deterministic)
     constexpr bool STL = STATS && (MT == 2 || C::T12P || C::T3);
@@ -584,11 +604,14 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 pbase[a] = (ty * DW_ + tx0 + l15) * PD;
             }
             const int tb = (org.n * H + (org.h0 + ORG)) * W + (org.w0 + ORG);
+            constexpr int NBM = C::MERGE ? MT : 1;  // M tiles per pass over the B fragments
 #pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                f32x4 acc[NPW];
+            for (int b0 = 0; b0 < MT; b0 += NBM) {
+                f32x4 accm[NBM][NPW];
 #pragma unroll
-                for (int a = 0; a < NPW; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int bm = 0; bm < NBM; ++bm)
+#pragma unroll
+                    for (int a = 0; a < NPW; ++a) accm[bm][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 uint4 bcur[NPW], bnxt[NPW];
                 auto load_b = [&](uint4 (&dst)[NPW], int kc) {
                     bool bv;
@@ -604,11 +627,15 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                     load_b(bcur, 0);
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc) {
-                        const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
+                        uint4 wf[NBM];
+#pragma unroll
+                        for (int bm = 0; bm < NBM; ++bm) wf[bm] = s_wf[((b0 + bm) * KC + kc) * 64 + lane];
                         if (kc + 1 < KC) load_b(bnxt, kc + 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
+                        for (int bm = 0; bm < NBM; ++bm)
+#pragma unroll
+                            for (int a = 0; a < NPW; ++a) accm[bm][a] = mfma16(wf[bm], bcur[a], accm[bm][a]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int a = 0; a < NPW; ++a) bcur[a] = bnxt[a];
@@ -616,13 +643,21 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                 } else {  // (8 fewer live registers: what lets the 12-row tile of the 8 -> 16 channel shape fit 128)
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc) {
-                        const uint4 wf = s_wf[(b * KC + kc) * 64 + lane];
+                        uint4 wf[NBM];
+#pragma unroll
+                        for (int bm = 0; bm < NBM; ++bm) wf[bm] = s_wf[((b0 + bm) * KC + kc) * 64 + lane];
                         load_b(bcur, kc);
 #pragma unroll
-                        for (int a = 0; a < NPW; ++a) acc[a] = mfma16(wf, bcur[a], acc[a]);
+                        for (int bm = 0; bm < NBM; ++bm)
+#pragma unroll
+                            for (int a = 0; a < NPW; ++a) accm[bm][a] = mfma16(wf[bm], bcur[a], accm[bm][a]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#pragma unroll
+              for (int bm = 0; bm < NBM; ++bm) {
+                const int b = b0 + bm;
+                f32x4 (&acc)[NPW] = accm[bm];
                 const int m0 = b * 16 + (lane >> 4) * 4;
                 const int ms = (FULL && CIN == 8) ? (m0 & 7) : m0;  // (duplicate rows store to the address of the row they duplicate)
                 const bool in_a = ms < x.Ca;
@@ -701,6 +736,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
                         *reinterpret_cast<f32x4*>(q2) = o2;
                     }
                 }
+              }
             }
         }
         MM_MARK(2)
@@ -712,8 +748,9 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
         {
             constexpr int LOWN = OCRS_MM_NOCOMPUTE ? 0 : ((C::TAPU == 9) ? KS : KS / 2);
             const bf16* xo = tileX + (ks_own0 * 32 + prow) * PX + pcol;
-            const bf16* dq = tileD + ks_own0 * DW_ * PD + off_own;
+            const bf16* dq = tileD + ks_own0 * DW_ * PD + off_own[0];
 #if OCRS_MM_GPIPE
+            static_assert(NOWN == 1, "the explicit fragment pipeline is written for one own unit");
             bf16x8 afc[MT], bfc[NTO];
 #pragma unroll
             for (int a = 0; a < MT; ++a) afc[a] = lds_tr8(xo + a * 16, xo + a * 16 + 16 * PX);
@@ -733,7 +770,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 #pragma unroll
                 for (int bb = 0; bb < NTO; ++bb)
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) accO[a][bb] = mfma16(afc[a], bfc[bb], accO[a][bb]);
+                    for (int a = 0; a < MT; ++a) accO[0][a][bb] = mfma16(afc[a], bfc[bb], accO[0][a][bb]);
                 if (i + 1 < LOWN) {
 #pragma unroll
                     for (int a = 0; a < MT; ++a) afc[a] = afn[a];
@@ -750,10 +787,14 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 #pragma unroll
                 for (int a = 0; a < MT; ++a) af[a] = lds_tr8(xn + a * 16, xn + a * 16 + 16 * PX);
 #pragma unroll
-                for (int bb = 0; bb < NTO; ++bb) {
-                    const bf16x8 bfr = lds_tr8(dn + bb * 16, dn + bb * 16 + 16 * PD);
+                for (int j = 0; j < NOWN; ++j) {  // (the x~ fragments of a k-step serve all own units)
+                    const bf16* dj = dn + (off_own[j] - off_own[0]);
 #pragma unroll
-                    for (int a = 0; a < MT; ++a) accO[a][bb] = mfma16(af[a], bfr, accO[a][bb]);
+                    for (int bb = 0; bb < NTO; ++bb) {
+                        const bf16x8 bfr = lds_tr8(dj + bb * 16, dj + bb * 16 + 16 * PD);
+#pragma unroll
+                        for (int a = 0; a < MT; ++a) accO[j][a][bb] = mfma16(af[a], bfr, accO[j][a][bb]);
+                    }
                 }
             }
 #endif
@@ -796,15 +837,17 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
 
     // ================= flush: G slots -> dWpw / dWdw partials of this block (workspace); stats partials =================
     __syncthreads();
-    float* slots = reinterpret_cast<float*>(smem);        // [wave][MT][NTO][4][64] own unit
-    float* slotS = slots + C::NW * MT * NTO * 256;         // [wave][4][64] this wave's sub-tile of the shared unit
+    float* slots = reinterpret_cast<float*>(smem);        // [own unit j * NW + wave][MT][NTO][4][64]
+    float* slotS = slots + C::NW * NOWN * MT * NTO * 256;  // [wave][4][64] this wave's sub-tile of the shared unit
     float* sstat = slotS + C::NW * 256;                    // [wave][2][MT*16] (register-accumulated stats)
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int j = 0; j < NOWN; ++j)
 #pragma unroll
-        for (int b = 0; b < NTO; ++b)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slots[((wave * MT + a) * NTO + b) * 256 + r * 64 + lane] = accO[a][b][r];
+            for (int b = 0; b < NTO; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slots[(((j * C::NW + wave) * MT + a) * NTO + b) * 256 + r * 64 + lane] = accO[j][a][b][r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) slotS[wave * 256 + r * 64 + lane] = accS[r];
     if constexpr (STATS && !STL) {
@@ -820,7 +863,7 @@ __global__ __launch_bounds__(512, (mm_bwd_lb<CIN, COUT, PPOOL>())) void k_mm_bwd
             }
     }
     if constexpr (STL) {
-        static_assert(!STL || C::NW * (MT * NTO + 1) * 256 * 4 <= C::OFF_PAR, "the G flush slots must not reach the LDS-resident stats");
+        static_assert(!STL || (C::NW * NOWN * MT * NTO + C::NW) * 256 * 4 <= C::OFF_PAR, "the G flush slots must not reach the LDS-resident stats");
         sstat = s_st;
     }
     __syncthreads();
@@ -933,11 +976,11 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
 }
 static int mm_th(int Cin, int Cout, int nst) { return OCRS_MF_TH_OF(Cin, Cout, nst); }  // forward tiles
 static int mm_bwd_bpc(int Cin, int Cout, int pooled = 0) {
-    if (Cin == 32 && Cout == 32) return OCRS_MM_C32_BPC;
+    if (Cin == 32 && Cout == 32) return OCRS_MM_C32_N256 ? 2 : OCRS_MM_C32_BPC;
     return (OCRS_MM_B3_16_8 && Cin == 16 && Cout == 8 && !pooled) ? 3 : 2;
 }
 static int mm_bwd_th(int Cin, int Cout, int pooled) {
-    if (Cin == 32 || Cout == 32) return mm_bwd_bpc(Cin, Cout) == 1 ? 16 : 8;
+    if (Cin == 32 || Cout == 32) return (mm_bwd_bpc(Cin, Cout) == 1 && !(OCRS_MM_C32_N256 && Cin == 32 && Cout == 32)) ? 16 : 8;
     return (pooled && Cin == 16 && Cout == 16) ? OCRS_MM_TH_16_16_P : OCRS_MM_TH_OF(Cin, Cout);
 }
 
