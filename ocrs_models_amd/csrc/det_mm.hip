@@ -57,6 +57,11 @@
 #define OCRS_MM_C32_BPC 1  // backward blocks per CU, Cin = 32 AND Cout = 32 (1: full register file, 16-row tiles: 144 / 506 us; 2: 8-row tiles, ~150 B of
                            // spills: 181 / 559 us).  Cin = 32, Cout = 16 always runs two blocks per CU (20-60 B of spills, 479 vs 529 us)
 #endif
+#ifndef OCRS_MM_S2G
+#define OCRS_MM_S2G 1  // the producers' second BatchNorm-backward sum S2 = sum ghat' x~ from the weight-gradient accumulators at the flush (as k_rs_bwd does):
+                       // sum_q dx~[q][c] x~[q][c] = sum_{tap,o} Weff[o][(tap,c)] G_tap[c][o] exactly (x~ [x~ > 0] = x~); the per-lane epilogue keeps S1 only.
+                       // S2 then sums the UNROUNDED dx~ (an unbiased 2^-9 / sqrt(pixels) relative difference, the same as in det_rs.hip)
+#endif
 #ifndef OCRS_MM_C32_N256
 #define OCRS_MM_C32_N256 1  // backward, Cin = 32 AND Cout = 32: TWO independent 256-thread workgroups per CU (256 registers each, 8-row tiles) instead of one
                             // 512-thread workgroup -- the same two waves per SIMD, but the barrier waits / commit / epilogue of one workgroup (35-40 % of a
@@ -704,7 +709,7 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
                                 // the producer's backward reads the STORED (rounded) gradient; x~ > 0 <=> bn(z) > 0 for the ReLU producers that ask
                                 const float gh = xq[i] > 0.f ? Elem<bf16>::round(v[i]) : 0.f;
                                 t1[i] += gh;
-                                t2[i] = fmaf(gh, xq[i], t2[i]);
+                                if constexpr (!OCRS_MM_S2G) t2[i] = fmaf(gh, xq[i], t2[i]);
                             }
                         }
                     }
@@ -713,7 +718,7 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         st1[b][i] += t1[i];
-                        st2[b][i] += t2[i];
+                        if constexpr (!OCRS_MM_S2G) st2[b][i] += t2[i];
                     }
                 }
                 if constexpr (STL) {
@@ -721,19 +726,21 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         r1[i] = quad16_sum(t1[i]);
-                        r2[i] = quad16_sum(t2[i]);
+                        if constexpr (!OCRS_MM_S2G) r2[i] = quad16_sum(t2[i]);
                     }
                     if ((lane & 15) == 0) {
                         float* q1 = s_st + (wave * 2 + 0) * MT * 16 + m0;
-                        float* q2 = s_st + (wave * 2 + 1) * MT * 16 + m0;
-                        f32x4 o1 = *reinterpret_cast<f32x4*>(q1), o2 = *reinterpret_cast<f32x4*>(q2);
+                        f32x4 o1 = *reinterpret_cast<f32x4*>(q1);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            o1[i] += r1[i];
-                            o2[i] += r2[i];
-                        }
+                        for (int i = 0; i < 4; ++i) o1[i] += r1[i];
                         *reinterpret_cast<f32x4*>(q1) = o1;
-                        *reinterpret_cast<f32x4*>(q2) = o2;
+                        if constexpr (!OCRS_MM_S2G) {
+                            float* q2 = s_st + (wave * 2 + 1) * MT * 16 + m0;
+                            f32x4 o2 = *reinterpret_cast<f32x4*>(q2);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o2[i] += r2[i];
+                            *reinterpret_cast<f32x4*>(q2) = o2;
+                        }
                     }
                 }
               }
@@ -855,7 +862,7 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
         for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v1 = quad16_sum(st1[a][i]), v2 = quad16_sum(st2[a][i]);
+                const float v1 = quad16_sum(st1[a][i]), v2 = OCRS_MM_S2G ? 0.f : quad16_sum(st2[a][i]);
                 if ((lane & 15) == 0) {
                     sstat[(wave * 2 + 0) * MT * 16 + a * 16 + (lane >> 4) * 4 + i] = v1;
                     sstat[(wave * 2 + 1) * MT * 16 + a * 16 + (lane >> 4) * 4 + i] = v2;
@@ -904,7 +911,12 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
         float s = 0.f;
         if constexpr (STATS) {
             const int c = e >> 1, which = e & 1;
-            for (int w = 0; w < C::NW; ++w) s += sstat[(w * 2 + which) * MT * 16 + c];
+            if (OCRS_MM_S2G && which) {  // S2 from G, with the bf16 effective weights the dgrad used
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int o = 0; o < COUT; ++o) s = fmaf(bf2f(f2bf(wdw[c * 9 + tap] * wpw[o * ldw + c])), Gval(tap, c, o), s);
+            } else {
+                for (int w = 0; w < C::NW; ++w) s += sstat[(w * 2 + which) * MT * 16 + c];
+            }
         }
         part[COUT * CIN + 9 * CIN + e] = s;
     }
