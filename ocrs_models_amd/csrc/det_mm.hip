@@ -1309,8 +1309,7 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
         const int d = (tid + j * NT) / CGB, dy = d / DW_, dx = d - dy * DW_;
         xi_dyx[j] = dy | (dx << 16);
     }
-    u32x4 xr[XU ? 1 : NST][XU ? 1 : C::NXI];
-    unsigned xru[XU ? C::NXI : 1];  // XU: one bf16 per item
+    u32x4 xr[NST][C::NXI];  // (XU: the aligned 16-byte group of eight u values that holds the item's pixel)
     float we[XU ? 8 : 1];
     if constexpr (XU) {
 #pragma unroll
@@ -1335,17 +1334,16 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                     const int dy = xi_dyx[j] & 0xffff, dx = xi_dyx[j] >> 16, h = o.h0 - 1 + dy, w = o.w0 - 1 + dx;
                     const bool it_ok = (j + 1) * NT <= DP * CGB || tid + j * NT < DP * CGB;  // (a compile-time `true` for all but the last round)
                     const bool ok = it_ok && (decltype(INSIDE)::value || ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W));
-                    if constexpr (XU) {
-                        const bf16* src = ok ? xu.u + (corner + dy * W + dx) : xu.u;
-                        xru[j] = src->v;  // (compiler-waited: see mm_fwd_launch)
+                    // XU: a 2-byte item would be a lone 32-bit asm destination (hipcc then pairs it as the don't-care high half of 64-bit address
+                    // arithmetic while the load is in flight); every lane loads the aligned group of 8 pixels around its own instead -- the same
+                    // instruction as the other forms, an eighth of their lines -- and picks its pixel at the commit (row starts and tile origins
+                    // are multiples of 8 pixels: the position inside the group is (dx - 1) & 7, tile-invariant)
+                    const bf16* src = XU ? (ok ? xu.u + ((corner + dy * W + dx) & ~7) : xu.u) : (ok ? cb + (dy * W + dx) * pitch : base);
+                    if constexpr (FULL) {
+                        xr[st][j] = gload16_opaque(src);
                     } else {
-                        const bf16* src = ok ? cb + (dy * W + dx) * pitch : base;
-                        if constexpr (FULL) {
-                            xr[st][j] = gload16_opaque(src);
-                        } else {
-                            const uint4 q = *reinterpret_cast<const uint4*>(src);
-                            xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
-                        }
+                        const uint4 q = *reinterpret_cast<const uint4*>(src);
+                        xr[st][j] = (u32x4){q.x, q.y, q.z, q.w};
                     }
                     okx |= ok ? 1u << (st * C::NXI + j) : 0u;
                 }
@@ -1359,7 +1357,6 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     // FULL: the hand-written waits.  `pend_stores`: the previous tile's epilogue stores were issued after these loads (false for the first tile)
     auto wait_loads = [&](bool pend_stores) {
         if constexpr (FULL) {
-            static_assert(!XU, "the u-plane form runs compiler-waited");
             if (pend_stores) {
                 static_for_wait<NLOAD, NSTORE>(&xr[0][0]);
             } else {
@@ -1436,7 +1433,10 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
                         float v[4] = {0.f, 0.f, 0.f, 0.f};
                         if (okx & (1u << (st * C::NXI + j))) {
                             if constexpr (XU) {
-                                const float uv = __uint_as_float(xru[j] << 16);
+                                const int sel = ((xi_dyx[j] >> 16) + 7) & 7;
+                                const u32x4 q = xr[0][j];
+                                const unsigned w2 = (sel & 4) ? ((sel & 2) ? q.w : q.z) : ((sel & 2) ? q.y : q.x);
+                                const float uv = __uint_as_float((sel & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) v[i] = Elem<bf16>::round(we[hf * 4 + i] * uv);  // (cgb = 0: one 8-channel group)
                             } else {
@@ -1636,13 +1636,14 @@ static void mm_fwd_launch(const Src2<bf16>& x, const float* tra, const float* tr
         hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, PO_, FU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin, xu); \
     }
     if constexpr (CINB == 8 && NST == 1) {
-        if (xu.u) {
-            // the block behind the first block (never pooled), always on the compiler-waited path: a hand-waited 2-byte asm load leaves a lone 32-bit
-            // destination register, and hipcc pairs such a register as the don't-care high half of v_mad_u64_u32 address arithmetic while the
-            // load is in flight (harmless, but tools/check_opaque_loads.py cannot tell it from a real use) -- the 14 bytes per pixel this form does
-            // not read are worth more than the hand-written waits
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
-            hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin, xu);
+        if (xu.u) {  // the block behind the first block (never pooled)
+#define MF_LAUNCH_XU(FU_)                                                                                                                                 \
+    {                                                                                                                                                     \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_fwd<CINB, NST, COUT, false, FU_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM); \
+        hipLaunchKernelGGL((k_mm_fwd<CINB, NST, COUT, false, FU_, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, z, ws, tg, gamma, pooled, fin, xu); \
+    }
+            if (full) MF_LAUNCH_XU(true) else MF_LAUNCH_XU(false)
+#undef MF_LAUNCH_XU
             return;
         }
     }
@@ -1710,7 +1711,7 @@ int ocrs_mm_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float*
 int ocrs_mm_fwd_fin_xu(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, void* z, float* ws, unsigned* counter, long count,
                        const float* bn_w, const float* bn_b, float eps, float momentum, float* tr, float* saved, float* run_mean, float* run_var, long long* nbt,
                        float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
-    OCRS_CHECK_ARG(xu && wexp && counter && count > 0 && bn_w && bn_b && tr && saved && (Cout == 8 || Cout == 16));
+    OCRS_CHECK_ARG(xu && wexp && counter && count > 0 && bn_w && bn_b && tr && saved && (Cout == 8 || Cout == 16) && W % 8 == 0);  // (aligned 8-pixel groups)
     const FwdFin fin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo};
     return mm_fwd_impl(nullptr, nullptr, 8, 0, tra, nullptr, wdw, wpw, z, ws, nullptr, nullptr, Cout, N, H, W, dtype, fin, st, XuSrc{(const bf16*)xu, wexp});
 }

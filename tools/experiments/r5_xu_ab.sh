@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_det_ops_gpu.py tests/test_edge_cases_gpu.py tests/test_det_model_gpu.py -x -q 2>&1 | tail -3
+bash tools/experiments/r5_det_ab.sh "default" "z OCRS_C1_NOZ=0"
