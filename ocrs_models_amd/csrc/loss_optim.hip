@@ -26,6 +26,17 @@ struct LossState {            // device-resident, one per loss call
 
 __device__ __forceinline__ unsigned loss_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
+// Workspace behind the two histograms (ocrs_loss_hist_bytes): per-block partials, reduced in a fixed order by the one-block scan kernels -- the
+// element counts of k_bce_fwd and the sums of k_select_hist's last pass (1024 blocks x 2 same-address fp64 atomics were a 30 us serial tail
+// on each of those kernels, and made the loss depend on their arrival order in its last bits).
+constexpr int LOSS_MAXB = 1024;                              // blocks of the streaming kernels
+constexpr int LOSS_HIST_WORDS = 2 * 2048;
+struct LossParts {
+    unsigned long long cnt[LOSS_MAXB][2];                    // k_bce_fwd: #pos, #neg of the block
+    double sum[LOSS_MAXB][2];                                // last k_select_hist pass: sum of the block's losses above the 21-bit prefix, per class
+};
+__device__ __forceinline__ LossParts* loss_parts(unsigned* hist) { return reinterpret_cast<LossParts*>(hist + LOSS_HIST_WORDS); }
+
 // log(1 - p) for p in [0, 1] with log1p accuracy from ONE logf: log1p(x) = log(u) - ((u - 1) - x) / u, u = fl(1 + x)  (x = -p).
 // (OCML's log1pf costs ~3x a logf; the loss forward was VALU-bound on it.)  p = 1 -> -inf (clamped by the caller).
 __device__ __forceinline__ float log1p_neg(float p) {
@@ -81,7 +92,11 @@ __device__ __forceinline__ void stqb(unsigned char* p, long q, const QuadB<VEC>&
 
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ lpx,
-                                                 unsigned char* __restrict__ cls, LossState* __restrict__ stt, long P) {
+                                                 unsigned char* __restrict__ cls, unsigned* __restrict__ hist, long P) {
+    // the first radix-select pass (top 11 bits of every classified element: it needs neither k nor a prefix) rides on this kernel
+    __shared__ unsigned s_h[LOSS_HIST_WORDS];
+    for (int i = threadIdx.x; i < LOSS_HIST_WORDS; i += 256) s_h[i] = 0;
+    __syncthreads();
     unsigned long long np = 0, nn = 0;
     const long nq = P / VEC;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
@@ -100,18 +115,23 @@ __global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ pred,
         }
         stq<VEC>(lpx, q, lq);
         stqb<VEC>(cls, q, cq);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (cq.v[e]) atomicAdd(&s_h[(cq.v[e] - 1) * 2048 + (loss_key(lq.v[e]) >> 20)], 1u);
     }
     if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) {  // tail
         const long i = nq * VEC + threadIdx.x;
         const float p = pred[i], t0 = target[i];
         const unsigned char c = t0 > 0.5f ? 1 : (t0 < 0.5f ? 2 : 0);
         const float t = fminf(fmaxf(t0, 0.f), 1.f);
-        lpx[i] = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1p_neg(p), -100.f));
+        const float l = -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(log1p_neg(p), -100.f));
+        lpx[i] = l;
         cls[i] = c;
         np += c == 1;
         nn += c == 2;
+        if (c) atomicAdd(&s_h[(c - 1) * 2048 + (loss_key(l) >> 20)], 1u);
     }
-    // one pair of global atomics per BLOCK: same-address atomics serialise at ~15 ns each (8192 waves x 2 were 0.24 ms)
+    // the block's counts: one partial per block (same-address global atomics serialise at ~15 ns each)
     __shared__ unsigned s_cnt[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -124,18 +144,9 @@ __global__ __launch_bounds__(256) void k_bce_fwd(const float* __restrict__ pred,
         atomicAdd(&s_cnt[1], (unsigned)nn);
     }
     __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&stt->cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-}
-
-__global__ void k_select_init(LossState* stt) {
-    const unsigned long long k = stt->cnt[0] < stt->cnt[1] ? stt->cnt[0] : stt->cnt[1];
-    stt->k = k;
-    for (int c = 0; c < 2; ++c) {
-        stt->prefix[c] = 0;
-        stt->need[c] = k;
-        stt->ties[c] = 0;
-        stt->sum_gt[c] = 0.0;
-    }
+    if (threadIdx.x < 2) loss_parts(hist)->cnt[blockIdx.x][threadIdx.x] = s_cnt[threadIdx.x];
+    for (int i = threadIdx.x; i < LOSS_HIST_WORDS; i += 256)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
 }
 
 // pass: 0 -> bits 30..20 (2048 bins), 1 -> bits 19..10 (1024), 2 -> bits 9..0 (1024)
@@ -155,11 +166,19 @@ __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ l
     pass_bits(pass, shift, nb);
     const unsigned pf0 = stt->prefix[0], pf1 = stt->prefix[1];
     const int hs = shift + (pass == 0 ? 11 : 10);  // bits above the current digit
+    // last pass: an element whose upper 21 bits exceed the prefix lies above the threshold whatever the last digit turns out to be -- summed here
+    // (the elements inside the prefix bucket are summed from the histogram by k_select_scan: a key IS its value), so no further pass over lpx
+    double s0 = 0.0, s1 = 0.0;
     auto visit = [&](unsigned char c, float v) {
         if (!c) return;
         const unsigned key = loss_key(v);
         const unsigned pf = c == 1 ? pf0 : pf1;
-        if (pass == 0 || (key >> hs) == pf) atomicAdd(&s_h[(c - 1) * 2048 + ((key >> shift) & (nb - 1))], 1u);
+        const unsigned up = key >> hs;
+        if (pass == 0 || up == pf) atomicAdd(&s_h[(c - 1) * 2048 + ((key >> shift) & (nb - 1))], 1u);
+        if (pass == 2 && up > pf) {
+            if (c == 1) s0 += (double)v;
+            else s1 += (double)v;
+        }
     };
     const long nq = P / VEC;
     // four quads' loads in flight per thread (one per iteration left these passes latency-bound: 2-3 TB/s)
@@ -188,117 +207,153 @@ __global__ __launch_bounds__(256) void k_select_hist(const float* __restrict__ l
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+    if (pass == 2) {  // (fixed order inside the block; the blocks' partials are added in block order by k_select_scan: a reproducible loss)
+        __shared__ double s_sum[2][4];
+        for (int o = 32; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64);
+            s1 += __shfl_xor(s1, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_sum[0][threadIdx.x >> 6] = s0;
+            s_sum[1][threadIdx.x >> 6] = s1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) loss_parts(hist)->sum[blockIdx.x][threadIdx.x] = (s_sum[threadIdx.x][0] + s_sum[threadIdx.x][1]) + (s_sum[threadIdx.x][2] + s_sum[threadIdx.x][3]);
+    }
 }
 
-// one block of 256 threads: find the bin holding the need-th largest element, per class (blockIdx.x = class)
-__global__ __launch_bounds__(256) void k_select_scan(LossState* __restrict__ stt, unsigned* __restrict__ hist, int pass) {
+// ONE block of 256 threads after each histogram pass: per class, the bin that holds the need-th largest element.  Pass 0 first reduces the
+// blocks' element counts (k = min(#pos, #neg)) and initialises the selection state; pass 2 finishes the loss: sum above the threshold =
+// the blocks' partial sums of k_select_hist (added in block order) + the histogram bins above the chosen one (a key is its value), then
+// loss = mean of the 2k selected elements (ties at the threshold weighted need / ties).
+__global__ __launch_bounds__(256) void k_select_scan(LossState* __restrict__ stt, unsigned* __restrict__ hist, int pass, int nblk, float* __restrict__ loss_out) {
     __shared__ unsigned long long s_sum[256];
+    __shared__ double s_d[256];
+    __shared__ unsigned long long s_need[2], s_ties[2], s_k;
+    __shared__ int s_bin[2];
     int shift, nb;
     pass_bits(pass, shift, nb);
-    const int c = blockIdx.x;
-    unsigned* h = hist + c * 2048;
     const int per = nb / 256;
     const int tid = threadIdx.x;
-    // thread t owns bins [nb - (t+1)*per, nb - t*per) : descending order over t
-    unsigned long long loc = 0;
-    for (int j = 0; j < per; ++j) loc += h[nb - 1 - (tid * per + j)];
-    s_sum[tid] = loc;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = 0;
-        for (int t = 0; t < 256; ++t) {
-            const unsigned long long v = s_sum[t];
-            s_sum[t] = run;  // exclusive prefix (count of strictly larger digits before this thread's bins)
-            run += v;
+    LossParts* lp = loss_parts(hist);
+    auto block_sum_u64 = [&](unsigned long long v) -> unsigned long long {
+        __syncthreads();
+        s_sum[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_sum[tid] += s_sum[tid + o];
+            __syncthreads();
         }
-    }
-    __syncthreads();
-    const unsigned long long need = stt->need[c];
-    const unsigned long long before = s_sum[tid];
-    if (need > 0 && before < need && before + loc >= need) {
-        unsigned long long run = before;
-        for (int j = 0; j < per; ++j) {
-            const int bin = nb - 1 - (tid * per + j);
-            const unsigned long long v = h[bin];
-            if (run + v >= need) {
-                stt->prefix[c] = (stt->prefix[c] << (pass == 0 ? 11 : 10)) | (unsigned)bin;
-                stt->need[c] = need - run;
-                stt->ties[c] = v;
-                break;
-            }
-            run += v;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 2048; i += 256) h[i] = 0;  // ready for the next pass
-}
-
-template <int VEC>
-__global__ __launch_bounds__(256) void k_topk_sum(const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
-                                                  LossState* __restrict__ stt, long P) {
-    const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
-    double s0 = 0.0, s1 = 0.0;
-    auto visit = [&](unsigned char c, float v) {
-        if (!c) return;
-        const unsigned key = loss_key(v);
-        if (c == 1) {
-            if (key > t0) s0 += (double)v;
-        } else {
-            if (key > t1) s1 += (double)v;
-        }
+        return s_sum[0];
     };
-    const long nq = P / VEC;
-    // four quads' loads in flight per thread (one per iteration left these passes latency-bound: 2-3 TB/s)
-    const long stride = (long)gridDim.x * 256;
-    long q = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; q + 3 * stride < nq; q += 4 * stride) {
-        QuadB<VEC> cq[4];
-        Quad<VEC> lq[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            cq[u] = ldqb<VEC>(cls, q + u * stride);
-            lq[u] = ldq<VEC>(lpx, q + u * stride);
+    auto block_sum_f64 = [&](double v) -> double {  // fixed tree: reproducible
+        __syncthreads();
+        s_d[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_d[tid] += s_d[tid + o];
+            __syncthreads();
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) visit(cq[u].v[e], lq[u].v[e]);
+        return s_d[0];
+    };
+    if (pass == 0) {
+        unsigned long long c0 = 0, c1 = 0;
+        for (int b = tid; b < nblk; b += 256) {
+            c0 += lp->cnt[b][0];
+            c1 += lp->cnt[b][1];
+        }
+        const unsigned long long n0 = block_sum_u64(c0), n1 = block_sum_u64(c1);
+        if (tid == 0) {
+            const unsigned long long k = n0 < n1 ? n0 : n1;
+            stt->cnt[0] = n0;
+            stt->cnt[1] = n1;
+            stt->k = k;
+            s_k = k;
+            for (int c = 0; c < 2; ++c) {
+                stt->prefix[c] = 0;
+                stt->ties[c] = 0;
+                stt->sum_gt[c] = 0.0;
+                s_need[c] = k;
+            }
+        }
+    } else if (tid == 0) {
+        s_need[0] = stt->need[0];
+        s_need[1] = stt->need[1];
+        s_k = stt->k;
     }
-    for (; q < nq; q += stride) {
-        const QuadB<VEC> cq = ldqb<VEC>(cls, q);
-        const Quad<VEC> lq = ldq<VEC>(lpx, q);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) visit(cq.v[e], lq.v[e]);
-    }
-    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < P - nq * VEC) visit(cls[nq * VEC + threadIdx.x], lpx[nq * VEC + threadIdx.x]);
-    __shared__ double s_sum[2][4];
-    for (int o = 32; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o, 64);
-        s1 += __shfl_xor(s1, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_sum[0][threadIdx.x >> 6] = s0;
-        s_sum[1][threadIdx.x >> 6] = s1;
-    }
+    if (tid < 2) s_bin[tid] = -1;
     __syncthreads();
-    if (threadIdx.x < 2) {  // one global atomic per block and class
-        const double v = (s_sum[threadIdx.x][0] + s_sum[threadIdx.x][1]) + (s_sum[threadIdx.x][2] + s_sum[threadIdx.x][3]);
-        if (v != 0.0) atomicAdd(&stt->sum_gt[threadIdx.x], v);
-    }
-}
-
-__global__ void k_loss_final(LossState* stt, float* loss_out) {
-    const unsigned long long k = stt->k;
     double tot = 0.0;
     for (int c = 0; c < 2; ++c) {
-        const double thr = (double)__uint_as_float(stt->prefix[c]);
-        tot += stt->sum_gt[c] + (double)stt->need[c] * thr;
-        stt->frac[c] = stt->ties[c] ? (float)((double)stt->need[c] / (double)stt->ties[c]) : 0.f;
+        unsigned* h = hist + c * 2048;
+        // thread t owns bins [nb - (t+1)*per, nb - t*per) : descending order over t
+        unsigned long long loc = 0;
+        for (int j = 0; j < per; ++j) loc += h[nb - 1 - (tid * per + j)];
+        const unsigned pfx = pass == 0 ? 0u : stt->prefix[c];  // (read by every thread in front of the barriers: the finder below overwrites it)
+        __syncthreads();
+        s_sum[tid] = loc;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long run = 0;
+            for (int t = 0; t < 256; ++t) {
+                const unsigned long long v = s_sum[t];
+                s_sum[t] = run;  // exclusive prefix (count of strictly larger digits before this thread's bins)
+                run += v;
+            }
+        }
+        __syncthreads();
+        const unsigned long long need = s_need[c];
+        const unsigned long long before = s_sum[tid];
+        if (need > 0 && before < need && before + loc >= need) {
+            unsigned long long run = before;
+            for (int j = 0; j < per; ++j) {
+                const int bin = nb - 1 - (tid * per + j);
+                const unsigned long long v = h[bin];
+                if (run + v >= need) {
+                    stt->prefix[c] = (pfx << (pass == 0 ? 11 : 10)) | (unsigned)bin;
+                    stt->need[c] = need - run;
+                    stt->ties[c] = v;
+                    s_need[c] = need - run;
+                    s_ties[c] = v;
+                    s_bin[c] = bin;
+                    break;
+                }
+                run += v;
+            }
+        } else if (need == 0 && tid == 0) {
+            stt->need[c] = 0;
+        }
+        __syncthreads();
+        if (pass == 2) {
+            const int bin = s_bin[c];
+            const unsigned long long ties = bin >= 0 ? s_ties[c] : 0ull, needc = bin >= 0 ? s_need[c] : 0ull;
+            const unsigned thr = bin >= 0 ? ((pfx << 10) | (unsigned)bin) : pfx;
+            // the prefix bucket's elements above the chosen bin, from the histogram
+            double in_b = 0.0;
+            if (bin >= 0)
+                for (int j = 0; j < per; ++j) {
+                    const int bj = nb - 1 - (tid * per + j);
+                    if (bj > bin && h[bj]) in_b += (double)h[bj] * (double)__uint_as_float((pfx << 10) | (unsigned)bj);
+                }
+            double above = 0.0;
+            for (int b = tid; b < nblk; b += 256) above += lp->sum[b][c];
+            const double sum_gt = block_sum_f64(above) + block_sum_f64(in_b);
+            if (tid == 0) {
+                stt->sum_gt[c] = sum_gt;
+                stt->frac[c] = ties ? (float)((double)needc / (double)ties) : 0.f;
+            }
+            tot += sum_gt + (double)needc * (double)__uint_as_float(thr);
+        }
+        __syncthreads();
     }
-    const float loss = k ? (float)(tot / (2.0 * (double)k)) : __uint_as_float(0x7fc00000u);  // mean of an empty tensor = NaN
-    stt->loss = loss;
-    stt->inv2k = k ? (float)(1.0 / (2.0 * (double)k)) : 0.f;
-    *loss_out = loss;
+    for (int i = tid; i < LOSS_HIST_WORDS; i += 256) hist[i] = 0;  // ready for the next pass / the next call
+    if (pass == 2 && tid == 0) {
+        const unsigned long long k = s_k;
+        const float loss = k ? (float)(tot / (2.0 * (double)k)) : __uint_as_float(0x7fc00000u);  // mean of an empty tensor = NaN
+        stt->loss = loss;
+        stt->inv2k = k ? (float)(1.0 / (2.0 * (double)k)) : 0.f;
+        *loss_out = loss;
+    }
 }
 
 // d loss / d pred: weight * (p - t) / max(p (1 - p), 1e-12)   (ATen binary_cross_entropy_backward)
@@ -430,37 +485,34 @@ static inline int ew_grid(long items) {
 extern "C" {
 
 long ocrs_loss_state_bytes() { return (long)sizeof(LossState); }
-long ocrs_loss_hist_bytes() { return 2 * 2048 * (long)sizeof(unsigned); }
+long ocrs_loss_hist_bytes() { return LOSS_HIST_WORDS * (long)sizeof(unsigned) + (long)sizeof(LossParts); }  // the two histograms + the per-block partials
 
 // Class-balanced BCE forward (train_detection.py:225-263).  pred/target fp32 [P]; lpx fp32 [P] and cls u8 [P] are saved
 // for backward; state (ocrs_loss_state_bytes) and hist (ocrs_loss_hist_bytes) are device workspaces; loss_out fp32 [1].
+// 7 launches: the elementwise loss + first histogram, then (scan | histogram) x 2, the last histogram pass also summing what lies above the
+// prefix, and a final scan that finishes the loss (round 5; before: 12 launches with two further passes over the loss map).
 int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, unsigned char* cls, void* state, void* hist, float* loss_out,
                           long P, hipStream_t st) {
     OCRS_CHECK_ARG(pred && target && lpx && cls && state && hist && loss_out && P > 0);
     LossState* stt = (LossState*)state;
-    if (hipMemsetAsync(state, 0, sizeof(LossState), st) != hipSuccess) return OCRS_ERR_HIP;
-    if (hipMemsetAsync(hist, 0, 2 * 2048 * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    if (hipMemsetAsync(hist, 0, LOSS_HIST_WORDS * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;  // (the state is written before it is read)
     int grid = ew_grid((P + 3) / 4);
-    if (grid > 1024) grid = 1024;  // streaming kernels that end in same-address atomics: 4 blocks per CU are plenty
+    if (grid > LOSS_MAXB) grid = LOSS_MAXB;  // 4 blocks per CU are plenty; LossParts holds one partial per block
     const bool vec = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(lpx)) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(cls) & 3) == 0;
     if (vec)
-        hipLaunchKernelGGL(k_bce_fwd<4>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
+        hipLaunchKernelGGL(k_bce_fwd<4>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, (unsigned*)hist, P);
     else
-        hipLaunchKernelGGL(k_bce_fwd<1>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, stt, P);
-    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, st, stt);
+        hipLaunchKernelGGL(k_bce_fwd<1>, dim3(grid), dim3(256), 0, st, pred, target, lpx, cls, (unsigned*)hist, P);
     for (int pass = 0; pass < 3; ++pass) {
-        if (vec)
-            hipLaunchKernelGGL(k_select_hist<4>, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
-        else
-            hipLaunchKernelGGL(k_select_hist<1>, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
-        hipLaunchKernelGGL(k_select_scan, dim3(2), dim3(256), 0, st, stt, (unsigned*)hist, pass);
+        if (pass > 0) {
+            if (vec)
+                hipLaunchKernelGGL(k_select_hist<4>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
+            else
+                hipLaunchKernelGGL(k_select_hist<1>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, (unsigned*)hist, pass, P);
+        }
+        hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(256), 0, st, stt, (unsigned*)hist, pass, grid, loss_out);
     }
-    if (vec)
-        hipLaunchKernelGGL(k_topk_sum<4>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
-    else
-        hipLaunchKernelGGL(k_topk_sum<1>, dim3(grid), dim3(256), 0, st, lpx, cls, stt, P);
-    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(1), 0, st, stt, loss_out);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
