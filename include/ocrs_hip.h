@@ -45,6 +45,12 @@ int ocrs_pack_frags_multi(const long long* table, int n, long max_frag_threads, 
  */
 int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk,
                   void* z, double* gstat, const float* gamma, void* pooled, int Cout, int N, int H, int W, int dtype, hipStream_t st);
+/* ocrs_dwpw_fwd + ocrs_bn_finalize in one launch (models.py:11-23 for the deep levels, 32..256 channels in bf16): the last workgroup done finalises
+   the BatchNorm statistics.  counter: a zeroed device word (left zeroed); count .. lo as ocrs_bn_finalize.  No fused pooling. */
+long ocrs_dwpw_fwd_fin_supported(int Cin, int Cout, int dtype);
+int ocrs_dwpw_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
+                      double* gstat, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps, float momentum, float* tr, float* saved,
+                      float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout); /* 1 / 0 */
 /* The same block forward on the matrix cores (csrc/det_mm.hip; bf16, Cin and Cout in {8, 16, 32} and the 32 | 32 concat): depthwise and
  * pointwise conv composed into one 3x3 implicit GEMM (effective weight Wpw[o][c] * Wdw[c][tap] built from the fp32 masters wdw [Cin][9],
@@ -180,6 +186,9 @@ int ocrs_balanced_bce_fwd(const float* pred, const float* target, float* lpx, un
                           long P, hipStream_t st);
 int ocrs_balanced_bce_bwd(const float* pred, const float* target, const float* lpx, const unsigned char* cls, const void* state,
                           const float* gout, float* gpred, long P, hipStream_t st);
+/* dst[table[r][0] + i] += src[table[r][1] + i], i < table[r][2], r < nrows (table: int32 [nrows][3], device): the ~10 fp64 accumulator folds of a
+   detection backward (out_conv / first-block weights, ConvTranspose biases: ocrs_models/models.py:93-143 autograd) in one launch. */
+int ocrs_fold64_multi(const int* table, int nrows, float* dst, const double* src, hipStream_t st);
 
 /* ------------------------------------------------------------------ recognition (CRNN) ------ */
 /* nn.Conv2d forward / dgrad, GRU input projections, nn.Linear as one implicit-GEMM kernel (ocrs_models/models.py:189-240, 245, 248).

@@ -554,3 +554,56 @@ __device__ __forceinline__ void bn_fin_coef(const BnFin& fin, int COUT, float* s
         }
     }
 }
+
+// ---- BatchNorm2d training statistics finalised by the LAST workgroup of the forward launch that produced them (one launch less per block)
+struct FwdFin {
+    unsigned* counter;  // null: plain partials, the caller runs ocrs_bn_finalize_parts
+    long count;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *tr, *saved, *run_mean, *run_var;
+    long long* nbt;
+    float lo;
+};
+__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, long count, int c, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                                    float* tr, float* saved, float* run_mean, float* run_var, float lo) {
+    const double mean = sum / (double)count;
+    double var = sumsq / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    tr[c] = sc;
+    tr[C + c] = beta[c] - (float)mean * sc;
+    tr[2 * C + c] = lo;
+    saved[c] = (float)mean;
+    saved[C + c] = rstd;
+    if (run_mean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// Forward kernels that accumulate their batch sums into gstat [2][C] (fp64 device-scope atomics): after its own adds every workgroup bumps
+// fin.counter; the one that sees all the others done reads the totals (device-scope loads: the atomics were executed at the memory side) and
+// does k_bn_finalize's arithmetic.  Call with all threads of the block; `s_flag`: a shared int.
+__device__ __forceinline__ void bn_finalize_last_block(const FwdFin& fin, const double* gstat, int C, int tid, int nt, int* s_flag) {
+    if (!fin.counter) return;
+    // this thread's atomics are acknowledged (performed at the memory side: device-scope read-modify-writes bypass the XCD's L2) before the arrival
+    // below is issued.  NOT __threadfence(): its release writes back every dirty line of the L2 -- the output tensor this launch has just stored --
+    // and made the deep-level launches 3x slower
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (*s_flag == 0) return;
+    for (int c = tid; c < C; c += nt) {
+        const double sum = __hip_atomic_load(gstat + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double sq = __hip_atomic_load(gstat + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bn_finalize_channel(sum, sq, fin.count, c, C, fin.gamma, fin.beta, fin.eps, fin.momentum, fin.tr, fin.saved, fin.run_mean, fin.run_var, fin.lo);
+    }
+    if (tid == 0) {
+        if (fin.nbt) *fin.nbt += 1;
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for a replay of the same launch)
+    }
+}

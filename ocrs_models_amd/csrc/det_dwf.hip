@@ -35,7 +35,7 @@ __device__ __forceinline__ void unpack8w(const uint4& r, float (&v)[8]) {
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(512) void k_dwf(Src2<bf16> x, const float* __restrict__ tra, const float* __restrict__ trb, const float* __restrict__ wdw,
-                                             const void* __restrict__ wpk, bf16* __restrict__ z, double* __restrict__ gstat, Tiling2 tg) {
+                                             const void* __restrict__ wpk, bf16* __restrict__ z, double* __restrict__ gstat, Tiling2 tg, FwdFin fin) {
     using C = DwfCfg<CIN, COUT>;
     constexpr int NT = C::NT, TW = C::TW, TP = C::TP, HWp = C::HWp, HP = C::HP, CGI = C::CGI, PXC = C::PXC;
     constexpr int NXI = C::NXI, NUI = C::NUI, MTO = C::MTO, NKD = C::NKD, MPW = C::MPW, NPW = C::NPW;
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(512) void k_dwf(Src2<bf16> x, const float* __restri
         for (int w = 0; w < C::NW; ++w) s += s_st[(w * 2 + which) * COUT + m];
         atomicAdd(&gstat[i], (double)s);
     }
+    bn_finalize_last_block(fin, gstat, COUT, tid, NT, reinterpret_cast<int*>(smem));  // (the tiles are dead; s_st lives behind them)
 }
 
 extern "C" {
@@ -215,7 +216,7 @@ long det_dwf_supported(int Cin, int Cout, int dtype) {
 }
 
 int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                   double* gstat, int Cout, int N, int H, int W, hipStream_t st) {
+                   double* gstat, int Cout, int N, int H, int W, hipStream_t st, const FwdFin& fin) {
     const int Cin = Ca + Cb;
     OCRS_CHECK_ARG(det_dwf_supported(Cin, Cout, 1) && Ca % 8 == 0 && Cb % 8 == 0);
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
@@ -235,7 +236,7 @@ int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* 
         const long cap = (long)kNumCU * (CI_ <= 128 ? 2 : 1); /* resident blocks (<= 128 registers up to 128 input channels) */                                                                \
         if (g > cap) g = cap;                                                                                                                \
         if (g >= 8) g &= ~7L;                                                                                                                \
-        hipLaunchKernelGGL((k_dwf<CI_, CO_>), dim3((int)g), dim3(512), CC::SMEM, st, x, tra, trb, wdw, wpk, (bf16*)z, gstat, tg);            \
+        hipLaunchKernelGGL((k_dwf<CI_, CO_>), dim3((int)g), dim3(512), CC::SMEM, st, x, tra, trb, wdw, wpk, (bf16*)z, gstat, tg, fin);       \
         done = true;                                                                                                                         \
     }
     DWF_CASE(32, 64) DWF_CASE(64, 64) DWF_CASE(64, 128) DWF_CASE(128, 64) DWF_CASE(128, 128) DWF_CASE(128, 256) DWF_CASE(256, 128) DWF_CASE(256, 256)

@@ -584,7 +584,7 @@ long det_c1v2_supported(int N, int H, int W);  // det_c1.hip
 int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st,
                         void* uplane);
 int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
-                   double* gstat, int Cout, int N, int H, int W, hipStream_t st);
+                   double* gstat, int Cout, int N, int H, int W, hipStream_t st, const FwdFin& fin);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) {
     if (det_dwf_supported(Cin, Cout, 1)) return 0;  // (the deep-level kernel is faster than the fusion saves: the max-pool stays its own pass there)
     return Cout <= 64 && (Cin < 32 || Cin % 32 == 0) ? 1 : 0;
@@ -600,9 +600,23 @@ int ocrs_dwpw_fwd(const void* xa, const void* xb, int Ca, int Cb, const float* t
     OCRS_CHECK_ARG(Ca % 8 == 0 && Cb % 8 == 0 && Cin >= 8 && (Cin < 32 || Cin % 32 == 0) && Cout % 8 == 0 && Cout <= 256);
     OCRS_CHECK_ARG((Cb == 0) == (xb == nullptr));
     OCRS_CHECK_ARG((long)N * H * W < (1L << 31));
-    if (!pooled && det_dwf_supported(Cin, Cout, dtype)) return det_dwf_launch(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st);
+    if (!pooled && det_dwf_supported(Cin, Cout, dtype))
+        return det_dwf_launch(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st, FwdFin{nullptr, 0, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f});
     return dtype == 1 ? dispatch_dwpw_fwd<bf16>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st)
                       : dispatch_dwpw_fwd<float>(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, gamma, pooled, st);
+}
+
+// ocrs_dwpw_fwd + ocrs_bn_finalize in one launch (the deep-level forward kernel, det_dwf.hip: ocrs_dwpw_fwd_fin_supported): the last workgroup done
+// finalises the BatchNorm statistics -- counter: a zeroed device word (left zeroed); count, bn_w .. lo: as ocrs_bn_finalize.  No pooling.
+long ocrs_dwpw_fwd_fin_supported(int Cin, int Cout, int dtype) { return det_dwf_supported(Cin, Cout, dtype); }
+int ocrs_dwpw_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
+                      double* gstat, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps, float momentum, float* tr, float* saved,
+                      float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W, int dtype, hipStream_t st) {
+    const int Cin = Ca + Cb;
+    OCRS_CHECK_ARG(xa && tra && wdw && wpk && z && gstat && (Cb == 0 || trb) && (Cb == 0) == (xb == nullptr));
+    OCRS_CHECK_ARG(counter && count > 0 && bn_w && bn_b && tr && saved && ocrs_dwpw_fwd_fin_supported(Cin, Cout, dtype) && (long)N * H * W < (1L << 31));
+    return det_dwf_launch(xa, xb, Ca, Cb, tra, trb, wdw, wpk, z, gstat, Cout, N, H, W, st,
+                          FwdFin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo});
 }
 
 // First block (1 -> 8): img fp32 (N,1,H,W); wdw [9]; wpw [8]; z [P][8]; gstat [2][8] accumulated (caller zeroes).

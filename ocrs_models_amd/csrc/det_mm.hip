@@ -1192,15 +1192,6 @@ struct MfCfg {
 // partial with agent-scope (sc1, write-through) stores, drains them, takes a ticket from an agent-scope counter; the workgroup that draws the last
 // ticket reads all partials with agent-scope loads (they may sit behind another XCD's L2) and does what k_bn_finalize_parts does, in the same
 // association order (bit-identical results) -- one ~6 us launch less per block on the forward's critical path.  counter: one zeroed word per launch.
-struct FwdFin {
-    unsigned* counter;  // null: plain partials, the caller runs ocrs_bn_finalize_parts
-    long count;
-    const float *gamma, *beta;
-    float eps, momentum;
-    float *tr, *saved, *run_mean, *run_var;
-    long long* nbt;
-    float lo;
-};
 // the arithmetic of k_bn_finalize_parts for element column `col` (0..31) of 32-element window `win`, chain `chain` (0..7); red: [windows][8][32] doubles
 template <bool AGENT>
 __device__ __forceinline__ double bn_parts_chain_sum(const float* __restrict__ parts, int nparts, int C, int e, int chain) {
@@ -1220,24 +1211,6 @@ __device__ __forceinline__ double bn_parts_chain_sum(const float* __restrict__ p
         s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     return s;
-}
-__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, long count, int c, int C, const float* gamma, const float* beta, float eps, float momentum,
-                                                    float* tr, float* saved, float* run_mean, float* run_var, float lo) {
-    const double mean = sum / (double)count;
-    double var = sumsq / (double)count - mean * mean;
-    if (var < 0) var = 0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    tr[c] = sc;
-    tr[C + c] = beta[c] - (float)mean * sc;
-    tr[2 * C + c] = lo;
-    saved[c] = (float)mean;
-    saved[C + c] = rstd;
-    if (run_mean) {
-        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-    }
 }
 
 // FULL (the launcher sets it when every tile lies inside the image: H % TH == 0, W % TW == 0, even sizes when pooling): every global store of

@@ -476,6 +476,11 @@ __global__ void k_fill_f32(float* p, float v, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
 }
 
+__global__ void k_fold64_multi(const int* __restrict__ table, float* __restrict__ dst, const double* __restrict__ src) {
+    const int d = table[blockIdx.x * 3], s0 = table[blockIdx.x * 3 + 1], n = table[blockIdx.x * 3 + 2];
+    for (int i = threadIdx.x; i < n; i += 64) dst[d + i] = (float)((double)dst[d + i] + src[s0 + i]);
+}
+
 static inline int ew_grid(long items) {
     long g = (items + 255) / 256;
     const long cap = (long)kNumCU * 8;
@@ -562,6 +567,15 @@ int ocrs_adam_step_dev(const long long* table, const int* chunks, int nchunks, d
     OCRS_CHECK_ARG(table && chunks && nchunks > 0 && step);
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step);
     hipLaunchKernelGGL(k_multi_adam_dev, dim3(nchunks), dim3(256), 0, st, table, chunks, b1, b2, eps, lr, step, gscale);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// dst[table[r][0] + i] += src[table[r][1] + i] for i < table[r][2], r < nrows: the fp64 accumulators of a detection backward (head, first block,
+// ConvTranspose biases: ~10 tensors of <= 17 elements) folded into the flat fp32 gradient buffer by one launch (models.py: fold64).
+int ocrs_fold64_multi(const int* table, int nrows, float* dst, const double* src, hipStream_t st) {
+    OCRS_CHECK_ARG(table && nrows > 0 && dst && src);
+    hipLaunchKernelGGL(k_fold64_multi, dim3(nrows), dim3(64), 0, st, table, dst, src);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -142,11 +142,37 @@ class _DetRun:
         pool = getattr(self, "_zpool", None)
         n8 = (n + 7) // 8 * 8
         if pool is None or self._zoff + n8 > pool.numel():
+            self.fold_flush()  # (deferred folds name offsets in the pool they were carved from)
             pool = self._zpool = torch.zeros(max(8192, n8), dtype=torch.float64, device=self.dev)
             self._zoff = 0
         out = pool[self._zoff:self._zoff + n]
         self._zoff += n8
         return out
+
+    def fold64(self, dst, src64):
+        """dst (a view into this backward's flat fp32 gradient buffer) += src64 (fp64 accumulators carved by zeros64).  Single-GPU runs collect
+        these ~10 tiny adds of a step and run them as ONE launch at the end of the backward (ocrs_fold64_multi); with a gradient bucketer
+        (DDP: stages are reported as they complete) or outside a backward the add runs at once."""
+        flat = getattr(self, "_flat", None)
+        if flat is None or self._defer_folds is False or src64._base is not self._zpool:
+            dst.view(-1).add_(src64)
+            return
+        self._folds.append((dst.storage_offset(), src64.storage_offset(), src64.numel()))
+
+    _FOLD_TABLES = {}
+
+    def fold_flush(self):
+        folds = getattr(self, "_folds", None)
+        if not folds:
+            return
+        key = (self.dev, tuple(folds))
+        tab = _DetRun._FOLD_TABLES.get(key)
+        if tab is None:  # (the same offsets every step: the device copy of the table is made once)
+            if len(_DetRun._FOLD_TABLES) > 64:
+                _DetRun._FOLD_TABLES.clear()
+            tab = _DetRun._FOLD_TABLES[key] = torch.tensor(folds, dtype=torch.int32).to(self.dev)
+        self.L.fold64_multi(ptr(tab), len(folds), ptr(self._flat), ptr(self._zpool))
+        folds.clear()
 
     def pack(self, src, mode, K, M, K2, s1, s2, sm):
         """MFMA weight fragments of one layer: from this step's multi-pack buffer (prepack) or, outside a full forward, packed here."""
@@ -256,9 +282,18 @@ class _DetRun:
         if pool and self.fuse_pool and L.dwpw_fwd_pool_supported(Cin, Cout):
             pooled, gamma = self.empty(N, H // 2, W // 2, Cout), P[f"{prefix}.seq.2.weight"]
         self.pooled_by_block = pooled
-        L.dwpw_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, b.C if b is not None else 0, ptr(a.tr),
-                   ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
-        tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, Cout)
+        if self.train and self.fold_fwd_fin and pooled is None and L.dwpw_fwd_fin_supported(Cin, Cout, self.dt):
+            # deep levels: the BatchNorm statistics are finalised by the last workgroup of the forward launch (ocrs_bn_finalize's arithmetic)
+            bnp, Bf = f"{prefix}.seq.2", self.Bf
+            tr, saved = self.empty(3, Cout, dtype=torch.float32), self.empty(2, Cout, dtype=torch.float32)
+            L.dwpw_fwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, a.C, b.C if b is not None else 0, ptr(a.tr), ptr(b.tr) if b is not None else None,
+                           ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), ptr(self.zeros64(1)), N * H * W, ptr(P[f"{bnp}.weight"]), ptr(P[f"{bnp}.bias"]), 1e-5, 0.1,
+                           ptr(tr), ptr(saved), ptr(Bf[f"{bnp}.running_mean"]), ptr(Bf[f"{bnp}.running_var"]), ptr(Bf[f"{bnp}.num_batches_tracked"]), 0.0,
+                           Cout, N, H, W, self.dt)
+        else:
+            L.dwpw_fwd(ptr(a.t), ptr(b.t) if b is not None else None, a.C, b.C if b is not None else 0, ptr(a.tr),
+                       ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
+            tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, Cout)
         r = _BlockRec()
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
         self.recs[prefix] = r
@@ -365,8 +400,8 @@ class _DetRun:
         if r.Cin == 1:
             acc = self.zeros64(17)  # fp64 accumulators (order-independent), folded into the fp32 gradients below
             L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(acc), N, H, W, self.dt)
-            self.G[f"{prefix}.seq.1.weight"].view(-1).add_(acc[:8])
-            self.G[f"{prefix}.seq.0.weight"].view(-1).add_(acc[8:17])
+            self.fold64(self.G[f"{prefix}.seq.1.weight"], acc[:8])
+            self.fold64(self.G[f"{prefix}.seq.0.weight"], acc[8:17])
             return None, None
         a, b = r.a, r.b
         Ca, Cb = a.C, (b.C if b is not None else 0)
@@ -443,6 +478,8 @@ class _DetRun:
                     off += n
             stage_end[stage] = off
         bucketer = getattr(self.mod, "_grad_bucketer", None)
+        self._flat, self._folds = flat, []
+        self._defer_folds = bucketer is None and self.capture is None and os.environ.get("OCRS_DEFER_FOLDS", "1") != "0"
         done = [0]
         # Side stream for work that nothing downstream in the backward reads (the deep-level ConvTranspose weight / bias gradients): it overlaps the
         # latency-bound deep-level kernels that follow on the main stream.  A stage is reported to the gradient bucketer only after the main stream
@@ -487,8 +524,8 @@ class _DetRun:
             L.head_bwd(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
                        N * H * W, self.dt)
         self._head_gl = g if head_gl else None
-        self.G["out_conv.0.weight"].view(-1).add_(acc[:8])
-        self.G["out_conv.0.bias"].view(-1).add_(acc[8:9])
+        self.fold64(self.G["out_conv.0.weight"], acc[:8])
+        self.fold64(self.G["out_conv.0.bias"], acc[8:9])
         if self.capture is not None:
             self.capture["out_conv"] = {"gpred": gpred, "g": g}
         stage_done("out_conv")
@@ -517,14 +554,17 @@ class _DetRun:
                 side.wait_stream(main)  # its operands (x, the output gradient, the zeroed accumulators) are ready in main-stream order
                 with torch.cuda.stream(side):
                     L.convt_bwd_parts(*args, 2, self.dt)
-                    self.G[f"up.{i}.up.bias"].add_(db64)
+                    if not self._defer_folds:
+                        self.G[f"up.{i}.up.bias"].add_(db64)
+                if self._defer_folds:
+                    self.fold64(self.G[f"up.{i}.up.bias"], db64)  # (runs at the end of the backward, behind the join with the side stream)
                 keep.extend((gxa, ws, db64, wpk_d, up_in.t))
                 L.convt_bwd_parts(*args, 1, self.dt)
                 stage_done(f"up.{i}", side_work=True)
             else:
                 flush_pending()
                 L.convt_bwd(*args, self.dt)
-                self.G[f"up.{i}.up.bias"].add_(db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
+                self.fold64(self.G[f"up.{i}.up.bias"], db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
                 stage_done(f"up.{i}")
             if self.capture is not None:
                 self.capture[f"up.{i}.up"] = {"g": gxa, "dx": dx}
@@ -542,6 +582,10 @@ class _DetRun:
         g1, _ = self.block_bwd("in_conv.seq.1", gs[0], gs[1], 0)
         self.block_bwd("in_conv.seq.0", g1, None, 0)
         flush_pending()
+        if side is not None and self._defer_folds:
+            main.wait_stream(side)  # (a no-op when flush_pending just joined)
+        self.fold_flush()
+        self._flat = None
         stage_done("in_conv")
         if bucketer is not None:
             bucketer.finish(flat)

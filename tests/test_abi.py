@@ -25,7 +25,7 @@ def test_size_queries_work_without_gpu():
 
     L = lib()
     assert L.opt_chunk() == 2048
-    assert L.loss_state_bytes() > 0 and L.loss_hist_bytes() == 2 * 2048 * 4
+    assert L.loss_state_bytes() > 0 and L.loss_hist_bytes() == 2 * 2048 * 4 + 1024 * 2 * 16  # the two histograms + per-block count / sum partials
     assert L.pack_frags_bytes(32, 16, 1) == 64 * 8 * 2
     assert L.pack_frags_bytes(33, 17, 0) == 2 * 2 * 64 * 8 * 4
 
