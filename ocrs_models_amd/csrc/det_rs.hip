@@ -48,12 +48,27 @@
 #ifndef OCRS_RS_WPS_G2
 #define OCRS_RS_WPS_G2 3  // two gradient tensors: 8 more prefetch registers per set (139 VGPRs; at the 128 cap hipcc spills loop invariants, and a scratch reload is a vmcnt(0))
 #endif
+#ifndef OCRS_RS_8_16
+#define OCRS_RS_8_16 1  // 8 -> 16 channels on this kernel (two waves per SIMD, per-channel coefficients of the 16-channel side in vector registers): 772 -> 725 us at
+                        // level 0.  16 -> 8 and 16 -> 16 were measured too (-DOCRS_RS_16): 754 vs 645 us and 660 vs 227 us -- they stay on k_mm_bwd
+#endif
+#ifndef OCRS_RS_816_SC
+#define OCRS_RS_816_SC 1
+#endif
 #ifndef OCRS_RS_WPS_16
 #define OCRS_RS_WPS_16 2  // a 16-channel side: twice the prefetch registers / coefficient pairs / G accumulators (spills at the 168-register cap of 3)
 #endif
+#ifndef OCRS_RS_WPS_8_16
+#define OCRS_RS_WPS_8_16 2  // 8 -> 16 channels, one gradient tensor: fits 168 registers without spills, but three workgroups per CU measured 831 us against 725 us
+                            // with two (level 0; k_mm_bwd: 772 us) -- as for 8 -> 8 channels the memory side prefers fewer streams
+#endif
 template <int CIN, int COUT, bool G2>
-constexpr int rs_wps() { return (CIN == 8 && COUT == 8) ? (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : OCRS_RS_WPS_16; }
-static int rs_wps_rt(int Cin, int Cout, int g2) { return (Cin == 8 && Cout == 8) ? (g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : OCRS_RS_WPS_16; }
+constexpr int rs_wps() {
+    return (CIN == 8 && COUT == 8) ? (G2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : ((CIN == 8 && COUT == 16 && !G2) ? OCRS_RS_WPS_8_16 : OCRS_RS_WPS_16);
+}
+static int rs_wps_rt(int Cin, int Cout, int g2) {
+    return (Cin == 8 && Cout == 8) ? (g2 ? OCRS_RS_WPS_G2 : OCRS_RS_WPS) : ((Cin == 8 && Cout == 16 && !g2) ? OCRS_RS_WPS_8_16 : OCRS_RS_WPS_16);
+}
 
 namespace {
 
@@ -293,23 +308,39 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     __syncthreads();
 
     // ---- per-channel coefficients: one operand of every packed fma from scalar registers, the other one pinned into a VGPR pair
+    // (a 16-channel side: its coefficients do not fit the scalar register file next to the descriptors -- hipcc then spills SGPRs inside the tick
+    //  loop -- so that side keeps all of them in vector registers: these instantiations run two waves per SIMD with 256 registers each)
+    constexpr bool SO = COUT == 8, SI = CIN == 8;  // scalar-register coefficients
+    auto sv2 = [](auto SC, float a, float b) -> f32x2 {
+        if constexpr (decltype(SC)::value) return (f32x2){usc(a), usc(b)};
+        else return vreg((f32x2){a, b});
+    };
+    using BO = std::integral_constant<bool, SO>;
+    using BI = std::integral_constant<bool, SI>;
+    using BC = std::integral_constant<bool, SO || (SI && OCRS_RS_816_SC)>;  // 8 -> 16 channels: the dz coefficients A, B stay scalar (32 SGPRs), the BatchNorm scale goes to vector registers
     f32x2 bs2[COUT / 2], bt2[COUT / 2], ca2[COUT / 2], cb2[COUT / 2], cc2[COUT / 2], sc2[CIN / 2], sh2[CIN / 2];
     float lo1[CIN];
 #pragma unroll
     for (int i = 0; i < COUT / 2; ++i) {
-        bs2[i] = (f32x2){usc(s_bn[2 * i]), usc(s_bn[2 * i + 1])};
+        bs2[i] = sv2(BO{}, s_bn[2 * i], s_bn[2 * i + 1]);
         bt2[i] = vreg((f32x2){s_bn[COUT + 2 * i], s_bn[COUT + 2 * i + 1]});
-        ca2[i] = (f32x2){usc(s_cf[2 * i]), usc(s_cf[2 * i + 1])};
-        cb2[i] = (f32x2){usc(s_cf[COUT + 2 * i]), usc(s_cf[COUT + 2 * i + 1])};
+        ca2[i] = sv2(BC{}, s_cf[2 * i], s_cf[2 * i + 1]);
+        cb2[i] = sv2(BC{}, s_cf[COUT + 2 * i], s_cf[COUT + 2 * i + 1]);
         cc2[i] = vreg((f32x2){s_cf[2 * COUT + 2 * i], s_cf[2 * COUT + 2 * i + 1]});
     }
 #pragma unroll
     for (int i = 0; i < CIN / 2; ++i) {
-        sc2[i] = (f32x2){usc(s_trx[2 * i]), usc(s_trx[2 * i + 1])};
+        sc2[i] = sv2(BI{}, s_trx[2 * i], s_trx[2 * i + 1]);
         sh2[i] = vreg((f32x2){s_trx[CIN + 2 * i], s_trx[CIN + 2 * i + 1]});
     }
 #pragma unroll
-    for (int i = 0; i < CIN; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
+    for (int i = 0; i < CIN; ++i) {
+        if constexpr (SI) lo1[i] = usc(s_trx[2 * CIN + i]);
+        else {
+            lo1[i] = s_trx[2 * CIN + i];
+            asm volatile("" : "+v"(lo1[i]));
+        }
+    }
 
     float wh[HEAD ? 8 : 1], we[XU ? 8 : 1];
     if constexpr (HEAD) {
@@ -481,8 +512,13 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
                     xin = unpk(pxr[S][j][k]);
                 }
                 f32x2 v = __builtin_elementwise_fma(xin, sc2[ci], sh2[ci]);
-                asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * ci]));
-                asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * ci + 1]));
+                if constexpr (SI) {
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * ci]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * ci + 1]));
+                } else {
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "v"(lo1[2 * ci]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "v"(lo1[2 * ci + 1]));
+                }
                 const unsigned pk = cvt_pk(v.x, v.y);
                 w[k] = okx ? pk : 0u;
                 // [x~ > 0] per half word: x~ is a non-negative bf16 (ReLU producers: lo = +0 and v_max(-0, +0) = +0), so bits != 0 <=> x~ > 0
@@ -674,20 +710,23 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     for (int e = tid; e < COUT * CIN; e += C::NT) {
         const int o = e / CIN, c = e - o * CIN;
         float s = 0.f;
-#pragma unroll
+#pragma unroll 1  // (once per block: not worth the registers -- unrolled, the 8 -> 16 channel instantiation spills here)
         for (int tap = 0; tap < 9; ++tap) s = fmaf(A.wdw[c * 9 + tap], Gv(c, tap, o), s);
         part[e] = s;
     }
     for (int e = tid; e < 9 * CIN; e += C::NT) {
         const int c = e / 9, tap = e - c * 9;
         float s = 0.f;
+#pragma unroll 1
         for (int o = 0; o < COUT; ++o) s = fmaf(A.wpw[o * A.ldw + c], Gv(c, tap, o), s);
         part[COUT * CIN + e] = s;
     }
     for (int e = tid; e < 2 * CIN; e += C::NT) {  // [CIN][S1 | S2] with the bf16 effective weights the dgrad used
         const int c = e >> 1, which = e & 1;
         float s = 0.f;
+#pragma unroll 1
         for (int tap = 0; tap < 9; ++tap)
+#pragma unroll 1
             for (int o = 0; o < COUT; ++o) {
                 const float we = bf2f(f2bf(A.wdw[c * 9 + tap] * A.wpw[o * A.ldw + c]));
                 s = fmaf(we, Gv(which ? c : CIN + c, tap, o), s);
@@ -707,7 +746,11 @@ bool rs_bwd_supported(int Ca, int Cb, int Cout, int pooled, int N, int H, int W)
     // (the kernel is written for Cin / Cout in {8, 16}, but only 8 -> 8 is instantiated: with 16 channels on either side the per-channel coefficients
     //  no longer fit the scalar register file next to the descriptors -- hipcc spills SGPRs to scratch inside the tick loop, 256 VGPRs + 40-88 B of
     //  scratch -- and a scratch reload in that loop is a vmcnt(0); those shapes need LDS-resident coefficients first)
-    if (!(Cin == 8 && Cout == 8)) return false;
+#ifdef OCRS_RS_16
+    if (!((Cin == 8 || Cin == 16) && (Cout == 8 || Cout == 16))) return false;
+#else
+    if (!(Cin == 8 && (Cout == 8 || (OCRS_RS_8_16 && Cout == 16)))) return false;
+#endif
     if (Cb != 0 && !(Ca == 8 && Cb == 8)) return false;
     const long bytes = (long)N * H * W * (Cin > Cout ? Cin : Cout) * 2;
     return bytes < (1L << 31) && H >= 2 && W >= 2;
@@ -780,6 +823,12 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
         }                                                                                 \
     }
     RS_CASE(8, 8)
+#if OCRS_RS_8_16
+    RS_CASE(8, 16)
+#endif
+#ifdef OCRS_RS_16
+    RS_CASE(16, 8) RS_CASE(16, 16)
+#endif
 #undef RS_CASE
 #undef RS_LAUNCH
 }

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+V=$GRAFT_REPO_ROOT/ocrs_models_amd/variants
+timeout 900 python -m pytest tests/test_det_ops_gpu.py tests/test_det_bf16_layerwise_gpu.py tests/test_det_model_gpu.py tests/test_edge_cases_gpu.py -x -q 2>&1 | tail -4
+bash tools/experiments/r5_det_ab.sh "w3" "w2 OCRS_LIB_PATH=$V/libocrs_hip_rs816w2.so" "mm OCRS_LIB_PATH=$V/libocrs_hip_nos2g.so"
+bash tools/run_trace_step.sh
