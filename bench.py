@@ -91,6 +91,9 @@ def det_alg_elems_per_image(H: int, W: int) -> int:
 ALG_BYTES_ARGS = {
     "dwpw_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_fwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "mm_fwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
+    "mm_fwd_fin_xu": ("N", "H", "W", "Cout"),
+    "dwpw_fwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "pw_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "pw_bwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
@@ -111,7 +114,7 @@ FAMILIES = list(ALG_BYTES_ARGS)
 PROF_STEPS = 2  # timed steps whose dominant-pass launches are individually timed (dispatch-packet timestamps, csrc/prof.hip)
 PASSES = {
     "block_bwd": ("mm_bwd", "mm_bwd_fin", "mm_bwd_fin_head", "mm_bwd_fin_xu", "pw_bwd", "pw_bwd_fin", "dw_bwd", "bn_bwd_reduce"),
-    "block_fwd": ("mm_fwd", "dwpw_fwd"),
+    "block_fwd": ("mm_fwd", "mm_fwd_fin", "mm_fwd_fin_xu", "dwpw_fwd", "dwpw_fwd_fin"),
     "convt_fwd": ("convt_fwd",),
     "convt_bwd": ("convt_bwd", "convt_bwd_parts"),
     "maxpool_fwd": ("maxpool_fwd",),
@@ -130,14 +133,19 @@ def alg_bytes(name, a, sz):
     from ocrs_models_amd._lib import ARG_NAMES
 
     v = dict(zip(ARG_NAMES["ocrs_" + name], a))
-    if name in ("dwpw_fwd", "mm_fwd"):  # x (Ca+Cb) in, z (Cout) out
+    if name in ("dwpw_fwd", "dwpw_fwd_fin", "mm_fwd", "mm_fwd_fin"):  # x (Ca+Cb) in, z (Cout) out
         return v["N"] * v["H"] * v["W"] * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
+    if name == "mm_fwd_fin_xu":  # in_conv.seq.1: SURVEY 8(d) books x (8 channels) in, z out -- the launch itself reads the 2-byte u plane instead of x
+        return v["N"] * v["H"] * v["W"] * (8 + v["Cout"]) * sz
     if name in ("pw_bwd", "pw_bwd_fin", "mm_bwd", "mm_bwd_fin"):  # the whole block backward: x, z, g in; dL/dx out
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cb"] + v["Cout"]) * sz
-    if name == "mm_bwd_fin_head":  # the block in front of out_conv: its 8-channel output gradient is never stored -- x, z, gl (fp32) in; dL/dx out.
-        return v["N"] * v["H"] * v["W"] * ((2 * v["Ca"] + v["Cout"]) * sz + 4)  # (booked with the bytes it really needs, not the 2 (Cin + Cout) of 8(d))
-    if name == "mm_bwd_fin_xu":  # the block behind the first block: its 8-channel input is rebuilt from the 2-byte u plane -- u, z, g in; dL/dx out
-        return v["N"] * v["H"] * v["W"] * ((8 + 2 * v["Cout"]) * sz + 2)
+    # SURVEY 8(d) books every block backward with 2 (Cin + Cout) elements per pixel.  The two ends of the net MOVE fewer bytes than that (round 5):
+    # the block in front of out_conv reads gl (4 B / pixel) instead of its 8-channel output gradient, the block behind the first block reads the
+    # 2-byte u plane instead of its 8-channel input -- `roofline.traffic` (PMC) shows the bytes really moved, `achieved` stays on the 8(d) figure
+    if name == "mm_bwd_fin_head":
+        return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cout"]) * sz
+    if name == "mm_bwd_fin_xu":
+        return v["N"] * v["H"] * v["W"] * 2 * (8 + v["Cout"]) * sz
     if name in ("dw_bwd", "bn_bwd_reduce"):
         return 0.0
     if name == "convt_fwd":  # x in, out out

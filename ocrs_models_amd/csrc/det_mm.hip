@@ -67,6 +67,9 @@
                             // 512-thread workgroup -- the same two waves per SIMD, but the barrier waits / commit / epilogue of one workgroup (35-40 % of a
                             // tile at one workgroup per CU: tools/runs/mm_prof.sh) run under the MFMA phases of the other
 #endif
+#ifndef OCRS_MM_C3216_N256
+#define OCRS_MM_C3216_N256 1  // the same form for Cin = 32 -> Cout = 16 (which spills 12-44 B per lane at two 512-thread workgroups per CU): 382 -> 366 us at level 1
+#endif
 #ifndef OCRS_MM_C32_MERGE
 #define OCRS_MM_C32_MERGE 1  // ... and both M tiles of the dgrad in ONE pass over the B fragments (the LDS reads of that phase halve: 16 more accumulator registers)
 #endif
@@ -118,7 +121,7 @@ struct MmPitch {  // bf16 elements per pixel of an LDS tile: 16 / 32-byte rows a
 
 template <int CIN, int COUT, bool PPOOL = false>
 struct MmCfg {
-    static constexpr bool N256 = OCRS_MM_C32_N256 && CIN == 32 && COUT == 32;  // two 256-thread workgroups per CU with the full register file each
+    static constexpr bool N256 = (OCRS_MM_C32_N256 && CIN == 32 && COUT == 32) || (OCRS_MM_C3216_N256 && CIN == 32 && COUT == 16);  // two 256-thread workgroups per CU with the full register file each
     static constexpr int NT = N256 ? 256 : 512, NW = NT / 64;          // 8 (4) waves
     // Cin = 32 (two M tiles, 16-24 more live registers than fit 128 without spilling -- and a scratch reload inside the pipelined loop waits for
     // every prefetched load): ONE block per CU with the full register file and 16-row tiles; everything else: two blocks per CU, 8-row tiles
@@ -129,7 +132,7 @@ struct MmCfg {
     static constexpr bool MERGE = N256 && OCRS_MM_C32_MERGE;            // dgrad: both M tiles per pass
     static constexpr int TP = TW * TH;
     static constexpr bool T12P = CIN == 16 && COUT == 16 && TH == 12;  // 12-row 16 -> 16 tile (pooled or direct gradient): needs the two register diets below to fit 128
-    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3 && !(OCRS_MM_C32_N256 && OCRS_MM_C32_MERGE && !OCRS_MM_C32_MERGE_BDB && CIN == 32 && COUT == 32);  // dgrad B fragments double-buffered across K chunks
+    static constexpr bool BDB = OCRS_MM_BDB && (!OCRS_MM_BDB_EXCL || (!(CIN == 8 && COUT == 16 && TH == 12) && !T12P)) && !T3 && !(N256 && OCRS_MM_C32_MERGE && !OCRS_MM_C32_MERGE_BDB);  // dgrad B fragments double-buffered across K chunks
     static constexpr int DW_ = TW + 2, DH_ = TH + 2, DP = DW_ * DH_;  // domain = tile + 1-pixel ring
     static constexpr int CGI = CIN / 8, CGO = COUT / 8;
     static constexpr int PD = MmPitch<COUT>::V, PX = MmPitch<CIN>::V;
@@ -213,6 +216,11 @@ __device__ __forceinline__ Raw8<bf16> raw8_of(const u32x4& v) {
 // forward: Cin = 8 needs < 80 registers and ~10 KB of LDS: three blocks per CU (more bytes in flight: these launches are latency-bound)
 template <int CINB, int COUT>
 constexpr int mm_fwd_lb() { return CINB == 8 ? 2 * OCRS_MF_BPC8 : ((CINB == 16 && COUT == 8) ? 2 * OCRS_MF_BPC16_8 : 4); }
+// the last-workgroup finalisation of the forward statistics is compiled into every shape but Cin = 16 -> Cout = 8: at that shape's 80-register cap (three
+// blocks per CU) the extra code made hipcc spill a 64-bit index pair that the prefetch issue reloads from scratch -- behind an s_waitcnt vmcnt(0), i.e.
+// behind the acknowledgement of the previous tile's stores (397 -> 454-472 us at level 0); the launcher runs k_bn_finalize_parts for it instead
+template <int CINB, int COUT>
+constexpr bool mm_fwd_fink() { return !(CINB == 16 && COUT == 8); }
 template <int CIN, int COUT, bool PPOOL>
 constexpr int mm_bwd_lb() { return MmCfg<CIN, COUT, PPOOL>::BPC * MmCfg<CIN, COUT, PPOOL>::NW / 4; }  // minimum waves per SIMD (2 = one 512-thread block per CU, 4 = two)
 }  // namespace
@@ -989,6 +997,7 @@ static int mm_grid(int th, int N, int H, int W, int pooled, int bpc = 2) {
 static int mm_th(int Cin, int Cout, int nst) { return OCRS_MF_TH_OF(Cin, Cout, nst); }  // forward tiles
 static int mm_bwd_bpc(int Cin, int Cout, int pooled = 0) {
     if (Cin == 32 && Cout == 32) return OCRS_MM_C32_N256 ? 2 : OCRS_MM_C32_BPC;
+    if (Cin == 32 && Cout == 16 && OCRS_MM_C3216_N256) return 2;
     return (OCRS_MM_B3_16_8 && Cin == 16 && Cout == 8 && !pooled) ? 3 : 2;
 }
 static int mm_bwd_th(int Cin, int Cout, int pooled) {
@@ -1544,9 +1553,10 @@ __global__ __launch_bounds__(512, (mm_fwd_lb<CINB, COUT>())) void k_mm_fwd(Src2<
     for (int e = tid; e < 2 * COUT; e += NT) {
         float s = 0.f;
         for (int w = 0; w < C::NW; ++w) s += s_stat[w * MT * 32 + e];
-        if (fin.counter) __hip_atomic_store(ws + (long)blockIdx.x * (2 * COUT) + e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sc1: visible across XCDs once drained)
+        if (mm_fwd_fink<CINB, COUT>() && fin.counter) __hip_atomic_store(ws + (long)blockIdx.x * (2 * COUT) + e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (sc1: visible across XCDs once drained)
         else ws[(long)blockIdx.x * (2 * COUT) + e] = s;
     }
+    if constexpr (!mm_fwd_fink<CINB, COUT>()) return;
     if (!fin.counter) return;
     // ---- last workgroup done: finalise the statistics here (see FwdFin)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1659,6 +1669,9 @@ static int mm_fwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
     if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, fin, st, xu);
     MF_CASE(8, 1, 8) MF_CASE(8, 1, 16) MF_CASE(16, 1, 8) MF_CASE(16, 1, 16) MF_CASE(16, 1, 32) MF_CASE(32, 1, 16) MF_CASE(32, 1, 32) MF_CASE(32, 2, 32)
 #undef MF_CASE
+    if (fin.counter && Cin == 16 && Cout == 8)  // (see mm_fwd_fink: this shape's statistics are finalised by their own launch)
+        hipLaunchKernelGGL(k_bn_finalize_parts, dim3((2 * Cout + 31) / 32), dim3(256), 0, st, ws, nb, fin.count, Cout, fin.gamma, fin.beta, fin.eps, fin.momentum,
+                           fin.tr, fin.saved, fin.run_mean, fin.run_var, fin.nbt, fin.lo);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
