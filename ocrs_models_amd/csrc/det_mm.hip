@@ -1649,6 +1649,7 @@ long ocrs_mm_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
 }
 // number of per-block statistics partials ocrs_mm_fwd writes (ws = that many x 2 * Cout floats)
 long ocrs_mm_fwd_nparts(int Ca, int Cb, int Cout, int N, int H, int W) {
+    if (rs_fwd_supported(Ca, Cb, Cout, N, H, W)) return rs_fwd_blocks(N, H, W);  // (also the grid of the tiled kernel when such a launch pools: persistent, any size)
     const int cinb = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int th = mm_th(cinb, Cout, (Ca == 32 && Cb == 32) ? 2 : 1);
     return mm_grid(th, N, H, W, 0, cinb == 8 ? OCRS_MF_BPC8 : ((cinb == 16 && Cout == 8) ? OCRS_MF_BPC16_8 : 2));
@@ -1665,6 +1666,11 @@ static int mm_fwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
     const int Cin = Ca + Cb;
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
     const int nb = (int)ocrs_mm_fwd_nparts(Ca, Cb, Cout, N, H, W);
+    if (!pooled && rs_fwd_supported(Ca, Cb, Cout, N, H, W)) {  // the row-streaming kernel (det_rs.hip)
+        rs_fwd_launch((const bf16*)xa, xu.u, xu.wexp, tra, wdw, wpw, (bf16*)z, ws, Cout, N, H, W, nb, fin, st);
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
 #define MF_CASE(CB_, NS_, CO_) \
     if (Cin == CB_ * NS_ && Cout == CO_ && (NS_ == 1 || Ca == 32)) mm_fwd_launch<CB_, NS_, CO_>(x, tra, trb, wdw, wpw, (bf16*)z, ws, gamma, (bf16*)pooled, N, H, W, nb, fin, st, xu);
     MF_CASE(8, 1, 8) MF_CASE(8, 1, 16) MF_CASE(16, 1, 8) MF_CASE(16, 1, 16) MF_CASE(16, 1, 32) MF_CASE(32, 1, 16) MF_CASE(32, 1, 32) MF_CASE(32, 2, 32)

@@ -172,6 +172,14 @@ __device__ __forceinline__ unsigned bload4_opaque(const i32x4& rsrc, int voff) {
     asm volatile("buffer_load_dword %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "=&v"(r) : "v"(voff), "s"(rsrc) : "memory");
     return r;
 }
+// in-place forms ("+v": the load's destination IS the variable's current register -- with a fresh "=&v" output hipcc may give the value a new register
+// and join the two at a loop header with a copy issued while the load is still in flight, which tools/check_rs_loads.py caught in k_rs_fwd)
+__device__ __forceinline__ void bload16_inplace(u32x4& r, const i32x4& rsrc, int voff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "+v"(r) : "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void bload2_inplace(unsigned& r, const i32x4& rsrc, int voff) {
+    asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" OCRS_RS_LD_HINT : "+v"(r) : "v"(voff), "s"(rsrc) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm(unsigned& r) {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -250,6 +258,23 @@ struct RsGen {  // (all wave-uniform: scalar registers)
         return t;
     }
 };
+
+// element e of [C][2] summed over the per-block partials by chain `chain` (of 8): k_bn_finalize_parts's association order (det_mm.hip: bn_parts_chain_sum<true>)
+__device__ __forceinline__ double rs_parts_chain_sum(const float* __restrict__ parts, int nparts, int C, int e, int chain) {
+    double s = 0.0;
+    if (e < 2 * C) {
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto ld = [&](long i) -> double { return (double)__hip_atomic_load(parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        int b = chain;
+        for (; b + 56 < nparts; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += ld((long)(b + 8 * u) * 2 * C + e);
+        }
+        for (int u = 0; b < nparts; b += 8, ++u) a[u & 7] += ld((long)b * 2 * C + e);
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    return s;
+}
 
 }  // namespace
 
@@ -735,6 +760,312 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     }
 }
 
+// =============================================================================================================================================
+// Row-streaming FORWARD of a DepthwiseConv block with 8 input channels (reference ocrs_models/models.py:7-28; levels 0 of the U-Net: in_conv.seq.1,
+// down.0's first block, the block in front of out_conv): z = Weff (*) x~ as in k_mm_fwd (det_mm.hip), with k_rs_bwd's execution structure -- a wave
+// owns a 30-column strip and marches down the image two rows per tick, its x~ rows live in a wave-private 6-row LDS ring (no workgroup barrier in
+// the main loop), rows are loaded two ticks ahead through buffer descriptors with hand-counted waits, per-channel load-transform coefficients are
+// scalar-register operands.  Cout = 8: the 16-row MFMA M tile carries (row parity, output channel): one MFMA set per tick yields both rows of the
+// pair (K = 4 ring rows x 3 columns x 8 channels = 96: three chunks of 32 plus one of zero padding -- 8 MFMAs per 60 output pixels); Cout = 16:
+// one pass per row.  The output goes through a per-wave LDS staging area so that every lane stores one pixel's channels (16-byte stores), the
+// per-channel batch sums of the STORED values are per-lane register accumulators (reduced once, at the end), written as per-block partials in
+// k_mm_fwd's layout and finalised by the last workgroup (FwdFin).  XU: the input is the first block's u plane (see k_rs_bwd).
+// The tiled kernel needs ~8-10 ps per pixel for these shapes whatever they read (in_conv.seq.1 from the 2-byte u plane: 340 us for 18 B / pixel);
+// their per-tile instruction stream, not memory, is what bounds it.
+// k_rs_fwd's prefetch sets live in AGPRs named in the asm text (see the kernel): set S = a[32 + 4 S : 35 + 4 S] (hipcc allocates its own accumulation registers from a0 upwards: MFMA accumulators of the 16-channel form)
+template <int S>
+__device__ __forceinline__ void rsf_load16(const i32x4& rsrc, int voff) {
+    if constexpr (S == 0) asm volatile("buffer_load_dwordx4 a[32:35], %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a32", "a33", "a34", "a35");
+    else asm volatile("buffer_load_dwordx4 a[36:39], %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a36", "a37", "a38", "a39");
+}
+template <int S>
+__device__ __forceinline__ void rsf_load2(const i32x4& rsrc, int voff) {
+    if constexpr (S == 0) asm volatile("buffer_load_ushort a32, %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a32");
+    else asm volatile("buffer_load_ushort a36, %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a36");
+}
+template <int S, int Y>
+__device__ __forceinline__ u32x4 rsf_take16() {
+    static_assert(Y >= 0 && Y < 64, "vmcnt is a 6-bit field");
+    unsigned x, y, z, w;
+    if constexpr (S == 0)
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35"
+                     : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(Y) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39"
+                     : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(Y) : "memory");
+    return (u32x4){x, y, z, w};
+}
+template <int S, int Y>
+__device__ __forceinline__ unsigned rsf_take2() {
+    unsigned x;
+    if constexpr (S == 0) asm volatile("s_waitcnt vmcnt(%1)\n\tv_accvgpr_read_b32 %0, a32" : "=v"(x) : "n"(Y) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%1)\n\tv_accvgpr_read_b32 %0, a36" : "=v"(x) : "n"(Y) : "memory");
+    return x;
+}
+// a 16-byte store the hardware range check drops (offset 0xffffffff): keeps the prologue's operation count equal to a tick's
+__device__ __forceinline__ void rsf_dropped_store(const i32x4& rsrc) {
+    const int off = -1;
+    const u32x4 zero = (u32x4){0u, 0u, 0u, 0u};
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(zero), "v"(off), "s"(rsrc) : "memory");
+}
+struct RsfArgs {
+    const bf16 *x, *xu;
+    const float *wexp, *tra, *wdw, *wpw;
+    bf16* z;
+    float* ws;
+    int N, H, W, NS, NP, NB, PB, njobs;
+    FwdFin fin;
+};
+#ifndef OCRS_RSF_WPS
+#define OCRS_RSF_WPS 3  // resident 4-wave workgroups per CU (per launch at level 0, XU | plain: 3: 240 | 226 us, 4: 255 | 254 us; the tiled kernel: 340 | 279 us)
+#endif
+template <int COUT>
+struct RsfCfg {
+    static constexpr int NW = 4, NT = 256, SW = 30, CIN = 8;
+    static constexpr int PXB = CIN * 2, ROWB = 34 * PXB, RROWS = 6, RINGB = RROWS * ROWB + 64;
+    static constexpr bool DUAL = COUT == 8;
+    static constexpr int NPASS = DUAL ? 1 : 2, NDY = DUAL ? 4 : 3, KC = NDY;  // a K chunk = one ring row: 4 column slots (the fourth carries zero weights) x 8 channels
+    static constexpr int NZ = COUT / 8;                 // 16-byte output items per lane and tick
+    static constexpr int STB = 2 * 32 * COUT * 2;       // staging of a row pair's output
+    static constexpr int OFF_RING = 64, OFF_ST = OFF_RING + NW * RINGB, OFF_WF = OFF_ST + NW * STB, OFF_PAR = OFF_WF + KC * 1024;
+    static constexpr int PAR_FLOATS = 3 * CIN + 9 * CIN + COUT * CIN + NW * 2 * COUT;  // trx | w9 | wp | per-wave stat slots
+    static constexpr int SMEM = OFF_PAR + PAR_FLOATS * 4;
+    static_assert(64 + (8 * 32 + 32) * 8 <= OFF_ST, "the finalisation's reduction area fits the dead rings");
+};
+
+template <int COUT, bool XU>
+__global__ __launch_bounds__(256, OCRS_RSF_WPS) void k_rs_fwd(RsfArgs A) {
+    using C = RsfCfg<COUT>;
+    constexpr int CIN = 8, PXB = C::PXB, ROWB = C::ROWB, RINGB = C::RINGB, KC = C::KC, NZ = C::NZ, SW = C::SW;
+    constexpr bool DUAL = C::DUAL;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    uint4* s_wf = reinterpret_cast<uint4*>(smem + C::OFF_WF);
+    float* s_trx = reinterpret_cast<float*>(smem + C::OFF_PAR);  // [3][8] scale | shift | lo
+    float* s_w9 = s_trx + 3 * CIN;                               // [8][9]
+    float* s_wp = s_w9 + 9 * CIN;                                // [COUT][8]
+    float* s_st = s_wp + COUT * CIN;                             // [wave][COUT][2]
+    const int H = A.H, W = A.W;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < 3 * CIN; i += C::NT) s_trx[i] = A.tra[i];
+    for (int i = tid; i < 9 * CIN; i += C::NT) s_w9[i] = A.wdw[i];
+    for (int i = tid; i < COUT * CIN; i += C::NT) s_wp[i] = A.wpw[i];
+    for (int i = tid; i < C::OFF_WF / 16; i += C::NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);  // (the rings' pad positions stay zero)
+    __syncthreads();
+    // A[m][k]: chunk = ring row dy; K slot (lane group kgl, j) = (column offset kx = kgl, input channel j); the input pixel (dy, kx) is conv tap
+    // (ky, kx) = (dy - rp, kx) of output row rp.  DUAL: m = (rp, o); otherwise m = o and the fragment is that of rp = 0 (pass ps reads rows ps + dy)
+    for (int f = tid; f < KC * 64; f += C::NT) {
+        const int l = f & 63, dy = f >> 6, m = l & 15, kx = l >> 4;
+        const int rp = DUAL ? (m >> 3) : 0, o = DUAL ? (m & 7) : m, ky = dy - rp;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (kx <= 2 && ky >= 0 && ky <= 2) ? s_w9[j * 9 + ky * 3 + kx] * s_wp[o * CIN + j] : 0.f;
+        s_wf[f] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+    __syncthreads();
+    f32x2 sc2[4], sh2[4];
+    float lo1[8], we[XU ? 8 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sc2[i] = (f32x2){usc(s_trx[2 * i]), usc(s_trx[2 * i + 1])};
+        sh2[i] = vreg((f32x2){s_trx[CIN + 2 * i], s_trx[CIN + 2 * i + 1]});
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
+    if constexpr (XU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) we[i] = usc(A.wexp[i]);
+    }
+    u32x4 wfr[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const uint4 q = s_wf[kc * 64 + lane];
+        wfr[kc] = (u32x4){q.x, q.y, q.z, q.w};
+    }
+    const unsigned npix = (unsigned)A.N * (unsigned)H * (unsigned)W;
+    const i32x4 r_x = XU ? make_rsrc(A.xu, npix * 2) : make_rsrc(A.x, npix * PXB);
+    const __amdgpu_buffer_rsrc_t w_z = __builtin_amdgcn_make_buffer_rsrc((void*)A.z, 0, npix * COUT * 2, 0x00020000);
+    const i32x4 w_zi = make_rsrc(A.z, npix * COUT * 2);
+
+    const int rr = lane >> 5, px = lane & 31;  // commit / store: this lane's (row of the pair, staged pixel)
+    const unsigned ring_w = C::OFF_RING + wave * RINGB;
+    const unsigned wl = ring_w + rr * ROWB + (px + 1) * PXB;
+    const unsigned lbl = (l15 + kg) * PXB;     // B fragments: output pixel l15 (+ 16 per N tile) reads ring position l15 + kx
+    const int st_rp = DUAL ? (kg >> 1) : 0, st_ch = DUAL ? (kg & 1) * 4 : kg * 4;
+    const unsigned stw = C::OFF_ST + wave * C::STB + (st_rp * 32 + l15) * (COUT * 2) + st_ch * 2;
+    const unsigned str = C::OFF_ST + wave * C::STB + (rr * 32 + px) * (COUT * 2);
+
+    f32x2 s1[COUT / 2], s2[COUT / 2];  // batch sums of this lane's stored values (channel pairs)
+#pragma unroll
+    for (int i = 0; i < COUT / 2; ++i) s1[i] = s2[i] = (f32x2){0.f, 0.f};
+
+    const int nblk = gridDim.x;
+    const int vblk = (nblk & 7) == 0 ? (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    RsGen gen(vblk * C::NW + wave, A.njobs, nblk * C::NW, A.NS, A.NB, A.PB, A.NP);
+
+    auto corner = [&](const RsTick& t) -> int {
+        const int qc = t.q < 0 ? 0 : (t.q >= A.NP ? A.NP - 1 : t.q);
+        return (t.n * H + 2 * qc) * W + SW * t.s - 1;
+    };
+    auto issue = [&](auto ST, const RsTick& t) {
+        constexpr int S = decltype(ST)::value;
+        const int cp = corner(t);
+        if constexpr (XU) rsf_load2<S>(r_x, (cp + rr * W + px) * 2);
+        else rsf_load16<S>(r_x, (cp + rr * W + px) * PXB);
+    };
+    constexpr int NLOADS = 1, NSTORE = NZ;
+    auto commit = [&](auto ST, auto YOUNGER, const RsTick& t) {
+        constexpr int S = decltype(ST)::value;
+        constexpr int Y = decltype(YOUNGER)::value;
+        u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (XU) raw.x = rsf_take2<S, Y>();
+        else raw = rsf_take16<S, Y>();
+        const int col = SW * t.s - 1 + px, row = 2 * t.q + rr;
+        const bool ok = (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H;
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x2 xin;
+            if constexpr (XU) {
+                const float uv = __uint_as_float(raw.x << 16);
+                xin = unpk(cvt_pk(uv * we[2 * k], uv * we[2 * k + 1]));
+            } else {
+                xin = unpk(raw[k]);
+            }
+            f32x2 v = __builtin_elementwise_fma(xin, sc2[k], sh2[k]);
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * k]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * k + 1]));
+            const unsigned pk = cvt_pk(v.x, v.y);
+            w[k] = ok ? pk : 0u;  // (zeros outside the image: the convolution's padding)
+        }
+        *reinterpret_cast<uint4*>(smem + wl + (unsigned)(2 * t.qm3) * ROWB) = make_uint4(w[0], w[1], w[2], w[3]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](const RsTick& t) {
+        const int cp = t.q - 1;  // the pair computed: output rows 2cp, 2cp + 1 from input rows 2cp - 1 .. 2cp + 2 = ring rows (2 qm3 + 3 + dy) mod 6
+        unsigned ra[4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const int r = 2 * t.qm3 + 3 + dy;
+            ra[dy] = ring_w + (unsigned)(r >= 6 ? r - 6 : r) * ROWB + lbl;
+        }
+        const int colbase = SW * t.s - 1;
+        const int pix0 = (t.n * H + 2 * cp) * W + colbase;
+        const bool comp = t.comp != 0;
+#pragma unroll
+        for (int ps = 0; ps < C::NPASS; ++ps) {
+            f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(smem + ra[ps + kc] + nt * 16 * PXB);
+                    acc[nt] = mfma_bf(wfr[kc], (u32x4){q.x, q.y, q.z, q.w}, acc[nt]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)  // (compiler-visible converts: see k_rs_bwd)
+                *reinterpret_cast<uint2*>(smem + stw + ((DUAL ? 0 : ps * 32) + nt * 16) * (COUT * 2)) =
+                    make_uint2(pack2bf(acc[nt][0], acc[nt][1]), pack2bf(acc[nt][2], acc[nt][3]));
+        }
+        const bool ok = comp && 2 * cp + rr < H && px >= 1 && px <= SW && colbase + px < W;
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            const uint4 q = *reinterpret_cast<const uint4*>(smem + str + 16 * j);
+            const int off = (pix0 + rr * W + px) * (COUT * 2) + 16 * j;
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, w_z, ok ? off : -1, 0, 0);
+            const unsigned qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x2 v = unpk(qq[k]);
+                if (!ok) v = (f32x2){0.f, 0.f};
+                s1[4 * j + k] += v;
+                s2[4 * j + k] = __builtin_elementwise_fma(v, v, s2[4 * j + k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    RsTick t0 = gen.next(), t1 = gen.next();
+    // Prefetch registers.  The row loads of a tick are issued two ticks ahead and must not be waited for early, so they are asm statements hipcc does
+    // not see through, with hand-counted waits (vector memory operations retire in order) -- and their destinations are ACCUMULATION registers named
+    // in the asm text (set 0: a[32:35], set 1: a[36:39]): hipcc allocates no value of its own there (the kernel needs ~100 of its 168 registers; the
+    // build checks that no AGPR access exists outside these statements), so no live-range split or copy can ever touch a register with a load in
+    // flight.  (With VGPR destinations tied to C++ variables -- k_rs_bwd's form -- hipcc kept a set in different registers in the prologue and in the
+    // loop and joined them with copies issued while the loads were in flight; tools/check_rs_loads.py caught it.  Compiler-visible loads got
+    // vmcnt(1) instead of vmcnt(3): every tick then waited for the load it had just issued.)
+    // ONE loop without peeled first ticks: the prologue issues the steady state's operation sequence L0 St L1 St with stores the range check drops.
+    auto dummy_stores = [&]() {
+#pragma unroll
+        for (int j = 0; j < NSTORE; ++j) rsf_dropped_store(w_zi);
+    };
+    issue(S0{}, t0);
+    dummy_stores();
+    issue(S1{}, t1);
+    dummy_stores();
+    auto tick = [&](auto ST, RsTick& t) __attribute__((always_inline)) {
+        commit(ST, std::integral_constant<int, NLOADS + 2 * NSTORE>{}, t);
+        const RsTick tn = gen.next();
+        issue(ST, tn);
+        compute(t);
+        t = tn;
+    };
+    while (t0.valid) {
+        tick(S0{}, t0);
+        if (!t1.valid) break;
+        tick(S1{}, t1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dead ticks' loads)
+
+    // ---- batch sums: lanes -> wave -> workgroup partial [COUT][sum | sum of squares] (k_mm_fwd's layout), then the last workgroup finalises
+#pragma unroll
+    for (int i = 0; i < COUT / 2; ++i) {
+        const float a0 = wave_sum(s1[i].x), a1 = wave_sum(s1[i].y), b0 = wave_sum(s2[i].x), b1 = wave_sum(s2[i].y);
+        if (lane == 0) {
+            s_st[(wave * COUT + 2 * i) * 2 + 0] = a0;
+            s_st[(wave * COUT + 2 * i) * 2 + 1] = b0;
+            s_st[(wave * COUT + 2 * i + 1) * 2 + 0] = a1;
+            s_st[(wave * COUT + 2 * i + 1) * 2 + 1] = b1;
+        }
+    }
+    __syncthreads();
+    const FwdFin& fin = A.fin;
+    for (int e = tid; e < 2 * COUT; e += C::NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < C::NW; ++w) s += s_st[w * COUT * 2 + e];
+        if (fin.counter) __hip_atomic_store(A.ws + (long)blockIdx.x * (2 * COUT) + e, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else A.ws[(long)blockIdx.x * (2 * COUT) + e] = s;
+    }
+    if (!fin.counter) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_flag = reinterpret_cast<int*>(smem);
+    double* red = reinterpret_cast<double*>(smem + 64);  // [8 chains][32 columns] + [32] (the rings are dead)
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (*s_flag == 0) return;
+    static_assert(2 * COUT <= 32 && C::NT == 256, "one 32-element window x 8 chains x 32 columns = the 256 threads");
+    const int col = tid & 31, chain = tid >> 5;
+    red[chain * 32 + col] = rs_parts_chain_sum(A.ws, gridDim.x, COUT, col, chain);
+    __syncthreads();
+    if (chain == 0) {
+        const double tot = ((red[col] + red[32 + col]) + (red[64 + col] + red[96 + col])) + ((red[128 + col] + red[160 + col]) + (red[192 + col] + red[224 + col]));
+        red[256 + col] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (fin.nbt) *fin.nbt += 1;
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (chain == 0 && col < 2 * COUT && !(col & 1))
+        bn_finalize_channel(red[256 + col], red[256 + col + 1], fin.count, col >> 1, COUT, fin.gamma, fin.beta, fin.eps, fin.momentum, fin.tr, fin.saved, fin.run_mean,
+                            fin.run_var, fin.lo);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 static int rs_env() {
     static const int v = env_int("OCRS_RS", 1);
@@ -831,4 +1162,47 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
 #endif
 #undef RS_CASE
 #undef RS_LAUNCH
+}
+
+// ---- row-streaming forward (k_rs_fwd): Cin = 8 (one source or the u plane), Cout in {8, 16}, no fused pooling
+bool rs_fwd_supported(int Ca, int Cb, int Cout, int N, int H, int W) {
+    static const int on = env_int("OCRS_RSF", 1);
+    // (Cout = 16 -- one pass per row, 12 MFMAs per tick; the kernel is written for it, -DOCRS_RSF_16 instantiates it at OCRS_RSF_WPS <= 3 -- measured
+    //  432 us against k_mm_fwd's 346 us at level 0: not built by default)
+#ifdef OCRS_RSF_16
+    if (!on || Ca != 8 || Cb != 0 || !(Cout == 8 || Cout == 16)) return false;
+#else
+    if (!on || Ca != 8 || Cb != 0 || Cout != 8) return false;
+#endif
+    return (long)N * H * W * Cout * 2 < (1L << 31) && H >= 2 && W >= 2;
+}
+int rs_fwd_blocks(int N, int H, int W) {
+    int NS, NP, NB, PB, njobs, nb;
+    rs_geometry(N, H, W, OCRS_RSF_WPS, NS, NP, NB, PB, njobs, nb);
+    return nb;
+}
+void rs_fwd_launch(const bf16* x, const bf16* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, bf16* z, float* ws, int Cout, int N, int H,
+                   int W, int nb, const FwdFin& fin, hipStream_t st) {
+    RsfArgs a;
+    a.x = x; a.xu = xu; a.wexp = wexp; a.tra = tra; a.wdw = wdw; a.wpw = wpw; a.z = z; a.ws = ws;
+    a.N = N; a.H = H; a.W = W;
+    int nb_geo;
+    rs_geometry(N, H, W, OCRS_RSF_WPS, a.NS, a.NP, a.NB, a.PB, a.njobs, nb_geo);
+    (void)nb_geo;  // (the caller's nb = rs_fwd_blocks(): the number of partials it allocated)
+    a.fin = fin;
+#define RSF_LAUNCH(CO_, XU_)                                                                                                              \
+    {                                                                                                                                     \
+        using CC = RsfCfg<CO_>;                                                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_fwd<CO_, XU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);    \
+        OCRS_LAUNCH_T((k_rs_fwd<CO_, XU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                                    \
+    }
+    if (Cout == 8) {
+        if (xu) RSF_LAUNCH(8, true) else RSF_LAUNCH(8, false)
+    }
+#ifdef OCRS_RSF_16
+    else {
+        if (xu) RSF_LAUNCH(16, true) else RSF_LAUNCH(16, false)
+    }
+#endif
+#undef RSF_LAUNCH
 }

@@ -5,7 +5,8 @@ before the hand-written wait, the kernel reads or stores stale bytes.  The waits
 comment (`s_waitcnt vmcnt(N) ; releases v[a:b]`), so the check is an exact forward data-flow over the kernel's control-flow graph:
     in flight  :=  destination registers of asm `buffer_load_dword[x4]`, until an asm wait that names them (or an asm `s_waitcnt vmcnt(0)`)
     violation  :=  any compiler-generated instruction that mentions a register in flight, or any scratch access in a kernel with such loads
-(union at joins, iterated to a fixed point).  Exit status 1 on a violation.
+(union at joins, iterated to a fixed point).  Kernels whose asm loads name ACCUMULATION registers as destinations (k_rs_fwd: a[0:3], a[4:7]) are
+checked for the stronger property that no compiler-generated instruction mentions those registers at all.  Exit status 1 on a violation.
 
 usage: python tools/check_rs_loads.py [extra hipcc flags ...]      (OCRS_CHECK_HIPCC / OCRS_CHECK_FLAGS / OCRS_CHECK_SRC as check_opaque_loads.py)
 """
@@ -23,6 +24,15 @@ def vregs(text):
     for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
         out |= set(range(int(a), int(b) + 1))
     for a in re.findall(r"\bv(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+def aregs(text):
+    out = set()
+    for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", text):
+        out |= set(range(int(a), int(b) + 1))
+    for a in re.findall(r"\ba(\d+)\b", text):
         out.add(int(a))
     return out
 
@@ -54,6 +64,16 @@ def check(txt):
         if not any(a and t.startswith("buffer_load_dword") for _, t, a in ins):
             continue
         nk += 1
+        # prefetch sets in accumulation registers named in the asm text (k_rs_fwd): hipcc must not use those registers for anything, anywhere
+        mine = set()
+        for _, t, a in ins:
+            if a and t.startswith("buffer_load_"):
+                mine |= aregs(t.split(",")[0])
+        if mine:
+            for ln, t, a in ins:
+                hit = aregs(t.split(";")[0]) & mine
+                if hit and not a:
+                    bad.append(f"{name}: line {ln + 1}: a{sorted(hit)} (an asm prefetch destination) used by compiler-generated code: {t}")
         n = len(ins)
         succ = [[] for _ in range(n)]
         for k, (_, t, _) in enumerate(ins):
