@@ -1667,7 +1667,7 @@ static int mm_fwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
     Src2<bf16> x{(const bf16*)xa, (const bf16*)xb, Ca, Cb};
     const int nb = (int)ocrs_mm_fwd_nparts(Ca, Cb, Cout, N, H, W);
     if (!pooled && rs_fwd_supported(Ca, Cb, Cout, N, H, W)) {  // the row-streaming kernel (det_rs.hip)
-        rs_fwd_launch((const bf16*)xa, xu.u, xu.wexp, tra, wdw, wpw, (bf16*)z, ws, Cout, N, H, W, nb, fin, st);
+        rs_fwd_launch(x, xu.u, xu.wexp, tra, trb, wdw, wpw, (bf16*)z, ws, Cout, N, H, W, nb, fin, st);
         OCRS_LAUNCH_CHECK();
         return OCRS_OK;
     }

@@ -12,8 +12,8 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
                    const BnFin& fin, hipStream_t st, const float* gl = nullptr, const float* whead = nullptr,
                    const bf16* xu = nullptr, const float* wexp = nullptr);  // gl / whead: k_rs_bwd<..., HEAD>; xu / wexp: k_rs_bwd<..., XU>
 
-// forward (Cin = 8 from one source or from the first block's u plane, Cout in {8, 16}, no fused pooling): k_rs_fwd
+// forward (Cin = 8 from one source or from the first block's u plane, or Cin = 16 from one source or the 8 | 8 concat; Cout = 8; no fused pooling): k_rs_fwd
 bool rs_fwd_supported(int Ca, int Cb, int Cout, int N, int H, int W);
 int rs_fwd_blocks(int N, int H, int W);  // = the number of per-block statistics partials [Cout][2] the launch writes
-void rs_fwd_launch(const bf16* x, const bf16* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, bf16* z, float* ws, int Cout, int N, int H,
-                   int W, int nb, const FwdFin& fin, hipStream_t st);
+void rs_fwd_launch(const Src2<bf16>& x, const bf16* xu, const float* wexp, const float* tra, const float* trb, const float* wdw, const float* wpw, bf16* z, float* ws,
+                   int Cout, int N, int H, int W, int nb, const FwdFin& fin, hipStream_t st);

@@ -772,28 +772,42 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 // k_mm_fwd's layout and finalised by the last workgroup (FwdFin).  XU: the input is the first block's u plane (see k_rs_bwd).
 // The tiled kernel needs ~8-10 ps per pixel for these shapes whatever they read (in_conv.seq.1 from the 2-byte u plane: 340 us for 18 B / pixel);
 // their per-tile instruction stream, not memory, is what bounds it.
-// k_rs_fwd's prefetch sets live in AGPRs named in the asm text (see the kernel): set S = a[32 + 4 S : 35 + 4 S] (hipcc allocates its own accumulation registers from a0 upwards: MFMA accumulators of the 16-channel form)
-template <int S>
-__device__ __forceinline__ void rsf_load16(const i32x4& rsrc, int voff) {
-    if constexpr (S == 0) asm volatile("buffer_load_dwordx4 a[32:35], %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a32", "a33", "a34", "a35");
-    else asm volatile("buffer_load_dwordx4 a[36:39], %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a36", "a37", "a38", "a39");
+// k_rs_fwd's prefetch vectors live in AGPRs named in the asm text (see the kernel): vector IDX = a[32 + 4 IDX : 35 + 4 IDX] (hipcc allocates its own
+// accumulation registers, if any, from a0 upwards; tools/check_rs_loads.py fails the build if compiler-generated code ever mentions one of these)
+template <int IDX>
+__device__ __forceinline__ void rsf_load16(const i32x4& rsrc, int voff);
+template <int IDX, int Y>
+__device__ __forceinline__ u32x4 rsf_take16();
+#define RSF_VEC(IDX_, R0, R1, R2, R3)                                                                                                                 \
+    template <>                                                                                                                                       \
+    __device__ __forceinline__ void rsf_load16<IDX_>(const i32x4& rsrc, int voff) {                                                                   \
+        asm volatile("buffer_load_dwordx4 a[" #R0 ":" #R3 "], %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a" #R0, "a" #R1, "a" #R2, "a" #R3); \
+    }                                                                                                                                                 \
+    template <int Y>                                                                                                                                  \
+    __device__ __forceinline__ u32x4 rsf_take16_##IDX_() {                                                                                            \
+        static_assert(Y >= 0 && Y < 64, "vmcnt is a 6-bit field");                                                                                    \
+        unsigned x, y, z, w;                                                                                                                          \
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2              \
+                     "\n\tv_accvgpr_read_b32 %3, a" #R3                                                                                               \
+                     : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(Y) : "memory");                                                                       \
+        return (u32x4){x, y, z, w};                                                                                                                   \
+    }
+RSF_VEC(0, 32, 33, 34, 35)
+RSF_VEC(1, 36, 37, 38, 39)
+RSF_VEC(2, 40, 41, 42, 43)
+RSF_VEC(3, 44, 45, 46, 47)
+#undef RSF_VEC
+template <int IDX, int Y>
+__device__ __forceinline__ u32x4 rsf_take16() {
+    if constexpr (IDX == 0) return rsf_take16_0<Y>();
+    else if constexpr (IDX == 1) return rsf_take16_1<Y>();
+    else if constexpr (IDX == 2) return rsf_take16_2<Y>();
+    else return rsf_take16_3<Y>();
 }
 template <int S>
 __device__ __forceinline__ void rsf_load2(const i32x4& rsrc, int voff) {
     if constexpr (S == 0) asm volatile("buffer_load_ushort a32, %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a32");
     else asm volatile("buffer_load_ushort a36, %0, %1, 0 offen" : : "v"(voff), "s"(rsrc) : "memory", "a36");
-}
-template <int S, int Y>
-__device__ __forceinline__ u32x4 rsf_take16() {
-    static_assert(Y >= 0 && Y < 64, "vmcnt is a 6-bit field");
-    unsigned x, y, z, w;
-    if constexpr (S == 0)
-        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35"
-                     : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(Y) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39"
-                     : "=v"(x), "=v"(y), "=v"(z), "=v"(w) : "n"(Y) : "memory");
-    return (u32x4){x, y, z, w};
 }
 template <int S, int Y>
 __device__ __forceinline__ unsigned rsf_take2() {
@@ -809,8 +823,9 @@ __device__ __forceinline__ void rsf_dropped_store(const i32x4& rsrc) {
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(zero), "v"(off), "s"(rsrc) : "memory");
 }
 struct RsfArgs {
-    const bf16 *x, *xu;
-    const float *wexp, *tra, *wdw, *wpw;
+    const bf16 *xa, *xb, *xu;  // xa | xb: the (concatenated) input, Ca | Cb channels; xu: the u plane instead (Cin = 8)
+    int Ca, Cb;
+    const float *wexp, *tra, *trb, *wdw, *wpw;
     bf16* z;
     float* ws;
     int N, H, W, NS, NP, NB, PB, njobs;
@@ -819,13 +834,17 @@ struct RsfArgs {
 #ifndef OCRS_RSF_WPS
 #define OCRS_RSF_WPS 3  // resident 4-wave workgroups per CU (per launch at level 0, XU | plain: 3: 240 | 226 us, 4: 255 | 254 us; the tiled kernel: 340 | 279 us)
 #endif
-template <int COUT>
+template <int CIN, int COUT>
 struct RsfCfg {
-    static constexpr int NW = 4, NT = 256, SW = 30, CIN = 8;
+    static_assert(CIN == 8 || (CIN == 16 && COUT == 8), "shapes of level 0: 8 -> 8 (| 16), 16 -> 8");
+    static constexpr int NW = 4, NT = 256, SW = 30;
     static constexpr int PXB = CIN * 2, ROWB = 34 * PXB, RROWS = 6, RINGB = RROWS * ROWB + 64;
     static constexpr bool DUAL = COUT == 8;
-    static constexpr int NPASS = DUAL ? 1 : 2, NDY = DUAL ? 4 : 3, KC = NDY;  // a K chunk = one ring row: 4 column slots (the fourth carries zero weights) x 8 channels
-    static constexpr int NZ = COUT / 8;                 // 16-byte output items per lane and tick
+    static constexpr int G8 = CIN / 8;                  // 8-channel groups per input pixel
+    static constexpr int TPC = 4 / G8;                  // column slots per 32-deep K chunk (a chunk lies inside ONE ring row)
+    static constexpr int CPD = (3 + TPC - 1) / TPC;     // chunks per ring row (slots past kx = 2 carry zero weights)
+    static constexpr int NPASS = DUAL ? 1 : 2, NDY = DUAL ? 4 : 3, KC = NDY * CPD;
+    static constexpr int NX = CIN / 8, NZ = COUT / 8;   // 16-byte input / output items per lane and tick
     static constexpr int STB = 2 * 32 * COUT * 2;       // staging of a row pair's output
     static constexpr int OFF_RING = 64, OFF_ST = OFF_RING + NW * RINGB, OFF_WF = OFF_ST + NW * STB, OFF_PAR = OFF_WF + KC * 1024;
     static constexpr int PAR_FLOATS = 3 * CIN + 9 * CIN + COUT * CIN + NW * 2 * COUT;  // trx | w9 | wp | per-wave stat slots
@@ -833,46 +852,52 @@ struct RsfCfg {
     static_assert(64 + (8 * 32 + 32) * 8 <= OFF_ST, "the finalisation's reduction area fits the dead rings");
 };
 
-template <int COUT, bool XU>
+template <int CIN, int COUT, bool XU>
 __global__ __launch_bounds__(256, OCRS_RSF_WPS) void k_rs_fwd(RsfArgs A) {
-    using C = RsfCfg<COUT>;
-    constexpr int CIN = 8, PXB = C::PXB, ROWB = C::ROWB, RINGB = C::RINGB, KC = C::KC, NZ = C::NZ, SW = C::SW;
+    static_assert(!XU || CIN == 8, "u plane: the 8-channel output of the first block");
+    using C = RsfCfg<CIN, COUT>;
+    constexpr int PXB = C::PXB, ROWB = C::ROWB, RINGB = C::RINGB, KC = C::KC, NX = C::NX, NZ = C::NZ, SW = C::SW, G8 = C::G8, TPC = C::TPC, CPD = C::CPD;
     constexpr bool DUAL = C::DUAL;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     uint4* s_wf = reinterpret_cast<uint4*>(smem + C::OFF_WF);
-    float* s_trx = reinterpret_cast<float*>(smem + C::OFF_PAR);  // [3][8] scale | shift | lo
-    float* s_w9 = s_trx + 3 * CIN;                               // [8][9]
-    float* s_wp = s_w9 + 9 * CIN;                                // [COUT][8]
+    float* s_trx = reinterpret_cast<float*>(smem + C::OFF_PAR);  // [3][CIN] scale | shift | lo
+    float* s_w9 = s_trx + 3 * CIN;                               // [CIN][9]
+    float* s_wp = s_w9 + 9 * CIN;                                // [COUT][CIN]
     float* s_st = s_wp + COUT * CIN;                             // [wave][COUT][2]
-    const int H = A.H, W = A.W;
+    const int H = A.H, W = A.W, Ca = A.Ca, Cb = A.Cb;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int i = tid; i < 3 * CIN; i += C::NT) s_trx[i] = A.tra[i];
+    for (int i = tid; i < 3 * CIN; i += C::NT) {
+        const int r = i / CIN, c = i - r * CIN;
+        s_trx[i] = c < Ca ? A.tra[r * Ca + c] : A.trb[r * Cb + (c - Ca)];
+    }
     for (int i = tid; i < 9 * CIN; i += C::NT) s_w9[i] = A.wdw[i];
     for (int i = tid; i < COUT * CIN; i += C::NT) s_wp[i] = A.wpw[i];
     for (int i = tid; i < C::OFF_WF / 16; i += C::NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);  // (the rings' pad positions stay zero)
     __syncthreads();
-    // A[m][k]: chunk = ring row dy; K slot (lane group kgl, j) = (column offset kx = kgl, input channel j); the input pixel (dy, kx) is conv tap
-    // (ky, kx) = (dy - rp, kx) of output row rp.  DUAL: m = (rp, o); otherwise m = o and the fragment is that of rp = 0 (pass ps reads rows ps + dy)
+    // A[m][k]: chunk kc = (ring row dy, part h); K slot (lane group kgl, j) = (column offset kx = h * TPC + kgl / G8, input channel (kgl % G8) * 8 + j); the
+    // input pixel (dy, kx) is conv tap (ky, kx) = (dy - rp, kx) of output row rp.  DUAL: m = (rp, o); otherwise m = o and the fragment is that of
+    // rp = 0 (pass ps reads rows ps + dy)
     for (int f = tid; f < KC * 64; f += C::NT) {
-        const int l = f & 63, dy = f >> 6, m = l & 15, kx = l >> 4;
+        const int l = f & 63, kc = f >> 6, dy = kc / CPD, h = kc - dy * CPD, m = l & 15, kgl = l >> 4;
+        const int kx = h * TPC + kgl / G8, c0 = (kgl % G8) * 8;
         const int rp = DUAL ? (m >> 3) : 0, o = DUAL ? (m & 7) : m, ky = dy - rp;
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (kx <= 2 && ky >= 0 && ky <= 2) ? s_w9[j * 9 + ky * 3 + kx] * s_wp[o * CIN + j] : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (kx <= 2 && ky >= 0 && ky <= 2) ? s_w9[(c0 + j) * 9 + ky * 3 + kx] * s_wp[o * CIN + c0 + j] : 0.f;
         s_wf[f] = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
     }
     __syncthreads();
-    f32x2 sc2[4], sh2[4];
-    float lo1[8], we[XU ? 8 : 1];
+    f32x2 sc2[CIN / 2], sh2[CIN / 2];
+    float lo1[CIN], we[XU ? 8 : 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < CIN / 2; ++i) {
         sc2[i] = (f32x2){usc(s_trx[2 * i]), usc(s_trx[2 * i + 1])};
         sh2[i] = vreg((f32x2){s_trx[CIN + 2 * i], s_trx[CIN + 2 * i + 1]});
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
+    for (int i = 0; i < CIN; ++i) lo1[i] = usc(s_trx[2 * CIN + i]);
     if constexpr (XU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) we[i] = usc(A.wexp[i]);
@@ -884,14 +909,15 @@ __global__ __launch_bounds__(256, OCRS_RSF_WPS) void k_rs_fwd(RsfArgs A) {
         wfr[kc] = (u32x4){q.x, q.y, q.z, q.w};
     }
     const unsigned npix = (unsigned)A.N * (unsigned)H * (unsigned)W;
-    const i32x4 r_x = XU ? make_rsrc(A.xu, npix * 2) : make_rsrc(A.x, npix * PXB);
+    const i32x4 r_xa = XU ? make_rsrc(A.xu, npix * 2) : make_rsrc(A.xa, npix * Ca * 2);
+    const i32x4 r_xb = make_rsrc(Cb ? A.xb : A.xa, npix * (Cb ? Cb : Ca) * 2);
     const __amdgpu_buffer_rsrc_t w_z = __builtin_amdgcn_make_buffer_rsrc((void*)A.z, 0, npix * COUT * 2, 0x00020000);
     const i32x4 w_zi = make_rsrc(A.z, npix * COUT * 2);
 
     const int rr = lane >> 5, px = lane & 31;  // commit / store: this lane's (row of the pair, staged pixel)
     const unsigned ring_w = C::OFF_RING + wave * RINGB;
     const unsigned wl = ring_w + rr * ROWB + (px + 1) * PXB;
-    const unsigned lbl = (l15 + kg) * PXB;     // B fragments: output pixel l15 (+ 16 per N tile) reads ring position l15 + kx
+    const unsigned lbl = (l15 + kg / G8) * PXB + (kg % G8) * 16;  // B fragments: output pixel l15 (+ 16 per N tile) reads ring position l15 + kx
     const int st_rp = DUAL ? (kg >> 1) : 0, st_ch = DUAL ? (kg & 1) * 4 : kg * 4;
     const unsigned stw = C::OFF_ST + wave * C::STB + (st_rp * 32 + l15) * (COUT * 2) + st_ch * 2;
     const unsigned str = C::OFF_ST + wave * C::STB + (rr * 32 + px) * (COUT * 2);
@@ -911,35 +937,52 @@ __global__ __launch_bounds__(256, OCRS_RSF_WPS) void k_rs_fwd(RsfArgs A) {
     auto issue = [&](auto ST, const RsTick& t) {
         constexpr int S = decltype(ST)::value;
         const int cp = corner(t);
-        if constexpr (XU) rsf_load2<S>(r_x, (cp + rr * W + px) * 2);
-        else rsf_load16<S>(r_x, (cp + rr * W + px) * PXB);
+        if constexpr (XU) {
+            rsf_load2<S>(r_xa, (cp + rr * W + px) * 2);
+        } else {
+            const int pi = cp + rr * W + px;
+            // item j = channels 8j .. 8j + 7 of the concatenated input: from xa when 8j < Ca, else from xb
+            if constexpr (NX == 1) {
+                rsf_load16<S>(r_xa, pi * (Ca * 2));
+            } else {
+                rsf_load16<S * 2>(r_xa, pi * (Ca * 2));
+                if (Ca > 8) rsf_load16<S * 2 + 1>(r_xa, pi * (Ca * 2) + 16);  // (wave-uniform branch: both sides issue ONE load)
+                else rsf_load16<S * 2 + 1>(r_xb, pi * (Cb * 2));
+            }
+        }
     };
-    constexpr int NLOADS = 1, NSTORE = NZ;
+    constexpr int NLOADS = NX, NSTORE = NZ;
     auto commit = [&](auto ST, auto YOUNGER, const RsTick& t) {
         constexpr int S = decltype(ST)::value;
         constexpr int Y = decltype(YOUNGER)::value;
-        u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
-        if constexpr (XU) raw.x = rsf_take2<S, Y>();
-        else raw = rsf_take16<S, Y>();
         const int col = SW * t.s - 1 + px, row = 2 * t.q + rr;
         const bool ok = (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H;
-        unsigned w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            f32x2 xin;
-            if constexpr (XU) {
-                const float uv = __uint_as_float(raw.x << 16);
-                xin = unpk(cvt_pk(uv * we[2 * k], uv * we[2 * k + 1]));
-            } else {
-                xin = unpk(raw[k]);
+        for (int j = 0; j < NX; ++j) {
+            u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
+            // (the set's loads were issued together and retire in order: the wait for its last one, written on the first take, covers them all)
+            if constexpr (XU) raw.x = rsf_take2<S, Y>();
+            else if (j == 0) raw = rsf_take16<S * NX, Y>();
+            else raw = rsf_take16<S * NX + (NX - 1), Y>();
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = 4 * j + k;
+                f32x2 xin;
+                if constexpr (XU) {
+                    const float uv = __uint_as_float(raw.x << 16);
+                    xin = unpk(cvt_pk(uv * we[2 * k], uv * we[2 * k + 1]));
+                } else {
+                    xin = unpk(raw[k]);
+                }
+                f32x2 v = __builtin_elementwise_fma(xin, sc2[ci], sh2[ci]);
+                asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * ci]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * ci + 1]));
+                const unsigned pk = cvt_pk(v.x, v.y);
+                w[k] = ok ? pk : 0u;  // (zeros outside the image: the convolution's padding)
             }
-            f32x2 v = __builtin_elementwise_fma(xin, sc2[k], sh2[k]);
-            asm("v_max_f32 %0, %1, %2" : "=v"(v.x) : "v"(v.x), "s"(lo1[2 * k]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(v.y) : "v"(v.y), "s"(lo1[2 * k + 1]));
-            const unsigned pk = cvt_pk(v.x, v.y);
-            w[k] = ok ? pk : 0u;  // (zeros outside the image: the convolution's padding)
+            *reinterpret_cast<uint4*>(smem + wl + (unsigned)(2 * t.qm3) * ROWB + 16 * j) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        *reinterpret_cast<uint4*>(smem + wl + (unsigned)(2 * t.qm3) * ROWB) = make_uint4(w[0], w[1], w[2], w[3]);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto compute = [&](const RsTick& t) {
@@ -958,9 +1001,10 @@ __global__ __launch_bounds__(256, OCRS_RSF_WPS) void k_rs_fwd(RsfArgs A) {
             f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
+                const int dy = kc / CPD, h = kc - dy * CPD;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(smem + ra[ps + kc] + nt * 16 * PXB);
+                    const uint4 q = *reinterpret_cast<const uint4*>(smem + ra[ps + dy] + (h * TPC + nt * 16) * PXB);
                     acc[nt] = mfma_bf(wfr[kc], (u32x4){q.x, q.y, q.z, q.w}, acc[nt]);
                 }
             }
@@ -1164,44 +1208,48 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
 #undef RS_LAUNCH
 }
 
-// ---- row-streaming forward (k_rs_fwd): Cin = 8 (one source or the u plane), Cout in {8, 16}, no fused pooling
+// ---- row-streaming forward (k_rs_fwd): Cin = 8 (one source or the u plane) or 16 (one source or the 8 | 8 concat), Cout = 8, no fused pooling
 bool rs_fwd_supported(int Ca, int Cb, int Cout, int N, int H, int W) {
     static const int on = env_int("OCRS_RSF", 1);
+    static const int on16 = env_int("OCRS_RSF_C16", 1);  // the 16 -> 8 channel block of level 0
     // (Cout = 16 -- one pass per row, 12 MFMAs per tick; the kernel is written for it, -DOCRS_RSF_16 instantiates it at OCRS_RSF_WPS <= 3 -- measured
     //  432 us against k_mm_fwd's 346 us at level 0: not built by default)
+    const int Cin = Ca + Cb;
+    bool shape = (Ca == 8 && Cb == 0 && Cout == 8) || (on16 && Cin == 16 && (Cb == 0 || Ca == 8) && Cout == 8);
 #ifdef OCRS_RSF_16
-    if (!on || Ca != 8 || Cb != 0 || !(Cout == 8 || Cout == 16)) return false;
-#else
-    if (!on || Ca != 8 || Cb != 0 || Cout != 8) return false;
+    shape = shape || (Ca == 8 && Cb == 0 && Cout == 16);
 #endif
-    return (long)N * H * W * Cout * 2 < (1L << 31) && H >= 2 && W >= 2;
+    if (!on || !shape) return false;
+    return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1L << 31) && H >= 2 && W >= 2;
 }
 int rs_fwd_blocks(int N, int H, int W) {
     int NS, NP, NB, PB, njobs, nb;
     rs_geometry(N, H, W, OCRS_RSF_WPS, NS, NP, NB, PB, njobs, nb);
     return nb;
 }
-void rs_fwd_launch(const bf16* x, const bf16* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, bf16* z, float* ws, int Cout, int N, int H,
-                   int W, int nb, const FwdFin& fin, hipStream_t st) {
+void rs_fwd_launch(const Src2<bf16>& x, const bf16* xu, const float* wexp, const float* tra, const float* trb, const float* wdw, const float* wpw, bf16* z, float* ws,
+                   int Cout, int N, int H, int W, int nb, const FwdFin& fin, hipStream_t st) {
     RsfArgs a;
-    a.x = x; a.xu = xu; a.wexp = wexp; a.tra = tra; a.wdw = wdw; a.wpw = wpw; a.z = z; a.ws = ws;
+    a.xa = x.a; a.xb = x.b; a.Ca = x.Ca; a.Cb = x.Cb; a.xu = xu; a.wexp = wexp; a.tra = tra; a.trb = trb; a.wdw = wdw; a.wpw = wpw; a.z = z; a.ws = ws;
     a.N = N; a.H = H; a.W = W;
     int nb_geo;
     rs_geometry(N, H, W, OCRS_RSF_WPS, a.NS, a.NP, a.NB, a.PB, a.njobs, nb_geo);
     (void)nb_geo;  // (the caller's nb = rs_fwd_blocks(): the number of partials it allocated)
     a.fin = fin;
-#define RSF_LAUNCH(CO_, XU_)                                                                                                              \
-    {                                                                                                                                     \
-        using CC = RsfCfg<CO_>;                                                                                                           \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_fwd<CO_, XU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);    \
-        OCRS_LAUNCH_T((k_rs_fwd<CO_, XU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                                    \
+#define RSF_LAUNCH(CI_, CO_, XU_)                                                                                                              \
+    {                                                                                                                                          \
+        using CC = RsfCfg<CI_, CO_>;                                                                                                           \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_fwd<CI_, CO_, XU_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);    \
+        OCRS_LAUNCH_T((k_rs_fwd<CI_, CO_, XU_>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);                                                    \
     }
-    if (Cout == 8) {
-        if (xu) RSF_LAUNCH(8, true) else RSF_LAUNCH(8, false)
+    const int Cin = x.Ca + x.Cb;
+    if (Cin == 16) RSF_LAUNCH(16, 8, false)
+    else if (Cout == 8) {
+        if (xu) RSF_LAUNCH(8, 8, true) else RSF_LAUNCH(8, 8, false)
     }
 #ifdef OCRS_RSF_16
     else {
-        if (xu) RSF_LAUNCH(16, true) else RSF_LAUNCH(16, false)
+        if (xu) RSF_LAUNCH(8, 16, true) else RSF_LAUNCH(8, 16, false)
     }
 #endif
 #undef RSF_LAUNCH
