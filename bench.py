@@ -684,11 +684,8 @@ def main():
                 t = mask_u8.to(dev, non_blocking=True).float()
             else:
                 x, t = img, mask
-            pred = net(x)
-            loss = oa.balanced_cross_entropy_loss(pred, t)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            # the train() loop body of the drop-in API (ocrs_models_amd/train_detection.py:train_step = train_detection.py:87-98 of the reference)
+            loss = oa.train_detection.train_step(net, opt, {"image": x, "text_mask": t}, dev)
             if ref_style:
                 return float(loss.item())
             return loss

@@ -177,6 +177,12 @@ int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* p
    (gy[p][c] = gl[p] * w[c] is formed by the consumer, ocrs_mm_bwd_fin_head). */
 int ocrs_head_bwd_gl(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, float* gl, double* acc64,
                      const float* saved, double* gsum, long P, int dtype, hipStream_t st);
+/* ocrs_balanced_bce_bwd + ocrs_head_bwd_gl in one pass (the autograd of train_detection.py:225-263's loss followed by models.py:143's out_conv + Sigmoid
+   backward): dL/dpred is formed on the fly from what ocrs_balanced_bce_fwd saved (pred, target, lpx, cls, state) and gout [1], the upstream gradient
+   of the scalar loss; it is never written to memory.  P % 4 == 0; saved / gsum as ocrs_head_bwd (required). */
+int ocrs_head_bwd_loss(const void* z, const float* tr, const float* w, const float* pred, const float* target, const float* lpx, const unsigned char* cls,
+                       const void* state, const float* gout, float* gl, double* acc64, const float* saved, double* gsum, long P, int dtype,
+                       hipStream_t st);
 
 /* ------------------------------------------------------------------ detection loss ---------- */
 /* balanced_cross_entropy_loss (ocrs_models/train_detection.py:225-263), forward and backward. */

@@ -5,3 +5,4 @@ from . import checkpoint, export, graph, input_pipeline, optim, sampler, text  #
 from .losses import CTCLoss, balanced_cross_entropy_loss  # noqa: F401
 from .models import DetectionModel  # noqa: F401
 from .recognition import RecognitionModel  # noqa: F401
+from . import losses, train_detection, train_rec  # noqa: F401,E402

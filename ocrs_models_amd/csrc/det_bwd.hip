@@ -8,6 +8,7 @@
 //   k_dw_bwd           dx~ = dw3x3^T(du), dWdw
 // plus ConvTranspose2d dgrad / wgrad, head backward, first-block (1->8) backward.
 #include "det_common.h"
+#include "loss_state.h"
 
 // ----------------------------------------------------------------------------------------------
 template <class T>
@@ -1239,6 +1240,87 @@ __global__ __launch_bounds__(256) void k_head_bwd(const T* __restrict__ z, const
     }
 }
 
+// Balanced-BCE backward + head backward in ONE pass (round 5): dL/dpred is formed on the fly from what the loss forward saved (class map,
+// per-pixel loss, the two radix-select thresholds: the arithmetic of k_bce_bwd in loss_optim.hip, operation for operation) instead of being
+// written by k_bce_bwd (4 B per pixel) and read back here (4 B) -- 33 instead of 45 B per pixel over the two launches, one launch and one
+// 134 MB buffer less per step.  Four pixels per thread and iteration (16-byte loads of pred / target / lpx, one dword of classes, four 16-byte z
+// vectors, one 16-byte gl store).  Only the gl form (k_rs_bwd<..., HEAD> consumes gl); P % 4 == 0.
+template <class T>
+__global__ __launch_bounds__(256) void k_head_bwd_loss(const T* __restrict__ z, const float* __restrict__ tr, const float* __restrict__ w,
+                                                       const float* __restrict__ pred, const float* __restrict__ target,
+                                                       const float* __restrict__ lpx, const unsigned char* __restrict__ cls,
+                                                       const LossState* __restrict__ stt, const float* __restrict__ gout,
+                                                       double* __restrict__ acc64 /*[9]: dw[8] | db*/, const float* __restrict__ saved /*[2][8]*/,
+                                                       double* __restrict__ gsum /*[2][8]*/, long P, float* __restrict__ gl_out /*[P]*/) {
+    __shared__ float s_slots[4 * 25];
+    float wv[8], sc[8], sh[8], lo[8], mu[8], acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st1[8], st2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wv[i] = w[i];
+        sc[i] = tr[i];
+        sh[i] = tr[8 + i];
+        lo[i] = tr[16 + i];
+        mu[i] = saved[i];
+        st1[i] = st2[i] = 0.f;
+    }
+    const unsigned t0 = stt->prefix[0], t1 = stt->prefix[1];
+    const float f0 = stt->frac[0], f1 = stt->frac[1];
+    const float s = gout[0] * stt->inv2k;
+    const long nq = P >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const float4 p4 = reinterpret_cast<const float4*>(pred)[q], t4 = reinterpret_cast<const float4*>(target)[q];
+        const float4 l4 = reinterpret_cast<const float4*>(lpx)[q];
+        const unsigned c4 = reinterpret_cast<const unsigned*>(cls)[q];
+        float v[4][8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load8(z + (q * 4 + e) * 8, v[e]);
+        const float pe[4] = {p4.x, p4.y, p4.z, p4.w}, te[4] = {t4.x, t4.y, t4.z, t4.w}, le[4] = {l4.x, l4.y, l4.z, l4.w};
+        float gle[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned c = (c4 >> (8 * e)) & 0xffu;
+            const float pr = pe[e];
+            float gp = 0.f;  // k_bce_bwd's grad()
+            if (c) {
+                const unsigned key = loss_key(le[e]);
+                const unsigned thr = c == 1 ? t0 : t1;
+                const float wgt = key > thr ? 1.f : (key == thr ? (c == 1 ? f0 : f1) : 0.f);
+                if (wgt != 0.f) {
+                    const float t = fminf(fmaxf(te[e], 0.f), 1.f);
+                    gp = s * wgt * (pr - t) / fmaxf((1.f - pr) * pr, 1e-12f);
+                }
+            }
+            const float gl = gp * (1.f - pr) * pr;
+            gle[e] = gl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pre = fmaf(v[e][i], sc[i], sh[i]);
+                const float xv = fmaxf(pre, lo[i]);
+                acc[i] = fmaf(gl, xv, acc[i]);
+                const float gh = pre > 0.f ? Elem<T>::round(gl * wv[i]) : 0.f;  // what the block's backward forms from gl
+                st1[i] += gh;
+                st2[i] = fmaf(gh, v[e][i] - mu[i], st2[i]);
+            }
+            acc[8] += gl;
+        }
+        reinterpret_cast<float4*>(gl_out)[q] = make_float4(gle[0], gle[1], gle[2], gle[3]);
+    }
+    float all[25];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) all[i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        all[9 + i] = st1[i];
+        all[17 + i] = st2[i];
+    }
+    const float tot = block_sum_det<25>(all, s_slots);
+    if (threadIdx.x < 9) atomicAdd(&acc64[threadIdx.x], (double)tot);
+    if (threadIdx.x >= 9 && threadIdx.x < 25) {
+        const int i = threadIdx.x - 9;
+        atomicAdd(&gsum[i], (double)(i < 8 ? tot : tot * saved[8 + (i - 8)]));
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -1681,6 +1763,25 @@ int ocrs_head_bwd_gl(const void* z, const float* tr, const float* w, const float
                      const float* saved, double* gsum, long P, int dtype, hipStream_t st) {
     OCRS_CHECK_ARG(gl);
     return head_bwd_impl(z, tr, w, pred, gpred, nullptr, gl, acc64, saved, gsum, P, dtype, st);
+}
+// ocrs_balanced_bce_bwd + ocrs_head_bwd_gl in one pass: dL/dpred is formed on the fly from the loss forward's saved tensors (pred, target, lpx, cls,
+// state: ocrs_balanced_bce_fwd) and gout [1] (the upstream gradient of the scalar loss) -- reference: the autograd of train_detection.py:225-263
+// followed by models.py:143's 1x1 conv + sigmoid backward.  P % 4 == 0, saved / gsum required.
+int ocrs_head_bwd_loss(const void* z, const float* tr, const float* w, const float* pred, const float* target, const float* lpx, const unsigned char* cls,
+                       const void* state, const float* gout, float* gl, double* acc64, const float* saved, double* gsum, long P, int dtype,
+                       hipStream_t st) {
+    OCRS_CHECK_ARG(z && tr && w && pred && target && lpx && cls && state && gout && gl && acc64 && saved && gsum && P > 0 && P % 4 == 0);
+    static const int bpc = env_int("OCRS_HEADL_BPC", 8);
+    int grid = ew_grid(P / 4);
+    if (grid > kNumCU * bpc) grid = kNumCU * bpc;
+    if (dtype == 1)
+        hipLaunchKernelGGL(k_head_bwd_loss<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)z, tr, w, pred, target, lpx, cls, (const LossState*)state,
+                           gout, acc64, saved, gsum, P, gl);
+    else
+        hipLaunchKernelGGL(k_head_bwd_loss<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, target, lpx, cls,
+                           (const LossState*)state, gout, acc64, saved, gsum, P, gl);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
 }
 
 }  // extern "C"

@@ -12,19 +12,7 @@
 // clip_grad_norm_ (train_rec.py:148) as multi-tensor sum-of-squares + scale.
 #include "common.h"
 
-struct LossState {            // device-resident, one per loss call
-    unsigned long long cnt[2];   // #pos, #neg
-    unsigned long long k;        // min(cnt)
-    unsigned prefix[2];          // radix-select prefix / final threshold bits per class
-    unsigned long long need[2];  // how many still to take inside the current prefix bucket
-    unsigned long long ties[2];  // elements equal to the threshold
-    double sum_gt[2];            // sum of losses strictly above the threshold
-    float loss;
-    float frac[2];               // need / ties
-    float inv2k;                 // 1 / (2k)
-};
-
-__device__ __forceinline__ unsigned loss_key(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+#include "loss_state.h"
 
 // Workspace behind the two histograms (ocrs_loss_hist_bytes): per-block partials, reduced in a fixed order by the one-block scan kernels -- the
 // element counts of k_bce_fwd and the sums of k_select_hist's last pass (1024 blocks x 2 same-address fp64 atomics were a 30 us serial tail

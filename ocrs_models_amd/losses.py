@@ -5,6 +5,7 @@
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -12,10 +13,61 @@ import torch
 from ._lib import lib, ptr
 
 
+# ---- loss backward fused into the network's head backward (round 5) -------------------------------------------------------------------
+# Inside ``fused_head_backward()`` the loss's backward does not launch k_bce_bwd: it returns a stride-0 view of a cached device zero (the
+# "marker") and parks what it saved; the detection network's backward (models._DetRun.backward) recognises the marker and runs ONE kernel
+# that forms dL/dpred on the fly (ocrs_head_bwd_loss: 33 instead of 45 B per pixel, one launch and a 4 B/pixel buffer less).  The marker's
+# VALUE is zero, so anything autograd does linearly with it stays correct: if pred had a second consumer the engine hands the network
+# `other + 0` and the parked gradient is materialised and added.  The contract of the context: no tensor / node hooks that rescale or
+# retain pred's gradient (pred.retain_grad() would record the marker).  The deferral happens only when pred is the direct output of
+# ocrs_models_amd.DetectionModel.  A plain module global, not a thread-local: backward runs on autograd's device thread.
+_FUSE = {"on": False}
+_PENDING = {}  # device index -> (pred, target, lpx, cls, state, gout)
+_ZERO = {}     # device index -> fp32 [1] zero, never written
+
+
+@contextlib.contextmanager
+def fused_head_backward():
+    """``with fused_head_backward(): loss.backward()`` -- see above; used by train_detection.train_step."""
+    prev, _FUSE["on"] = _FUSE["on"], True
+    try:
+        yield
+    finally:
+        _FUSE["on"] = prev
+        if not prev and _PENDING:
+            _PENDING.clear()
+            raise RuntimeError("fused_head_backward(): a deferred loss gradient was never consumed by a DetectionModel backward")
+
+
+def _zero_marker(dev):
+    z = _ZERO.get(dev.index)
+    if z is None:
+        z = _ZERO[dev.index] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return z
+
+
+def take_deferred(gpred: torch.Tensor):
+    """For models._DetRun.backward: (saved, is_marker).  saved = the parked (pred, target, lpx, cls, state, gout) of this device or None;
+    is_marker = `gpred` is the untouched marker (no other gradient was accumulated into it)."""
+    saved = _PENDING.pop(gpred.device.index, None)
+    if saved is None:
+        return None, False
+    z = _ZERO.get(gpred.device.index)
+    return saved, (z is not None and gpred.data_ptr() == z.data_ptr() and all(s == 0 for s in gpred.stride()))
+
+
+def materialize_deferred(saved) -> torch.Tensor:
+    pred, target, lpx, cls, state, g = saved
+    gpred = torch.empty_like(pred)
+    lib().balanced_bce_bwd(ptr(pred), ptr(target), ptr(lpx), ptr(cls), ptr(state), ptr(g), ptr(gpred), pred.numel())
+    return gpred
+
+
 class _BalancedBCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
         L = lib()
+        ctx.from_det = type(pred.grad_fn).__name__ == "_DetFnBackward" and pred.is_contiguous() and pred.dtype == torch.float32
         pred = pred.contiguous().float()
         target = target.contiguous().float()
         P = pred.numel()
@@ -32,8 +84,11 @@ class _BalancedBCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         pred, target, lpx, cls, state = ctx.saved_tensors
-        gpred = torch.empty_like(pred)
         g = gout.contiguous().float().reshape(1)
+        if _FUSE["on"] and ctx.from_det and pred.device.index not in _PENDING:
+            _PENDING[pred.device.index] = (pred, target, lpx, cls, state, g)
+            return _zero_marker(pred.device).expand(pred.shape), None
+        gpred = torch.empty_like(pred)
         lib().balanced_bce_bwd(ptr(pred), ptr(target), ptr(lpx), ptr(cls), ptr(state), ptr(g), ptr(gpred), pred.numel())
         return gpred, None
 

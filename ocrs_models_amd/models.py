@@ -503,7 +503,12 @@ class _DetRun:
                     stage_done(st)
                 pending.clear()
                 keep.clear()
-        gpred = gpred.contiguous().float()
+        from . import losses as _losses
+        deferred, is_marker = _losses.take_deferred(gpred)  # (losses.fused_head_backward: the loss's backward parked its gradient)
+        if deferred is not None and not is_marker:
+            gpred = gpred + _losses.materialize_deferred(deferred)  # pred had another consumer: autograd handed us `other + 0`
+            deferred = None
+        gpred = gpred.contiguous().float() if deferred is None else None
         up = self.head_in
         sv = gs_head = None
         if self.fuse_bn_bwd and up.src is not None:  # the head is this block's only consumer and reads its z anyway
@@ -515,7 +520,15 @@ class _DetRun:
         r_up = self.recs.get(up.src) if up.src is not None else None
         head_gl = (self.head_gl and self.capture is None and gs_head is not None and r_up is not None and r_up.b is None and self.use_mm and self.fold_fin
                    and L.mm_bwd_head_supported(r_up.a.C, 0, r_up.Cout, N, H, W, self.dt))
-        if head_gl:
+        if deferred is not None and not (head_gl and (N * H * W) % 4 == 0 and deferred[0].data_ptr() == self.pred.data_ptr()):
+            gpred, deferred = _losses.materialize_deferred(deferred), None
+        if deferred is not None:
+            # dL/dpred formed on the fly from the loss forward's saved tensors: k_bce_bwd + k_head_bwd in one pass
+            g = self.empty(N, H, W, dtype=torch.float32)
+            _, d_target, d_lpx, d_cls, d_state, d_gout = deferred
+            L.head_bwd_loss(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(d_target), ptr(d_lpx), ptr(d_cls), ptr(d_state),
+                            ptr(d_gout), ptr(g), ptr(acc), ptr(sv), ptr(gs_head), N * H * W, self.dt)
+        elif head_gl:
             g = self.empty(N, H, W, dtype=torch.float32)
             L.head_bwd_gl(ptr(up.t), ptr(up.tr), ptr(P["out_conv.0.weight"]), ptr(self.pred), ptr(gpred), ptr(g), ptr(acc), ptr(sv), ptr(gs_head),
                           N * H * W, self.dt)

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 
 from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401  (train_detection.py:198-215)
-from .losses import balanced_cross_entropy_loss
+from .losses import balanced_cross_entropy_loss, fused_head_backward
 from .models import DetectionModel
 from .optim import Adam
 
@@ -23,7 +23,12 @@ def train_step(model, optimizer, batch: dict, device, loss_fn=balanced_cross_ent
     pred_masks = model(img)
     loss = loss_fn(pred_masks, masks)
     optimizer.zero_grad()
-    loss.backward()
+    if loss_fn is balanced_cross_entropy_loss:
+        # pred's only consumer is the built-in loss: its backward is folded into the network's head backward (losses.fused_head_backward)
+        with fused_head_backward():
+            loss.backward()
+    else:
+        loss.backward()
     optimizer.step()
     return loss.detach()
 
