@@ -169,6 +169,15 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
 long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype);
 int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                          const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
+/* Deferred second stage of the block backward (models.py:7-28 backward; no reference counterpart -- it is launch scheduling): between _begin and _flush
+   the block-backward entry points (ocrs_mm_bwd*, ocrs_pw_bwd*, ocrs_dw_bwd) (1) finalise the BatchNorm-backward sums they produce for their input's
+   producers (gsum_a / gsum_b) in the last workgroup of the block kernel, using state carved from `scratch` (ndoubles ZEROED fp64 values, left zeroed),
+   and (2) queue the single-writer reductions of their weight-gradient partials instead of launching them; _flush launches all queued reductions as
+   ONE kernel on `st` and ends the mode.  `scratch` and every workspace `ws` passed meanwhile must stay valid until _flush has been queued; dwpw /
+   dwdw are complete only after it.  Results are bit-identical to the undeferred launches except for the gsum sums (exact fp64 sums of the fp32
+   per-block partials instead of fp32 chain sums).  Per-process state: one backward at a time. */
+int ocrs_bwd_defer_begin(double* scratch, long ndoubles);
+int ocrs_bwd_defer_flush(hipStream_t st);
 /* autograd of out_conv + sigmoid. */
 /* acc64 [9] fp64 = dw [8] | db, ACCUMULATED (caller-zeroed, caller adds it to the fp32 gradients; see ocrs_dwpw_c1_bwd). */
 int ocrs_head_bwd(const void* z, const float* tr, const float* w, const float* pred, const float* gpred, void* gy, double* acc64,

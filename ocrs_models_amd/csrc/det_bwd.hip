@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, (Elem<T>::is_bf16 && STATS) ? OCRS_DW_BLOCKS :
                                                 const float* __restrict__ wdw /*master [C][9]*/, const T* __restrict__ du,
                                                 T* __restrict__ gxa, T* __restrict__ gxb, float* __restrict__ dwdw /*[C][9]*/,
                                                 float* __restrict__ ws /*[gridDim.x][C][9 (+2)] block partials or null*/,
-                                                const float* __restrict__ saved_a, const float* __restrict__ saved_b, int stat_mask, Tiling2 tg) {
+                                                const float* __restrict__ saved_a, const float* __restrict__ saved_b, int stat_mask, Tiling2 tg, BwdLast bl) {
     // slab of SC = CG*8 channels per block (grid.y); a thread owns 4 channels (36 dW accumulators) of TWO horizontally adjacent pixels:
     // the pair shares 6 of its 9 du taps and all weights (12 + 9 LDS vector reads instead of 36), and the tile doubles to
     // 8 x (32/CG) pixels (halo re-read 1.33-1.56x instead of 1.4-1.875x, per-tile bookkeeping amortised over twice the pixels)
@@ -689,8 +689,16 @@ __global__ __launch_bounds__(256, (Elem<T>::is_bf16 && STATS) ? OCRS_DW_BLOCKS :
         for (int m = 0; m < 256 / CQ; ++m) v += src[m * CQ];
         if (t < 9)
             flush_w(dwdw, ws, (cb + c) * 9 + t, C * NROW, v);
-        else
+        else {
             ws[(long)blockIdx.x * (C * NROW) + C * t + cb + c] = v;  // rows 9, 10: [C] each (STATS requires a workspace)
+            if (bl.raw) bwd_last_add(bl, C, cb + c, t - 9, v);
+        }
+    }
+    if constexpr (STATS) {
+        if (bl.raw) {  // the producers' sums finalised here by the last workgroup (BwdLast in det_common.h): k_dw_partials_reduce leaves the dependency chain
+            __syncthreads();
+            bwd_last_finish(bl, C, nullptr, nullptr, tid, 256, reinterpret_cast<int*>(s_mem));
+        }
     }
 }
 // second stage of k_dw_bwd's flush: dwdw[e] += sum_b ws[b][e] (e < 9C); with stats (nrow = 11) rows 9/10 are scaled (row 10 by rstd)
@@ -1322,6 +1330,55 @@ __global__ __launch_bounds__(256) void k_head_bwd_loss(const T* __restrict__ z, 
 }
 
 // ----------------------------------------------------------------------------------------------
+// Deferred second stage of the block backward's flushes (round 5; see BwdLast in det_common.h).  Between ocrs_bwd_defer_begin and
+// ocrs_bwd_defer_flush the single-writer reductions of weight-gradient partials (k_mm_bwd_reduce's weight part, k_wgrad_partials_reduce,
+// k_dw_partials_reduce's tap rows) are not launched but queued; the flush runs them all as ONE launch (same column-sum order: bit-identical
+// gradients).  Per-process state (one process per GPU, one backward at a time).
+// ----------------------------------------------------------------------------------------------
+struct RedJob {
+    const float* ws;
+    float *d0, *d1;
+    int nb, nelem, n0, cin0, ldw0, n1, blk0;
+};
+constexpr int RED_MAXJOBS = 48;
+struct RedJobs {
+    int njobs;
+    RedJob j[RED_MAXJOBS];
+};
+__global__ __launch_bounds__(256) void k_reduce_multi(RedJobs J) {
+    int k = 0;
+    while (k + 1 < J.njobs && (int)blockIdx.x >= J.j[k + 1].blk0) ++k;
+    const RedJob& q = J.j[k];
+    const long e = (long)((int)blockIdx.x - q.blk0) * 32 + (threadIdx.x & 31);
+    float s;
+    if (!det_column_sum(q.ws, q.nb, q.nelem, e < q.n0 + q.n1 ? e : (long)q.nelem, s)) return;
+    if (e < q.n0)
+        q.d0[(e / q.cin0) * q.ldw0 + e % q.cin0] += s;
+    else
+        q.d1[e - q.n0] += s;
+}
+static struct {
+    bool on = false;
+    double* scratch = nullptr;
+    long cap = 0, used = 0;
+    int nblocks = 0;
+    RedJobs jobs;
+} g_defer;
+double* bwd_defer_scratch(int ndoubles) {
+    if (!g_defer.on || g_defer.used + ndoubles > g_defer.cap) return nullptr;
+    double* p = g_defer.scratch + g_defer.used;
+    g_defer.used += (ndoubles + 1) & ~1L;
+    return p;
+}
+bool bwd_defer_reduce(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1) {
+    if (!g_defer.on || g_defer.jobs.njobs >= RED_MAXJOBS || n0 + n1 <= 0) return false;
+    RedJob& q = g_defer.jobs.j[g_defer.jobs.njobs++];
+    q = RedJob{ws, d0, d1, nb, nelem, n0, cin0 > 0 ? cin0 : 1, ldw0, n1, g_defer.nblocks};
+    g_defer.nblocks += (n0 + n1 + 31) / 32;
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
 static inline int ew_grid(long items) {
@@ -1432,6 +1489,7 @@ extern "C" {
 // [Cout][Cin]); dz is formed on the fly from (g1 [+g2], z, bn, coef), u is recomputed from the block input.
 // wpk_d = ocrs_pack_frags(mode 0, K=Cout, M=Cin) of W^T.
 void k_wgrad_partials_reduce_launch(const float* ws, int nb, int nelem, float* dw, int cin, int ldw, hipStream_t st) {
+    if (bwd_defer_reduce(ws, nb, nelem, dw, nelem, cin, ldw, nullptr, 0)) return;  // (ocrs_bwd_defer_begin .. _flush: one launch for all of them)
     OCRS_LAUNCH_T(k_wgrad_partials_reduce, dim3((nelem + 31) / 32), dim3(256), 0, st, ws, nb, nelem, dw, cin, ldw);
 }
 // det_pw2.hip: two-pixel-per-thread pipelined kernel for bf16, Cin, Cout <= 32 (levels 0-2)
@@ -1574,10 +1632,21 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
         Src2<T_> x{(const T_*)xa, (const T_*)xb, Ca, Cb};                                                                                 \
         if (stat_mask)                                                                                                                    \
             OCRS_LAUNCH_T((k_dw_bwd<T_, CG_, true>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
-                               dwdw, ws, saved_a, saved_b, stat_mask, tg);                                                                \
+                               dwdw, ws, saved_a, saved_b, stat_mask, tg, bl);                                                            \
         else                                                                                                                              \
             OCRS_LAUNCH_T((k_dw_bwd<T_, CG_, false>), dim3(gx, gy), dim3(256), smem, st, x, tra, trb, wdw, (const T_*)du, (T_*)gxa, (T_*)gxb, \
-                               dwdw, ws, saved_a, saved_b, 0, tg);                                                                        \
+                               dwdw, ws, saved_a, saved_b, 0, tg, bl);                                                                    \
+    }
+    BwdLast bl{nullptr, nullptr, gsum_a, gsum_b, saved_a, saved_b, Ca, 1};
+    // k_dw_bwd (the deep levels: 768 short workgroups per launch): the drain + ticket at the end of every workgroup costs what the ~5 us reduce launch
+    // it takes off the chain saves -- A/B on one box, whole step: 12.19 / 12.18 ms with it, 12.14 / 12.10 ms without (and 12.23 / 12.20 ms with nothing
+    // deferred) -- so it is off by default here; k_mm_bwd / k_rs_bwd (levels 0-2) keep it
+    static const int last_on = env_int("OCRS_BWD_LAST", 1) && env_int("OCRS_BWD_LAST_DW", 0);
+    if (stat_mask && last_on) {
+        if (double* p = bwd_defer_scratch(BWD_LAST_SLOTS * 2 * C + 2)) {
+            bl.raw = p;
+            bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * C);
+        }
     }
     if (dtype == 1) {
         if (cg == 1) DWB(bf16, 1) else if (cg == 2) DWB(bf16, 2) else DWB(bf16, 4)
@@ -1587,8 +1656,15 @@ int ocrs_dw_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra
 #undef DWB
     if (ws) {
         const int nrow = stat_mask ? 11 : 9;
-        OCRS_LAUNCH_T(k_dw_partials_reduce, dim3((C * nrow + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
-                           gsum_b, saved_a, saved_b);
+        // deferred second stage: with the sums done in the block kernel (or none asked for) only the tap rows are left, and nothing in the backward reads them
+        static const int dwq = env_int("OCRS_BWD_DW_QUEUE", 1);
+        if (dwq && (bl.raw || !stat_mask) && bwd_defer_reduce(ws, gx, C * nrow, nullptr, 0, 1, 1, dwdw, 9 * C)) {
+        } else if (bl.raw) {
+            OCRS_LAUNCH_T(k_dw_partials_reduce, dim3((C * 9 + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, (double*)nullptr, (double*)nullptr, saved_a, saved_b);
+        } else {
+            OCRS_LAUNCH_T(k_dw_partials_reduce, dim3((C * nrow + 31) / 32), dim3(256), 0, st, ws, gx, C, Ca, nrow, dwdw, gsum_a,
+                               gsum_b, saved_a, saved_b);
+        }
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1780,6 +1856,29 @@ int ocrs_head_bwd_loss(const void* z, const float* tr, const float* w, const flo
     else
         hipLaunchKernelGGL(k_head_bwd_loss<float>, dim3(grid), dim3(256), 0, st, (const float*)z, tr, w, pred, target, lpx, cls,
                            (const LossState*)state, gout, acc64, saved, gsum, P, gl);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+// Deferred second stage (see the queue above).  scratch: ndoubles zeroed fp64 values the block-backward launches carve their last-workgroup
+// finalisation state from (16 Cin + 2 each; left zeroed), valid -- like every workspace `ws` passed meanwhile -- until ocrs_bwd_defer_flush, which
+// launches the queued weight-gradient reductions as one kernel on `st` (the stream of the launches that produced the partials) and ends the mode.
+int ocrs_bwd_defer_begin(double* scratch, long ndoubles) {
+    OCRS_CHECK_ARG(!g_defer.on && (scratch || ndoubles == 0) && ndoubles >= 0);
+    g_defer.on = true;
+    g_defer.scratch = scratch;
+    g_defer.cap = ndoubles;
+    g_defer.used = 0;
+    g_defer.nblocks = 0;
+    g_defer.jobs.njobs = 0;
+    return OCRS_OK;
+}
+int ocrs_bwd_defer_flush(hipStream_t st) {
+    const bool was = g_defer.on;
+    g_defer.on = false;
+    if (!was || g_defer.jobs.njobs == 0) return OCRS_OK;
+    hipLaunchKernelGGL(k_reduce_multi, dim3(g_defer.nblocks), dim3(256), 0, st, g_defer.jobs);
+    g_defer.jobs.njobs = 0;
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -555,6 +555,67 @@ __device__ __forceinline__ void bn_fin_coef(const BnFin& fin, int COUT, float* s
     }
 }
 
+// ---- block backward: the producers' BatchNorm-backward sums finalised by the LAST workgroup of the launch (round 5) -------------------------------
+// k_mm_bwd / k_rs_bwd / k_dw_bwd hand the raw sums of the gradient flowing into their input's producers (S1 = sum ghat', S2 = sum ghat' x~) to a
+// single-writer reduce kernel that also sums the weight-gradient partials -- a ~7 us launch per block ON the backward's dependency chain (the next
+// block's kernel derives its dz coefficients from those sums), 27 of them per step.  With `raw` set, every workgroup instead adds its fp32 partial
+// sums into fp64 device-scope atomics (an fp64 sum of fp32 values of comparable magnitude is exact, hence order-independent: still bit-reproducible),
+// drains them (s_waitcnt vmcnt(0), not __threadfence: see bn_finalize_last_block) and takes a ticket; the workgroup that draws the last ticket
+// converts the totals exactly as the reduce kernel does, adds them to gsum_a / gsum_b and re-zeroes raw / counter (ready for a replay).  What is
+// left for the reduce kernel -- the weight gradients, which nothing in the backward reads -- is queued and runs as ONE launch at the end of the
+// backward (ocrs_bwd_defer_begin / ocrs_bwd_defer_flush in det_bwd.hip).
+struct BwdLast {
+    double* raw;        // [BWD_LAST_SLOTS][2][CIN] fp64, zeroed (null: off -- the launcher runs the reduce kernel in line)
+    unsigned* counter;  // one zeroed word
+    double *gsum_a, *gsum_b;
+    const float *saved_a, *saved_b;
+    int Ca;             // channels of source a (the rest belong to source b)
+    int mode;           // 0: S1 | S2 = sum ghat' | sum ghat' x~ (k_mm_bwd_reduce's conversion);  1: sum ghat | sum ghat (z - mean) (k_dw_partials_reduce's: x rstd)
+};
+constexpr int BWD_LAST_SLOTS = 8;  // replicas of the raw sums, by workgroup index: same-address atomics serialise at the memory side (~15 ns each; 768 workgroups
+                                   // finishing together on one replica cost as much as the launch this replaces)
+__device__ __forceinline__ void bwd_last_add(const BwdLast& bl, int CIN, int c, int which, float v) {
+    atomicAdd(bl.raw + ((blockIdx.x + blockIdx.y) & (BWD_LAST_SLOTS - 1)) * 2 * CIN + which * CIN + c, (double)v);
+}
+// call with all threads of the block after the bwd_last_add calls; tra / trb: the sources' load transforms [3][C] (mode 0); s_flag: a free LDS int
+__device__ __forceinline__ void bwd_last_finish(const BwdLast& bl, int CIN, const float* __restrict__ tra, const float* __restrict__ trb, int tid, int nt,
+                                                int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *s_flag = __hip_atomic_fetch_add(bl.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1 ? 1 : 0;
+    __syncthreads();
+    if (*s_flag == 0) return;
+    for (int c = tid; c < CIN; c += nt) {
+        double S1 = 0.0, S2 = 0.0;  // (exact sums: any order gives the same bits)
+        for (int k = 0; k < BWD_LAST_SLOTS; ++k) {
+            double* r = bl.raw + k * 2 * CIN;
+            S1 += __hip_atomic_load(r + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            S2 += __hip_atomic_load(r + CIN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(r + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(r + CIN + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool in_a = c < bl.Ca;
+        double* gs = in_a ? bl.gsum_a : bl.gsum_b;
+        if (!gs) continue;
+        const int cc = in_a ? c : c - bl.Ca, Cs = in_a ? bl.Ca : CIN - bl.Ca;
+        const float* sv = in_a ? bl.saved_a : bl.saved_b;
+        const double mean = sv[cc], rstd = sv[Cs + cc];
+        gs[cc] += S1;
+        if (bl.mode == 0) {
+            const float* tr = in_a ? tra : trb;
+            const double sc = tr[cc], sh = tr[Cs + cc];
+            if (sc != 0.0) gs[Cs + cc] += rstd * ((S2 - sh * S1) / sc - mean * S1);
+        } else {
+            gs[Cs + cc] += (double)((float)S2 * sv[Cs + cc]);
+        }
+    }
+    if (tid == 0) __hip_atomic_store(bl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// host side (det_bwd.hip): scratch for one launch (null outside ocrs_bwd_defer_begin .. _flush or when it is used up), and the queue of deferred
+// weight-gradient reductions: columns [0, n0) of ws[nb][nelem] += into d0[(e / cin0) * ldw0 + e % cin0], columns [n0, n0 + n1) into d1[e - n0]
+double* bwd_defer_scratch(int ndoubles);
+bool bwd_defer_reduce(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1);
+
 // ---- BatchNorm2d training statistics finalised by the LAST workgroup of the forward launch that produced them (one launch less per block)
 struct FwdFin {
     unsigned* counter;  // null: plain partials, the caller runs ocrs_bn_finalize_parts

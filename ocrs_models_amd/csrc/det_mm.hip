@@ -236,7 +236,7 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
                                                    const float* __restrict__ wpw /*[COUT][ldw], already offset*/, int ldw,
                                                    const bf16* __restrict__ g1, const bf16* __restrict__ g2, const bf16* __restrict__ z,
                                                    const float* __restrict__ bn, const float* __restrict__ coef, bf16* __restrict__ gxa,
-                                                   bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg, BnFin fin) {
+                                                   bf16* __restrict__ gxb, float* __restrict__ ws, Tiling2 tg, BnFin fin, BwdLast bl) {
     using C = MmCfg<CIN, COUT, PPOOL>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, TP = C::TP, DW_ = C::DW_, DP = C::DP, CGI = C::CGI, CGO = C::CGO, PD = C::PD, PX = C::PX;
     constexpr int MT = C::MT, NTO = C::NTO, KC = C::KC, NPW = C::NPW, KS = C::KS;
@@ -927,6 +927,13 @@ __global__ __launch_bounds__((MmCfg<CIN, COUT, PPOOL>::NT), (mm_bwd_lb<CIN, COUT
             }
         }
         part[COUT * CIN + 9 * CIN + e] = s;
+        if (STATS && bl.raw) bwd_last_add(bl, CIN, e >> 1, e & 1, s);
+    }
+    if constexpr (STATS) {
+        if (bl.raw) {  // the producers' sums finalised here by the last workgroup (BwdLast): the reduce kernel leaves the dependency chain
+            __syncthreads();  // (every read of the flush slots is done: smem[0] is free)
+            bwd_last_finish(bl, CIN, tra, trb, tid, NT, reinterpret_cast<int*>(smem));
+        }
     }
 }
 
@@ -1008,7 +1015,7 @@ static int mm_bwd_th(int Cin, int Cout, int pooled) {
 template <int CIN, int COUT, bool PPOOL, bool G2, bool STATS>
 static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                            const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, int N, int H, int W, int nb, const BnFin& fin,
-                           hipStream_t st) {
+                           const BwdLast& bl, hipStream_t st) {
     using CC = MmCfg<CIN, COUT, PPOOL>;
     Tiling2 tg = make_tiling2(N, H + (PPOOL ? 1 : 0), W + (PPOOL ? 1 : 0), CC::TW, CC::TH);  // pooled: origins shifted by -1 -> one more row / column of tiles may be needed
     tg.H = H;
@@ -1019,20 +1026,20 @@ static void mm_bwd_launch1(const Src2<bf16>& x, const float* tra, const float* t
         if (full_on && W % CC::TW == 0) {  // every tile COLUMN inside the image: unconditional stores + hand-written prefetch waits
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
             OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef,
-                          gxa, gxb, ws, tg, fin);
+                          gxa, gxb, ws, tg, fin, bl);
             return;
         }
     }
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
     OCRS_LAUNCH_T((k_mm_bwd<CIN, COUT, PPOOL, G2, STATS, false>), dim3(nb), dim3(CC::NT), CC::SMEM, st, x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb,
-                  ws, tg, fin);
+                  ws, tg, fin, bl);
 }
 
 template <int CIN, int COUT>
 static void mm_bwd_dispatch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                             int pooled, const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int N, int H, int W,
-                            int nb, const BnFin& fin, hipStream_t st) {
-#define MMB(PP, GG, SS) mm_bwd_launch1<CIN, COUT, PP, GG, SS>(x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb, ws, N, H, W, nb, fin, st)
+                            int nb, const BnFin& fin, const BwdLast& bl, hipStream_t st) {
+#define MMB(PP, GG, SS) mm_bwd_launch1<CIN, COUT, PP, GG, SS>(x, tra, trb, wdw, wpw, ldw, g1, g2, z, bn, coef, gxa, gxb, ws, N, H, W, nb, fin, bl, st)
     if (pooled) {
         if (g2) { if (stats) MMB(true, true, true); else MMB(true, true, false); }
         else    { if (stats) MMB(true, false, true); else MMB(true, false, false); }
@@ -1041,6 +1048,30 @@ static void mm_bwd_dispatch(const Src2<bf16>& x, const float* tra, const float* 
         else    { if (stats) MMB(false, false, true); else MMB(false, false, false); }
     }
 #undef MMB
+}
+
+// in-kernel finalisation state for one block-backward launch (off: raw = null) and the launch's second stage
+static BwdLast mm_bwd_last(bool want, int Cin, int Ca, double* gsA, double* gsB, const float* svA, const float* svB) {
+    BwdLast bl{nullptr, nullptr, gsA, gsB, svA, svB, Ca, 0};
+    static const int on = env_int("OCRS_BWD_LAST", 1);
+    if (!want || !on) return bl;
+    double* p = bwd_defer_scratch(BWD_LAST_SLOTS * 2 * Cin + 2);
+    if (p) {
+        bl.raw = p;
+        bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
+    }
+    return bl;
+}
+static void mm_bwd_second_stage(const float* ws, int nb, int Cin, int Cout, int Ca, float* dwpw, int ldw, float* dwdw, double* gsA, double* gsB, const float* svA,
+                                const float* svB, const float* tA, const float* tB, const BwdLast& bl, bool may_defer, hipStream_t st) {
+    const int ne = Cout * Cin + 11 * Cin;
+    if (bl.raw) {  // the sums are done in the block kernel: only the weight gradients are left, and nothing in the backward reads them
+        gsA = gsB = nullptr;
+        if (may_defer && bwd_defer_reduce(ws, nb, ne, dwpw, Cout * Cin, Cin, ldw, dwdw, 9 * Cin)) return;
+    } else if (may_defer && !gsA && !gsB && bwd_defer_reduce(ws, nb, ne, dwpw, Cout * Cin, Cin, ldw, dwdw, 9 * Cin)) {
+        return;
+    }
+    OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, Ca, dwpw, ldw, dwdw, gsA, gsB, svA, svB, tA, tB);
 }
 
 extern "C" {
@@ -1094,15 +1125,17 @@ static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
                           : mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout, pooled ? 1 : 0));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
-        if (rs) rs_bwd_launch(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, coef, ga, gb, ws, stats, Cout, N, H, W, fin, st);
+        // deferred second stage (ocrs_bwd_defer_begin): the producers' sums by the last workgroup of the block kernel, the weight-gradient reduce queued.
+        // (a split launch pair shares `ws`: the first launch's partials would be overwritten before a queued reduce ran -- those stay in line)
+        const BwdLast bl = mm_bwd_last(stats && !split, Cin, x.Ca, gsA, gsB, svA, svB);
+        if (rs) rs_bwd_launch(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, coef, ga, gb, ws, stats, Cout, N, H, W, fin, st, nullptr, nullptr,
+                              nullptr, nullptr, bl);
 #define MM_CASE(CI_, CO_)                                                                                                             \
     if (!rs && Cin == CI_ && Cout == CO_)                                                                                             \
-        mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, fin, st);
+        mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, fin, bl, st);
         MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
 #undef MM_CASE
-        const int ne = Cout * Cin + 11 * Cin;
-        OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA,
-                           svB, tA, tB);
+        mm_bwd_second_stage(ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA, svB, tA, tB, bl, !split, st);
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
@@ -1120,11 +1153,10 @@ int ocrs_mm_bwd_fin_head(const void* xa, int Ca, const float* tra, const float* 
     const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
     Src2<bf16> x{(const bf16*)xa, nullptr, Ca, 0};
     const int nb = rs_bwd_blocks(Ca, Cout, N, H, W, 0);
+    const BwdLast bl = mm_bwd_last(gsum_a != nullptr, Ca, Ca, gsum_a, nullptr, saved_a, nullptr);
     rs_bwd_launch(x, tra, nullptr, wdw, wpw, Ca, nullptr, nullptr, (const bf16*)z, bn, nullptr, (bf16*)gxa, nullptr, ws, gsum_a != nullptr, Cout, N, H, W, fin, st, gl,
-                  whead);
-    const int ne = Cout * Ca + 11 * Ca;
-    OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, Ca, Cout, Ca, dwpw, Ca, dwdw, gsum_a, (double*)nullptr, saved_a, (const float*)nullptr,
-                  tra, (const float*)nullptr);
+                  whead, nullptr, nullptr, bl);
+    mm_bwd_second_stage(ws, nb, Ca, Cout, Ca, dwpw, Ca, dwdw, gsum_a, nullptr, saved_a, nullptr, tra, nullptr, bl, true, st);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
@@ -1139,11 +1171,10 @@ int ocrs_mm_bwd_fin_xu(const void* xu, const float* wexp, const float* tra, cons
     const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
     Src2<bf16> x{nullptr, nullptr, 8, 0};
     const int nb = rs_bwd_blocks(8, Cout, N, H, W, g2 != nullptr);
+    const BwdLast bl = mm_bwd_last(gsum_a != nullptr, 8, 8, gsum_a, nullptr, saved_a, nullptr);
     rs_bwd_launch(x, tra, nullptr, wdw, wpw, 8, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, nullptr, (bf16*)gxa, nullptr, ws, gsum_a != nullptr, Cout, N, H, W,
-                  fin, st, nullptr, nullptr, (const bf16*)xu, wexp);
-    const int ne = Cout * 8 + 11 * 8;
-    OCRS_LAUNCH_T(k_mm_bwd_reduce, dim3((ne + 31) / 32), dim3(256), 0, st, ws, nb, 8, Cout, 8, dwpw, 8, dwdw, gsum_a, (double*)nullptr, saved_a, (const float*)nullptr, tra,
-                  (const float*)nullptr);
+                  fin, st, nullptr, nullptr, (const bf16*)xu, wexp, bl);
+    mm_bwd_second_stage(ws, nb, 8, Cout, 8, dwpw, 8, dwdw, gsum_a, nullptr, saved_a, nullptr, tra, nullptr, bl, true, st);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -90,6 +90,7 @@ struct RsArgs {
     int N, H, W, NS, NP;
     int NB, PB, njobs;  // row blocks per image, row pairs per block, jobs = N * NB * NS
     BnFin fin;
+    BwdLast bl;
 };
 
 template <int CIN, int COUT>
@@ -757,6 +758,11 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
                 s = fmaf(we, Gv(which ? c : CIN + c, tap, o), s);
             }
         part[COUT * CIN + 9 * CIN + e] = s;
+        if (A.bl.raw) bwd_last_add(A.bl, CIN, c, which, s);
+    }
+    if (A.bl.raw) {  // the producers' sums finalised here by the last workgroup (BwdLast in det_common.h)
+        __syncthreads();  // (every read of the flush slots is done: smem[0] is free)
+        bwd_last_finish(A.bl, CIN, A.tra, A.trb, tid, C::NT, reinterpret_cast<int*>(smem));
     }
 }
 
@@ -1150,8 +1156,9 @@ int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
 }
 void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                    const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
-                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead, const bf16* xu, const float* wexp) {
+                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead, const bf16* xu, const float* wexp, const BwdLast& bl) {
     RsArgs a;
+    a.bl = bl;
     a.gl = gl;
     a.whead = whead;
     a.xu = xu;

@@ -130,12 +130,18 @@ class _DetRun:
         # test tap (tests/test_det_bf16_layerwise_gpu.py): when the module carries a dict ``_capture`` every backward stage records the gradient
         # tensors it consumed / produced there, and the run itself (saved activations) is kept alive in it; None in production
         self.capture = getattr(mod, "_capture", None)
+        self._keep_ws, self._deferring = [], False
         if self.capture is not None:
             self.capture["run"] = self
 
     # -- helpers ---------------------------------------------------------------------------------
     def empty(self, *shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.dev)
+
+    def _hold(self, ws):
+        keep = getattr(self, "_keep_ws", None)  # (absent when a block backward is driven directly, outside backward(): nothing is deferred then)
+        if keep is not None:
+            keep.append(ws)
 
     def zeros64(self, n):
         """n zeroed float64 values carved from one per-step pool (one fill launch instead of ~50 small memsets)."""
@@ -421,6 +427,7 @@ class _DetRun:
             sva, gsa = stat_target(a)
             svb, gsb = stat_target(b)
             ws = self.empty(L.mm_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
+            self._hold(ws)  # (its reduction may be queued until the end of the backward)
             gl = getattr(self, "_head_gl", None)
             if gl is not None and g1 is gl:  # the block in front of out_conv: its output gradient is formed from gl inside the launch
                 self._head_gl = None
@@ -446,6 +453,7 @@ class _DetRun:
             return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
+        self._hold(ws)  # (its reduction may be queued until the end of the backward)
         if fold_pw:
             L.pw_bwd_fin(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(g1),
                          ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(wpk_d), ptr(du),
@@ -457,6 +465,7 @@ class _DetRun:
         gxa = self.empty(N, H, W, Ca) if need_gx else None
         gxb = self.empty(N, H, W, Cb) if (need_gx and b is not None) else None
         ws = self.empty(L.dw_bwd_ws_floats(r.Cin, N, H, W), dtype=torch.float32)
+        self._hold(ws)  # (its reduction may be queued until the end of the backward)
         sva, gsa = stat_target(a)
         svb, gsb = stat_target(b)
         L.dw_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(du),
@@ -464,6 +473,16 @@ class _DetRun:
         return gxa, gxb
 
     def backward(self, gpred):
+        self._deferring = False
+        try:
+            return self._backward(gpred)
+        finally:
+            if self._deferring:  # (an exception on the way: leave the library's deferral mode)
+                self._deferring = False
+                self.L.bwd_defer_flush()
+            self._keep_ws = []
+
+    def _backward(self, gpred):
         L, P, N, w = self.L, self.P, self.N, DEPTH_SCALE
         H, W = self.HW
         flat = torch.zeros(sum(p.numel() for p in P.values()), dtype=torch.float32, device=self.dev)
@@ -480,6 +499,14 @@ class _DetRun:
         bucketer = getattr(self.mod, "_grad_bucketer", None)
         self._flat, self._folds = flat, []
         self._defer_folds = bucketer is None and self.capture is None and os.environ.get("OCRS_DEFER_FOLDS", "1") != "0"
+        # Deferred second stage (ocrs_bwd_defer_begin): the block kernels finalise the BatchNorm-backward sums they produce in their last workgroup and
+        # the ~27 single-writer weight-gradient reductions of a backward run as ONE launch at its end.  Not with a gradient bucketer (a stage's
+        # gradients must be complete when it is reported).  The workspaces must outlive the flush: self._keep_ws.
+        self._keep_ws = []
+        if bucketer is None and self.capture is None and os.environ.get("OCRS_BWD_DEFER", "1") != "0":
+            scratch = _bwd_scratch(self.dev)
+            L.bwd_defer_begin(ptr(scratch), scratch.numel())
+            self._deferring = True
         done = [0]
         # Side stream for work that nothing downstream in the backward reads (the deep-level ConvTranspose weight / bias gradients): it overlaps the
         # latency-bound deep-level kernels that follow on the main stream.  A stage is reported to the gradient bucketer only after the main stream
@@ -597,6 +624,9 @@ class _DetRun:
         flush_pending()
         if side is not None and self._defer_folds:
             main.wait_stream(side)  # (a no-op when flush_pending just joined)
+        if self._deferring:
+            self._deferring = False
+            L.bwd_defer_flush()  # every queued weight-gradient reduction, one launch
         self.fold_flush()
         self._flat = None
         stage_done("in_conv")
@@ -608,6 +638,16 @@ class _DetRun:
 
 
 _SIDE = {}
+_BWD_SCRATCH = {}
+
+
+def _bwd_scratch(dev):
+    """Zeroed fp64 scratch of the block kernels' last-workgroup finalisation (ocrs_bwd_defer_begin): allocated once per device, every launch leaves
+    its share zeroed."""
+    t = _BWD_SCRATCH.get(dev)
+    if t is None:
+        t = _BWD_SCRATCH[dev] = torch.zeros(65536, dtype=torch.float64, device=dev)
+    return t
 
 
 def _side_stream(dev):
