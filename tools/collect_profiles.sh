@@ -12,8 +12,8 @@ cp $(find gpurun_out/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_
 bash tools/run_trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step.txt $OUT/${TAG}_step_trace.txt
 # 4. HBM traffic (two separate PMC passes, kernel-trace only)
 bash tools/run_pmc_hbm.sh ${TAG}_pmc_hbm.csv > $OUT/pmc_hbm.log 2>&1; cp gpurun_out/${TAG}_pmc_hbm.csv $OUT/
-# 5. SQ counters of the matrix-core block kernels at level 0 / 1
-bash tools/run_pmc_sq.sh "k_mm_bwd<8, 8, false, false, true, true>|k_mm_bwd<16, 16, true, true, true, false>|k_mm_bwd<8, 16, false, false, true, true>|k_mm_bwd<32, 32, true, true, true, false>|k_mm_fwd<8, 1, 8, false, true>|k_mm_fwd<16, 1, 16, true, true>|k_mm_fwd<32, 1, 32, true, true>" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
+# 5. SQ counters of the matrix-core / row-streaming block kernels (every instantiation of the step)
+bash tools/run_pmc_sq.sh "k_mm_bwd<|k_rs_bwd<|k_mm_fwd<|k_rs_fwd<" > /dev/null 2>&1; cp gpurun_out/pmc_sq.txt $OUT/${TAG}_pmc_sq.txt
 # 6. CRNN: per-kernel time, and the MFMA-busy counter of the convolution kernels (separate PMC pass)
 bash tools/run_trace_crnn.sh > /dev/null 2>&1; cp gpurun_out/crnn_stats.txt $OUT/${TAG}_crnn_kernel_stats.txt
 rm -rf gpurun_out/pmc_mfma; timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/prof_crnn.py --steps 2 --warmup 1 > gpurun_out/pmc_mfma.log 2>&1
