@@ -1087,7 +1087,9 @@ long ocrs_mm_bwd_supported(int Ca, int Cb, int Cout, int dtype) {
 long ocrs_mm_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = (Ca == 32 && Cb == 32) ? 32 : Ca + Cb;
     const int nb0 = mm_grid(mm_bwd_th(Cin, Cout, 0), N, H, W, 0, mm_bwd_bpc(Cin, Cout, 0)), nb1 = mm_grid(mm_bwd_th(Cin, Cout, 1), N, H, W, 1, mm_bwd_bpc(Cin, Cout, 1));
-    const long tiled = (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin + 1024);  // per block: its partials + 4 KB of scratch lines (stores of rows below the image)
+    // per block: its partials + 4 KB of scratch lines (stores of rows below the image); a 32 | 32 concat input runs as two launches, each with its own half
+    // (so that both second stages can be deferred: ocrs_bwd_defer_begin)
+    const long tiled = (long)(nb0 > nb1 ? nb0 : nb1) * (Cout * Cin + 11 * Cin + 1024) * ((Ca == 32 && Cb == 32) ? 2 : 1);
     const long rs = rs_bwd_supported(Ca, Cb, Cout, 0, N, H, W) ? (long)rs_bwd_blocks(Cin, Cout, N, H, W, 0) * (Cout * Cin + 11 * Cin) : 0;  // row-streaming form (det_rs.hip)
     return tiled > rs ? tiled : rs;
 }
@@ -1125,9 +1127,11 @@ static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
                           : mm_grid(mm_bwd_th(Cin, Cout, pooled ? 1 : 0), N, H, W, pooled ? 1 : 0, mm_bwd_bpc(Cin, Cout, pooled ? 1 : 0));
         const float* wd = wdw + c_off * 9;
         const float* wp = wpw + c_off;
-        // deferred second stage (ocrs_bwd_defer_begin): the producers' sums by the last workgroup of the block kernel, the weight-gradient reduce queued.
-        // (a split launch pair shares `ws`: the first launch's partials would be overwritten before a queued reduce ran -- those stay in line)
-        const BwdLast bl = mm_bwd_last(stats && !split, Cin, x.Ca, gsA, gsB, svA, svB);
+        // deferred second stage (ocrs_bwd_defer_begin): the producers' sums by the last workgroup of the block kernel, the weight-gradient reduce queued
+        // (the two launches of a split pair write their partials to separate halves of ws)
+        float* const ws_full = ws;
+        ws = ws_full + (size_t)part * nb * (Cout * Cin + 11 * Cin + 1024);
+        const BwdLast bl = mm_bwd_last(stats, Cin, x.Ca, gsA, gsB, svA, svB);
         if (rs) rs_bwd_launch(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, coef, ga, gb, ws, stats, Cout, N, H, W, fin, st, nullptr, nullptr,
                               nullptr, nullptr, bl);
 #define MM_CASE(CI_, CO_)                                                                                                             \
@@ -1135,7 +1139,8 @@ static int mm_bwd_impl(const void* xa, const void* xb, int Ca, int Cb, const flo
         mm_bwd_dispatch<CI_, CO_>(x, tA, tB, wd, wp, CinTot, (const bf16*)g1, (const bf16*)g2, pooled, (const bf16*)z, bn, coef, ga, gb, ws, stats, N, H, W, nb, fin, bl, st);
         MM_CASE(8, 8) MM_CASE(8, 16) MM_CASE(16, 8) MM_CASE(16, 16) MM_CASE(16, 32) MM_CASE(32, 16) MM_CASE(32, 32)
 #undef MM_CASE
-        mm_bwd_second_stage(ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA, svB, tA, tB, bl, !split, st);
+        mm_bwd_second_stage(ws, nb, Cin, Cout, x.Ca, dwpw + c_off, CinTot, dwdw + c_off * 9, gsA, gsB, svA, svB, tA, tB, bl, true, st);
+        ws = ws_full;
     }
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
