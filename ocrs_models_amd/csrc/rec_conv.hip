@@ -1790,9 +1790,15 @@ int ocrs_conv0_fwd(const float* img, const float* w, const float* bias, void* ou
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }
+int conv0_bwd_mm_launch(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
+                        hipStream_t st);  // rec_conv0.hip: the matrix-core form (bf16 gradient, even H and W)
 int ocrs_conv0_bwd(const float* img, const float* w, const float* bias, const void* g, float* dW, float* db, int N, int H, int W, int dtype,
                    hipStream_t st) {
     OCRS_CHECK_ARG(img && w && bias && g && dW && db);
+    if (conv0_bwd_mm_launch(img, w, bias, g, dW, db, N, H, W, dtype, st)) {
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
     const int grid = ew_grid((long)N * (H / 2) * (W / 2) * 4);
     if (dtype == 1)
         hipLaunchKernelGGL(k_conv0_bwd<bf16>, dim3(grid), dim3(256), 0, st, img, w, bias, (const bf16*)g, dW, db, N, H, W);

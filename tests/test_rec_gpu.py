@@ -86,12 +86,16 @@ def test_conv_igemm_fwd_dgrad_wgrad(dev, dtype, ci, co, k, pad, H, W, N):
     assert rel(r.G["w"], wr.grad) < t_dw, "wgrad"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv0_fused(dev, dtype):
+@pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 64, 24)), (torch.bfloat16, (2, 64, 24)),
+                                         # k_conv0_bwd_mm (rec_conv0.hip, bf16 gradient): the production row length (7 steps of 32 pooled pixels, the last
+                                         # one 8 wide), a one-pixel tail step, rows shorter than a step, several images; odd W falls back to k_conv0_bwd
+                                         (torch.bfloat16, (3, 64, 400)), (torch.bfloat16, (2, 32, 66)), (torch.bfloat16, (5, 8, 130)),
+                                         (torch.bfloat16, (2, 16, 37))])
+def test_conv0_fused(dev, dtype, shape):
     from ocrs_models_amd._lib import ptr
 
     g = torch.Generator().manual_seed(2)
-    N, H, W = 2, 64, 24
+    N, H, W = shape
     img = (torch.rand(N, 1, H, W, generator=g) - 0.5).to(dev)
     w = (torch.randn(32, 1, 3, 3, generator=g) / 3).to(dev)
     b = (0.1 * torch.randn(32, generator=g)).to(dev)
@@ -107,7 +111,9 @@ def test_conv0_fused(dev, dtype):
     dW, db = torch.zeros_like(w), torch.zeros_like(b)
     r.L.conv0_bwd(ptr(img), ptr(w), ptr(b), ptr(gy), ptr(dW), ptr(db), N, H, W, r.dt)
     torch.cuda.synchronize()
-    assert rel(dW, wr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    # (the larger shapes: torch's own fp32 backward differs from either kernel by 2-3e-4 in dW at B = 256 -- window ties resolved differently)
+    t_dw = 1e-4 if N * H * W < 10000 else 5e-4
+    assert rel(dW, wr.grad) < t_dw and rel(db, br.grad) < 1e-4, (rel(dW, wr.grad), rel(db, br.grad))
 
 
 def test_log_softmax_and_ctc_match_torch(dev):
