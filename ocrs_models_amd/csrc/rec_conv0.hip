@@ -27,8 +27,8 @@ constexpr int C0_IMG_B = 4 * C0_PITCH * 4;           // 4 rows
 // consecutive K rows, which at these pitches share 4 / 8 bank groups (the writes were 69 of the first version's 198 us).  a: granule ^ ((row >> 2) & 7),
 // patch: granule + ((row >> 3) & 3) mod 4 -- the four rows of a transpose read share row >> 2 and row >> 3, so a read stays 4 rows x 32 contiguous
 // bytes (conflict-free) and only its address changes
-constexpr int C0_S2_B = 128 * 32 * 2;                // a  [K = o * 32 + n][32 channels] bf16
-constexpr int C0_B2_B = 128 * 16 * 2;                // patch [K][16 columns: 9 taps | 1 | 0 ...] bf16, hi and lo
+constexpr int C0_S2_B = 64 * 32 * 2;                 // a  [K = (o & 1) * 32 + n][32 channels] bf16: two pooling positions at a time (C0_PH phases per step)
+constexpr int C0_B2_B = 64 * 16 * 2;                 // patch [K][16 columns: 9 taps | 1 | 0 ...] bf16, hi and lo
 constexpr int C0_WAVE_B = 2 * C0_IMG_B + C0_S2_B + 2 * C0_B2_B;  // image rows as fp32 and as packed (hi | lo << 16) bf16 pairs
 constexpr int C0_SMEM = 4 * C0_WAVE_B;
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ void wave_lds_fence() {  // order this wave's LDS wri
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void k_conv0_bwd_mm(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 3) void k_conv0_bwd_mm(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                                         const bf16* __restrict__ g, float* __restrict__ dW, float* __restrict__ db, int N, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,6 +146,10 @@ __global__ __launch_bounds__(256, 2) void k_conv0_bwd_mm(const float* __restrict
                 else sacc[o][i] += aw[i] * b;
             }
         }
+        // ---- two phases of two pooling positions each: a / patch rows of 64 (position, pixel) pairs -> GEMM 2 over K = 64.  (Half the LDS per wave: three
+        // workgroups per CU instead of two -- the step is a chain of LDS round trips, and what hides them is other waves.)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
         // ---- window arg-max (first maximum, ReLU floor 0: k_conv0_bwd's rule) -> a[o][channel] = g or 0, as bf16 bits
         // accumulator v of a lane = channel 8 (v / 4) + 4 half + v % 4 -> the lane's gradient quad q = v / 4, element v % 4
 #pragma unroll
@@ -166,10 +170,11 @@ __global__ __launch_bounds__(256, 2) void k_conv0_bwd_mm(const float* __restrict
             }
             const unsigned g0l = gq[q].x & 0xffffu, g0h = gq[q].x & 0xffff0000u, g1l = gq[q].y & 0xffffu, g1h = gq[q].y & 0xffff0000u;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int ol = 0; ol < 2; ++ol) {
+                const int o = 2 * ph + ol;
                 const unsigned x = (wsel[0][o] ? g0l : 0u) | (wsel[1][o] ? g0h : 0u), y = (wsel[2][o] ? g1l : 0u) | (wsel[3][o] ? g1h : 0u);
                 if (C0_ABL != 2 || x == 0x1234)
-                *reinterpret_cast<uint2*>(S2 + (o * 32 + n) * 32 + (((q * 2 + half) ^ ((n >> 2) & 7)) << 2)) = make_uint2(x, y);
+                *reinterpret_cast<uint2*>(S2 + (ol * 32 + n) * 32 + (((q * 2 + half) ^ ((n >> 2) & 7)) << 2)) = make_uint2(x, y);
             }
         }
         // ---- the patch matrix: this lane's K slots of GEMM 1 are its columns (k = 2 i + half) of row (o, n), as hi / lo bf16.  The two lanes of a
@@ -177,17 +182,18 @@ __global__ __launch_bounds__(256, 2) void k_conv0_bwd_mm(const float* __restrict
         // leaves the even column's word in one result and the odd column's in the other, in both halves); the half-0 lane writes the pair's hi
         // dword, the half-1 lane its lo dword (one v_perm_b32 with a lane-constant selector): 20 dword writes per lane, no 16-bit arithmetic
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
+        for (int ol = 0; ol < 2; ++ol)
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
+                const int o = 2 * ph + ol;
                 const auto sw = __builtin_amdgcn_permlane32_swap(hv[o][i], hv[o][i], false, false);  // sw[0]: column 2 i, sw[1]: column 2 i + 1
                 const unsigned word = __builtin_amdgcn_perm(sw[1], sw[0], psel);
-                if (C0_ABL != 2 || word == 0x1234) reinterpret_cast<unsigned*>(half ? Bl : Bh)[(o * 32 + n) * 8 + ((i + 2 * (n >> 3)) & 7)] = word;
+                if (C0_ABL != 2 || word == 0x1234) reinterpret_cast<unsigned*>(half ? Bl : Bh)[(ol * 32 + n) * 8 + ((i + 2 * (n >> 3)) & 7)] = word;
             }
         wave_lds_fence();
-        // ---- GEMM 2: dW[ch][k] += a^T patch, K = 128 (pixel, position) rows
+        // ---- GEMM 2: dW[ch][k] += a^T patch, K = 64 (pixel, position) rows per phase
 #pragma unroll
-        for (int ks = 0; ks < ((C0_ABL == 1 || C0_ABL == 2) ? 0 : 4); ++ks) {
+        for (int ks = 0; ks < ((C0_ABL == 1 || C0_ABL == 2) ? 0 : 2); ++ks) {
             const int r0 = ks * 32 + trow;
             // (rows r0 .. r0 + 3 and r0 + 4 .. r0 + 7: n = row & 31; both groups of four share (n >> 3), each shares its (n >> 2))
             const int nb0 = r0 & 31, nb1 = (r0 + 4) & 31;
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void k_conv0_bwd_mm(const float* __restrict
             }
         }
         wave_lds_fence();
+        }
     }
     // ---- flush: lane (column l15, rows 16 a + 4 kg + r) -> workgroup sum through LDS (fixed order), one float atomic per element and workgroup
     __syncthreads();
@@ -232,7 +239,7 @@ extern "C" int conv0_bwd_mm_launch(const float* img, const float* w, const float
         attr.done();
     }
     const long nsteps = (long)N * (H / 2) * (((W / 2) + 31) / 32);
-    static const int bpc = env_int("OCRS_CONV0_MM_BPC", 2);
+    static const int bpc = env_int("OCRS_CONV0_MM_BPC", 3);
     long grid = (nsteps + 3) / 4;
     if (grid > (long)kNumCU * bpc) grid = (long)kNumCU * bpc;
     hipLaunchKernelGGL(k_conv0_bwd_mm, dim3((int)grid), dim3(256), C0_SMEM, st, img, w, bias, (const bf16*)g, dW, db, N, H, W);
