@@ -1364,6 +1364,20 @@ static struct {
     int nblocks = 0;
     RedJobs jobs;
 } g_defer;
+// workspace for per-block partials of launches whose entry points take none (the CRNN's bias / first-layer sums: rec_conv.hip, rec_conv0.hip,
+// rec_gru_seq.hip): a per-process device buffer, bump-allocated between _begin and _flush; null outside that window or when it is used up
+static float* g_defer_ws = nullptr;
+static long g_defer_ws_used = 0;
+constexpr long DEFER_WS_FLOATS = 8L << 20;  // 32 MB
+float* bwd_defer_ws(long nfloats) {
+    if (!g_defer.on || nfloats <= 0) return nullptr;
+    if (!g_defer_ws && hipMalloc(reinterpret_cast<void**>(&g_defer_ws), DEFER_WS_FLOATS * sizeof(float)) != hipSuccess) return nullptr;
+    const long n = (nfloats + 63) & ~63L;
+    if (g_defer_ws_used + n > DEFER_WS_FLOATS) return nullptr;
+    float* p = g_defer_ws + g_defer_ws_used;
+    g_defer_ws_used += n;
+    return p;
+}
 double* bwd_defer_scratch(int ndoubles) {
     if (!g_defer.on || g_defer.used + ndoubles > g_defer.cap) return nullptr;
     double* p = g_defer.scratch + g_defer.used;
@@ -1871,6 +1885,7 @@ int ocrs_bwd_defer_begin(double* scratch, long ndoubles) {
     g_defer.used = 0;
     g_defer.nblocks = 0;
     g_defer.jobs.njobs = 0;
+    g_defer_ws_used = 0;
     return OCRS_OK;
 }
 int ocrs_bwd_defer_flush(hipStream_t st) {

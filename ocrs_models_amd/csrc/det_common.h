@@ -614,6 +614,8 @@ __device__ __forceinline__ void bwd_last_finish(const BwdLast& bl, int CIN, cons
 // host side (det_bwd.hip): scratch for one launch (null outside ocrs_bwd_defer_begin .. _flush or when it is used up), and the queue of deferred
 // weight-gradient reductions: columns [0, n0) of ws[nb][nelem] += into d0[(e / cin0) * ldw0 + e % cin0], columns [n0, n0 + n1) into d1[e - n0]
 double* bwd_defer_scratch(int ndoubles);
+float* rec_defer_partials(int nb, int n, float* out);  // rec_conv.hip: partial buffer [nb][n] + queued column sum into out [n] (null: not deferring)
+float* bwd_defer_ws(long nfloats);  // per-block-partial workspace for launches whose entry points take none (null: not deferring / used up)
 bool bwd_defer_reduce(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1);
 
 // ---- BatchNorm2d training statistics finalised by the LAST workgroup of the forward launch that produced them (one launch less per block)

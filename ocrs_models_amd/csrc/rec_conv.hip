@@ -957,7 +957,8 @@ __global__ __launch_bounds__(256) void k_rec_bn_reduce_t(const T* __restrict__ g
 template <class T, int PH, int PW, int NTB>
 __global__ __launch_bounds__(NTB) void k_dz_apply_t(const T* __restrict__ g, const T* __restrict__ z, const float* __restrict__ bn,
                                                     const float* __restrict__ coef, T* __restrict__ dz, int C, int N, int H, int W,
-                                                    float* __restrict__ dsum /*nullable [C]: += column sums of the stored dz (a bias gradient)*/) {
+                                                    float* __restrict__ dsum /*nullable [C]: += column sums of the stored dz (a bias gradient)*/,
+                                                    float* __restrict__ dsum_ws /*nullable: per-block partials [gridDim.x][C] instead of the atomics (rec_defer_partials)*/) {
     const int CG = C / 8, Hp = H / PH, Wp = W / PW;
     const long gtid = (long)blockIdx.x * NTB + threadIdx.x, nthr = (long)gridDim.x * NTB;
     const int c0 = (int)(gtid % CG) * 8;  // (fixed per thread, see k_act_pool_fwd_t)
@@ -1014,7 +1015,8 @@ __global__ __launch_bounds__(NTB) void k_dz_apply_t(const T* __restrict__ g, con
         for (int c = threadIdx.x; c < C; c += NTB) {
             float a = 0.f;
             for (int t = c >> 3; t < NTB; t += CG) a += s_all[t][c & 7];
-            atomicAdd(&dsum[c], a);
+            if (dsum_ws) dsum_ws[(long)blockIdx.x * C + c] = a;
+            else atomicAdd(&dsum[c], a);
         }
     }
 }
@@ -1101,31 +1103,33 @@ __global__ __launch_bounds__(256) void k_avgpool_dz(const float* __restrict__ gs
 }
 
 // per-column sum of a [rows][ld] fp32/bf16 matrix (bias gradients)
+// ws (nullable, round 5): per-block partials [gridDim.x][C] instead of the cross-block float atomics -- summed in a fixed order by the deferred
+// reduce launch (ocrs_bwd_defer_begin / _flush, det_bwd.hip).  The in-block sums are fixed-order slots (no LDS float atomics) either way.
 template <class T>
-__global__ __launch_bounds__(256) void k_col_sum(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows) {
-    extern __shared__ float s_acc[];
-    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
+__global__ __launch_bounds__(256) void k_col_sum(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows, float* __restrict__ ws) {
+    extern __shared__ float s_acc[];  // [2 row phases][C]
     const int c = threadIdx.x % 128;
     const int sub = threadIdx.x / 128;
     for (int cb = 0; cb < C; cb += 128) {
         if (cb + c < C) {
             float s = 0.f;
             for (long r = (long)blockIdx.x * 2 + sub; r < rows; r += (long)gridDim.x * 2) s += Elem<T>::ld(a + r * ld + cb + c);
-            atomicAdd(&s_acc[cb + c], s);
+            s_acc[sub * C + cb + c] = s;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const float v = s_acc[i] + s_acc[C + i];
+        if (ws) ws[(long)blockIdx.x * C + i] = v;
+        else atomicAdd(&out[i], v);
+    }
 }
 
 // The same for C % 4 == 0 and 4-element-aligned rows: a thread owns 4 consecutive columns (one 16 / 8-byte load per row), 64 column quads
 // x 4 row phases per block, four rows in flight per thread; per-block partials pre-reduced in LDS, then C atomics per block (grid <= 2/CU).
 template <class T>
-__global__ __launch_bounds__(256) void k_col_sum4(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows) {
-    extern __shared__ float s_acc[];
-    for (int i = threadIdx.x; i < C; i += 256) s_acc[i] = 0.f;
-    __syncthreads();
+__global__ __launch_bounds__(256) void k_col_sum4(const T* __restrict__ a, int ld, int C, float* __restrict__ out, long rows, float* __restrict__ ws) {
+    extern __shared__ float s_acc[];  // [4 row phases][C]
     const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const long rstep = (long)gridDim.x * 4;
     for (int cb = 0; cb < C; cb += 256) {
@@ -1155,13 +1159,26 @@ __global__ __launch_bounds__(256) void k_col_sum4(const T* __restrict__ a, int l
                 for (int i = 0; i < 4; ++i) s[i] += v[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&s_acc[c + i], s[i]);
+            for (int i = 0; i < 4; ++i) s_acc[ph * C + c + i] = s[i];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], s_acc[i]);
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const float v = (s_acc[i] + s_acc[C + i]) + (s_acc[2 * C + i] + s_acc[3 * C + i]);
+        if (ws) ws[(long)blockIdx.x * C + i] = v;
+        else atomicAdd(&out[i], v);
+    }
 }
 
+// Deferred mode (ocrs_bwd_defer_begin .. _flush): a launch that would end in cross-block float atomics onto out [n] writes per-block partials
+// [nb][n] instead and queues their fixed-order column sum (k_reduce_multi, det_bwd.hip) -- the sums become bit-reproducible.  Returns the partial
+// buffer, or null (not deferring / pool or queue full): the launch then falls back to the atomics.
+float* rec_defer_partials(int nb, int n, float* out) {
+    float* ws = bwd_defer_ws((long)nb * n);
+    if (!ws) return nullptr;
+    if (!bwd_defer_reduce(ws, nb, n, out, n, n, n, nullptr, 0)) return nullptr;
+    return ws;
+}
 // ---------------------------------------------------------------------------------------------------------------------
 static inline int ew_grid(long items) {
     long g = (items + 255) / 256;
@@ -1872,18 +1889,20 @@ int ocrs_dz_apply(const void* g, const void* z, const float* bn, const float* co
     int grid = ew_grid((long)N * ((H + PH - 1) / PH) * ((W + PW - 1) / PW) * (C / 8));
     const bool fast = window_fast() && H % PH == 0 && W % PW == 0 && 256 % (C / 8) == 0;
     static const int ds_bpc = env_int("OCRS_DZ_DSUM_BPC", 1);
+    float* dsum_ws = nullptr;
     if (dsum && fast) {  // 1024-thread blocks, every one ending in C same-address atomics
         grid = (grid + 3) / 4;
         if (grid > ds_bpc * kNumCU) grid = ds_bpc * kNumCU;
+        if ((PH == 2 && (PW == 2 || PW == 1)) || (PH == 1 && PW == 1)) dsum_ws = rec_defer_partials(grid, C, dsum);  // (the shapes DZA covers)
     }
 #define DZA(T_, PH_, PW_)                                                                                                                    \
     if (PH == PH_ && PW == PW_) {                                                                                                            \
         if (dsum)                                                                                                                            \
             hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_, 1024>), dim3(grid), dim3(1024), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, \
-                               dsum);                                                                                                        \
+                               dsum, dsum_ws);                                                                                               \
         else                                                                                                                                 \
             hipLaunchKernelGGL((k_dz_apply_t<T_, PH_, PW_, 256>), dim3(grid), dim3(256), 0, st, (const T_*)g, (const T_*)z, bn, coef, (T_*)dz, C, N, H, W, \
-                               dsum);                                                                                                        \
+                               dsum, dsum_ws);                                                                                               \
         OCRS_LAUNCH_CHECK();                                                                                                                 \
         return OCRS_OK;                                                                                                                      \
     }
@@ -1941,19 +1960,21 @@ int ocrs_col_sum(const void* a, int ld, int C, float* out, long rows, int dtype,
         long g4 = (rows + 15) / 16;  // >= 4 rows per thread before another block is worth its C trailing atomics
         if (g4 > 2 * kNumCU) g4 = 2 * kNumCU;
         if (g4 < 1) g4 = 1;
+        float* ws = rec_defer_partials((int)g4, C, out);  // (deferring: per-block partials + one queued fixed-order reduce instead of float atomics)
         if (dtype == 1)
-            hipLaunchKernelGGL(k_col_sum4<bf16>, dim3((int)g4), dim3(256), C * sizeof(float), st, (const bf16*)a, ld, C, out, rows);
+            hipLaunchKernelGGL(k_col_sum4<bf16>, dim3((int)g4), dim3(256), 4 * C * sizeof(float), st, (const bf16*)a, ld, C, out, rows, ws);
         else
-            hipLaunchKernelGGL(k_col_sum4<float>, dim3((int)g4), dim3(256), C * sizeof(float), st, (const float*)a, ld, C, out, rows);
+            hipLaunchKernelGGL(k_col_sum4<float>, dim3((int)g4), dim3(256), 4 * C * sizeof(float), st, (const float*)a, ld, C, out, rows, ws);
         OCRS_LAUNCH_CHECK();
         return OCRS_OK;
     }
     long g = (rows + 1) / 2;
     if (g > 1024) g = 1024;
+    float* ws = rec_defer_partials((int)g, C, out);
     if (dtype == 1)
-        hipLaunchKernelGGL(k_col_sum<bf16>, dim3((int)g), dim3(256), C * sizeof(float), st, (const bf16*)a, ld, C, out, rows);
+        hipLaunchKernelGGL(k_col_sum<bf16>, dim3((int)g), dim3(256), 2 * C * sizeof(float), st, (const bf16*)a, ld, C, out, rows, ws);
     else
-        hipLaunchKernelGGL(k_col_sum<float>, dim3((int)g), dim3(256), C * sizeof(float), st, (const float*)a, ld, C, out, rows);
+        hipLaunchKernelGGL(k_col_sum<float>, dim3((int)g), dim3(256), 2 * C * sizeof(float), st, (const float*)a, ld, C, out, rows, ws);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -40,7 +40,8 @@ __device__ __forceinline__ void wave_lds_fence() {  // order this wave's LDS wri
 }  // namespace
 
 __global__ __launch_bounds__(256, 3) void k_conv0_bwd_mm(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
-                                                        const bf16* __restrict__ g, float* __restrict__ dW, float* __restrict__ db, int N, int H, int W) {
+                                                        const bf16* __restrict__ g, float* __restrict__ dW, float* __restrict__ db, int N, int H, int W,
+                                                        float* __restrict__ ws /*nullable: per-block partials [gridDim.x][320] = dW [32][9] | db [32] instead of the atomics*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, half = lane >> 5;  // GEMM 1: this lane's pixel column / K slot (and 4-row block of the accumulator layout)
@@ -222,7 +223,9 @@ __global__ __launch_bounds__(256, 3) void k_conv0_bwd_mm(const float* __restrict
     for (int e = tid; e < 32 * 10; e += 256) {
         const int c = e / 10, k = e - c * 10;
         const float v = (red[(0 * 32 + c) * 16 + k] + red[(1 * 32 + c) * 16 + k]) + (red[(2 * 32 + c) * 16 + k] + red[(3 * 32 + c) * 16 + k]);
-        if (k < 9)
+        if (ws)
+            ws[(long)blockIdx.x * 320 + (k < 9 ? c * 9 + k : 288 + c)] = v;
+        else if (k < 9)
             atomicAdd(&dW[c * 9 + k], v);
         else
             atomicAdd(&db[c], v);
@@ -242,6 +245,9 @@ extern "C" int conv0_bwd_mm_launch(const float* img, const float* w, const float
     static const int bpc = env_int("OCRS_CONV0_MM_BPC", 3);
     long grid = (nsteps + 3) / 4;
     if (grid > (long)kNumCU * bpc) grid = (long)kNumCU * bpc;
-    hipLaunchKernelGGL(k_conv0_bwd_mm, dim3((int)grid), dim3(256), C0_SMEM, st, img, w, bias, (const bf16*)g, dW, db, N, H, W);
+    // deferring (ocrs_bwd_defer_begin): per-block partials + one queued fixed-order column sum instead of 320 float atomics per workgroup
+    float* ws = bwd_defer_ws(grid * 320);
+    if (ws && !bwd_defer_reduce(ws, (int)grid, 320, dW, 288, 288, 288, db, 32)) ws = nullptr;
+    hipLaunchKernelGGL(k_conv0_bwd_mm, dim3((int)grid), dim3(256), C0_SMEM, st, img, w, bias, (const bf16*)g, dW, db, N, H, W, ws);
     return 1;
 }

@@ -25,6 +25,7 @@
 // EXACT = true: v_mfma_f32_16x16x4_f32 (the reference's fp32 arithmetic); false: split-bf16 x3 (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32
 // accumulation: fp32-class, ~2^-17 relative per product, 5x fewer MFMA cycles) -- the same switch as the projection GEMMs (OCRS_GRU_X3).
 #include "common.h"
+float* rec_defer_partials(int nb, int n, float* out);  // rec_conv.hip (deferred, fixed-order second stage: det_common.h)
 
 #ifndef OCRS_GRU_FAST_ACT
 #define OCRS_GRU_FAST_ACT 1  // throughput mode: hardware exp2 / rcp in the gate activations (0: libm, as the exact-fp32 mode always uses)
@@ -454,7 +455,9 @@ template <bool EXACT>
 __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ out,
                                                         const float* __restrict__ whh, float* __restrict__ dgi, float* __restrict__ dgh, int T, int N,
                                                         unsigned* sync, unsigned* err, float* xws, int ngroups, int try_fast,
-                                                        float* __restrict__ dbih, float* __restrict__ dbhh) {
+                                                        float* __restrict__ dbih, float* __restrict__ dbhh, float* __restrict__ ws_ih, float* __restrict__ ws_hh) {
+    // ws_ih / ws_hh (nullable, round 5): per-batch-group partials [ngroups / 2][2 * S3] of the bias gradients instead of the cross-group float atomics,
+    // summed in a fixed order by the deferred reduce launch (rec_defer_partials)
     __shared__ float red[4][2][16][17];
     __shared__ int s_ok, s_fast;
     int group, jt;
@@ -624,11 +627,16 @@ __global__ __launch_bounds__(512, 2) void k_gru_seq_bwd(const float* __restrict_
 #pragma unroll
             for (int w = 0; w < 8; ++w) a += rs[(w * 4 + q) * 16 + u];
             const int col = d * S3 + jt * 16 + u;
+            const long prow = (long)(group >> 1) * (2 * S3);
+            auto acc = [&](float* out, float* ws, int c) {
+                if (ws) ws[prow + c] = a;
+                else atomicAdd(&out[c], a);
+            };
             if (q < 3) {
-                if (dbih) atomicAdd(&dbih[col + q * SH], a);
-                if (dbhh && q < 2) atomicAdd(&dbhh[col + q * SH], a);
+                if (dbih) acc(dbih, ws_ih, col + q * SH);
+                if (dbhh && q < 2) acc(dbhh, ws_hh, col + q * SH);
             } else if (dbhh) {
-                atomicAdd(&dbhh[col + 2 * SH], a);
+                acc(dbhh, ws_hh, col + 2 * SH);
             }
         }
     }
@@ -703,10 +711,13 @@ int ocrs_gru_seq_bwd(const float* dout, const float* saved, const float* out, co
     OCRS_CHECK_ARG(dout && saved && out && whh && dgi && dgh && sync && err && xws && T > 0 && N > 0 && ocrs_gru_seq_supported(N));
     const int ng = seq_groups(N);
     if (hipMemsetAsync(sync, 0, (size_t)ng * SYNC_STRIDE * sizeof(unsigned), st) != hipSuccess) return OCRS_ERR_HIP;
+    // deferring (ocrs_bwd_defer_begin): the bias gradients as per-batch-group partials + a queued fixed-order sum instead of float atomics
+    float* ws_ih = dbih ? rec_defer_partials(ng / 2, 2 * S3, dbih) : nullptr;
+    float* ws_hh = dbhh ? rec_defer_partials(ng / 2, 2 * S3, dbhh) : nullptr;
     if (exact)
-        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh);
+        hipLaunchKernelGGL(k_gru_seq_bwd<true>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh, ws_ih, ws_hh);
     else
-        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh);
+        hipLaunchKernelGGL(k_gru_seq_bwd<false>, dim3(seq_grid(N)), dim3(512), 0, st, dout, saved, out, whh, dgi, dgh, T, N, sync, err, xws, ng, seq_try_fast(), dbih, dbhh, ws_ih, ws_hh);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

@@ -330,6 +330,12 @@ class _RecRun:
         return dz
 
     def backward(self, g_lp):
+        try:
+            return self._backward(g_lp)
+        finally:
+            self.L.bwd_defer_flush()  # (a no-op after a complete backward; after an exception it leaves the library's deferral mode)
+
+    def _backward(self, g_lp):
         L, P, N, S = self.L, self.P, self.N, self
         T, W2, W = S.T, S.W2, self.W
         rows = T * N
@@ -354,6 +360,13 @@ class _RecRun:
         main = torch.cuda.current_stream()
         self._side = _rec_side_stream(self.dev) if _REC_OVERLAP else None
         self._keep = []
+        # Deferred second stage (ocrs_bwd_defer_begin / _flush, round 5): the launches that used to end in cross-block float atomics (bias column sums,
+        # the first layer's weight gradient, the GRU bias sums) write per-block partials into the library's workspace and queue a fixed-order column
+        # sum; ONE launch at the end of the backward runs them all -- the step's gradients are bit-reproducible.  Not with a gradient bucketer (a
+        # stage's gradients must be complete when it is reported).
+        deferring = bucketer is None and os.environ.get("OCRS_BWD_DEFER", "1") != "0"
+        if deferring:
+            L.bwd_defer_begin(None, 0)
 
         def join_side():
             if self._side is not None and self._keep:
@@ -456,6 +469,8 @@ class _RecRun:
                     W, self.dt)
         join_side()
         self._side = None
+        if deferring:
+            L.bwd_defer_flush()  # (behind the join: partials written on the side stream are complete in main-stream order)
         stage_done("conv.0.")
         if bucketer is not None:
             bucketer.finish(flat)
