@@ -169,6 +169,19 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
 long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype);
 int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                          const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
+/* Fused first-block backward (round 5; models.py:115 in_conv = DoubleConv(1, 8): the backward of its first DepthwiseConv block).  The block's weight gradient is
+   linear in dL/dx~ of its only consumer, so ocrs_mm_bwd_fin_xu_c1 -- ocrs_mm_bwd_fin_xu for in_conv.seq.1 -- accumulates, instead of storing dL/dx~ (16 B / pixel),
+   the sums c1acc [8][32] fp64 (caller-zeroed: R[c] = sum ghat1[c] u, T[tap] = sum (sum_c wexp[c] A[c] ghat1[c]) img(tap), 8 replicas) from the network input
+   img [N H W] fp32; ocrs_dwpw_c1_fwd_us is ocrs_dwpw_c1_fwd_u that also accumulates the forward-only sums fsum [20] fp64 (caller-zeroed: sum u | sum u^2 |
+   sum u img(tap) [9] | sum img(tap) [9]); ocrs_c1_bwd_fin combines both with the block's BatchNorm-backward coefficients coef [3][8] (ocrs_bn_bwd_finalize)
+   into acc64 [17] += dWpw [8] | dWdw [9] -- the output of ocrs_dwpw_c1_bwd, which is then not needed. */
+int ocrs_dwpw_c1_fwd_us(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, double* fsum, int N, int H, int W, int dtype,
+                        hipStream_t st);
+int ocrs_mm_bwd_fin_xu_c1(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, const void* g1, const void* g2, const void* z,
+                          const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, float* dwpw, float* dwdw,
+                          float* ws, const float* saved_a, double* gsum_a, const float* img, double* c1acc, int Cout, int N, int H, int W, int dtype,
+                          hipStream_t st);
+int ocrs_c1_bwd_fin(const double* c1acc, const double* fsum, const float* coef, const float* wexp, double* acc64, hipStream_t st);
 /* Deferred second stage of the block backward (models.py:7-28 backward; no reference counterpart -- it is launch scheduling): between _begin and _flush
    the block-backward entry points (ocrs_mm_bwd*, ocrs_pw_bwd*, ocrs_dw_bwd) (1) finalise the BatchNorm-backward sums they produce for their input's
    producers (gsum_a / gsum_b) in the last workgroup of the block kernel, using state carved from `scratch` (ndoubles ZEROED fp64 values, left zeroed),

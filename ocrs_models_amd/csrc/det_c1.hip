@@ -64,10 +64,18 @@ __device__ __forceinline__ void c1_finish_img(const C1Img& im, const C1Item& it,
 // uplane (bf16 [N][H][W], nullable; round 5): the block output is rank one over the channels -- z[p][c] = round(Wpw[c] * u[p]) with the ROUNDED depthwise
 // output u -- so 2 bytes per pixel carry all of it: consumers that take the u plane (k_rs_bwd<..., XU>, k_c1_bwd2<..., ZU>) rebuild z with one multiply
 // and one rounding per channel instead of reading 16 bytes
-template <class T>
+// FS (round 5): also the forward-only sums the fused first-block backward needs (k_rs_bwd<..., C1> + k_c1_bwd_fin): fsum [20] fp64 +=
+//   sum u | sum u^2 | sum u img(tap) [9] | sum img(tap) [9]   over all output pixels (u = the rounded depthwise output, img(tap) zero outside the image)
+template <class T, bool FS>
 __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, const float* __restrict__ wdw, const float* __restrict__ wpw,
-                                                 T* __restrict__ z, double* __restrict__ gstat, int N, int H, int W, bf16* __restrict__ uplane) {
-    __shared__ float s_slots[4 * 16];
+                                                 T* __restrict__ z, double* __restrict__ gstat, int N, int H, int W, bf16* __restrict__ uplane,
+                                                 double* __restrict__ fsum) {
+    __shared__ float s_slots[4 * 20];
+    float fs[FS ? 20 : 1];
+    if constexpr (FS) {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) fs[i] = 0.f;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float wd[9], wp[8];
 #pragma unroll
@@ -87,6 +95,15 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
 #pragma unroll
             for (int k = 0; k < 9; ++k) u = fmaf(wd[k], nb[q + k / 3][k % 3], u);
             u = Elem<T>::round(u);
+            if constexpr (FS) {
+                fs[0] += u;
+                fs[1] = fmaf(u, u, fs[1]);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    fs[2 + k] = fmaf(u, nb[q + k / 3][k % 3], fs[2 + k]);
+                    fs[11 + k] += nb[q + k / 3][k % 3];
+                }
+            }
 #ifdef OCRS_INJECT_BATCH_BUG
             if (uplane) uplane[((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);
 #else
@@ -129,6 +146,33 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
     }
     const float tot = block_sum_det<16>(all, s_slots);
     if (threadIdx.x < 16) atomicAdd(&gstat[threadIdx.x], (double)tot);
+    if constexpr (FS) {
+        __syncthreads();
+        const float ft = block_sum_det<20>(fs, s_slots);
+        if (threadIdx.x < 20) atomicAdd(&fsum[threadIdx.x], (double)ft);
+    }
+}
+
+// The first block's weight gradient from sums (round 5; see k_rs_bwd<..., C1>): with dz[c] = A[c] ghat1[c] + B[c] z1[c] + C[c] (coef = [A | B | C], the block's
+// BatchNorm-backward coefficients once its batch sums are complete) and z1[c] = wexp[c] u,
+//   dWpw[c]  = sum_p dz[c] u           = A[c] R[c] + B[c] wexp[c] sum u^2 + C[c] sum u
+//   dWdw[k]  = sum_p (sum_c wexp[c] dz[c]) img(k) = T[k] + sum_c wexp[c] (B[c] wexp[c] sum u img(k) + C[c] sum img(k))
+// acc64 [17] += dWpw [8] | dWdw [9] (the layout of ocrs_dwpw_c1_bwd).  z1 is taken as wexp u (its bf16 rounding, a zero-mean 2^-9 relative perturbation per
+// element, is not carried through the two forward-only sums).
+__global__ void k_c1_bwd_fin(const double* __restrict__ c1acc /*[8][32]*/, const double* __restrict__ fsum /*[20]*/, const float* __restrict__ coef /*[3][8]*/,
+                             const float* __restrict__ wexp /*[8]*/, double* __restrict__ acc64 /*[17]*/) {
+    const int i = threadIdx.x;
+    if (i >= 17) return;
+    double s = 0.0;
+    for (int k = 0; k < 8; ++k) s += c1acc[k * 32 + i];  // (exact sums of fp32 partials: any order gives the same bits)
+    if (i < 8) {
+        acc64[i] += (double)coef[i] * s + (double)coef[8 + i] * (double)wexp[i] * fsum[1] + (double)coef[16 + i] * fsum[0];
+    } else {
+        const int k = i - 8;
+        double t = s;
+        for (int c = 0; c < 8; ++c) t += (double)wexp[c] * ((double)coef[8 + c] * (double)wexp[c] * fsum[2 + k] + (double)coef[16 + c] * fsum[11 + k]);
+        acc64[i] += t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -232,13 +276,20 @@ static int c1v2_grid(int N, int H, int W, int bpc) {
 }
 
 int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st,
-                        void* uplane) {
+                        void* uplane, double* fsum) {
     static const int bpc = env_int("OCRS_C1V2_FWD_BPC", 8);
     const int grid = c1v2_grid(N, H, W, bpc);
-    if (dtype == 1)
-        hipLaunchKernelGGL(k_c1_fwd2<bf16>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, N, H, W, (bf16*)uplane);
+    if (dtype == 1 && fsum)
+        hipLaunchKernelGGL((k_c1_fwd2<bf16, true>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, N, H, W, (bf16*)uplane, fsum);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((k_c1_fwd2<bf16, false>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (bf16*)z, gstat, N, H, W, (bf16*)uplane, (double*)nullptr);
     else
-        hipLaunchKernelGGL(k_c1_fwd2<float>, dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, N, H, W, (bf16*)nullptr);
+        hipLaunchKernelGGL((k_c1_fwd2<float, false>), dim3(grid), dim3(256), 0, st, img, wdw, wpw, (float*)z, gstat, N, H, W, (bf16*)nullptr, (double*)nullptr);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+int det_c1_bwd_fin_launch(const double* c1acc, const double* fsum, const float* coef, const float* wexp, double* acc64, hipStream_t st) {
+    hipLaunchKernelGGL(k_c1_bwd_fin, dim3(1), dim3(64), 0, st, c1acc, fsum, coef, wexp, acc64);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

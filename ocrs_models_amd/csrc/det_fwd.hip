@@ -582,7 +582,8 @@ extern "C" {
 long det_dwf_supported(int Cin, int Cout, int dtype);  // det_dwf.hip: deep-level forward, a whole tile at once (no fused max-pool)
 long det_c1v2_supported(int N, int H, int W);  // det_c1.hip
 int det_c1v2_fwd_launch(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype, hipStream_t st,
-                        void* uplane);
+                        void* uplane, double* fsum);
+int det_c1_bwd_fin_launch(const double* c1acc, const double* fsum, const float* coef, const float* wexp, double* acc64, hipStream_t st);
 int det_dwf_launch(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const void* wpk, void* z,
                    double* gstat, int Cout, int N, int H, int W, hipStream_t st, const FwdFin& fin);
 long ocrs_dwpw_fwd_pool_supported(int Cin, int Cout) {
@@ -623,7 +624,7 @@ int ocrs_dwpw_fwd_fin(const void* xa, const void* xb, int Ca, int Cb, const floa
 int ocrs_dwpw_c1_fwd(const float* img, const float* wdw, const float* wpw, void* z, double* gstat, int N, int H, int W, int dtype,
                      hipStream_t st) {
     OCRS_CHECK_ARG(img && wdw && wpw && z && gstat);
-    if (det_c1v2_supported(N, H, W)) return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, nullptr);  // det_c1.hip
+    if (det_c1v2_supported(N, H, W)) return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, nullptr, nullptr);  // det_c1.hip
     const long P = (long)N * H * W;
     const int grid = ew_grid(P);
     if (dtype == 1)
@@ -640,7 +641,20 @@ long ocrs_dwpw_c1_u_supported(int N, int H, int W, int dtype) { return dtype == 
 int ocrs_dwpw_c1_fwd_u(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, int N, int H, int W, int dtype,
                        hipStream_t st) {
     OCRS_CHECK_ARG(img && wdw && wpw && uplane && gstat && ocrs_dwpw_c1_u_supported(N, H, W, dtype));  // (z may be null: only the u plane is written)
-    return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, uplane);
+    return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, uplane, nullptr);
+}
+// ocrs_dwpw_c1_fwd_u that also accumulates the forward-only sums of the fused first-block backward (ocrs_mm_bwd_fin_xu_c1 + ocrs_c1_bwd_fin):
+// fsum [20] fp64 (zeroed by the caller) += sum u | sum u^2 | sum u img(tap) [9] | sum img(tap) [9]
+int ocrs_dwpw_c1_fwd_us(const float* img, const float* wdw, const float* wpw, void* z, void* uplane, double* gstat, double* fsum, int N, int H, int W, int dtype,
+                        hipStream_t st) {
+    OCRS_CHECK_ARG(img && wdw && wpw && uplane && gstat && fsum && dtype == 1 && ocrs_dwpw_c1_u_supported(N, H, W, dtype));
+    return det_c1v2_fwd_launch(img, wdw, wpw, z, gstat, N, H, W, dtype, st, uplane, fsum);
+}
+// The first block's weight gradient from the sums of ocrs_dwpw_c1_fwd_us (fsum) and ocrs_mm_bwd_fin_xu_c1 (c1acc [8][32] fp64) and the block's
+// BatchNorm-backward coefficients coef [3][8] (ocrs_bn_bwd_finalize): acc64 [17] += dWpw [8] | dWdw [9], as ocrs_dwpw_c1_bwd.
+int ocrs_c1_bwd_fin(const double* c1acc, const double* fsum, const float* coef, const float* wexp, double* acc64, hipStream_t st) {
+    OCRS_CHECK_ARG(c1acc && fsum && coef && wexp && acc64);
+    return det_c1_bwd_fin_launch(c1acc, fsum, coef, wexp, acc64, st);
 }
 
 // BatchNorm2d batch statistics -> load transform (reference: nn.BatchNorm2d at models.py:23, training mode).

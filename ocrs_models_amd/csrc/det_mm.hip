@@ -1184,6 +1184,26 @@ int ocrs_mm_bwd_fin_xu(const void* xu, const float* wexp, const float* tra, cons
     return OCRS_OK;
 }
 
+// ocrs_mm_bwd_fin_xu that ALSO accumulates the first block's weight-gradient sums (k_rs_bwd<..., C1>: see det_rs.hip) from the network input img [N H W] fp32 into
+// c1acc [8][32] fp64 (zeroed by the caller) and stores NO input gradient: the first block (models.py:115) is this block's only producer and needs dL/dx~ only
+// for its weight gradient, which ocrs_c1_bwd_fin then forms from the sums.
+int ocrs_mm_bwd_fin_xu_c1(const void* xu, const float* wexp, const float* tra, const float* wdw, const float* wpw, const void* g1, const void* g2, const void* z,
+                          const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, float* dwpw, float* dwdw,
+                          float* ws, const float* saved_a, double* gsum_a, const float* img, double* c1acc, int Cout, int N, int H, int W, int dtype,
+                          hipStream_t st) {
+    OCRS_CHECK_ARG(xu && wexp && tra && wdw && wpw && g1 && z && bn && gsum && gamma && saved && dgamma && dbeta && dwpw && dwdw && ws && img && c1acc);
+    OCRS_CHECK_ARG(Cout == 8 && ocrs_mm_bwd_head_supported(8, 0, Cout, N, H, W, dtype) && (!gsum_a || saved_a));
+    const BnFin fin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W};
+    Src2<bf16> x{nullptr, nullptr, 8, 0};
+    const int nb = rs_bwd_blocks(8, Cout, N, H, W, g2 != nullptr);
+    const BwdLast bl = mm_bwd_last(gsum_a != nullptr, 8, 8, gsum_a, nullptr, saved_a, nullptr);
+    rs_bwd_launch(x, tra, nullptr, wdw, wpw, 8, (const bf16*)g1, (const bf16*)g2, (const bf16*)z, bn, nullptr, nullptr, nullptr, ws, gsum_a != nullptr, Cout, N, H, W,
+                  fin, st, nullptr, nullptr, (const bf16*)xu, wexp, bl, img, c1acc);
+    mm_bwd_second_stage(ws, nb, 8, Cout, 8, dwpw, 8, dwdw, gsum_a, nullptr, saved_a, nullptr, tra, nullptr, bl, true, st);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
 int ocrs_mm_bwd(const void* xa, const void* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const void* g1,
                 const void* g2, int pooled, const void* z, const float* bn, const float* coef, void* gxa, void* gxb, float* dwpw, float* dwdw, float* ws,
                 const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b, int Cout, int N, int H, int W, int dtype, hipStream_t st) {

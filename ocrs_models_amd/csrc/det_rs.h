@@ -11,7 +11,8 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
                    const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
                    const BnFin& fin, hipStream_t st, const float* gl = nullptr, const float* whead = nullptr,
                    const bf16* xu = nullptr, const float* wexp = nullptr,  // gl / whead: k_rs_bwd<..., HEAD>; xu / wexp: k_rs_bwd<..., XU>
-                   const BwdLast& bl = BwdLast{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0});  // bl.raw: the producers' sums finalised by the last workgroup
+                   const BwdLast& bl = BwdLast{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0},  // bl.raw: the producers' sums finalised by the last workgroup
+                   const float* img = nullptr, double* c1acc = nullptr);  // img / c1acc (with xu): k_rs_bwd<..., C1> -- the first block's sums, no dx~ store
 
 // forward (Cin = 8 from one source or from the first block's u plane, or Cin = 16 from one source or the 8 | 8 concat; Cout = 8; no fused pooling): k_rs_fwd
 bool rs_fwd_supported(int Ca, int Cb, int Cout, int N, int H, int W);

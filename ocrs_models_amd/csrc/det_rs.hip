@@ -84,6 +84,8 @@ struct RsArgs {
     const float *gl, *whead;  // HEAD: dL/dlogit [N H W] fp32 and out_conv's weight [8] instead of g1 / g2
     const bf16* xu;           // XU: the block input as the first block's rank-one generator u [N H W] (bf16) ...
     const float* wexp;        //     ... and its pointwise weight [8]: x[p][c] = round(wexp[c] * u[p])
+    const float* img;         // C1: the network input [N H W] fp32 (the first block's input) ...
+    double* c1acc;            //     ... and its sums [8 replicas][32] fp64 (zeroed): [0, 8) R[c] = sum ghat1[c] u, [8, 17) T[tap] = sum du img(tap)
     const float *bn, *coef;
     bf16 *gxa, *gxb;
     float* ws;
@@ -281,10 +283,18 @@ __device__ __forceinline__ double rs_parts_chain_sum(const float* __restrict__ p
 
 // HEAD: the block in front of out_conv -- dL/dy[p][c] = round(gl[p] * whead[c]) formed here from ocrs_head_bwd_gl's 4-byte-per-pixel gl (see there)
 // XU: the block behind the first block (in_conv.seq.1) -- its input x[p][c] = round(wexp[c] * u[p]) is rebuilt from the 2-byte-per-pixel u plane (k_c1_fwd2)
-template <int CIN, int COUT, bool G2, bool SPLIT, bool HEAD = false, bool XU = false>
+// C1 (round 5, with XU): the weight gradient of the FIRST block (models.py:115, Conv2d(1, 8) depthwise + pointwise) is linear in what this launch has in
+// its hands -- dz1[c] = A[c] ghat1[c] + B[c] z1[c] + C[c] with A = gamma rstd known from the forward and ghat1 = dx~ [x~ > 0] formed here -- so instead
+// of writing dx~ (16 B / pixel) for a separate pass (k_c1_bwd2: reads it back + the image, 170 us) a lane accumulates, for its pixel,
+//   R[c] += ghat1[c] u   and   T[tap] += (sum_c wexp[c] A[c] ghat1[c]) img[p + tap]
+// (17 per-lane accumulators; the image comes in as one more prefetched dword per lane and tick and lives in a wave-private LDS ring next to u);
+// k_c1_bwd_fin combines them with the forward-only sums (k_c1_fwd2: sum u, u^2, u img(tap), img(tap)) once the batch sums S1 / S2 are complete.
+// This launch then stores no dx~ at all.
+template <int CIN, int COUT, bool G2, bool SPLIT, bool HEAD = false, bool XU = false, bool C1 = false>
 __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArgs A) {
     static_assert(!HEAD || (!G2 && COUT == 8), "head gradient: one 8-channel source");
     static_assert(!XU || (CIN == 8 && !SPLIT), "u plane: one 8-channel source");
+    static_assert(!C1 || XU, "first-block sums: the block behind the first block");
     using C = RsCfg<CIN, COUT>;
     constexpr int PDB = C::PDB, ROWB = C::ROWB, RINGB = C::RINGB, XPB = C::XPB, KC = C::KC, NU = C::NU, MTG = C::MTG, NZ = C::NZ, NX = C::NX, SW = C::SW;
     constexpr int G8 = C::G8, TPC = C::TPC, CPD = C::CPD, UPK = C::UPK;
@@ -314,6 +324,10 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     for (int i = tid; i < 9 * CIN; i += C::NT) s_w9[i] = A.wdw[i];
     for (int i = tid; i < COUT * CIN; i += C::NT) s_wp[i] = A.wpw[(i / CIN) * A.ldw + (i % CIN)];
     for (int i = tid; i < C::OFF_WF / 16; i += C::NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    constexpr int C1ROW = 34 * 4, C1PLANE = 6 * C1ROW, C1B = 2 * C1PLANE + 32;  // per wave: image ring | u ring, fp32 [6 rows][34] (positions 0 / 33 stay zero)
+    if constexpr (C1) {
+        for (int i = tid; i < C::NW * C1B / 4; i += C::NT) reinterpret_cast<float*>(smem + C::SMEM)[i] = 0.f;
+    }
     __syncthreads();
     // A[m][k] of the dgrad GEMM.  Chunk kc = (ring row dy, part h); K slot (lane group kgl, j): column offset dxi = h * TPC + kgl / G8 (dz pixel =
     // output pixel + dxi - 1), channel o = (kgl % G8) * 8 + j.  The dz pixel (dy, dxi) is conv tap (ky, kx) = (rp + 2 - dy, 2 - dxi) of the
@@ -383,6 +397,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     const i32x4 r_z = make_rsrc(A.z, npix * PDB), r_g1 = HEAD ? make_rsrc(A.gl, npix * 4) : make_rsrc(A.g1, npix * PDB),
                 r_g2 = make_rsrc(G2 ? A.g2 : A.g1, npix * PDB);
     const i32x4 r_xa = XU ? make_rsrc(A.xu, npix * 2) : make_rsrc(A.xa, npix * Ca * 2), r_xb = make_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 2);
+    const i32x4 r_img = make_rsrc(C1 ? (const void*)A.img : (const void*)A.z, npix * (C1 ? 4u : (unsigned)PDB));
     const __amdgpu_buffer_rsrc_t w_a = __builtin_amdgcn_make_buffer_rsrc((void*)A.gxa, 0, npix * Ca * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_b = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? A.gxb : A.gxa), 0, npix * (SPLIT ? Cb : Ca) * 2, 0x00020000);
 
@@ -436,6 +451,18 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     u32x4 pz[2][NZ], pg[2][HEAD ? 1 : NZ], pg2[2][G2 ? NZ : 1], pxr[2][NX];
     unsigned pgl[2] = {0u, 0u};  // HEAD: this lane's gl
     unsigned pxu[2] = {0u, 0u};  // XU: this lane's u (bf16 bits)
+    unsigned pim[2] = {0u, 0u};  // C1: this lane's image pixel (fp32 bits)
+    const unsigned c1_w = C::SMEM + wave * C1B;  // C1: this wave's image / u rings
+    float c1R[C1 ? 8 : 1], c1T[C1 ? 9 : 1], c1k[C1 ? 8 : 1];
+    if constexpr (C1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            c1R[i] = 0.f;
+            c1k[i] = usc(A.wexp[i] * s_trx[i]);  // wexp[c] * (gamma rstd)[c]: the load transform's scale IS A[c]
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c1T[i] = 0.f;
+    }
     auto corner = [&](const RsTick& t) -> int {  // pixel index of (row 2q clamped into the image, column 30 s - 1): may be -1 / beyond a row end
         const int qc = t.q < 0 ? 0 : (t.q >= A.NP ? A.NP - 1 : t.q);
 #ifdef OCRS_RS_NOLOAD  // (floor-measurement build: every tick re-reads the same lines)
@@ -454,6 +481,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             if constexpr (G2) pg2[S][j] = bload16_opaque(r_g2, oz + lz + 16 * j);
         }
         if constexpr (HEAD) pgl[S] = bload4_opaque(r_g1, (cp + rr * W + px) * 4);
+        if constexpr (C1) pim[S] = bload4_opaque(r_img, (cp + rr * W + px) * 4);
         if constexpr (XU) {
             pxu[S] = bload2_opaque(r_xa, (cp + rr * W + px) * 2);
         } else {
@@ -466,9 +494,9 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     };
     // operations a tick issues: its loads (behind its commit), then its compute's stores
 #ifdef OCRS_RS_NOCOMPUTE
-    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX, NSTORE = 0;
+    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX + (C1 ? 1 : 0), NSTORE = 0;
 #else
-    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX, NSTORE = NX;
+    constexpr int NLOADS = NZ * (G2 ? 3 : (HEAD ? 1 : 2)) + (HEAD ? 1 : 0) + NX + (C1 ? 1 : 0), NSTORE = C1 ? 0 : NX;  // (C1: dx~ is consumed here, not stored)
 #endif
     auto commit = [&](auto ST, auto YOUNGER, const RsTick& t) {
         constexpr int S = decltype(ST)::value;
@@ -480,6 +508,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
 #endif
             if constexpr (XU) wait_vm<Y>(pxu[S]);
             else wait_vm<Y>(pxr[S][NX - 1]);
+            if constexpr (C1) wait_vm<Y>(pim[S]);
 #pragma unroll
             for (int j = 0; j < NZ; ++j) {
                 wait_vm<Y>(pz[S][j]);
@@ -497,6 +526,11 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
         const bool ok = (unsigned)col < (unsigned)W && (unsigned)row < (unsigned)H;
         const bool okx = ok && px >= 1 && px <= SW;
         const unsigned wrow = (unsigned)(2 * t.qm3) * ROWB;
+        if constexpr (C1) {  // image and u of this lane's pixel into the wave's rings (row 2 qm3 + rr, position px + 1; zero outside the image)
+            const unsigned ro = c1_w + (unsigned)((2 * t.qm3 + rr) * C1ROW + (px + 1) * 4);
+            *reinterpret_cast<float*>(smem + ro) = ok ? __uint_as_float(pim[S]) : 0.f;
+            *reinterpret_cast<float*>(smem + ro + C1PLANE) = ok ? __uint_as_float(pxu[S] << 16) : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < NZ; ++j) {
             unsigned w[4];
@@ -608,20 +642,58 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
                     make_uint2(pack2bf(acc[nt][0], acc[nt][1]), pack2bf(acc[nt][2], acc[nt][3]));
             }
         }
+        uint4 c1q = make_uint4(0, 0, 0, 0);
+        bool c1ok = false;
         {
             const bool ok = comp && 2 * cp + rr < H && px >= 1 && px <= SW && colbase + px < W;
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
                 const uint4 q = *reinterpret_cast<const uint4*>(smem + str + 16 * j);
-                const bool in_a = !SPLIT || 8 * j < Ca;
-                const int off = pix0 * ((in_a ? Ca : Cb) * 2) + lxo[j];
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, in_a ? w_a : w_b, ok ? off : -1, 0, OCRS_RS_ST_AUX);
+                if constexpr (C1) {  // (dx~ of this lane's pixel stays here: see below)
+                    c1q = q;
+                    c1ok = ok;
+                } else {
+                    const bool in_a = !SPLIT || 8 * j < Ca;
+                    const int off = pix0 * ((in_a ? Ca : Cb) * 2) + lxo[j];
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){q.x, q.y, q.z, q.w}, in_a ? w_a : w_b, ok ? off : -1, 0, OCRS_RS_ST_AUX);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ================= G_tap[c][o] += x~^T dz(shifted), and the same with [x~ > 0] for the producers' BatchNorm-backward sums =================
         // (warm-up ticks skip this part: it holds no vector-memory operation, so the branch does not disturb the hand-counted waits)
         if (!comp) return;
+        if constexpr (C1) {
+            // ---- the first block's sums from this lane's pixel (row 2 cp + rr, column colbase + px): ghat1 = dx~ [x~ > 0] (the stored bf16 dx~ -- what
+            // k_c1_bwd2 read -- times the 0 / 1 mask plane of the x tile), du = sum_c (wexp A)[c] ghat1[c], then R += ghat1 u and T += du img(3 x 3)
+            const uint4 mk = *reinterpret_cast<const uint4*>(smem + xt_w + (unsigned)(cp & 1) * C::XSLOTB + C::XPLANEB + rr * C::XROWB + px * XPB);
+            const unsigned qw[4] = {c1ok ? c1q.x : 0u, c1ok ? c1q.y : 0u, c1ok ? c1q.z : 0u, c1ok ? c1q.w : 0u};
+            const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+            // ring rows of image rows 2 cp - 1 .. 2 cp + 2 are (2 qm3 + 3 + dy) mod 6 (as the dz ring); this lane's rows: dy = rr .. rr + 2, u: dy = rr + 1
+            unsigned cr[4];
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const int r = 2 * t.qm3 + 3 + dy;
+                cr[dy] = c1_w + (unsigned)((r >= 6 ? r - 6 : r) * C1ROW);
+            }
+            const unsigned r0 = rr ? cr[1] : cr[0], r1 = rr ? cr[2] : cr[1], r2 = rr ? cr[3] : cr[2];
+            const float uu = *reinterpret_cast<const float*>(smem + r1 + C1PLANE + (px + 1) * 4);
+            float du = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x2 gv = unpk(qw[k]), mv = unpk(mw[k]);
+                const float g0 = gv.x * mv.x, g1 = gv.y * mv.y;
+                du = fmaf(c1k[2 * k], g0, du);
+                du = fmaf(c1k[2 * k + 1], g1, du);
+                c1R[2 * k] = fmaf(g0, uu, c1R[2 * k]);
+                c1R[2 * k + 1] = fmaf(g1, uu, c1R[2 * k + 1]);
+            }
+            const unsigned rrow[3] = {r0, r1, r2};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) c1T[ky * 3 + kx] = fmaf(du, *reinterpret_cast<const float*>(smem + rrow[ky] + (px + kx) * 4), c1T[ky * 3 + kx]);
+        }
         const unsigned xa0 = lxa + (unsigned)(cp & 1) * C::XSLOTB;
         unsigned rw0[4], rw1[COUT == 8 ? 4 : 1];
 #pragma unroll
@@ -705,6 +777,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
         }
         if constexpr (HEAD) wait_vm<0>(pgl[S]);
         if constexpr (XU) wait_vm<0>(pxu[S]);
+        if constexpr (C1) wait_vm<0>(pim[S]);
         if constexpr (!XU) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) wait_vm<0>(pxr[S][j]);
@@ -759,6 +832,20 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             }
         part[COUT * CIN + 9 * CIN + e] = s;
         if (A.bl.raw) bwd_last_add(A.bl, CIN, c, which, s);
+    }
+    if constexpr (C1) {  // the first block's sums: lanes -> wave -> workgroup (fixed order) -> fp64 device atomics, 8 replicas by workgroup index (exact sums)
+        __syncthreads();
+        float* cred = reinterpret_cast<float*>(smem) + 64;  // [wave][17]
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            const float v = wave_sum(i < 8 ? c1R[i] : c1T[i - 8]);
+            if (lane == 0) cred[wave * 17 + i] = v;
+        }
+        __syncthreads();
+        if (tid < 17) {
+            const float v = (cred[tid] + cred[17 + tid]) + (cred[34 + tid] + cred[51 + tid]);
+            atomicAdd(A.c1acc + (blockIdx.x & 7) * 32 + tid, (double)v);
+        }
     }
     if (A.bl.raw) {  // the producers' sums finalised here by the last workgroup (BwdLast in det_common.h)
         __syncthreads();  // (every read of the flush slots is done: smem[0] is free)
@@ -1156,9 +1243,12 @@ int rs_bwd_blocks(int Cin, int Cout, int N, int H, int W, int g2) {
 }
 void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, const float* wdw, const float* wpw, int ldw, const bf16* g1, const bf16* g2,
                    const bf16* z, const float* bn, const float* coef, bf16* gxa, bf16* gxb, float* ws, bool stats, int Cout, int N, int H, int W,
-                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead, const bf16* xu, const float* wexp, const BwdLast& bl) {
+                   const BnFin& fin, hipStream_t st, const float* gl, const float* whead, const bf16* xu, const float* wexp, const BwdLast& bl, const float* img,
+                   double* c1acc) {
     RsArgs a;
     a.bl = bl;
+    a.img = img;
+    a.c1acc = c1acc;
     a.gl = gl;
     a.whead = whead;
     a.xu = xu;
@@ -1180,6 +1270,17 @@ void rs_bwd_launch(const Src2<bf16>& x, const float* tra, const float* trb, cons
     }
     if (xu) {  // the block behind the first block (8 -> 8 channels, input rebuilt from the u plane; one or two gradients)
         using CC = RsCfg<8, 8>;
+        if (img && c1acc) {  // C1: also the first block's weight-gradient sums, no dx~ store (+ the image / u rings behind the regular LDS layout)
+            constexpr int SM = CC::SMEM + CC::NW * (2 * 6 * 34 * 4 + 32);
+            if (g2) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, true, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+                OCRS_LAUNCH_T((k_rs_bwd<8, 8, true, false, false, true, true>), dim3(nb), dim3(CC::NT), SM, st, a);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, false, false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM);
+                OCRS_LAUNCH_T((k_rs_bwd<8, 8, false, false, false, true, true>), dim3(nb), dim3(CC::NT), SM, st, a);
+            }
+            return;
+        }
         if (g2) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs_bwd<8, 8, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM);
             OCRS_LAUNCH_T((k_rs_bwd<8, 8, true, false, false, true>), dim3(nb), dim3(CC::NT), CC::SMEM, st, a);

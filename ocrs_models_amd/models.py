@@ -76,7 +76,7 @@ class _Act:
 
 
 class _BlockRec:
-    __slots__ = ("prefix", "a", "b", "z", "tr", "saved", "Cin", "Cout", "H", "W")
+    __slots__ = ("prefix", "a", "b", "z", "tr", "saved", "Cin", "Cout", "H", "W", "fsum")
 
 
 _identity_cache: dict = {}
@@ -123,6 +123,7 @@ class _DetRun:
         self.fold_fin = os.environ.get("OCRS_FOLD_FIN", "1") != "0"
         self.fold_fwd_fin = os.environ.get("OCRS_FOLD_FWD_FIN", "1") != "0"
         self.c1_noz = os.environ.get("OCRS_C1_NOZ", "1") != "0"  # ... and does not store its 8-channel output at all when every consumer takes the u plane
+        self.c1_fuse = os.environ.get("OCRS_C1_FUSE", "1") != "0"  # the first block's weight gradient from sums accumulated by in_conv.seq.1's backward (no dL/dx~ store, no k_c1_bwd2 pass)
         self.c1_u = os.environ.get("OCRS_C1_U", "1") != "0"  # the first block also writes its 2-byte-per-pixel u plane (read by in_conv.seq.1's backward instead of z)
         self.head_gl = os.environ.get("OCRS_HEAD_GL", "1") != "0"  # out_conv's backward hands the last block gl (4 B / pixel) instead of its 8-channel gradient  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
@@ -301,6 +302,7 @@ class _DetRun:
                        ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpk), ptr(z), ptr(gstat), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
             tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, Cout)
         r = _BlockRec()
+        r.fsum = None
         r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
         self.recs[prefix] = r
         return _Act(z, tr, Cout, H, W, src=prefix)
@@ -309,7 +311,7 @@ class _DetRun:
         L, P, N = self.L, self.P, self.N
         z = self.empty(N, H, W, 8)
         gstat = self.zeros64(16)
-        uplane = None
+        uplane = fsum = None
         if self.train and self.c1_u and self.use_mm and L.dwpw_c1_u_supported(N, H, W, self.dt):
             uplane = torch.empty(N, H, W, dtype=torch.bfloat16, device=self.dev)
             # when every consumer of this block's output takes the u plane -- in_conv.seq.1's forward (ocrs_mm_fwd_fin_xu) and backward
@@ -317,7 +319,14 @@ class _DetRun:
             if (self.c1_noz and self.capture is None and self.fold_fwd_fin and self.fold_fin and self.fuse_bn_bwd and L.mm_fwd_supported(8, 0, 8, self.dt)
                     and L.mm_bwd_head_supported(8, 0, 8, N, H, W, self.dt)):
                 z = None
-            L.dwpw_c1_fwd_u(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(uplane), ptr(gstat), N, H, W, self.dt)
+            # round 5: with no stored 8-channel output the block's backward can also be fused away -- in_conv.seq.1's backward accumulates the first
+            # block's weight-gradient sums instead of storing its input gradient (ocrs_mm_bwd_fin_xu_c1), this launch adds the forward-only sums
+            fsum = self.zeros64(20) if (z is None and self.c1_fuse) else None
+            if fsum is not None:
+                L.dwpw_c1_fwd_us(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(uplane), ptr(gstat), ptr(fsum), N, H, W,
+                                 self.dt)
+            else:
+                L.dwpw_c1_fwd_u(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(uplane), ptr(gstat), N, H, W, self.dt)
         else:
             L.dwpw_c1_fwd(ptr(img), ptr(P[f"{prefix}.seq.0.weight"]), ptr(P[f"{prefix}.seq.1.weight"]), ptr(z), ptr(gstat), N, H, W, self.dt)
         tr, saved = self.bn_tr(f"{prefix}.seq.2", gstat, N * H * W, 8)
@@ -326,6 +335,7 @@ class _DetRun:
         self.recs[prefix] = r
         out = _Act(z, tr, 8, H, W, src=prefix)
         out.u, out.wexp = uplane, P[f"{prefix}.seq.1.weight"]
+        r.fsum = fsum if uplane is not None else None
         return out
 
     def double(self, prefix, a, b, Cout, pool=False):
@@ -405,7 +415,12 @@ class _DetRun:
         wdw, wpw = P[f"{prefix}.seq.0.weight"], P[f"{prefix}.seq.1.weight"]
         if r.Cin == 1:
             acc = self.zeros64(17)  # fp64 accumulators (order-independent), folded into the fp32 gradients below
-            L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(acc), N, H, W, self.dt)
+            c1acc = getattr(self, "_c1acc", None)
+            if c1acc is not None:  # the sums are already there (ocrs_mm_bwd_fin_xu_c1): no pass over the image and the gradient
+                self._c1acc = None
+                L.c1_bwd_fin(ptr(c1acc), ptr(r.fsum), ptr(coef), ptr(wpw), ptr(acc))
+            else:
+                L.dwpw_c1_bwd(ptr(self.x), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(acc), N, H, W, self.dt)
             self.fold64(self.G[f"{prefix}.seq.1.weight"], acc[:8])
             self.fold64(self.G[f"{prefix}.seq.0.weight"], acc[8:17])
             return None, None
@@ -437,6 +452,15 @@ class _DetRun:
                 return gxa, gxb
             if (fold and a.u is not None and b is None and not pooled and L.mm_bwd_head_supported(Ca, 0, C, N, H, W, self.dt)):
                 # the block behind the first block: its input is rebuilt from the first block's u plane (2 instead of 16 bytes per pixel)
+                r1 = self.recs.get(a.src) if a.src is not None else None
+                if r1 is not None and getattr(r1, "fsum", None) is not None and C == 8 and sva is not None and self.capture is None:
+                    # ... and its input gradient is not stored at all: the first block's weight-gradient sums are accumulated here
+                    c1acc = self.zeros64(8 * 32)
+                    L.mm_bwd_fin_xu_c1(ptr(a.u), ptr(a.wexp), ptr(a.tr), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved),
+                                       ptr(dgam), ptr(dbet), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva),
+                                       ptr(gsa), ptr(self.x), ptr(c1acc), C, N, H, W, self.dt)
+                    self._c1acc = c1acc
+                    return None, None
                 L.mm_bwd_fin_xu(ptr(a.u), ptr(a.wexp), ptr(a.tr), ptr(wdw), ptr(wpw), ptr(g1), ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved),
                                 ptr(dgam), ptr(dbet), ptr(gxa), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws),
                                 ptr(sva), ptr(gsa), C, N, H, W, self.dt)

@@ -207,9 +207,10 @@ def test_rank_one_ends_of_the_network_are_bit_identical_to_the_stored_paths(dev)
         t = (torch.rand(B, 1, H, W, generator=g) > 0.9).float().to(dev)
         sd = copy.deepcopy(m.state_dict())
         outs = []
-        for c1u, noz, hgl in (("1", "1", "1"), ("0", "0", "0"), ("1", "0", "0"), ("0", "0", "1"), ("1", "1", "0")):
-            # (OCRS_C1_NOZ: the first block does not store its 8-channel output at all -- in_conv.seq.1's forward reads the u plane too)
-            os.environ["OCRS_C1_U"], os.environ["OCRS_C1_NOZ"], os.environ["OCRS_HEAD_GL"] = c1u, noz, hgl
+        for c1u, noz, hgl, fuse in (("1", "1", "1", "0"), ("0", "0", "0", "0"), ("1", "0", "0", "0"), ("0", "0", "1", "0"), ("1", "1", "0", "0"), ("1", "1", "1", "1")):
+            # (OCRS_C1_NOZ: the first block does not store its 8-channel output at all -- in_conv.seq.1's forward reads the u plane too;
+            #  OCRS_C1_FUSE, the last variant: the first block's weight gradient from sums accumulated by in_conv.seq.1's backward -- see below)
+            os.environ["OCRS_C1_U"], os.environ["OCRS_C1_NOZ"], os.environ["OCRS_HEAD_GL"], os.environ["OCRS_C1_FUSE"] = c1u, noz, hgl, fuse
             try:
                 m.load_state_dict(sd)
                 m.zero_grad()
@@ -222,7 +223,20 @@ def test_rank_one_ends_of_the_network_are_bit_identical_to_the_stored_paths(dev)
                 os.environ.pop("OCRS_C1_U", None)
                 os.environ.pop("OCRS_C1_NOZ", None)
                 os.environ.pop("OCRS_HEAD_GL", None)
-        for o in outs[1:]:
+                os.environ.pop("OCRS_C1_FUSE", None)
+        for o in outs[1:-1]:
             assert torch.equal(o[0], outs[0][0]) and o[1] == outs[0][1]
             for k in o[2]:
                 assert torch.equal(o[2][k], outs[0][2][k]), k
+        # the fused first-block backward (k_rs_bwd<..., C1> + k_c1_bwd_fin): everything but the first block's two weight gradients is bit-identical;
+        # those are formed from sums (unrounded z1 = wexp u in the two forward-only terms, fp64 combination) instead of per pixel: the depthwise
+        # gradient agrees to 1e-4, the pointwise one -- analytically ~0 in front of a BatchNorm, pure rounding noise -- to 1e-4 of the depthwise norm
+        o = outs[-1]
+        assert torch.equal(o[0], outs[0][0]) and o[1] == outs[0][1]
+        fused_keys = ("in_conv.seq.0.seq.0.weight", "in_conv.seq.0.seq.1.weight")
+        for k in o[2]:
+            if k not in fused_keys:
+                assert torch.equal(o[2][k], outs[0][2][k]), k
+        ref0 = outs[0][2][fused_keys[0]].double()
+        assert float((o[2][fused_keys[0]].double() - ref0).norm() / ref0.norm()) < 1e-4
+        assert float((o[2][fused_keys[1]].double() - outs[0][2][fused_keys[1]].double()).abs().max()) < 1e-4 * float(ref0.norm())
