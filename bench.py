@@ -100,6 +100,7 @@ ALG_BYTES_ARGS = {
     "mm_bwd_fin": ("N", "H", "W", "Ca", "Cb", "Cout"),
     "mm_bwd_fin_head": ("N", "H", "W", "Ca", "Cout"),
     "mm_bwd_fin_xu": ("N", "H", "W", "Cout"),
+    "mm_bwd_fin_xu_c1": ("N", "H", "W", "Cout"),
     "dw_bwd": ("N", "H", "W", "Ca", "Cb"),
     "bn_bwd_reduce": ("N", "H", "W", "C"),
     "convt_fwd": ("N", "h", "w", "H", "W", "Cup", "Cout"),
@@ -113,7 +114,7 @@ FAMILIES = list(ALG_BYTES_ARGS)
 # block add their time to the pass and no bytes (their du round trip / second read of x are NOT algorithmic under 8(d)).
 PROF_STEPS = 2  # timed steps whose dominant-pass launches are individually timed (dispatch-packet timestamps, csrc/prof.hip)
 PASSES = {
-    "block_bwd": ("mm_bwd", "mm_bwd_fin", "mm_bwd_fin_head", "mm_bwd_fin_xu", "pw_bwd", "pw_bwd_fin", "dw_bwd", "bn_bwd_reduce"),
+    "block_bwd": ("mm_bwd", "mm_bwd_fin", "mm_bwd_fin_head", "mm_bwd_fin_xu", "mm_bwd_fin_xu_c1", "pw_bwd", "pw_bwd_fin", "dw_bwd", "bn_bwd_reduce"),
     "block_fwd": ("mm_fwd", "mm_fwd_fin", "mm_fwd_fin_xu", "dwpw_fwd", "dwpw_fwd_fin"),
     "convt_fwd": ("convt_fwd",),
     "convt_bwd": ("convt_bwd", "convt_bwd_parts"),
@@ -144,7 +145,7 @@ def alg_bytes(name, a, sz):
     # 2-byte u plane instead of its 8-channel input -- `roofline.traffic` (PMC) shows the bytes really moved, `achieved` stays on the 8(d) figure
     if name == "mm_bwd_fin_head":
         return v["N"] * v["H"] * v["W"] * 2 * (v["Ca"] + v["Cout"]) * sz
-    if name == "mm_bwd_fin_xu":
+    if name in ("mm_bwd_fin_xu", "mm_bwd_fin_xu_c1"):  # (_c1: the same block; its launch also accumulates the first block's weight-gradient sums and stores no dL/dx)
         return v["N"] * v["H"] * v["W"] * 2 * (8 + v["Cout"]) * sz
     if name in ("dw_bwd", "bn_bwd_reduce"):
         return 0.0

@@ -453,12 +453,13 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
     unsigned pxu[2] = {0u, 0u};  // XU: this lane's u (bf16 bits)
     unsigned pim[2] = {0u, 0u};  // C1: this lane's image pixel (fp32 bits)
     const unsigned c1_w = C::SMEM + wave * C1B;  // C1: this wave's image / u rings
-    float c1R[C1 ? 8 : 1], c1T[C1 ? 9 : 1], c1k[C1 ? 8 : 1];
+    f32x2 c1R[C1 ? 4 : 1], c1k[C1 ? 4 : 1];  // (channel pairs: packed fp32 FMAs)
+    float c1T[C1 ? 9 : 1];
     if constexpr (C1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            c1R[i] = 0.f;
-            c1k[i] = usc(A.wexp[i] * s_trx[i]);  // wexp[c] * (gamma rstd)[c]: the load transform's scale IS A[c]
+        for (int i = 0; i < 4; ++i) {
+            c1R[i] = (f32x2){0.f, 0.f};
+            c1k[i] = (f32x2){usc(A.wexp[2 * i] * s_trx[2 * i]), usc(A.wexp[2 * i + 1] * s_trx[2 * i + 1])};  // wexp[c] * (gamma rstd)[c]: the load transform's scale IS A[c]
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) c1T[i] = 0.f;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
             // ---- the first block's sums from this lane's pixel (row 2 cp + rr, column colbase + px): ghat1 = dx~ [x~ > 0] (the stored bf16 dx~ -- what
             // k_c1_bwd2 read -- times the 0 / 1 mask plane of the x tile), du = sum_c (wexp A)[c] ghat1[c], then R += ghat1 u and T += du img(3 x 3)
             const uint4 mk = *reinterpret_cast<const uint4*>(smem + xt_w + (unsigned)(cp & 1) * C::XSLOTB + C::XPLANEB + rr * C::XROWB + px * XPB);
-            const unsigned qw[4] = {c1ok ? c1q.x : 0u, c1ok ? c1q.y : 0u, c1ok ? c1q.z : 0u, c1ok ? c1q.w : 0u};
+            const unsigned qw[4] = {c1q.x, c1q.y, c1q.z, c1q.w};
             const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
             // ring rows of image rows 2 cp - 1 .. 2 cp + 2 are (2 qm3 + 3 + dy) mod 6 (as the dz ring); this lane's rows: dy = rr .. rr + 2, u: dy = rr + 1
             unsigned cr[4];
@@ -677,17 +678,17 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
                 cr[dy] = c1_w + (unsigned)((r >= 6 ? r - 6 : r) * C1ROW);
             }
             const unsigned r0 = rr ? cr[1] : cr[0], r1 = rr ? cr[2] : cr[1], r2 = rr ? cr[3] : cr[2];
-            const float uu = *reinterpret_cast<const float*>(smem + r1 + C1PLANE + (px + 1) * 4);
-            float du = 0.f;
+            // (a pixel outside the output -- halo lane, warm-up row -- contributes nothing: its u and du are zeroed, two selects instead of four)
+            const float uu = c1ok ? *reinterpret_cast<const float*>(smem + r1 + C1PLANE + (px + 1) * 4) : 0.f;
+            const f32x2 uu2 = (f32x2){uu, uu};
+            f32x2 du2 = (f32x2){0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const f32x2 gv = unpk(qw[k]), mv = unpk(mw[k]);
-                const float g0 = gv.x * mv.x, g1 = gv.y * mv.y;
-                du = fmaf(c1k[2 * k], g0, du);
-                du = fmaf(c1k[2 * k + 1], g1, du);
-                c1R[2 * k] = fmaf(g0, uu, c1R[2 * k]);
-                c1R[2 * k + 1] = fmaf(g1, uu, c1R[2 * k + 1]);
+                const f32x2 gp = unpk(qw[k]) * unpk(mw[k]);
+                du2 = __builtin_elementwise_fma(c1k[k], gp, du2);
+                c1R[k] = __builtin_elementwise_fma(gp, uu2, c1R[k]);
             }
+            const float du = c1ok ? du2.x + du2.y : 0.f;
             const unsigned rrow[3] = {r0, r1, r2};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(256, (rs_wps<CIN, COUT, G2>())) void k_rs_bwd(RsArg
         float* cred = reinterpret_cast<float*>(smem) + 64;  // [wave][17]
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
-            const float v = wave_sum(i < 8 ? c1R[i] : c1T[i - 8]);
+            const float v = wave_sum(i < 8 ? ((i & 1) ? c1R[i >> 1].y : c1R[i >> 1].x) : c1T[i - 8]);
             if (lane == 0) cred[wave * 17 + i] = v;
         }
         __syncthreads();
