@@ -816,6 +816,11 @@ def main():
                 "timing": f"per-launch dispatch timestamps (hipExtLaunchKernelGGL start/stop, no stream events) on the first {min(PROF_STEPS, args.steps)} "
                           f"of the {args.steps} timed steps, on the launch stream",
             }
+            if dom == "block_bwd" and timing.get("mm_bwd_fin_xu_c1"):
+                # the fused launch ALSO is the backward of the first block (1 -> 8 channels, SURVEY 8(d): 2 (1 + 8) elements / pixel), which used to be a pass of
+                # its own outside this figure; `frac` stays on the 25 blocks of the earlier rounds, this is the same time against all 26
+                extra = B * S * S * 2 * (1 + 8) * sz
+                out["roofline"]["frac_incl_first_block"] = round((st["alg_GB_per_step"] * 1e9 + extra) / (st["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             alg_step = 3 * sz * det_alg_elems_per_image(S, S) * B
             out["roofline"]["whole_step_alg_GB"] = round(alg_step / 1e9, 2)
             out["roofline"]["whole_step_frac"] = round(alg_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
