@@ -1731,7 +1731,10 @@ long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype)
 // 1 if ocrs_convt_bwd can also produce the BatchNorm-backward sums of the block that produced x (saved / gsum arguments)
 // (not for (32, 16): with the sums that instantiation needs 208 + 80 registers -> one block per CU, 122 -> 225 us; its block keeps the
 // 86-us ocrs_bn_bwd_reduce pass)
+long det_ctd_supported(int Cup, int Cout, int dtype);  // det_ctd.hip
 long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
+    static const int ctd_stats = env_int("OCRS_CTD_STATS", 1);  // the deep-level input-gradient kernel also produces the sums (round 5)
+    if (ctd_stats && det_ctd_supported(Cup, Cout, dtype)) return 1;
     return convt_wgrad_tr_ok(Cup, Cout, dtype) && !(Cup == 32 && Cout == 16) ? 1 : 0;
 }
 
@@ -1739,8 +1742,8 @@ long ocrs_convt_bwd_stats_supported(int Cup, int Cout, int dtype) {
 // its BatchNorm-backward sums [sum ghat | sum ghat*zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
 int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const void* wpk_d, void* dx, float* dW, float* dbias, double* dbias64, float* ws,
                          const float* saved, double* gsum, int Cup, int Cout, int N, int h, int w, int H, int W, int parts, int dtype, hipStream_t st);
-long det_ctd_supported(int Cup, int Cout, int dtype);  // det_ctd.hip
-int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, int N, int h, int w, int H, int W, hipStream_t st);
+int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, int N, int h, int w, int H, int W, hipStream_t st, const void* x,
+                   const float* tr, const float* saved, double* gsum);
 // 1 if ocrs_convt_bwd_parts can run the input gradient and the weight / bias gradients of this shape as separate calls (the generic deep-level path)
 long ocrs_convt_bwd_splittable(int Cup, int Cout, int dtype) { return convt_wgrad_tr_ok(Cup, Cout, dtype) ? 0 : 1; }
 
@@ -1786,7 +1789,7 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
     const long ntiles = (P + 63) / 64;
     const int gx = persistent_grid(ntiles, 8);
     if ((parts & 1) && det_ctd_supported(Cup, Cout, dtype)) {  // deep levels, bf16: the gradient region staged once (det_ctd.hip)
-        const int rc = det_ctd_launch(g, wpk_d, dx, Cup, Cout, N, h, w, H, W, st);
+        const int rc = det_ctd_launch(g, wpk_d, dx, Cup, Cout, N, h, w, H, W, st, x, tr, saved, gsum);  // (gsum: + the producer block's BatchNorm-backward sums)
         if (rc != OCRS_OK) return rc;
     } else if (parts & 1) {
 #define DG_CASE(T_, MT_)                                                                                                                     \

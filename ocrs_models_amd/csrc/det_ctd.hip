@@ -21,9 +21,14 @@ struct CtdCfg {
 };
 }  // namespace
 
-template <int CUP, int COUT>
+// STATS (round 5): x is the raw output z of the block that this ConvTranspose alone consumes, tr / saved its load transform / [mean | rstd]: the launch also
+// accumulates that block's BatchNorm-backward sums gsum [2][CUP] (fp64) += sum ghat | rstd sum ghat (z - mean), ghat = the STORED dx where bn(z) > 0 -- what
+// k_bn_bwd_reduce computed in a pass of its own over (dx, z) (34 + 13 + 26 us per step at the three deep levels).  Per-lane register accumulators over the
+// block's tiles, lanes -> DPP row sums -> waves through LDS in a fixed order -> one fp64 atomic per channel and block (exact sums of fp32 partials).
+template <int CUP, int COUT, bool STATS>
 __global__ __launch_bounds__(512) void k_ctd(const bf16* __restrict__ g, const void* __restrict__ wpk, bf16* __restrict__ dx, int h, int w, int H, int W,
-                                             int N) {
+                                             int N, const bf16* __restrict__ x, const float* __restrict__ tr, const float* __restrict__ saved,
+                                             double* __restrict__ gsum) {
     using C = CtdCfg<CUP, COUT>;
     constexpr int NT = C::NT, TW = C::TW, TH = C::TH, SW = C::SW, SP = C::SP, CG = C::CG, PXC = C::PXC, NXI = C::NXI, MTD = C::MTD, MPW = C::MPW, NPW = C::NPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,6 +45,19 @@ __global__ __launch_bounds__(512) void k_ctd(const bf16* __restrict__ g, const v
     const int m0w = MTD >= C::NW ? wave * MPW : wave % MTD, n0w = MTD >= C::NW ? 0 : (wave / MTD) * NPW;
     const int l15 = lane & 15, kq = lane >> 4;
 
+    float sc[STATS ? MPW : 1][4], sh[STATS ? MPW : 1][4], mu[STATS ? MPW : 1][4], st1[STATS ? MPW : 1][4], st2[STATS ? MPW : 1][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int a = 0; a < MPW; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = (m0w + a) * 16 + kq * 4 + r;
+                sc[a][r] = tr[ch];
+                sh[a][r] = tr[CUP + ch];
+                mu[a][r] = saved[ch];
+                st1[a][r] = st2[a][r] = 0.f;
+            }
+    }
     TileSched ts(ntiles);
     for (long t = ts.first; t < ts.end; t += ts.step) {
         const int n = (int)(t / tpi), r = (int)(t - (long)n * tpi);
@@ -91,9 +109,47 @@ __global__ __launch_bounds__(512) void k_ctd(const bf16* __restrict__ g, const v
                 bf16* dst = dx + (((long)n * h + qi) * w + qj) * CUP + m0w * 16 + kq * 4;
 #pragma unroll
                 for (int a = 0; a < MPW; ++a) store4(dst + a * 16, acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+                if constexpr (STATS) {
+                    const bf16* zs = x + (((long)n * h + qi) * w + qj) * CUP + m0w * 16 + kq * 4;
+#pragma unroll
+                    for (int a = 0; a < MPW; ++a) {
+                        const uint2 zq = *reinterpret_cast<const uint2*>(zs + a * 16);
+                        const float zv[4] = {__uint_as_float(zq.x << 16), __uint_as_float(zq.x & 0xffff0000u), __uint_as_float(zq.y << 16),
+                                             __uint_as_float(zq.y & 0xffff0000u)};
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; ++r2) {
+                            const float gh = fmaf(zv[r2], sc[a][r2], sh[a][r2]) > 0.f ? bf2f(f2bf(acc[a][b][r2])) : 0.f;  // (the stored, rounded gradient)
+                            st1[a][r2] += gh;
+                            st2[a][r2] = fmaf(gh, zv[r2] - mu[a][r2], st2[a][r2]);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();  // the staged region is free
+    }
+    if constexpr (STATS) {
+        float* slots = reinterpret_cast<float*>(smem);  // [wave][MPW * 16 channels][2]  (the staged region is free)
+#pragma unroll
+        for (int a = 0; a < MPW; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = quad16_sum(st1[a][r]), v2 = quad16_sum(st2[a][r]);
+                if (l15 == 0) {
+                    slots[((wave * MPW + a) * 16 + kq * 4 + r) * 2 + 0] = v1;
+                    slots[((wave * MPW + a) * 16 + kq * 4 + r) * 2 + 1] = v2;
+                }
+            }
+        __syncthreads();
+        for (int e = tid; e < 2 * CUP; e += NT) {
+            const int c = e >> 1, which = e & 1, mt = c >> 4;
+            float v = 0.f;
+            for (int wv = 0; wv < C::NW; ++wv) {  // the waves that own M tile mt (fixed order)
+                const int m0 = MTD >= C::NW ? wv * MPW : wv % MTD;
+                if (mt >= m0 && mt < m0 + MPW) v += slots[((wv * MPW + (mt - m0)) * 16 + (c & 15)) * 2 + which];
+            }
+            atomicAdd(&gsum[which * CUP + c], (double)(which ? v * saved[CUP + c] : v));
+        }
     }
 }
 
@@ -104,7 +160,8 @@ long det_ctd_supported(int Cup, int Cout, int dtype) {
     return on && dtype == 1 && ((Cup == 256 && Cout == 128) || (Cup == 128 && Cout == 64) || (Cup == 64 && Cout == 32));
 }
 
-int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, int N, int h, int w, int H, int W, hipStream_t st) {
+int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, int N, int h, int w, int H, int W, hipStream_t st, const void* x,
+                   const float* tr, const float* saved, double* gsum) {
     OCRS_CHECK_ARG(det_ctd_supported(Cup, Cout, 1));
     const long ntiles = (long)N * ((h + 7) / 8) * ((w + 7) / 8);
     const long cap = (long)kNumCU * (Cout <= 64 ? 2 : 1);
@@ -116,12 +173,19 @@ int det_ctd_launch(const void* g, const void* wpk, void* dx, int Cup, int Cout, 
         using CC = CtdCfg<CU_, CO_>;                                                                                                        \
         static DevOnce attr_set;                                                                                                       \
         if (attr_set.need()) {                                                                                                                    \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctd<CU_, CO_>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
-                hipSuccess)                                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctd<CU_, CO_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
+                    hipSuccess ||                                                                                                           \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ctd<CU_, CO_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CC::SMEM) != \
+                    hipSuccess)                                                                                                             \
                 return OCRS_ERR_HIP;                                                                                                        \
             attr_set.done();                                                                                                                \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((k_ctd<CU_, CO_>), dim3((int)gsz), dim3(512), CC::SMEM, st, (const bf16*)g, wpk, (bf16*)dx, h, w, H, W, N);      \
+        if (gsum)                                                                                                                           \
+            hipLaunchKernelGGL((k_ctd<CU_, CO_, true>), dim3((int)gsz), dim3(512), CC::SMEM, st, (const bf16*)g, wpk, (bf16*)dx, h, w, H, W, N, \
+                               (const bf16*)x, tr, saved, gsum);                                                                            \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_ctd<CU_, CO_, false>), dim3((int)gsz), dim3(512), CC::SMEM, st, (const bf16*)g, wpk, (bf16*)dx, h, w, H, W, N, \
+                               (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (double*)nullptr);                       \
     }
     CTD_CASE(256, 128) CTD_CASE(128, 64) CTD_CASE(64, 32)
 #undef CTD_CASE
