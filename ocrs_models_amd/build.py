@@ -60,7 +60,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # destination registers alone until the wait
         chk = os.path.join(os.path.dirname(HERE), "tools", "check_rs_loads.py" if asm_src == "det_rs.hip" else "check_opaque_loads.py")
         if not os.path.exists(chk):
-            knob = {"det_mm.hip": "OCRS_MM_FULL=0", "rec_conv3.hip": "OCRS_CONV_ROWS=0", "det_rs.hip": "OCRS_RS=0"}[asm_src]
+            knob = {"det_mm.hip": "OCRS_MM_FULL=0", "rec_conv3.hip": "OCRS_CONV_ROWS=0", "det_rs.hip": "OCRS_RS=0 OCRS_RSF=0"}[asm_src]
             print(f"WARNING: {os.path.basename(chk)} not found -- {asm_src}'s hand-waited asm loads were NOT verified against this "
                   f"compiler's register allocation (build from the repository tree, or run with {knob} to use the compiler-waited kernels)",
                   file=sys.stderr, flush=True)

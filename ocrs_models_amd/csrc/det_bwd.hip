@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_head_bwd_loss(const T* __restrict__ z, 
 // Deferred second stage of the block backward's flushes (round 5; see BwdLast in det_common.h).  Between ocrs_bwd_defer_begin and
 // ocrs_bwd_defer_flush the single-writer reductions of weight-gradient partials (k_mm_bwd_reduce's weight part, k_wgrad_partials_reduce,
 // k_dw_partials_reduce's tap rows) are not launched but queued; the flush runs them all as ONE launch (same column-sum order: bit-identical
-// gradients).  Per-process state (one process per GPU, one backward at a time).
+// gradients).  Per-device state (one backward at a time per device; `defer_state()` below).
 // ----------------------------------------------------------------------------------------------
 struct RedJob {
     const float* ws;
@@ -1357,39 +1357,64 @@ __global__ __launch_bounds__(256) void k_reduce_multi(RedJobs J) {
     else
         q.d1[e - q.n0] += s;
 }
-static struct {
+// One state per DEVICE: a backward of a second model on another GPU of the same process (autograd runs one worker thread per device) has
+// its own queue, scratch and partials workspace -- indexed by the calling thread's current device at every entry.
+struct DeferState {
     bool on = false;
     double* scratch = nullptr;
     long cap = 0, used = 0;
     int nblocks = 0;
     RedJobs jobs;
-} g_defer;
-// workspace for per-block partials of launches whose entry points take none (the CRNN's bias / first-layer sums: rec_conv.hip, rec_conv0.hip,
-// rec_gru_seq.hip): a per-process device buffer, bump-allocated between _begin and _flush; null outside that window or when it is used up
-static float* g_defer_ws = nullptr;
-static long g_defer_ws_used = 0;
+    // workspace for per-block partials of launches whose entry points take none (the CRNN's bias / first-layer sums: rec_conv.hip, rec_conv0.hip,
+    // rec_gru_seq.hip): a per-device buffer (allocated on that device at first use), bump-allocated between _begin and _flush; null outside that
+    // window, when it is used up, or when the allocation is refused (e.g. inside a stream capture: callers then take their atomic path)
+    float* ws = nullptr;
+    long ws_used = 0;
+};
+constexpr int DEFER_MAXDEV = 16;
+static DeferState g_defer_dev[DEFER_MAXDEV];
+static DeferState& defer_state() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DEFER_MAXDEV) d = 0;
+    return g_defer_dev[d];
+}
 constexpr long DEFER_WS_FLOATS = 8L << 20;  // 32 MB
 float* bwd_defer_ws(long nfloats) {
-    if (!g_defer.on || nfloats <= 0) return nullptr;
-    if (!g_defer_ws && hipMalloc(reinterpret_cast<void**>(&g_defer_ws), DEFER_WS_FLOATS * sizeof(float)) != hipSuccess) return nullptr;
+    DeferState& D = defer_state();
+    if (!D.on || nfloats <= 0) return nullptr;
+    if (!D.ws && hipMalloc(reinterpret_cast<void**>(&D.ws), DEFER_WS_FLOATS * sizeof(float)) != hipSuccess) {
+        D.ws = nullptr;
+        (void)hipGetLastError();
+        return nullptr;
+    }
     const long n = (nfloats + 63) & ~63L;
-    if (g_defer_ws_used + n > DEFER_WS_FLOATS) return nullptr;
-    float* p = g_defer_ws + g_defer_ws_used;
-    g_defer_ws_used += n;
+    if (D.ws_used + n > DEFER_WS_FLOATS) return nullptr;
+    float* p = D.ws + D.ws_used;
+    D.ws_used += n;
     return p;
 }
 double* bwd_defer_scratch(int ndoubles) {
-    if (!g_defer.on || g_defer.used + ndoubles > g_defer.cap) return nullptr;
-    double* p = g_defer.scratch + g_defer.used;
-    g_defer.used += (ndoubles + 1) & ~1L;
+    DeferState& D = defer_state();
+    if (!D.on || D.used + ndoubles > D.cap) return nullptr;
+    double* p = D.scratch + D.used;
+    D.used += (ndoubles + 1) & ~1L;
     return p;
 }
 bool bwd_defer_reduce(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1) {
-    if (!g_defer.on || g_defer.jobs.njobs >= RED_MAXJOBS || n0 + n1 <= 0) return false;
-    RedJob& q = g_defer.jobs.j[g_defer.jobs.njobs++];
-    q = RedJob{ws, d0, d1, nb, nelem, n0, cin0 > 0 ? cin0 : 1, ldw0, n1, g_defer.nblocks};
-    g_defer.nblocks += (n0 + n1 + 31) / 32;
+    DeferState& D = defer_state();
+    if (!D.on || D.jobs.njobs >= RED_MAXJOBS || n0 + n1 <= 0) return false;
+    RedJob& q = D.jobs.j[D.jobs.njobs++];
+    q = RedJob{ws, d0, d1, nb, nelem, n0, cin0 > 0 ? cin0 : 1, ldw0, n1, D.nblocks};
+    D.nblocks += (n0 + n1 + 31) / 32;
     return true;
+}
+// queue the reduction (deferral window open) or run it now as a one-job launch of the same kernel (same column-sum order: bit-identical gradients)
+void bwd_reduce_or_defer(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1, hipStream_t st) {
+    if (n0 + n1 <= 0 || bwd_defer_reduce(ws, nb, nelem, d0, n0, cin0, ldw0, d1, n1)) return;
+    RedJobs J;
+    J.njobs = 1;
+    J.j[0] = RedJob{ws, d0, d1, nb, nelem, n0, cin0 > 0 ? cin0 : 1, ldw0, n1, 0};
+    hipLaunchKernelGGL(k_reduce_multi, dim3((n0 + n1 + 31) / 32), dim3(256), 0, st, J);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1881,22 +1906,24 @@ int ocrs_head_bwd_loss(const void* z, const float* tr, const float* w, const flo
 // finalisation state from (16 Cin + 2 each; left zeroed), valid -- like every workspace `ws` passed meanwhile -- until ocrs_bwd_defer_flush, which
 // launches the queued weight-gradient reductions as one kernel on `st` (the stream of the launches that produced the partials) and ends the mode.
 int ocrs_bwd_defer_begin(double* scratch, long ndoubles) {
-    OCRS_CHECK_ARG(!g_defer.on && (scratch || ndoubles == 0) && ndoubles >= 0);
-    g_defer.on = true;
-    g_defer.scratch = scratch;
-    g_defer.cap = ndoubles;
-    g_defer.used = 0;
-    g_defer.nblocks = 0;
-    g_defer.jobs.njobs = 0;
-    g_defer_ws_used = 0;
+    DeferState& D = defer_state();
+    OCRS_CHECK_ARG(!D.on && (scratch || ndoubles == 0) && ndoubles >= 0);
+    D.on = true;
+    D.scratch = scratch;
+    D.cap = ndoubles;
+    D.used = 0;
+    D.nblocks = 0;
+    D.jobs.njobs = 0;
+    D.ws_used = 0;
     return OCRS_OK;
 }
 int ocrs_bwd_defer_flush(hipStream_t st) {
-    const bool was = g_defer.on;
-    g_defer.on = false;
-    if (!was || g_defer.jobs.njobs == 0) return OCRS_OK;
-    hipLaunchKernelGGL(k_reduce_multi, dim3(g_defer.nblocks), dim3(256), 0, st, g_defer.jobs);
-    g_defer.jobs.njobs = 0;
+    DeferState& D = defer_state();
+    const bool was = D.on;
+    D.on = false;
+    if (!was || D.jobs.njobs == 0) return OCRS_OK;
+    hipLaunchKernelGGL(k_reduce_multi, dim3(D.nblocks), dim3(256), 0, st, D.jobs);
+    D.jobs.njobs = 0;
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
 }

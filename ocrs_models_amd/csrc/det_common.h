@@ -617,6 +617,7 @@ double* bwd_defer_scratch(int ndoubles);
 float* rec_defer_partials(int nb, int n, float* out);  // rec_conv.hip: partial buffer [nb][n] + queued column sum into out [n] (null: not deferring)
 float* bwd_defer_ws(long nfloats);  // per-block-partial workspace for launches whose entry points take none (null: not deferring / used up)
 bool bwd_defer_reduce(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1);
+void bwd_reduce_or_defer(const float* ws, int nb, int nelem, float* d0, int n0, int cin0, int ldw0, float* d1, int n1, hipStream_t st);  // queue, or one-job launch now
 
 // ---- BatchNorm2d training statistics finalised by the LAST workgroup of the forward launch that produced them (one launch less per block)
 struct FwdFin {

@@ -1,0 +1,647 @@
+// fp32 (parity-mode) DepthwiseConv block kernels of the wide levels as register-resident ROW-STREAMING waves (round 6).
+//
+// The reference trains detection in fp32 (ocrs_models/train_detection.py:92-97, no autocast); fp32 is the only mode that meets north_star's
+// 1e-4.  Until round 5 that mode ran the round-1 tile kernels (k_dwpw_fwd / k_pw_bwd / k_dw_bwd, csrc/det_fwd.hip / det_bwd.hip): LDS-bandwidth
+// bound forward (1.6-2.0 TB/s on the fp32 bytes), a `du` round trip through HBM between the two backward kernels.  These kernels are the fp32
+// counterpart of csrc/det_rs.hip, but simpler: an fp32 pixel is 32-64 B, so ONE register layout serves every tensor and no LDS tile exists at all.
+//
+//   Layout "pixel x channel quad":  lane = (n, q), n = lane & 15 = pixel column of a 16-column strip, q = lane >> 4 = channel quad;
+//   a register set (4 VGPRs r = 0..3) holds channels 16 s + 4 q + r of that pixel.
+//     * it is what a 16-byte NHWC access gives (dwordx4 per lane, 1 KB contiguous per wave instruction for 16 channels),
+//     * it IS the D layout of v_mfma_f32_16x16x4_f32 (D[m = 4 q + r][n]) -- the pointwise output needs no re-arrangement -- and
+//     * it is a valid B operand of the same MFMA if K step r is made to contract over the channels {4 k + r}: the A fragments are packed that
+//       way once per wave (A_r[lane (m, k)] = W[m][4 k + r]), K steps are summed anyway.  Exact fp32 products, fp32 accumulation.
+//   The depthwise 3x3 is per channel: left / right neighbours are the adjacent lanes of the 16-lane DPP row (row_shr:1 / row_shl:1, folded into the
+//   VALU op), upper / lower neighbours are the previous rows, kept as three partial sums per channel.  A strip is 16 lanes = 14 output columns
+//   + one halo column each side (their outputs are discarded).  Rows are loaded through buffer descriptors (hardware range check: out-of-range
+//   lanes read 0 and their stores are dropped -- no divergent branch around any memory instruction, so hipcc's vmcnt counts stay exact), P rows
+//   ahead into a register ring; there is no LDS traffic and no barrier in the loop.  BatchNorm batch statistics: per-lane fp32 partials ->
+//   DPP row sums -> one fp64 atomic per (workgroup, channel) (an fp64 sum of fp32 values is exact, hence order-independent: bit-reproducible),
+//   finalised by the launch's last workgroup (bn_finalize_last_block).  Fused MaxPool2d(2) in its pre-BatchNorm form as in k_dwpw_fwd<.., POOL>.
+#include "det_common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+constexpr int DPP_SHR1 = 0x111;  // row_shr:1  result[i] = src[i - 1] within the 16-lane row (lane 0: 0)
+constexpr int DPP_SHL1 = 0x101;  // row_shl:1  result[i] = src[i + 1]                         (lane 15: 0)
+
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ f32x4 bld16(rsrc_t r, int off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+__device__ __forceinline__ void bst16(rsrc_t r, int off, const f32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0); }
+__device__ __forceinline__ f32x4 or4(const f32x4& a, const f32x4& b) {  // lanes get their value from exactly one of two range-checked loads (the other returned 0)
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, a) | __builtin_bit_cast(u32x4, b));
+}
+
+constexpr int RS32_COLS = 14;  // output columns of a strip (16 lanes - 2 halo lanes)
+
+struct Rs32Jobs {
+    int ncg, nrb, rb, njobs;  // column groups per row, row blocks per image, rows per block, jobs = N * nrb * ncg (column group fastest)
+};
+static inline Rs32Jobs rs32_jobs(int N, int H, int W, int cols, int rb) {
+    Rs32Jobs j;
+    j.ncg = (W + cols - 1) / cols;
+    j.rb = rb;
+    j.nrb = (H + rb - 1) / rb;
+    j.njobs = N * j.nrb * j.ncg;
+    return j;
+}
+
+struct Rs32F {
+    const float *xa, *xb, *tra, *trb, *wdw, *wpw, *gamma;
+    float *z, *pooled;
+    double* gstat;
+    int Ca, Cb, Cout, N, H, W;
+    Rs32Jobs jb;
+    FwdFin fin;
+};
+
+// XCD-aware static job schedule of a persistent grid (workgroup b runs on XCD b % 8): every XCD owns a contiguous eighth of the jobs and the four
+// waves of a workgroup take neighbouring jobs (neighbouring strips share their halo columns' cache lines in that XCD's L2)
+struct Rs32Sched {
+    int first, step, end;
+    __device__ __forceinline__ Rs32Sched(int njobs, int wave) {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) {
+            const int per = (njobs + 7) >> 3, xcd = blockIdx.x & 7;
+            first = xcd * per + (blockIdx.x >> 3) * 4 + wave;
+            step = (nb >> 3) * 4;
+            end = (xcd + 1) * per < njobs ? (xcd + 1) * per : njobs;
+        } else {
+            first = blockIdx.x * 4 + wave;
+            step = nb * 4;
+            end = njobs;
+        }
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// forward: x~ = max(x * scale + shift, lo) on load (producer's BatchNorm + ReLU; channel concat [a | b]) -> depthwise 3x3 (zero padding)
+// -> pointwise 1x1 on the fp32 matrix cores -> z store + sum z, sum z^2 (+ fused 2x2 max-pool of the pre-BatchNorm z).
+// NSET: register sets of 16 input channels (Cin <= 16 NSET); MT: 16-row M tiles of output channels; SPLIT: two sources; P: rows in flight.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <int NSET, int MT, bool SPLIT, bool POOL, int P>
+__global__ __launch_bounds__(256, (NSET * MT == 1) ? 3 : 2) void k_rs32_fwd(const Rs32F A) {
+    __shared__ float s_stat[4][2][16 * MT];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
+
+    // ---- per-lane constants: the lane's channel quad of every set
+    float sc[NSET][4], sh[NSET][4], lo[NSET][4], wd[NSET][4][9], af[MT][NSET][4];
+    int qa[NSET], qb[NSET];  // byte offset of the quad inside a pixel of source a / b, or -1: the quad does not come from that source
+    bool chok[NSET];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+        const int cb = 16 * s + 4 * q;
+        chok[s] = cb < Cin;
+        const bool in_a = cb < Ca;
+        qa[s] = (chok[s] && in_a) ? cb * 4 : -1;
+        qb[s] = (chok[s] && !in_a) ? (cb - Ca) * 4 : -1;
+        const float* tr = in_a ? A.tra : A.trb;
+        const int Cs = in_a ? Ca : Cb, cc = in_a ? cb : cb - Ca;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[s][r] = chok[s] ? tr[cc + r] : 0.f;
+            sh[s][r] = chok[s] ? tr[Cs + cc + r] : 0.f;
+            lo[s][r] = chok[s] ? tr[2 * Cs + cc + r] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wd[s][r][t] = chok[s] ? A.wdw[(cb + r) * 9 + t] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt][s][r] = (chok[s] && n + 16 * mt < Cout) ? A.wpw[(n + 16 * mt) * Cin + cb + r] : 0.f;  // A_r[(m, k)] = W[m][4 k + r]
+        }
+    }
+    float sg[MT][4];  // sign of the BatchNorm weight (POOL: the window's selected element is max z or min z)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sg[mt][r] = (POOL && 16 * mt + 4 * q + r < Cout && A.gamma[16 * mt + 4 * q + r] < 0.f) ? -1.f : 1.f;
+
+    const unsigned npix = (unsigned)A.N * H * W;
+    const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
+    const rsrc_t rz = mk_rsrc(A.z, npix * Cout * 4);
+    const int Hp = H >> 1, Wp = W >> 1;
+    const rsrc_t rp = mk_rsrc(POOL ? A.pooled : A.z, POOL ? (unsigned)A.N * Hp * Wp * Cout * 4 : npix * Cout * 4);
+    const int pa = Ca * 4, pb = Cb * 4, pz = Cout * 4;
+
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[mt][r] = s2[mt][r] = 0.f;
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < H) ? y0 + A.jb.rb : H;
+        const int col = cg * RS32_COLS + n - 1;
+        const bool colok = (unsigned)col < (unsigned)W;
+        const bool useful = n >= 1 && n <= RS32_COLS && col < W;
+        const int rowpix0 = img * H * W + col;  // + yy * W = the lane's pixel of row yy
+
+        f32x4 ring[P][NSET], ringb[SPLIT ? P : 1][NSET];
+        auto issue = [&](int k, int yy) {  // (unconditional instructions: rows outside the job / image are range-check misses, not branches)
+            const bool ok = colok && (unsigned)yy < (unsigned)H && yy <= y1;
+            const int pix = rowpix0 + yy * W;
+#pragma unroll
+            for (int s = 0; s < NSET; ++s) {
+                ring[k][s] = bld16(ra, (ok && qa[s] >= 0) ? (int)((unsigned)pix * (unsigned)pa + (unsigned)qa[s]) : -1);
+                if constexpr (SPLIT) ringb[k][s] = bld16(rbs, (ok && qb[s] >= 0) ? (int)((unsigned)pix * (unsigned)pb + (unsigned)qb[s]) : -1);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < P; ++k) issue(k, y0 - 1 + k);
+
+        float accA[NSET][4], accB[NSET][4];
+        f32x4 dprev[MT];
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accA[s][r] = accB[s][r] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dprev[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int yb = y0 - 1; yb <= y1; yb += P) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int yy = yb + k;  // (the last pass may run up to P - 1 rows past y1: loads miss the range check, stores are dropped)
+                // ---- x~ of input row yy (zero outside the image: the convolution's padding), then the next row's loads into the freed slot
+                const bool ok = colok && (unsigned)yy < (unsigned)H;
+                float X[NSET][4];
+#pragma unroll
+                for (int s = 0; s < NSET; ++s) {
+                    f32x4 v = ring[k][s];
+                    if constexpr (SPLIT) v = or4(v, ringb[k][s]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[s][r] = (ok && chok[s]) ? fmaxf(fmaf(v[r], sc[s][r], sh[s][r]), lo[s][r]) : 0.f;
+                }
+                issue(k, yy + P);
+                // ---- depthwise: row yy completes output row yy - 1 (kernel row 2), continues row yy (row 1), opens row yy + 1 (row 0)
+                float accC[NSET][4];
+#pragma unroll
+                for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = X[s][r], l = dpp_f<DPP_SHR1>(x), rr = dpp_f<DPP_SHL1>(x);
+                        const float* w = wd[s][r];
+                        accA[s][r] = fmaf(w[8], rr, fmaf(w[7], x, fmaf(w[6], l, accA[s][r])));
+                        accB[s][r] = fmaf(w[5], rr, fmaf(w[4], x, fmaf(w[3], l, accB[s][r])));
+                        accC[s][r] = fmaf(w[2], rr, fmaf(w[1], x, w[0] * l));
+                    }
+                const int yo = yy - 1;
+                {
+                    const bool rowo = yo >= y0 && yo < y1;
+                    const int opix = img * H * W + yo * W + col;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][s][r], accA[s][r], d, 0, 0, 0);
+                        const bool st = rowo && useful && 16 * mt + 4 * q < Cout;
+                        bst16(rz, st ? (int)((unsigned)opix * (unsigned)pz + (unsigned)(16 * mt + 4 * q) * 4u) : -1, d);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = st ? d[r] : 0.f;
+                            s1[mt][r] += v;
+                            s2[mt][r] = fmaf(v, v, s2[mt][r]);
+                        }
+                        if constexpr (POOL) {
+                            {  // yo odd = the window's second row: this lane's pixel, the next lane's, and the same two of the row above
+                                f32x4 m4;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float vv = fmaxf(sg[mt][r] * dprev[mt][r], sg[mt][r] * d[r]);
+                                    m4[r] = sg[mt][r] * fmaxf(vv, dpp_f<DPP_SHL1>(vv));
+                                }
+                                const bool ps = st && (yo & 1) && (n & 1) && (col >> 1) < Wp;  // (n odd <=> even column: col = 14 cg + n - 1)
+                                bst16(rp, ps ? ((img * Hp + (yo >> 1)) * Wp + (col >> 1)) * pz + (16 * mt + 4 * q) * 4 : -1, m4);
+                            }
+                            dprev[mt] = d;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accA[s][r] = accB[s][r];
+                        accB[s][r] = accC[s][r];
+                    }
+            }
+        }
+    }
+    // ---- batch statistics: DPP sum over the strip's 16 lanes -> one slot per (wave, channel) -> fp64 atomics per workgroup
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a1 = quad16_sum(s1[mt][r]), a2 = quad16_sum(s2[mt][r]);
+            if (n == 0) {
+                s_stat[wave][0][16 * mt + 4 * q + r] = a1;
+                s_stat[wave][1][16 * mt + 4 * q + r] = a2;
+            }
+        }
+    __syncthreads();
+    for (int c = tid; c < Cout; c += 256) {
+        atomicAdd(&A.gstat[c], (double)((s_stat[0][0][c] + s_stat[1][0][c]) + (s_stat[2][0][c] + s_stat[3][0][c])));
+        atomicAdd(&A.gstat[Cout + c], (double)((s_stat[0][1][c] + s_stat[1][1][c]) + (s_stat[2][1][c] + s_stat[3][1][c])));
+    }
+    bn_finalize_last_block(A.fin, A.gstat, Cout, tid, 256, &s_flag);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// backward of one block in ONE pass (Cin, Cout <= 16; direct gradient source): per pixel it reads g (+ g2), z and x once and writes dL/dx~ once
+// -- the 2 (Cin + Cout) elements of SURVEY 8(d); `du` is never stored (the round-1 pair k_pw_bwd + k_dw_bwd moved 2 Cout + 5 Cin).
+//   dz = A ghat + B z + C (BatchNorm / ReLU backward; A, B, C derived from the block's complete sums in the prologue: bn_fin_coef)
+//   du = Wpw^T dz                         fp32 MFMA, D layout over the input channels, valid on the halo lanes too (pointwise)
+//   dx~ = depthwise3x3^T(du)              rows yy-2 .. yy of du in registers, left / right by DPP -> stored for the centre row c = yy - 1
+//   dWdw[ch][tap] += du(c) x~(c + tap)    36 per-lane accumulators, x~ rows c-1 .. c+1 in registers
+//   u(c) = depthwise3x3(x~)  recomputed;  dWpw[o][ch] += sum_px dz(c)[o][px] u(c)[ch][px]: K = pixels -> both operands through a wave-private LDS
+//                                         transpose ([channel][pixel], written and read by the same wave: in order, no barrier) -> 4 fp32 MFMAs per row
+//   STATS: the producers' BatchNorm-backward sums  S1 = sum ghat', S2 = sum ghat' x~, ghat' = dx~ [x~ > 0]  (BwdLast mode 0: converted by the last workgroup)
+// Per-workgroup partials of the weight gradients go to ws (fixed-order second stage: bwd_reduce_or_defer), the producers' sums through exact fp64
+// atomics to the launch's last workgroup (bwd_last_finish): bit-reproducible.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct Rs32B {
+    const float *xa, *xb, *tra, *trb, *wdw, *wpw, *g1, *g2, *z, *bn;
+    float *gxa, *gxb, *ws;
+    int Ca, Cb, Cout, N, H, W;
+    Rs32Jobs jb;
+    BnFin fin;
+    BwdLast bl;
+};
+constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of the transpose buffers: 16-byte aligned rows, conflict-light
+
+// P = 1: the next row's loads are issued the moment this row's have been consumed and have the whole row's arithmetic (~1 us at two waves per SIMD)
+// to arrive; unrolling two rows (P = 2) costs ~100 registers (256 + spills) for nothing.
+template <bool SPLIT, bool G2, bool STATS, int P>
+__global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
+    __shared__ float s_cf[3 * 16];
+    __shared__ __attribute__((aligned(16))) float s_t[4][3][16 * RS32_TP];  // per wave: dz^T of rows yy (slot yy & 1) and yy - 1 | u^T
+    __shared__ float s_red[4][16 * 16 + 9 * 16 + 2 * 16];                   // per wave: dWpw | dWdw | S1 | S2
+    // per-channel constants, [row][16 channels]: a lane reads its quad of a row as ONE ds_read_b128 per use instead of holding 36 + 36 registers for the
+    // whole launch (at 256 registers the kernel spilled 23 .. 190 of them).  s_w: the 9 depthwise taps; s_k: 0 A, 1 B, 2 C (dz coefficients), 3 / 4 scale /
+    // shift of this block's ReLU mask, 5 / 6 / 7 scale / shift / lo of the input's load transform, 8 the producers' saved mean (STATS)
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 16];
+    __shared__ __attribute__((aligned(16))) float s_k[9 * 16];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
+    bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    __syncthreads();
+    if (tid < 16) {
+        const int c = tid;
+        const bool o = c < Cout, i = c < Cin, ia = c < Ca;
+        const float* tr = ia ? A.tra : A.trb;
+        const float* sv = ia ? A.bl.saved_a : A.bl.saved_b;
+        const bool want = STATS && (ia ? A.bl.gsum_a : A.bl.gsum_b) != nullptr;
+        const int Cs = ia ? Ca : Cb, cc = ia ? c : c - Ca;
+        s_k[0 * 16 + c] = o ? s_cf[c] : 0.f;
+        s_k[1 * 16 + c] = o ? s_cf[Cout + c] : 0.f;
+        s_k[2 * 16 + c] = o ? s_cf[2 * Cout + c] : 0.f;
+        s_k[3 * 16 + c] = o ? A.bn[c] : 0.f;
+        s_k[4 * 16 + c] = o ? A.bn[Cout + c] : 0.f;
+        s_k[5 * 16 + c] = i ? tr[cc] : 0.f;
+        s_k[6 * 16 + c] = i ? tr[Cs + cc] : 0.f;
+        s_k[7 * 16 + c] = i ? tr[2 * Cs + cc] : 0.f;
+        s_k[8 * 16 + c] = (i && want) ? sv[cc] : 0.f;
+        for (int t = 0; t < 9; ++t) s_w[t * 16 + c] = i ? A.wdw[c * 9 + t] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- per-lane constants: output-channel quad 4 q .. 4 q + 3 (g, z, dz) and input-channel quad 4 q .. 4 q + 3 (x, du, dx)
+    const int c4 = 4 * q;
+    const bool okO = c4 < Cout, okI = c4 < Cin, in_a = c4 < Ca;
+    float afd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) afd[r] = (c4 + r < Cout && n < Cin) ? A.wpw[(c4 + r) * Cin + n] : 0.f;  // A_r[(m = input channel, k)] = Wpw[4 k + r][m]
+    const unsigned npix = (unsigned)A.N * H * W;
+    const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
+    const rsrc_t rg1 = mk_rsrc(A.g1, npix * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, npix * Cout * 4), rz = mk_rsrc(A.z, npix * Cout * 4);
+    const rsrc_t wa = mk_rsrc(A.gxa, npix * Ca * 4), wb = mk_rsrc(SPLIT ? A.gxb : A.gxa, npix * (SPLIT ? Cb : Ca) * 4);
+    const unsigned pa = Ca * 4, pb = Cb * 4, po = Cout * 4;
+    const int qa = (okI && in_a) ? c4 * 4 : -1, qb = (okI && !in_a) ? (c4 - Ca) * 4 : -1;
+
+    float aw[4][9];  // dWdw partials of the lane's four channels
+    f32x4 dwpw = {0.f, 0.f, 0.f, 0.f};  // D[m = o][n = input channel]: lane (ch, k) reg r = dWpw[4 k + r][ch]
+    float st1[4], st2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        st1[r] = st2[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) aw[r][t] = 0.f;
+    }
+    float* tu = s_t[wave][2];
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < H) ? y0 + A.jb.rb : H;
+        const int col = cg * RS32_COLS + n - 1;
+        const bool colok = (unsigned)col < (unsigned)W;
+        const bool useful = n >= 1 && n <= RS32_COLS && col < W;
+        const int rowpix0 = img * H * W + col;
+
+        f32x4 rg[P], rg2v[G2 ? P : 1], rzv[P], rx[P], rxb[SPLIT ? P : 1];
+        auto issue = [&](int k, int yy) {
+            const bool ok = colok && (unsigned)yy < (unsigned)H && yy <= y1;
+            const unsigned pix = (unsigned)(rowpix0 + yy * W);
+            const int oo = (ok && okO) ? (int)(pix * po + (unsigned)c4 * 4u) : -1;
+            rg[k] = bld16(rg1, oo);
+            if constexpr (G2) rg2v[k] = bld16(rg2, oo);
+            rzv[k] = bld16(rz, oo);
+            rx[k] = bld16(ra, (ok && qa >= 0) ? (int)(pix * pa + (unsigned)qa) : -1);
+            if constexpr (SPLIT) rxb[k] = bld16(rbs, (ok && qb >= 0) ? (int)(pix * pb + (unsigned)qb) : -1);
+        };
+#pragma unroll
+        for (int k = 0; k < P; ++k) issue(k, y0 - 1 + k);
+
+        // rings: rows yy-2 (index 0), yy-1 (1), yy (2)
+        float X[3][4], DU[3][4], dzc[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[i][r] = DU[i][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dzc[r] = 0.f;
+
+        for (int yb = y0 - 1; yb <= y1; yb += P) {
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const int yy = yb + k;
+                const bool ok = colok && (unsigned)yy < (unsigned)H && yy <= y1;
+                // ---- rotate the rings, then fill index 2 with row yy
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    X[0][r] = X[1][r]; X[1][r] = X[2][r];
+                    DU[0][r] = DU[1][r]; DU[1][r] = DU[2][r];
+                }
+                int oz = 0;
+                asm volatile("" : "+v"(oz));  // (an opaque zero in the table addresses: keeps hipcc from hoisting the 18 constant vectors out of the loop)
+                const float* kk = s_k + c4 + oz;
+                const float* kw = s_w + c4 + oz;
+                {
+                    f32x4 gv = rg[k];
+                    if constexpr (G2) gv = gv + rg2v[k];
+                    const f32x4 zv = rzv[k];
+                    f32x4 xv = rx[k];
+                    if constexpr (SPLIT) xv = or4(xv, rxb[k]);
+                    const f32x4 cA = *reinterpret_cast<const f32x4*>(kk), cB = *reinterpret_cast<const f32x4*>(kk + 16), cC = *reinterpret_cast<const f32x4*>(kk + 32);
+                    const f32x4 msc = *reinterpret_cast<const f32x4*>(kk + 48), msh = *reinterpret_cast<const f32x4*>(kk + 64);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(kk + 80), sh = *reinterpret_cast<const f32x4*>(kk + 96), lo = *reinterpret_cast<const f32x4*>(kk + 112);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gh = fmaf(zv[r], msc[r], msh[r]) > 0.f ? gv[r] : 0.f;
+                        dzc[r] = (ok && okO) ? fmaf(cA[r], gh, fmaf(cB[r], zv[r], cC[r])) : 0.f;
+                        X[2][r] = (ok && okI) ? fmaxf(fmaf(xv[r], sc[r], sh[r]), lo[r]) : 0.f;
+                    }
+                }
+                issue(k, yy + P);
+                {
+                    float* tzw = s_t[wave][yy & 1];
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tzw[(c4 + r) * RS32_TP + n] = dzc[r];
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(afd[r], dzc[r], d, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) DU[2][r] = d[r];
+                }
+                // ---- centre row c = yy - 1
+                const int c = yy - 1;
+                const bool rowo = c >= y0 && c < y1;
+                const bool act = rowo && useful;
+                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+                float u[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dm[r] = act ? DU[1][r] : 0.f;
+                // dx~(c) = sum_{ky,kx} w[ky][kx] du(c + 1 - ky, col + 1 - kx):  ky = 0 -> row c + 1 (ring 2), kx = 0 -> column + 1 (row_shl)
+                // u(c)   = sum_{ky,kx} w[ky][kx] x~(c + ky - 1, col + kx - 1);  dWdw[ky][kx] += du(c) x~(c + ky - 1, col + kx - 1)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 0) * 16), w1 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 1) * 16),
+                                w2 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 2) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dv = DU[2 - ky][r];
+                        dx[r] = fmaf(w2[r], dpp_f<DPP_SHR1>(dv), fmaf(w1[r], dv, fmaf(w0[r], dpp_f<DPP_SHL1>(dv), dx[r])));
+                        const float xv = X[ky][r], xl = dpp_f<DPP_SHR1>(xv), xr = dpp_f<DPP_SHL1>(xv);
+                        u[r] = fmaf(w2[r], xr, fmaf(w1[r], xv, fmaf(w0[r], xl, u[r])));
+                        aw[r][ky * 3 + 0] = fmaf(dm[r], xl, aw[r][ky * 3 + 0]);
+                        aw[r][ky * 3 + 1] = fmaf(dm[r], xv, aw[r][ky * 3 + 1]);
+                        aw[r][ky * 3 + 2] = fmaf(dm[r], xr, aw[r][ky * 3 + 2]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!act) u[r] = 0.f;
+                    if constexpr (STATS) {
+                        const float gh = (act && X[1][r] > 0.f) ? dx[r] : 0.f;
+                        st1[r] += gh;
+                        st2[r] = fmaf(gh, X[1][r], st2[r]);
+                    }
+                }
+                {
+                    const unsigned opix = (unsigned)(img * H * W + c * W + col);
+                    bst16(wa, (act && qa >= 0) ? (int)(opix * pa + (unsigned)qa) : -1, dx);
+                    if constexpr (SPLIT) bst16(wb, (act && qb >= 0) ? (int)(opix * pb + (unsigned)qb) : -1, dx);
+                }
+                // ---- dWpw += dz(c) u(c)^T over the strip's 16 pixels (u is zero on the halo lanes and outside the job's rows)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tu[(c4 + r) * RS32_TP + n] = u[r];
+                {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(s_t[wave][c & 1] + n * RS32_TP + c4);  // A_t[(m = o, k)] = dz(c)[o][pixel 4 k + t] (written one tick ago)
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(tu + n * RS32_TP + c4);  // B_t[(k, n = ch)] = u[ch][pixel 4 k + t]
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) dwpw = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt], b4[tt], dwpw, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from interleaving the P unrolled rows: their temporaries would all be live at once -> spills)
+            }
+        }
+    }
+    // ---- per-workgroup partials: lanes -> wave (DPP row sums) -> LDS slot per wave -> fixed-order sum of the four waves
+    float* red = s_red[wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(c4 + r) * 16 + n] = dwpw[r];  // dWpw[o = 4 k + r][ch = n]: complete over the wave's pixels already
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = quad16_sum(aw[r][t]);
+            if (n == 0) red[256 + (c4 + r) * 9 + t] = v;
+        }
+        if constexpr (STATS) {
+            const float v1 = quad16_sum(st1[r]), v2 = quad16_sum(st2[r]);
+            if (n == 0) {
+                red[256 + 144 + c4 + r] = v1;
+                red[256 + 144 + 16 + c4 + r] = v2;
+            }
+        }
+    }
+    __syncthreads();
+    const int ne = Cout * Cin + 9 * Cin;
+    for (int e = tid; e < ne + (STATS ? 2 * Cin : 0); e += 256) {
+        int idx;
+        if (e < Cout * Cin)
+            idx = (e / Cin) * 16 + e % Cin;
+        else if (e < ne)
+            idx = 256 + (e - Cout * Cin);
+        else
+            idx = 256 + 144 + ((e - ne) / Cin) * 16 + (e - ne) % Cin;
+        const float v = (s_red[0][idx] + s_red[1][idx]) + (s_red[2][idx] + s_red[3][idx]);
+        if (e < ne)
+            A.ws[(long)blockIdx.x * ne + e] = v;
+        else if (A.bl.raw)
+            bwd_last_add(A.bl, Cin, (e - ne) % Cin, (e - ne) / Cin, v);
+    }
+    if constexpr (STATS) {
+        if (A.bl.raw) bwd_last_finish(A.bl, Cin, A.tra, A.trb, tid, 256, &s_flag);
+    }
+}
+
+namespace {
+static inline int rs32_grid(int njobs, int wg_per_cu) {
+    static const int bpc_env = env_int("OCRS_RS32_BPC", 0);
+    if (bpc_env > 0) wg_per_cu = bpc_env;
+    long g = (long)kNumCU * wg_per_cu;
+    const long need = (njobs + 3) / 4;
+    if (need < g) g = need;
+    if (g >= 8) g &= ~7L;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// zeroed fp64 scratch of the backward's last-workgroup finalisation (BwdLast): the deferral window's (ocrs_bwd_defer_begin) when one is open, else a
+// per-device buffer of this file (allocated and zeroed at first use; every launch leaves its share zeroed)
+static double* rs32_last_scratch(int ndoubles, hipStream_t st) {
+    if (double* p = bwd_defer_scratch(ndoubles)) return p;
+    static double* g_own[16] = {};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
+    constexpr int CAP = BWD_LAST_SLOTS * 2 * 16 + 2;
+    if (ndoubles > CAP) return nullptr;
+    if (!g_own[d]) {
+        double* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), CAP * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemsetAsync(p, 0, CAP * sizeof(double), st) != hipSuccess) return nullptr;
+        g_own[d] = p;
+    }
+    return g_own[d];
+}
+}  // namespace
+
+extern "C" {
+
+// 1 if ocrs_rs32_fwd runs this block shape: fp32 storage; Cin = Ca + Cb in {8, 16, 32}, a concat split only as 8 | 8 or 16 | 16; Cout in {8, 16, 32}.
+long ocrs_rs32_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
+    static const int on = env_int("OCRS_RS32", 1);
+    if (!on || dtype != 0) return 0;
+    const int Cin = Ca + Cb;
+    if (!(Cin == 8 || Cin == 16 || Cin == 32) || !(Cout == 8 || Cout == 16 || Cout == 32)) return 0;
+    if (Cb && !((Ca == 8 && Cb == 8) || (Ca == 16 && Cb == 16))) return 0;
+    return 1;
+}
+
+// DepthwiseConv block forward in fp32 (ocrs_models/models.py:11-23; channel concat of models.py:89 folded in as xa | xb), row-streaming form.
+//   xa / xb [P][Ca] / [P][Cb] fp32 NHWC; tra / trb their load transforms [3][C]; wdw [Cin][9], wpw [Cout][Cin]: the fp32 masters in the
+//   reference layout; z [P][Cout]; gstat [2][Cout] fp64 (sum z | sum z^2) ACCUMULATED (caller zeroes); gamma / pooled (nullable): also write
+//   MaxPool2d(2) (models.py:54) of the block output in its pre-BatchNorm form (see ocrs_dwpw_fwd).  counter (nullable): a zeroed device word --
+//   the launch's last workgroup finalises the BatchNorm statistics (count .. lo as ocrs_bn_finalize; ocrs_dwpw_fwd_fin's contract).
+int ocrs_rs32_fwd(const float* xa, const float* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, float* z,
+                  double* gstat, const float* gamma, float* pooled, unsigned* counter, long count, const float* bn_w, const float* bn_b, float eps,
+                  float momentum, float* tr, float* saved, float* run_mean, float* run_var, long long* nbt, float lo, int Cout, int N, int H, int W,
+                  hipStream_t st) {
+    OCRS_CHECK_ARG(ocrs_rs32_fwd_supported(Ca, Cb, Cout, 0) && xa && tra && wdw && wpw && z && gstat && (Cb == 0) == (xb == nullptr) && (Cb == 0 || trb));
+    OCRS_CHECK_ARG(N > 0 && H > 0 && W > 0 && (!pooled || gamma) && (!counter || (count > 0 && bn_w && bn_b && tr && saved)));
+    const int Cin = Ca + Cb, Cmax = Cin > Cout ? Cin : Cout;
+    OCRS_CHECK_ARG((long)N * H * W * Cmax * 4 < (1L << 32));  // 32-bit buffer offsets
+    static const int rb_env = env_int("OCRS_RS32_RB", 64);
+    const int rb = (rb_env > 1 ? rb_env : 64) & ~1;  // even: a pooling window's two rows belong to one job
+    Rs32F a{xa, xb, tra, trb, wdw, wpw, gamma, z, pooled, gstat, Ca, Cb, Cout, N, H, W, rs32_jobs(N, H, W, RS32_COLS, rb),
+            FwdFin{counter, count, bn_w, bn_b, eps, momentum, tr, saved, run_mean, run_var, nbt, lo}};
+    const int nset = Cin > 16 ? 2 : 1, mt = Cout > 16 ? 2 : 1;
+    const int grid = rs32_grid(a.jb.njobs, nset * mt == 1 ? 3 : 2);
+#define RS32F_CASE(NS_, MT_, SP_, PL_, P_)                                                                         \
+    if (nset == NS_ && mt == MT_ && (Cb != 0) == SP_ && (pooled != nullptr) == PL_) {                             \
+        OCRS_LAUNCH_T((k_rs32_fwd<NS_, MT_, SP_, PL_, P_>), dim3(grid), dim3(256), 0, st, a);                     \
+        OCRS_LAUNCH_CHECK();                                                                                      \
+        return OCRS_OK;                                                                                           \
+    }
+    RS32F_CASE(1, 1, false, false, 4) RS32F_CASE(1, 1, false, true, 4) RS32F_CASE(1, 1, true, false, 4) RS32F_CASE(1, 1, true, true, 4)
+    RS32F_CASE(1, 2, false, false, 4) RS32F_CASE(1, 2, false, true, 4) RS32F_CASE(1, 2, true, false, 4) RS32F_CASE(1, 2, true, true, 4)
+    RS32F_CASE(2, 1, false, false, 2) RS32F_CASE(2, 1, false, true, 2) RS32F_CASE(2, 1, true, false, 2) RS32F_CASE(2, 1, true, true, 2)
+    RS32F_CASE(2, 2, false, false, 2) RS32F_CASE(2, 2, false, true, 2) RS32F_CASE(2, 2, true, false, 2) RS32F_CASE(2, 2, true, true, 2)
+#undef RS32F_CASE
+    return OCRS_ERR_ARG;
+}
+
+// 1 if ocrs_rs32_bwd runs this block shape: fp32 storage, direct (not max-pooled) gradient source, Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}
+long ocrs_rs32_bwd_supported(int Ca, int Cb, int Cout, int pooled, int dtype) {
+    static const int on = env_int("OCRS_RS32", 1), onb = env_int("OCRS_RS32_BWD", 1);
+    if (!on || !onb || dtype != 0 || pooled) return 0;
+    const int Cin = Ca + Cb;
+    if (!(Cin == 8 || Cin == 16) || !(Cout == 8 || Cout == 16)) return 0;
+    if (Cb && !(Ca == 8 && Cb == 8)) return 0;
+    return 1;
+}
+static int rs32_bwd_rb() {
+    static const int rb_env = env_int("OCRS_RS32_RB", 64);
+    return (rb_env > 1 ? rb_env : 64) & ~1;
+}
+long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
+    const int Cin = Ca + Cb;
+    const Rs32Jobs jb = rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb());
+    return (long)rs32_grid(jb.njobs, 2) * (Cout * Cin + 9 * Cin);
+}
+
+// Backward of one DepthwiseConv block in fp32 as ONE row-streaming pass (replaces ocrs_bn_bwd_finalize + ocrs_pw_bwd + ocrs_dw_bwd; the reference's
+// autograd of models.py:11-23): xa | xb with load transforms tra | trb: the block input; wdw [Cin][9], wpw [Cout][Cin]: fp32 masters; g1 (+ g2,
+// nullable): dL/d(block output) at full resolution; z, bn: the block's stored pre-BatchNorm output and its load transform [3][Cout]; gsum [2][Cout]
+// fp64: the block's COMPLETE BatchNorm-backward sums (sum ghat | sum ghat zhat), gamma, saved [mean | rstd] -> the dz coefficients are derived in
+// the prologue, dgamma / dbeta are written; gxa | gxb: dL/dx~; dwpw / dwdw: ACCUMULATED through ws (ocrs_rs32_bwd_ws_floats() floats, alive until the
+// second stage ran: ocrs_bwd_defer_flush when a deferral window is open); saved_a / gsum_a, saved_b / gsum_b (nullable): as ocrs_dw_bwd.
+int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const float* g1,
+                  const float* g2, const float* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta,
+                  float* gxa, float* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
+                  int Cout, int N, int H, int W, hipStream_t st) {
+    OCRS_CHECK_ARG(ocrs_rs32_bwd_supported(Ca, Cb, Cout, 0, 0) && xa && tra && wdw && wpw && g1 && z && bn && gsum && gamma && saved && dgamma && dbeta);
+    OCRS_CHECK_ARG(gxa && dwpw && dwdw && ws && (Cb == 0) == (xb == nullptr) && (Cb == 0 || (trb && gxb)) && N > 0 && H > 0 && W > 0);
+    OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
+    const int Cin = Ca + Cb, Cmax = Cin > Cout ? Cin : Cout;
+    OCRS_CHECK_ARG((long)N * H * W * Cmax * 4 < (1L << 32));
+    const bool stats = gsum_a || gsum_b;
+    BwdLast bl{nullptr, nullptr, gsum_a, gsum_b, saved_a, saved_b, Ca, 0};
+    if (stats) {
+        double* p = rs32_last_scratch(BWD_LAST_SLOTS * 2 * Cin + 2, st);
+        if (!p) return OCRS_ERR_HIP;
+        bl.raw = p;
+        bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
+    }
+    Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W, rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()),
+            BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl};
+    const int grid = rs32_grid(a.jb.njobs, 2);
+#define RS32B_CASE(SP_, G2_, ST_)                                                                      \
+    if ((Cb != 0) == SP_ && (g2 != nullptr) == G2_ && stats == ST_) {                                 \
+        OCRS_LAUNCH_T((k_rs32_bwd<SP_, G2_, ST_, 1>), dim3(grid), dim3(256), 0, st, a);               \
+        OCRS_LAUNCH_CHECK();                                                                          \
+    }
+    RS32B_CASE(false, false, false) RS32B_CASE(false, false, true) RS32B_CASE(false, true, false) RS32B_CASE(false, true, true)
+    RS32B_CASE(true, false, false) RS32B_CASE(true, false, true) RS32B_CASE(true, true, false) RS32B_CASE(true, true, true)
+#undef RS32B_CASE
+    bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, Cin, dwdw, 9 * Cin, st);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
+}
+
+}  // extern "C"

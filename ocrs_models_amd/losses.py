@@ -22,7 +22,8 @@ from ._lib import lib, ptr
 # retain pred's gradient (pred.retain_grad() would record the marker).  The deferral happens only when pred is the direct output of
 # ocrs_models_amd.DetectionModel.  A plain module global, not a thread-local: backward runs on autograd's device thread.
 _FUSE = {"on": False}
-_PENDING = {}  # device index -> (pred, target, lpx, cls, state, gout)
+_PENDING = {}  # (device index, pred.data_ptr()) -> (pred, target, lpx, cls, state, gout): parked per prediction tensor, so that several forwards
+               # whose losses are built in any order inside one backward each get their own gradient
 _ZERO = {}     # device index -> fp32 [1] zero, never written
 
 
@@ -32,7 +33,14 @@ def fused_head_backward():
     prev, _FUSE["on"] = _FUSE["on"], True
     try:
         yield
-    finally:
+    except BaseException:
+        # an error between the loss's backward and the network's (an OOM, a version-counter check ...): drop what was parked and let the REAL
+        # error propagate instead of replacing it with "never consumed"
+        _FUSE["on"] = prev
+        if not prev:
+            _PENDING.clear()
+        raise
+    else:
         _FUSE["on"] = prev
         if not prev and _PENDING:
             _PENDING.clear()
@@ -46,14 +54,19 @@ def _zero_marker(dev):
     return z
 
 
-def take_deferred(gpred: torch.Tensor):
-    """For models._DetRun.backward: (saved, is_marker).  saved = the parked (pred, target, lpx, cls, state, gout) of this device or None;
-    is_marker = `gpred` is the untouched marker (no other gradient was accumulated into it)."""
-    saved = _PENDING.pop(gpred.device.index, None)
-    if saved is None:
-        return None, False
+def take_deferred(gpred: torch.Tensor, pred: torch.Tensor):
+    """For models._DetRun.backward: (saved, is_marker).  saved = the (pred, target, lpx, cls, state, gout) parked FOR THIS RUN'S `pred` (matched by
+    identity: another forward's parked gradient stays where it is) or None; is_marker = `gpred` is the untouched marker (no other gradient was
+    accumulated into it).  The marker with nothing parked for this pred is an error, never a zero gradient."""
     z = _ZERO.get(gpred.device.index)
-    return saved, (z is not None and gpred.data_ptr() == z.data_ptr() and all(s == 0 for s in gpred.stride()))
+    is_marker = z is not None and gpred.data_ptr() == z.data_ptr() and all(s == 0 for s in gpred.stride())
+    saved = _PENDING.pop((gpred.device.index, pred.data_ptr()), None)
+    if saved is None:
+        if is_marker:
+            raise RuntimeError("fused_head_backward(): the network's backward received the deferred-gradient marker but no loss gradient is parked "
+                               "for its prediction tensor")
+        return None, False
+    return saved, is_marker
 
 
 def materialize_deferred(saved) -> torch.Tensor:
@@ -85,8 +98,9 @@ class _BalancedBCE(torch.autograd.Function):
     def backward(ctx, gout):
         pred, target, lpx, cls, state = ctx.saved_tensors
         g = gout.contiguous().float().reshape(1)
-        if _FUSE["on"] and ctx.from_det and pred.device.index not in _PENDING:
-            _PENDING[pred.device.index] = (pred, target, lpx, cls, state, g)
+        key = (pred.device.index, pred.data_ptr())
+        if _FUSE["on"] and ctx.from_det and key not in _PENDING:
+            _PENDING[key] = (pred, target, lpx, cls, state, g)
             return _zero_marker(pred.device).expand(pred.shape), None
         gpred = torch.empty_like(pred)
         lib().balanced_bce_bwd(ptr(pred), ptr(target), ptr(lpx), ptr(cls), ptr(state), ptr(g), ptr(gpred), pred.numel())

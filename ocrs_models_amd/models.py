@@ -125,6 +125,7 @@ class _DetRun:
         self.c1_noz = os.environ.get("OCRS_C1_NOZ", "1") != "0"  # ... and does not store its 8-channel output at all when every consumer takes the u plane
         self.c1_fuse = os.environ.get("OCRS_C1_FUSE", "1") != "0"  # the first block's weight gradient from sums accumulated by in_conv.seq.1's backward (no dL/dx~ store, no k_c1_bwd2 pass)
         self.c1_u = os.environ.get("OCRS_C1_U", "1") != "0"  # the first block also writes its 2-byte-per-pixel u plane (read by in_conv.seq.1's backward instead of z)
+        self.use_rs32 = os.environ.get("OCRS_RS32", "1") != "0"  # fp32: the wide-level blocks as row-streaming waves (csrc/det_rs32.hip, round 6)
         self.head_gl = os.environ.get("OCRS_HEAD_GL", "1") != "0"  # out_conv's backward hands the last block gl (4 B / pixel) instead of its 8-channel gradient  # BatchNorm statistics finalised inside the matrix-core forward launch
         self.pooled_by_block = None
         self.x = x
@@ -149,6 +150,10 @@ class _DetRun:
         pool = getattr(self, "_zpool", None)
         n8 = (n + 7) // 8 * 8
         if pool is None or self._zoff + n8 > pool.numel():
+            if pool is not None and getattr(self, "_folds", None) and self.overlap:
+                # pool overflow in the middle of a backward (latent with the default net: ~6.6 k of the 8192 doubles): a queued fold may name a
+                # ConvTranspose bias accumulator that convt_bwd_parts(..., 2) is still writing on the side stream -- join it before folding
+                torch.cuda.current_stream().wait_stream(_side_stream(self.dev))
             self.fold_flush()  # (deferred folds name offsets in the pool they were carved from)
             pool = self._zpool = torch.zeros(max(8192, n8), dtype=torch.float64, device=self.dev)
             self._zoff = 0
@@ -280,6 +285,28 @@ class _DetRun:
                          ptr(z), ptr(parts), ptr(gamma), ptr(pooled), Cout, N, H, W, self.dt)
                 tr, saved = self.bn_tr(bnp, parts, N * H * W, Cout, nparts=nparts)
             r = _BlockRec()
+            r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
+            self.recs[prefix] = r
+            return _Act(z, tr, Cout, H, W, src=prefix)
+        if self.use_rs32 and L.rs32_fwd_supported(a.C, Cb, Cout, self.dt):
+            # fp32 (parity mode), wide levels: register-resident row-streaming waves (csrc/det_rs32.hip) -- no LDS tile, exact-fp32 matrix cores
+            pooled = gamma = None
+            if pool and self.fuse_pool:
+                pooled, gamma = self.empty(N, H // 2, W // 2, Cout), P[f"{prefix}.seq.2.weight"]
+            self.pooled_by_block = pooled
+            gstat = self.zeros64(2 * Cout)
+            bnp, Bf = f"{prefix}.seq.2", self.Bf
+            common = (ptr(a.t), ptr(b.t) if b is not None else None, a.C, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw), ptr(z),
+                      ptr(gstat), ptr(gamma), ptr(pooled))
+            if self.train and self.fold_fwd_fin:
+                tr, saved = self.empty(3, Cout, dtype=torch.float32), self.empty(2, Cout, dtype=torch.float32)
+                L.rs32_fwd(*common, ptr(self.zeros64(1)), N * H * W, ptr(P[f"{bnp}.weight"]), ptr(P[f"{bnp}.bias"]), 1e-5, 0.1, ptr(tr), ptr(saved),
+                           ptr(Bf[f"{bnp}.running_mean"]), ptr(Bf[f"{bnp}.running_var"]), ptr(Bf[f"{bnp}.num_batches_tracked"]), 0.0, Cout, N, H, W)
+            else:
+                L.rs32_fwd(*common, None, 0, None, None, 0.0, 0.0, None, None, None, None, None, 0.0, Cout, N, H, W)
+                tr, saved = self.bn_tr(bnp, gstat, N * H * W, Cout)
+            r = _BlockRec()
+            r.fsum = None
             r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
             self.recs[prefix] = r
             return _Act(z, tr, Cout, H, W, src=prefix)
@@ -475,6 +502,19 @@ class _DetRun:
                          ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
                          ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
             return gxa, gxb
+        if self.use_rs32 and need_gx and L.rs32_bwd_supported(Ca, Cb, C, 1 if pooled else 0, self.dt):
+            # fp32 (parity mode), wide levels: the whole block backward as ONE row-streaming pass (csrc/det_rs32.hip) -- dz coefficients derived in the
+            # prologue, `du` never stored, both weight gradients and the producers' BatchNorm-backward sums from the same registers
+            gxa = self.empty(N, H, W, Ca)
+            gxb = self.empty(N, H, W, Cb) if b is not None else None
+            sva, gsa = stat_target(a)
+            svb, gsb = stat_target(b)
+            ws = self.empty(L.rs32_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
+            self._hold(ws)  # (its reduction may be queued until the end of the backward)
+            L.rs32_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw), ptr(g1),
+                       ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(gxb),
+                       ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W)
+            return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
         self._hold(ws)  # (its reduction may be queued until the end of the backward)
@@ -555,7 +595,7 @@ class _DetRun:
                 pending.clear()
                 keep.clear()
         from . import losses as _losses
-        deferred, is_marker = _losses.take_deferred(gpred)  # (losses.fused_head_backward: the loss's backward parked its gradient)
+        deferred, is_marker = _losses.take_deferred(gpred, self.pred)  # (losses.fused_head_backward: the loss's backward parked its gradient)
         if deferred is not None and not is_marker:
             gpred = gpred + _losses.materialize_deferred(deferred)  # pred had another consumer: autograd handed us `other + 0`
             deferred = None

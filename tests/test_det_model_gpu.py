@@ -330,3 +330,50 @@ def test_fused_loss_head_backward_matches_separate_launches(dev, shape):
         assert cos > 0.999, (tag, cos)
     # a deferred gradient that no DetectionModel backward consumes is an error, not a silent zero
     assert not losses._PENDING
+
+
+@pytest.mark.gpu
+def test_fused_head_backward_two_forwards_losses_built_in_reverse_order():
+    """p1 = m(x1); p2 = m(x2); l2 = bce(p2); l1 = bce(p1); (l1 + l2).backward() inside fused_head_backward().  Each network backward must
+    consume the gradient parked for ITS prediction (matched by identity), whatever order the loss nodes and network nodes run in: the parameter
+    gradients equal the plain (unfused) backward of the same graph; nothing stays parked; an error inside the context is not masked."""
+    import ocrs_models_amd as oa
+    from ocrs_models_amd import losses
+
+    dev = torch.device("cuda:0")
+    r = np.random.RandomState(11)
+    B, H, W = 2, 64, 96
+    xs = [torch.from_numpy(r.uniform(-0.5, 0.5, (B, 1, H, W)).astype(np.float32)).to(dev) for _ in range(2)]
+    ms = [torch.from_numpy((r.uniform(0, 1, (B, 1, H, W)) > 0.85).astype(np.float32)).to(dev) for _ in range(2)]
+
+    def grads(fused):
+        m = _load(oa.DetectionModel(), 3).to(dev)  # fp32: the two paths are the same arithmetic up to summation order
+        m.train()
+        p1, p2 = m(xs[0]), m(xs[1])
+        l2 = oa.balanced_cross_entropy_loss(p2, ms[1])
+        l1 = oa.balanced_cross_entropy_loss(p1, ms[0])
+        loss = l1 + 2.0 * l2
+        if fused:
+            with losses.fused_head_backward():
+                loss.backward()
+        else:
+            loss.backward()
+        return {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+
+    g0, g1 = grads(False), grads(True)
+    assert not losses._PENDING
+    fa, fb = torch.cat([v.reshape(-1) for v in g0.values()]), torch.cat([v.reshape(-1) for v in g1.values()])
+    assert float((fa - fb).norm()) <= 1e-4 * float(fa.norm()), float((fa - fb).norm() / fa.norm())
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= 1e-3 * float(g0[k].norm()) + 1e-5 * float(fa.norm()), k
+
+    # an exception raised inside the context propagates as itself (not as "never consumed") and leaves nothing parked
+    m = _load(oa.DetectionModel(), 3).to(dev)
+    m.train()
+    p = m(xs[0])
+    l = oa.balanced_cross_entropy_loss(p, ms[0])
+    with pytest.raises(ZeroDivisionError):
+        with losses.fused_head_backward():
+            torch.autograd.grad(l, p)  # parks the gradient (no network backward consumes it) ...
+            1 / 0                      # ... and then something else fails
+    assert not losses._PENDING

@@ -102,12 +102,13 @@ def test_conv0_fused(dev, dtype, shape):
     r = _run(dev, dtype, N, H, W)
     out = r.empty(N, H // 2, W // 2, 32)
     r.L.conv0_fwd(ptr(img), ptr(w), ptr(b), ptr(out), N, H, W, r.dt)
-    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    ref = F.max_pool2d(torch.relu(F.conv2d(img, wr, br, padding=1)), 2)
+    # (the torch reference runs on the CPU: the comparand of a parity test is not a third-party GPU kernel)
+    wr, br = w.detach().cpu().clone().requires_grad_(True), b.detach().cpu().clone().requires_grad_(True)
+    ref = F.max_pool2d(torch.relu(F.conv2d(img.cpu(), wr, br, padding=1)), 2)
     tol = TOL[dtype]
     assert rel(nchw(out), ref) < tol
     gy = nhwc(torch.randn(N, 32, H // 2, W // 2, generator=g).to(dev), dtype)
-    ref.backward(nchw(gy))
+    ref.backward(nchw(gy).cpu())
     dW, db = torch.zeros_like(w), torch.zeros_like(b)
     r.L.conv0_bwd(ptr(img), ptr(w), ptr(b), ptr(gy), ptr(dW), ptr(db), N, H, W, r.dt)
     torch.cuda.synchronize()
@@ -324,13 +325,13 @@ def test_bn_relu_pool_forward_and_backward_pieces(dev, dtype, N, H, W, C, PH, PW
     out = torch.empty(N, Hp, Wp, C, dtype=dtype, device=dev)
     if PH * PW > 1:
         L.act_pool_fwd(ptr(z), ptr(tr), ptr(out), C, N, H, W, PH, PW, dt)
-    zr = nchw(z).requires_grad_(True)
-    y = F.max_pool2d(torch.relu(zr * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)), (PH, PW))
+    zr = nchw(z).cpu().requires_grad_(True)  # (torch reference on the CPU)
+    y = F.max_pool2d(torch.relu(zr * sc.cpu().view(1, C, 1, 1) + sh.cpu().view(1, C, 1, 1)), (PH, PW))
     if PH * PW > 1:
         assert rel(nchw(out), y) < TOL[dtype]
     gy = nhwc(torch.randn(N, C, Hp, Wp, generator=g).to(dev), dtype)
-    y.backward(nchw(gy))
-    ghat = zr.grad / sc.view(1, C, 1, 1)  # the pooled gradient routed to each window's first maximum, through the ReLU
+    y.backward(nchw(gy).cpu())
+    ghat = (zr.grad / sc.cpu().view(1, C, 1, 1)).to(dev)  # the pooled gradient routed to each window's first maximum, through the ReLU
     mean, rstd = (0.1 * torch.randn(C, generator=g)).to(dev), (0.5 + torch.rand(C, generator=g)).to(dev)
     saved = torch.stack([mean, rstd]).contiguous()
     gsum = torch.zeros(2 * C, dtype=torch.float64, device=dev)
