@@ -65,7 +65,8 @@ int ocrs_rs32_fwd(const float* xa, const float* xb, int Ca, int Cb, const float*
                   hipStream_t st);
 /* Backward of the same block in fp32 as ONE row-streaming pass (csrc/det_rs32.hip; the autograd of models.py:11-23 as train_detection.py:96 runs it):
  * replaces ocrs_bn_bwd_finalize + ocrs_pw_bwd + ocrs_dw_bwd -- per pixel g (+ g2), z and x are read once and dL/dx~ is written once, the depthwise-input
- * gradient `du` never goes to memory.  Direct (not max-pooled) gradient source; Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}.
+ * gradient `du` never goes to memory.  Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}.
+ * pooled = 1 (single source only): g1 / g2 are at half resolution and routed through MaxPool2d(2) (models.py:54) to each window's first maximum.
  * gsum [2][Cout] fp64: the block's COMPLETE BatchNorm-backward sums (the dz coefficients are derived in the prologue; dgamma / dbeta are written);
  * bn: the block's load transform [3][Cout]; dwpw / dwdw ACCUMULATED through ws (ocrs_rs32_bwd_ws_floats() floats; alive until ocrs_bwd_defer_flush
  * when a deferral window is open); saved_a / gsum_a, saved_b / gsum_b (nullable): as ocrs_dw_bwd. */
@@ -74,7 +75,7 @@ long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W);
 int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const float* g1,
                   const float* g2, const float* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta,
                   float* gxa, float* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
-                  int Cout, int N, int H, int W, hipStream_t st);
+                  int pooled, int Cout, int N, int H, int W, hipStream_t st);
 /* The same block forward on the matrix cores (csrc/det_mm.hip; bf16, Cin and Cout in {8, 16, 32} and the 32 | 32 concat): depthwise and
  * pointwise conv composed into one 3x3 implicit GEMM (effective weight Wpw[o][c] * Wdw[c][tap] built from the fp32 masters wdw [Cin][9],
  * wpw [Cout][Cin]).  The batch statistics go to ws as ocrs_mm_fwd_nparts() per-block partials [Cout][sum z | sum z^2] (fp32) that

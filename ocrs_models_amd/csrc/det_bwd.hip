@@ -1747,10 +1747,16 @@ static int convt_wgrad_tr_grid(int Cout, int N, int h, int w) {
     // (5-37 KB) that the reduce kernel reads back
     return persistent_grid((long)N * ((w + 15) / 16) * ((h + TH - 1) / TH), Cout >= 16 ? 2 : 3);
 }
+// det_rs32.hip: the fp32 weight / bias gradient of the wide levels as row-streaming waves (round 6)
+long det_rs32_ctw_supported(int Cup, int Cout, int dtype);
+long det_rs32_ctw_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype);
+int det_rs32_ctw_launch(const float* x, const float* tr, const float* g, float* dW, float* dbias, float* ws, int Cup, int Cout, int N, int h, int w, int H,
+                        int W, hipStream_t st);
 long ocrs_convt_bwd_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
     const long a = ocrs_wgrad_gather_ws_floats(Cup, Cout, 9, (long)N * h * w, dtype);
     const long b = convt_wgrad_tr_ok(Cup, Cout, dtype) ? (long)convt_wgrad_tr_grid(Cout, N, h, w) * (Cup * ((9 * Cout + 15) / 16 * 16) + Cout + 2 * Cup) : 0;
-    return a > b ? a : b;
+    const long c = det_rs32_ctw_ws_floats(Cup, Cout, N, h, w, dtype);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 // 1 if ocrs_convt_bwd can also produce the BatchNorm-backward sums of the block that produced x (saved / gsum arguments)
@@ -1840,6 +1846,8 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
     OCRS_LAUNCH_CHECK();
     }
     if (!(parts & 2)) return OCRS_OK;
+    if (ws && det_rs32_ctw_supported(Cup, Cout, dtype))  // fp32, wide levels: weight AND bias gradient (into dbias; dbias64 stays as the caller zeroed it)
+        return det_rs32_ctw_launch((const float*)x, tr, (const float*)g, dW, dbias, ws, Cup, Cout, N, h, w, H, W, st);
     {
         const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);
         if (rc != OCRS_OK) return rc;

@@ -282,10 +282,16 @@ constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of 
 
 // P = 1: the next row's loads are issued the moment this row's have been consumed and have the whole row's arithmetic (~1 us at two waves per SIMD)
 // to arrive; unrolling two rows (P = 2) costs ~100 registers (256 + spills) for nothing.
-template <bool SPLIT, bool G2, bool STATS, int P>
+// DUAL (Cin, Cout <= 8, single source): an 8-channel tensor fills only the lane groups q = 0, 1 -- the other half of every VALU instruction would idle
+// (the kernel is VALU-issue bound: ~450 instructions per strip row).  The wave then runs TWO strips side by side, strip q >> 1 in lane groups (2 s,
+// 2 s + 1): every per-channel instruction serves 28 columns, and ONE set of four MFMAs still yields du of both strips in place because the weight
+// fragment is block-diagonal over (strip, channel): A_r[(m, k)] = [m >> 3 == k >> 1] Wpw[4 (k & 1) + r][m & 7]  ->  D rows 0-7 = strip 0, 8-15 = strip 1.
+template <bool SPLIT, bool G2, bool STATS, int P, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
+    static_assert(!(DUAL && SPLIT), "two strips per wave: single-source 8-channel blocks only");
+    constexpr int TP2 = DUAL ? 36 : RS32_TP;  // pitch of a transpose row: 16 (or 2 x 16) pixels + pad
     __shared__ float s_cf[3 * 16];
-    __shared__ __attribute__((aligned(16))) float s_t[4][3][16 * RS32_TP];  // per wave: dz^T of rows yy (slot yy & 1) and yy - 1 | u^T
+    __shared__ __attribute__((aligned(16))) float s_t[4][3][16 * TP2];  // per wave: dz^T of rows yy (slot yy & 1) and yy - 1 | u^T
     __shared__ float s_red[4][16 * 16 + 9 * 16 + 2 * 16];                   // per wave: dWpw | dWdw | S1 | S2
     // per-channel constants, [row][16 channels]: a lane reads its quad of a row as ONE ds_read_b128 per use instead of holding 36 + 36 registers for the
     // whole launch (at 256 registers the kernel spilled 23 .. 190 of them).  s_w: the 9 depthwise taps; s_k: 0 A, 1 B, 2 C (dz coefficients), 3 / 4 scale /
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
     bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    for (int i = tid; i < 4 * 3 * 16 * TP2; i += 256) (&s_t[0][0][0])[i] = 0.f;  // (DUAL: the transpose rows 8 .. 15 are never written and must read 0)
     __syncthreads();
     if (tid < 16) {
         const int c = tid;
@@ -319,11 +326,15 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
     __syncthreads();
 
     // ---- per-lane constants: output-channel quad 4 q .. 4 q + 3 (g, z, dz) and input-channel quad 4 q .. 4 q + 3 (x, du, dx)
-    const int c4 = 4 * q;
+    const int sB = DUAL ? (q >> 1) : 0;             // the lane's strip
+    const int c4 = DUAL ? 4 * (q & 1) : 4 * q;      // the lane's channel quad
     const bool okO = c4 < Cout, okI = c4 < Cin, in_a = c4 < Ca;
     float afd[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) afd[r] = (c4 + r < Cout && n < Cin) ? A.wpw[(c4 + r) * Cin + n] : 0.f;  // A_r[(m = input channel, k)] = Wpw[4 k + r][m]
+    for (int r = 0; r < 4; ++r) {  // A_r[(m = input channel, k)] = Wpw[4 k + r][m]  (DUAL: block-diagonal over the two strips)
+        const int mc = DUAL ? (n & 7) : n;
+        afd[r] = (c4 + r < Cout && mc < Cin && (!DUAL || (n >> 3) == sB)) ? A.wpw[(c4 + r) * Cin + mc] : 0.f;
+    }
     const unsigned npix = (unsigned)A.N * H * W;
     const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
     const rsrc_t rg1 = mk_rsrc(A.g1, npix * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, npix * Cout * 4), rz = mk_rsrc(A.z, npix * Cout * 4);
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
     for (int job = sched.first; job < sched.end; job += sched.step) {
         const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
         const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < H) ? y0 + A.jb.rb : H;
-        const int col = cg * RS32_COLS + n - 1;
+        const int col = cg * (DUAL ? 2 * RS32_COLS : RS32_COLS) + sB * RS32_COLS + n - 1;
         const bool colok = (unsigned)col < (unsigned)W;
         const bool useful = n >= 1 && n <= RS32_COLS && col < W;
         const int rowpix0 = img * H * W + col;
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
                     f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        tzw[(c4 + r) * RS32_TP + n] = dzc[r];
+                        tzw[(c4 + r) * TP2 + sB * 16 + n] = dzc[r];
                         d = __builtin_amdgcn_mfma_f32_16x16x4f32(afd[r], dzc[r], d, 0, 0, 0);
                     }
 #pragma unroll
@@ -458,10 +469,11 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
                 }
                 // ---- dWpw += dz(c) u(c)^T over the strip's 16 pixels (u is zero on the halo lanes and outside the job's rows)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tu[(c4 + r) * RS32_TP + n] = u[r];
-                {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(s_t[wave][c & 1] + n * RS32_TP + c4);  // A_t[(m = o, k)] = dz(c)[o][pixel 4 k + t] (written one tick ago)
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(tu + n * RS32_TP + c4);  // B_t[(k, n = ch)] = u[ch][pixel 4 k + t]
+                for (int r = 0; r < 4; ++r) tu[(c4 + r) * TP2 + sB * 16 + n] = u[r];
+#pragma unroll
+                for (int sp = 0; sp < (DUAL ? 2 : 1); ++sp) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(s_t[wave][c & 1] + n * TP2 + sp * 16 + 4 * q);  // A_t[(m = o, k)] = dz(c)[o][pixel 4 k + t] (written one tick ago)
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(tu + n * TP2 + sp * 16 + 4 * q);  // B_t[(k, n = ch)] = u[ch][pixel 4 k + t]
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) dwpw = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt], b4[tt], dwpw, 0, 0, 0);
                 }
@@ -473,17 +485,18 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
     float* red = s_red[wave];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        red[(c4 + r) * 16 + n] = dwpw[r];  // dWpw[o = 4 k + r][ch = n]: complete over the wave's pixels already
+        red[(4 * q + r) * 16 + n] = dwpw[r];  // dWpw[o = 4 k + r][ch = n]: complete over the wave's pixels already
+        // (DUAL: rows 4 q + r >= 8 of the per-channel sums are the second strip's partials of channel 4 (q & 1) + r: added below)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float v = quad16_sum(aw[r][t]);
-            if (n == 0) red[256 + (c4 + r) * 9 + t] = v;
+            if (n == 0) red[256 + (4 * q + r) * 9 + t] = v;
         }
         if constexpr (STATS) {
             const float v1 = quad16_sum(st1[r]), v2 = quad16_sum(st2[r]);
             if (n == 0) {
-                red[256 + 144 + c4 + r] = v1;
-                red[256 + 144 + 16 + c4 + r] = v2;
+                red[256 + 144 + 4 * q + r] = v1;
+                red[256 + 144 + 16 + 4 * q + r] = v2;
             }
         }
     }
@@ -497,7 +510,11 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
             idx = 256 + (e - Cout * Cin);
         else
             idx = 256 + 144 + ((e - ne) / Cin) * 16 + (e - ne) % Cin;
-        const float v = (s_red[0][idx] + s_red[1][idx]) + (s_red[2][idx] + s_red[3][idx]);
+        float v = (s_red[0][idx] + s_red[1][idx]) + (s_red[2][idx] + s_red[3][idx]);
+        if (DUAL && e >= Cout * Cin) {
+            const int i2 = idx + (e < ne ? 72 : 8);
+            v += (s_red[0][i2] + s_red[1][i2]) + (s_red[2][i2] + s_red[3][i2]);
+        }
         if (e < ne)
             A.ws[(long)blockIdx.x * ne + e] = v;
         else if (A.bl.raw)
@@ -505,6 +522,383 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
     }
     if constexpr (STATS) {
         if (A.bl.raw) bwd_last_finish(A.bl, Cin, A.tra, A.trb, tid, 256, &s_flag);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The same one-pass backward for a block whose output feeds ONLY MaxPool2d(2) (models.py:54): the gradient g (+ g2) arrives at half resolution and is
+// routed to each 2 x 2 window's first maximum in post-ReLU space (row-major order, strict >: ocrs_bn_bwd_reduce's / ocrs_pw_bwd's rule).  A tick is a
+// ROW PAIR (2 i, 2 i + 1) = one row of windows; a window's two columns are adjacent lanes (quad_perm [1,0,3,2]), so a strip needs TWO halo columns
+// each side (12 output columns of 16 lanes) and a job two halo rows each side.  Rings hold rows 2 i - 2 .. 2 i + 1; the centre rows of a tick are
+// 2 i - 1 and 2 i.  Single source, Cin, Cout <= 16.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int RS32P_COLS = 12;
+
+struct Rs32Acc {
+    float aw[4][9];
+    f32x4 dwpw;
+    float st1[4], st2[4];
+};
+// centre row from the three ring rows around it: dx~, u (zeroed unless act), dWdw and the producers' sums accumulated
+template <bool STATS>
+__device__ __forceinline__ void rs32_centre(const float (&Xm)[4], const float (&X0)[4], const float (&Xp)[4], const float (&Dm)[4], const float (&D0)[4],
+                                            const float (&Dp)[4], const float* kw, bool act, f32x4& dx, float (&u)[4], Rs32Acc& acc) {
+    float dm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dm[r] = act ? D0[r] : 0.f;
+        dx[r] = 0.f;
+        u[r] = 0.f;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 0) * 16), w1 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 1) * 16),
+                    w2 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 2) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dv = ky == 0 ? Dp[r] : (ky == 1 ? D0[r] : Dm[r]);  // dx~(c) = sum w[ky][kx] du(c + 1 - ky, col + 1 - kx)
+            dx[r] = fmaf(w2[r], dpp_f<DPP_SHR1>(dv), fmaf(w1[r], dv, fmaf(w0[r], dpp_f<DPP_SHL1>(dv), dx[r])));
+            const float xv = ky == 0 ? Xm[r] : (ky == 1 ? X0[r] : Xp[r]);  // u(c) = sum w[ky][kx] x~(c + ky - 1, col + kx - 1)
+            const float xl = dpp_f<DPP_SHR1>(xv), xr = dpp_f<DPP_SHL1>(xv);
+            u[r] = fmaf(w2[r], xr, fmaf(w1[r], xv, fmaf(w0[r], xl, u[r])));
+            acc.aw[r][ky * 3 + 0] = fmaf(dm[r], xl, acc.aw[r][ky * 3 + 0]);
+            acc.aw[r][ky * 3 + 1] = fmaf(dm[r], xv, acc.aw[r][ky * 3 + 1]);
+            acc.aw[r][ky * 3 + 2] = fmaf(dm[r], xr, acc.aw[r][ky * 3 + 2]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!act) u[r] = 0.f;
+        if constexpr (STATS) {
+            const float gh = (act && X0[r] > 0.f) ? dx[r] : 0.f;
+            acc.st1[r] += gh;
+            acc.st2[r] = fmaf(gh, X0[r], acc.st2[r]);
+        }
+    }
+}
+
+template <bool G2, bool STATS>
+__global__ __launch_bounds__(256, 2) void k_rs32_bwdp(const Rs32B A) {
+    __shared__ float s_cf[3 * 16];
+    __shared__ __attribute__((aligned(16))) float s_t[4][5][16 * RS32_TP];  // per wave: dz^T of rows (row & 3) | u^T
+    __shared__ float s_red[4][16 * 16 + 9 * 16 + 2 * 16];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 16];
+    __shared__ __attribute__((aligned(16))) float s_k[8 * 16];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = A.Ca, Cout = A.Cout, H = A.H, W = A.W, Hp = H >> 1, Wp = W >> 1;
+    bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    __syncthreads();
+    if (tid < 16) {
+        const int c = tid;
+        const bool o = c < Cout, i = c < Cin;
+        s_k[0 * 16 + c] = o ? s_cf[c] : 0.f;
+        s_k[1 * 16 + c] = o ? s_cf[Cout + c] : 0.f;
+        s_k[2 * 16 + c] = o ? s_cf[2 * Cout + c] : 0.f;
+        s_k[3 * 16 + c] = o ? A.bn[c] : 0.f;
+        s_k[4 * 16 + c] = o ? A.bn[Cout + c] : 0.f;
+        s_k[5 * 16 + c] = i ? A.tra[c] : 0.f;
+        s_k[6 * 16 + c] = i ? A.tra[Cin + c] : 0.f;
+        s_k[7 * 16 + c] = i ? A.tra[2 * Cin + c] : 0.f;
+        for (int t = 0; t < 9; ++t) s_w[t * 16 + c] = i ? A.wdw[c * 9 + t] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = 4 * q;
+    const bool okO = c4 < Cout, okI = c4 < Cin;
+    float afd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) afd[r] = (c4 + r < Cout && n < Cin) ? A.wpw[(c4 + r) * Cin + n] : 0.f;
+    const unsigned npix = (unsigned)A.N * H * W, nppx = (unsigned)A.N * Hp * Wp;
+    const rsrc_t ra = mk_rsrc(A.xa, npix * Cin * 4), rz = mk_rsrc(A.z, npix * Cout * 4), wa = mk_rsrc(A.gxa, npix * Cin * 4);
+    const rsrc_t rg1 = mk_rsrc(A.g1, nppx * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, nppx * Cout * 4);
+    const unsigned pa = Cin * 4, po = Cout * 4;
+    const int e = n & 1;  // column parity inside the window (a strip starts at an even column)
+
+    Rs32Acc acc;
+    acc.dwpw = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc.st1[r] = acc.st2[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc.aw[r][t] = 0.f;
+    }
+    float* tu = s_t[wave][4];
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < H) ? y0 + A.jb.rb : H;
+        const int col = cg * RS32P_COLS + n - 2;
+        const bool colok = (unsigned)col < (unsigned)W;
+        const bool useful = n >= 2 && n < 2 + RS32P_COLS && col < W;
+        const int i0 = (y0 >> 1) - 1, i1 = y1 >> 1;  // ticks (row pairs) i0 .. i1
+
+        f32x4 pz0, pz1, px0, px1, pg, pg2;
+        auto issue = [&](int i) {
+            const bool live = i <= i1;
+            const int ya = 2 * i, yb = 2 * i + 1;
+            const bool oka = live && colok && (unsigned)ya < (unsigned)H, okb = live && colok && (unsigned)yb < (unsigned)H;
+            const unsigned pixa = (unsigned)((img * H + ya) * W + col), pixb = pixa + (unsigned)W;
+            pz0 = bld16(rz, (oka && okO) ? (int)(pixa * po + (unsigned)c4 * 4u) : -1);
+            pz1 = bld16(rz, (okb && okO) ? (int)(pixb * po + (unsigned)c4 * 4u) : -1);
+            px0 = bld16(ra, (oka && okI) ? (int)(pixa * pa + (unsigned)c4 * 4u) : -1);
+            px1 = bld16(ra, (okb && okI) ? (int)(pixb * pa + (unsigned)c4 * 4u) : -1);
+            const bool okp = live && colok && okO && (unsigned)i < (unsigned)Hp && (col >> 1) < Wp;
+            const int og = okp ? (int)((unsigned)((img * Hp + i) * Wp + (col >> 1)) * po + (unsigned)c4 * 4u) : -1;
+            pg = bld16(rg1, og);
+            if constexpr (G2) pg2 = bld16(rg2, og);
+        };
+        issue(i0);
+
+        float X[4][4], DU[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[a][r] = DU[a][r] = 0.f;
+
+        for (int i = i0; i <= i1; ++i) {
+            const int ya = 2 * i, yb = 2 * i + 1;
+            const bool oka = colok && (unsigned)ya < (unsigned)H, okb = colok && (unsigned)yb < (unsigned)H;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                X[0][r] = X[2][r]; X[1][r] = X[3][r];
+                DU[0][r] = DU[2][r]; DU[1][r] = DU[3][r];
+            }
+            int oz = 0;
+            asm volatile("" : "+v"(oz));
+            const float* kk = s_k + c4 + oz;
+            const float* kw = s_w + c4 + oz;
+            float dz0[4], dz1[4];
+            {
+                const f32x4 z0 = pz0, z1 = pz1, x0 = px0, x1 = px1;
+                f32x4 gv = pg;
+                if constexpr (G2) gv = gv + pg2;
+                const f32x4 cA = *reinterpret_cast<const f32x4*>(kk), cB = *reinterpret_cast<const f32x4*>(kk + 16), cC = *reinterpret_cast<const f32x4*>(kk + 32);
+                const f32x4 msc = *reinterpret_cast<const f32x4*>(kk + 48), msh = *reinterpret_cast<const f32x4*>(kk + 64);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(kk + 80), sh = *reinterpret_cast<const f32x4*>(kk + 96), lo = *reinterpret_cast<const f32x4*>(kk + 112);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // the window's first maximum in post-ReLU space, row-major order: (0,0) (0,1) (1,0) (1,1)
+                    const float a0 = fmaxf(fmaf(z0[r], msc[r], msh[r]), 0.f), a1 = fmaxf(fmaf(z1[r], msc[r], msh[r]), 0.f);
+                    const float b0 = dpp_f<0xB1>(a0), b1 = dpp_f<0xB1>(a1);  // the other column of the window (lane ^ 1)
+                    const float L0 = e ? b0 : a0, R0 = e ? a0 : b0, L1 = e ? b1 : a1, R1 = e ? a1 : b1;
+                    float best = L0;
+                    int k = 0;
+                    if (R0 > best) { best = R0; k = 1; }
+                    if (L1 > best) { best = L1; k = 2; }
+                    if (R1 > best) { best = R1; k = 3; }
+                    const float gp = best > 0.f ? gv[r] : 0.f;
+                    const float gh0 = (k == e) ? gp : 0.f, gh1 = (k == 2 + e) ? gp : 0.f;
+                    dz0[r] = (oka && okO) ? fmaf(cA[r], gh0, fmaf(cB[r], z0[r], cC[r])) : 0.f;
+                    dz1[r] = (okb && okO) ? fmaf(cA[r], gh1, fmaf(cB[r], z1[r], cC[r])) : 0.f;
+                    X[2][r] = (oka && okI) ? fmaxf(fmaf(x0[r], sc[r], sh[r]), lo[r]) : 0.f;
+                    X[3][r] = (okb && okI) ? fmaxf(fmaf(x1[r], sc[r], sh[r]), lo[r]) : 0.f;
+                }
+            }
+            issue(i + 1);
+            {
+                float* tza = s_t[wave][ya & 3];
+                float* tzb = s_t[wave][yb & 3];
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tza[(c4 + r) * RS32_TP + n] = dz0[r];
+                    tzb[(c4 + r) * RS32_TP + n] = dz1[r];
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afd[r], dz0[r], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afd[r], dz1[r], d1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    DU[2][r] = d0[r];
+                    DU[3][r] = d1[r];
+                }
+            }
+            // ---- centre rows 2 i - 1 (rings 0, 1, 2) and 2 i (rings 1, 2, 3)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c = 2 * i - 1 + half;
+                const bool act = useful && c >= y0 && c < y1;
+                f32x4 dx;
+                float u[4];
+                if (half == 0)
+                    rs32_centre<STATS>(X[0], X[1], X[2], DU[0], DU[1], DU[2], kw, act, dx, u, acc);
+                else
+                    rs32_centre<STATS>(X[1], X[2], X[3], DU[1], DU[2], DU[3], kw, act, dx, u, acc);
+                bst16(wa, (act && okI) ? (int)((unsigned)((img * H + c) * W + col) * pa + (unsigned)c4 * 4u) : -1, dx);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tu[(c4 + r) * RS32_TP + n] = u[r];
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(s_t[wave][c & 3] + n * RS32_TP + c4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(tu + n * RS32_TP + c4);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc.dwpw = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt], b4[tt], acc.dwpw, 0, 0, 0);
+            }
+        }
+    }
+    float* red = s_red[wave];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(c4 + r) * 16 + n] = acc.dwpw[r];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = quad16_sum(acc.aw[r][t]);
+            if (n == 0) red[256 + (c4 + r) * 9 + t] = v;
+        }
+        if constexpr (STATS) {
+            const float v1 = quad16_sum(acc.st1[r]), v2 = quad16_sum(acc.st2[r]);
+            if (n == 0) {
+                red[256 + 144 + c4 + r] = v1;
+                red[256 + 144 + 16 + c4 + r] = v2;
+            }
+        }
+    }
+    __syncthreads();
+    const int ne = Cout * Cin + 9 * Cin;
+    for (int el = tid; el < ne + (STATS ? 2 * Cin : 0); el += 256) {
+        int idx;
+        if (el < Cout * Cin)
+            idx = (el / Cin) * 16 + el % Cin;
+        else if (el < ne)
+            idx = 256 + (el - Cout * Cin);
+        else
+            idx = 256 + 144 + ((el - ne) / Cin) * 16 + (el - ne) % Cin;
+        const float v = (s_red[0][idx] + s_red[1][idx]) + (s_red[2][idx] + s_red[3][idx]);
+        if (el < ne)
+            A.ws[(long)blockIdx.x * ne + el] = v;
+        else if (A.bl.raw)
+            bwd_last_add(A.bl, Cin, (el - ne) % Cin, (el - ne) / Cin, v);
+    }
+    if constexpr (STATS) {
+        if (A.bl.raw) bwd_last_finish(A.bl, Cin, A.tra, A.trb, tid, 256, &s_flag);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(Cup -> Cout, k 3, s 2) weight + bias gradient in fp32 (models.py:76-78; train_detection.py:96 runs its autograd in fp32):
+//   dW[c][o][kh][kw] = sum_{n,i,j} x~[i][j][c] g[2 i + kh][2 j + kw][o],   db[o] = sum g[o]
+// a K = pixels GEMM with M = Cup and N = (position, o) = 9 Cout.  Row-streaming over the INPUT grid: a strip is 16 input pixels (no halo: every lane
+// loads its own 3 x 3 window of the output gradient -- neighbouring windows overlap in L1 / L2, HBM sees each byte once), x~ and the nine window
+// positions go through a wave-private LDS transpose ([row][16 pixels]) and every (16 x 16) tile of dW takes 4 exact-fp32 MFMAs per strip row.
+// Replaces k_wgrad_gather<float> + k_channel_sum for the wide levels: that gather kernel (383 registers, scatter-bound) took 3.4 / 2.0 / 0.8 ms at
+// levels 0 / 1 / 2 and, on the backward's side stream, kept whole CUs from the main stream's kernels (a 64-thread finalize launch waited 1.1 ms).
+// MT = Cup / 16;  CE = output channels per launch (8 or 16: Cout = 32 runs as two launches, o0 = 0 / 16);  NT = ceil(9 CE / 16) N tiles.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct Rs32CW {
+    const float *x, *tr, *g;
+    float* ws;  // per-WAVE partials [4 nb][Cup * 9 * CE + CE]: dW[c][o0 + oo][pos] at (c * CE + oo) * 9 + pos, then db[o0 + oo]
+    int Cup, Cout, o0, N, h, w, H, W;
+    Rs32Jobs jb;
+};
+
+template <int MT, int CE>
+__global__ __launch_bounds__(256, 2) void k_rs32_ctw(const Rs32CW A) {
+    constexpr int NT = (9 * CE + 15) / 16, PPS = 16 / CE;  // N tiles; window positions per register set (2 for CE = 8, 1 for CE = 16)
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: x~^T [16 MT][TP] | g^T [16 NT][TP]
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tx = s_dyn + wave * (16 * (MT + NT) * RS32_TP);
+    float* tg = tx + 16 * MT * RS32_TP;
+    const int Cup = A.Cup, Cout = A.Cout, h = A.h, w = A.w, H = A.H, W = A.W;
+    const int c4 = 4 * q;
+    // the lane's slot of a g set: window position (within the set) and channel quad
+    const int ppos = PPS == 2 ? (q >> 1) : 0, oq = PPS == 2 ? 4 * (q & 1) : c4;
+    float sc[MT][4], sh[MT][4], lo[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[mt][r] = A.tr[16 * mt + c4 + r];
+            sh[mt][r] = A.tr[Cup + 16 * mt + c4 + r];
+            lo[mt][r] = A.tr[2 * Cup + 16 * mt + c4 + r];
+        }
+    const unsigned npi = (unsigned)A.N * h * w, npo = (unsigned)A.N * H * W;
+    const rsrc_t rx = mk_rsrc(A.x, npi * Cup * 4), rg = mk_rsrc(A.g, npo * Cout * 4);
+    const unsigned px_ = Cup * 4, pg = Cout * 4;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < h) ? y0 + A.jb.rb : h;
+        const int j = cg * 16 + n;
+        const bool jok = j < w;
+        for (int i = y0; i < y1; ++i) {
+            // ---- loads: x (MT quads) and the window positions of this lane's slots
+            f32x4 xv[MT], gv[NT];
+            const unsigned ipix = (unsigned)((img * h + i) * w + j);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xv[mt] = bld16(rx, jok ? (int)(ipix * px_ + (unsigned)(16 * mt + c4) * 4u) : -1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pos = nt * PPS + ppos;  // 0 .. 8 (9: the empty half of the last set when CE = 8)
+                const int kh = pos / 3, kw = pos - 3 * kh;
+                const int oy = 2 * i + kh, ox = 2 * j + kw;
+                const bool ok = jok && pos < 9 && oy < H && ox < W;
+                gv[nt] = bld16(rg, ok ? (int)((unsigned)((img * H + oy) * W + ox) * pg + (unsigned)(A.o0 + oq) * 4u) : -1);
+            }
+            // ---- x~ and g transposed into the wave's LDS rows (same wave writes and reads: in order, no barrier)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tx[(16 * mt + c4 + r) * RS32_TP + n] = jok ? fmaxf(fmaf(xv[mt][r], sc[mt][r], sh[mt][r]), lo[mt][r]) : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pos = nt * PPS + ppos;
+                const int kh = pos / 3, kw = pos - 3 * kh;
+                // every output pixel belongs to exactly one (input pixel, position): kh, kw < 2, or the last input row / column
+                const bool own = (kh < 2 || i == h - 1) && (kw < 2 || j == w - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    tg[(16 * nt + c4 + r) * RS32_TP + n] = gv[nt][r];
+                    db[r] += own ? gv[nt][r] : 0.f;  // (out-of-range positions loaded 0)
+                }
+            }
+            f32x4 a4[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a4[mt] = *reinterpret_cast<const f32x4*>(tx + (16 * mt + n) * RS32_TP + c4);  // A_t[(m = c, k)] = x~[c][pixel 4 k + t]
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(tg + (16 * nt + n) * RS32_TP + c4);  // B_t[(k, n = column)] = g[column][pixel 4 k + t]
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][tt], b4[tt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the wave's partials: acc[mt][nt] lane (column jj = n, k) reg r = dW[c = 16 mt + 4 k + r][column 16 nt + jj], column = pos * CE + oo
+    const int ne = Cup * 9 * CE + CE;
+    float* out = A.ws + (long)(blockIdx.x * 4 + wave) * ne;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int colj = 16 * nt + n, pos = colj / CE, oo = colj - pos * CE;
+            if (pos < 9) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[((16 * mt + c4 + r) * CE + oo) * 9 + pos] = acc[mt][nt][r];
+            }
+        }
+    // bias gradient: lanes of one channel quad (all n; for CE = 8 both position halves q, q + 2) -> LDS -> one value per channel
+    __syncthreads();  // (every wave is done with its transpose rows: s_dyn is reused as [wave][q][r])
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = quad16_sum(db[r]);
+        if (n == 0) s_dyn[4096 + (wave * 4 + q) * 4 + r] = v;
+    }
+    __syncthreads();
+    if (lane < CE) {
+        const int oo = lane, qq = PPS == 2 ? (oo >> 2) : (oo >> 2), rr = oo & 3;
+        float v = s_dyn[4096 + (wave * 4 + qq) * 4 + rr];
+        if (PPS == 2) v += s_dyn[4096 + (wave * 4 + qq + 2) * 4 + rr];
+        out[Cup * 9 * CE + oo] = v;
     }
 }
 
@@ -542,6 +936,54 @@ static double* rs32_last_scratch(int ndoubles, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+// ---- ConvTranspose weight / bias gradient launcher for ocrs_convt_bwd_parts (det_bwd.hip): fp32, Cup in {16, 32}, Cout in {8, 16, 32}
+long det_rs32_ctw_supported(int Cup, int Cout, int dtype) {
+    static const int on = env_int("OCRS_RS32", 1), onc = env_int("OCRS_RS32_CTW", 1);
+    return (on && onc && dtype == 0 && (Cup == 16 || Cup == 32) && (Cout == 8 || Cout == 16 || Cout == 32)) ? 1 : 0;
+}
+}  // extern "C"
+static int rs32_ctw_rb() {
+    static const int rb_env = env_int("OCRS_RS32_CTW_RB", 32);
+    return rb_env > 0 ? rb_env : 32;
+}
+extern "C" {
+long det_rs32_ctw_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
+    if (!det_rs32_ctw_supported(Cup, Cout, dtype)) return 0;
+    const int CE = Cout >= 16 ? 16 : 8, nl = Cout / CE;
+    const Rs32Jobs jb = rs32_jobs(N, h, w, 16, rs32_ctw_rb());
+    return (long)rs32_grid(jb.njobs, 2) * 4 * (Cup * 9 * CE + CE) * nl;
+}
+int det_rs32_ctw_launch(const float* x, const float* tr, const float* g, float* dW, float* dbias, float* ws, int Cup, int Cout, int N, int h, int w, int H,
+                        int W, hipStream_t st) {
+    OCRS_CHECK_ARG(det_rs32_ctw_supported(Cup, Cout, 0) && x && tr && g && dW && dbias && ws);
+    OCRS_CHECK_ARG((long)N * H * W * Cout * 4 < (1L << 32) && (long)N * h * w * Cup * 4 < (1L << 32) && H <= 2 * h + 1 && W <= 2 * w + 1);
+    const int CE = Cout >= 16 ? 16 : 8, nl = Cout / CE, MT = Cup / 16, NT = (9 * CE + 15) / 16;
+    const Rs32Jobs jb = rs32_jobs(N, h, w, 16, rs32_ctw_rb());
+    const int grid = rs32_grid(jb.njobs, 2);
+    const int ne = Cup * 9 * CE + CE;
+    size_t smem = (size_t)4 * 16 * (MT + NT) * RS32_TP * sizeof(float);
+    if (smem < (4096 + 64) * sizeof(float)) smem = (4096 + 64) * sizeof(float);
+    for (int l = 0; l < nl; ++l) {
+        Rs32CW a{x, tr, g, ws + (long)l * grid * 4 * ne, Cup, Cout, l * CE, N, h, w, H, W, jb};
+#define CTW32_CASE(MT_, CE_)                                                                                    \
+    if (MT == MT_ && CE == CE_) {                                                                              \
+        static DevOnce once;                                                                                   \
+        if (once.need()) {                                                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs32_ctw<MT_, CE_>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) \
+                return OCRS_ERR_HIP;                                                                           \
+            once.done();                                                                                       \
+        }                                                                                                      \
+        OCRS_LAUNCH_T((k_rs32_ctw<MT_, CE_>), dim3(grid), dim3(256), smem, st, a);                             \
+    }
+        CTW32_CASE(1, 8) CTW32_CASE(1, 16) CTW32_CASE(2, 8) CTW32_CASE(2, 16)
+#undef CTW32_CASE
+        OCRS_LAUNCH_CHECK();
+        // dW[c][o0 + oo][pos] += column (c * CE + oo) * 9 + pos of the partials: rows of 9 CE elements at a pitch of 9 Cout; db[o0 + oo] behind them
+        bwd_reduce_or_defer(a.ws, grid * 4, ne, dW + (long)l * CE * 9, Cup * 9 * CE, 9 * CE, 9 * Cout, dbias + l * CE, CE, st);
+        OCRS_LAUNCH_CHECK();
+    }
+    return OCRS_OK;
+}
 
 // 1 if ocrs_rs32_fwd runs this block shape: fp32 storage; Cin = Ca + Cb in {8, 16, 32}, a concat split only as 8 | 8 or 16 | 16; Cout in {8, 16, 32}.
 long ocrs_rs32_fwd_supported(int Ca, int Cb, int Cout, int dtype) {
@@ -588,8 +1030,8 @@ int ocrs_rs32_fwd(const float* xa, const float* xb, int Ca, int Cb, const float*
 
 // 1 if ocrs_rs32_bwd runs this block shape: fp32 storage, direct (not max-pooled) gradient source, Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}
 long ocrs_rs32_bwd_supported(int Ca, int Cb, int Cout, int pooled, int dtype) {
-    static const int on = env_int("OCRS_RS32", 1), onb = env_int("OCRS_RS32_BWD", 1);
-    if (!on || !onb || dtype != 0 || pooled) return 0;
+    static const int on = env_int("OCRS_RS32", 1), onb = env_int("OCRS_RS32_BWD", 1), onp = env_int("OCRS_RS32_BWDP", 1);
+    if (!on || !onb || dtype != 0 || (pooled && (!onp || Cb))) return 0;
     const int Cin = Ca + Cb;
     if (!(Cin == 8 || Cin == 16) || !(Cout == 8 || Cout == 16)) return 0;
     if (Cb && !(Ca == 8 && Cb == 8)) return 0;
@@ -601,8 +1043,8 @@ static int rs32_bwd_rb() {
 }
 long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = Ca + Cb;
-    const Rs32Jobs jb = rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb());
-    return (long)rs32_grid(jb.njobs, 2) * (Cout * Cin + 9 * Cin);
+    const int ga = rs32_grid(rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()).njobs, 2), gp = rs32_grid(rs32_jobs(N, H, W, RS32P_COLS, rs32_bwd_rb()).njobs, 2);
+    return (long)(ga > gp ? ga : gp) * (Cout * Cin + 9 * Cin);  // (direct form: 14-column strips; pooled form: 12)
 }
 
 // Backward of one DepthwiseConv block in fp32 as ONE row-streaming pass (replaces ocrs_bn_bwd_finalize + ocrs_pw_bwd + ocrs_dw_bwd; the reference's
@@ -614,8 +1056,8 @@ long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
 int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float* tra, const float* trb, const float* wdw, const float* wpw, const float* g1,
                   const float* g2, const float* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta,
                   float* gxa, float* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
-                  int Cout, int N, int H, int W, hipStream_t st) {
-    OCRS_CHECK_ARG(ocrs_rs32_bwd_supported(Ca, Cb, Cout, 0, 0) && xa && tra && wdw && wpw && g1 && z && bn && gsum && gamma && saved && dgamma && dbeta);
+                  int pooled, int Cout, int N, int H, int W, hipStream_t st) {
+    OCRS_CHECK_ARG(ocrs_rs32_bwd_supported(Ca, Cb, Cout, pooled, 0) && xa && tra && wdw && wpw && g1 && z && bn && gsum && gamma && saved && dgamma && dbeta);
     OCRS_CHECK_ARG(gxa && dwpw && dwdw && ws && (Cb == 0) == (xb == nullptr) && (Cb == 0 || (trb && gxb)) && N > 0 && H > 0 && W > 0);
     OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
     const int Cin = Ca + Cb, Cmax = Cin > Cout ? Cin : Cout;
@@ -628,12 +1070,34 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
         bl.raw = p;
         bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
     }
-    Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W, rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()),
-            BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl};
+    static const int dual_on = env_int("OCRS_RS32_DUAL", 1);
+    const bool dual = dual_on && !pooled && Cb == 0 && Cin == 8 && Cout == 8;  // two 14-column strips per wave (8-channel tensors fill half the lanes)
+    Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W,
+            rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl};
     const int grid = rs32_grid(a.jb.njobs, 2);
+    if (pooled) {
+        OCRS_CHECK_ARG(H >= 2 && W >= 2);
+#define RS32P_CASE(G2_, ST_)                                                                    \
+    if ((g2 != nullptr) == G2_ && stats == ST_) {                                               \
+        OCRS_LAUNCH_T((k_rs32_bwdp<G2_, ST_>), dim3(grid), dim3(256), 0, st, a);                \
+        OCRS_LAUNCH_CHECK();                                                                    \
+    }
+        RS32P_CASE(false, false) RS32P_CASE(false, true) RS32P_CASE(true, false) RS32P_CASE(true, true)
+#undef RS32P_CASE
+        bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, Cin, dwdw, 9 * Cin, st);
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
 #define RS32B_CASE(SP_, G2_, ST_)                                                                      \
     if ((Cb != 0) == SP_ && (g2 != nullptr) == G2_ && stats == ST_) {                                 \
-        OCRS_LAUNCH_T((k_rs32_bwd<SP_, G2_, ST_, 1>), dim3(grid), dim3(256), 0, st, a);               \
+        if constexpr (!SP_) {                                                                         \
+            if (dual)                                                                                 \
+                OCRS_LAUNCH_T((k_rs32_bwd<false, G2_, ST_, 1, true>), dim3(grid), dim3(256), 0, st, a); \
+            else                                                                                      \
+                OCRS_LAUNCH_T((k_rs32_bwd<false, G2_, ST_, 1, false>), dim3(grid), dim3(256), 0, st, a); \
+        } else {                                                                                      \
+            OCRS_LAUNCH_T((k_rs32_bwd<SP_, G2_, ST_, 1>), dim3(grid), dim3(256), 0, st, a);           \
+        }                                                                                             \
         OCRS_LAUNCH_CHECK();                                                                          \
     }
     RS32B_CASE(false, false, false) RS32B_CASE(false, false, true) RS32B_CASE(false, true, false) RS32B_CASE(false, true, true)

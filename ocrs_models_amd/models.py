@@ -513,7 +513,8 @@ class _DetRun:
             self._hold(ws)  # (its reduction may be queued until the end of the backward)
             L.rs32_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw), ptr(g1),
                        ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(gxb),
-                       ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W)
+                       ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb),
+                       1 if pooled else 0, C, N, H, W)
             return gxa, gxb
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
@@ -645,6 +646,7 @@ class _DetRun:
             wpk_d = self.pack(P[f"up.{i}.up.weight"], 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
             dx = self.empty(N, up_in.H, up_in.W, Cup)
             ws = self.empty(L.convt_bwd_ws_floats(Cup, Cout, N, up_in.H, up_in.W, self.dt), dtype=torch.float32)
+            self._hold(ws)  # (the fp32 row-streaming weight-gradient kernel queues its second stage until the end of the backward)
             sv = gs_up = None
             if self.fuse_bn_bwd and up_in.src is not None and L.convt_bwd_stats_supported(Cup, Cout, self.dt):
                 # the ConvTranspose is this block's only consumer and stages its z anyway: it also produces the block's BatchNorm-backward sums
