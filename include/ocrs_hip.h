@@ -116,6 +116,11 @@ int ocrs_maxpool_fwd(const void* z, const float* tr, void* out, int C, int N, in
 /* nn.ConvTranspose2d(k=3, s=2) + crop (models.py:76-78, 82-87). */
 int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float* bias, void* out, int Cup, int Cout, int N, int h, int w,
                    int H, int W, int dtype, hipStream_t st);
+/* The same ConvTranspose2d forward in fp32 as row-streaming waves over the input grid (csrc/det_rs32.hip, round 6): (Cup, Cout) in {(16, 8), (32, 16),
+   (32, 32)}; wt = the fp32 MASTER weight [Cup][Cout][3][3] (no packed fragments: the effective per-parity fragments are built in LDS per workgroup). */
+long ocrs_rs32_convt_fwd_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
+int ocrs_rs32_convt_fwd(const float* x, const float* tr, const float* wt, const float* bias, float* out, int Cup, int Cout, int N, int h, int w, int H, int W,
+                        hipStream_t st);
 /* out_conv: nn.Conv2d(8, 1, 1) + nn.Sigmoid (models.py:125-129). */
 int ocrs_head_fwd(const void* z, const float* tr, const float* w, const float* b, float* pred, long P, int dtype, hipStream_t st);
 

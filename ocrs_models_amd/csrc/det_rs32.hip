@@ -902,6 +902,121 @@ __global__ __launch_bounds__(256, 2) void k_rs32_ctw(const Rs32CW A) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d(Cup -> Cout, k 3, s 2) + bias + crop, forward, fp32 (models.py:76-78, 87).  Row-streaming over the INPUT grid: input pixel (i, j) owns
+// the four output pixels (2 i + py, 2 j + px); out[2i+py][2j+px][o] = b[o] + sum_{di in D(py), dj in D(px)} sum_c x~[i-di][j-dj][c] W[c][o][py+2di][px+2dj],
+// D(0) = {0, 1}, D(1) = {0}: a GEMM with M = (parity, o) = 4 Cout, K = (neighbour, c) = 4 Cup whose B operands are the x~ registers of this row and the
+// previous one and their left neighbours (DPP row_shr:1): a strip is 16 lanes = 15 input columns + the left halo lane.  The effective weight fragments
+// (zero where a parity has no such neighbour) are built once per workgroup in LDS, [tile][neighbour][set][lane][4 K steps]: one ds_read_b128 per four
+// MFMAs.  The extra output row / column 2 h, 2 w (kept when the skip tensor is odd-sized) come from the tick i = h / the lane j = w, whose own x~ is 0.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct Rs32CF {
+    const float *x, *tr, *wt, *bias;  // wt: master [Cup][Cout][3][3]
+    float* out;
+    int Cup, Cout, N, h, w, H, W;
+    Rs32Jobs jb;  // over (h + 1) x (w + 1) input positions, 15 columns per strip
+};
+
+template <int NSET, int MT>
+__global__ __launch_bounds__(256, 2) void k_rs32_ctf(const Rs32CF A) {
+    extern __shared__ __attribute__((aligned(16))) float s_af[];  // [MT][4 nb][NSET][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cup = A.Cup, Cout = A.Cout, h = A.h, w = A.w, H = A.H, W = A.W;
+    for (int e = tid; e < MT * 4 * NSET * 64 * 4; e += 256) {
+        const int r = e & 3, ln = (e >> 2) & 63, rest = e >> 8, s = rest % NSET, nb = (rest / NSET) & 3, mt = rest / (NSET * 4);
+        const int m = 16 * mt + (ln & 15), par = m / Cout, o = m - par * Cout, py = par >> 1, px = par & 1;
+        const int c = 16 * s + 4 * (ln >> 4) + r, di = nb >> 1, dj = nb & 1;
+        const bool ok = par < 4 && c < Cup && !(py == 1 && di == 1) && !(px == 1 && dj == 1);
+        s_af[e] = ok ? A.wt[((c * Cout + o) * 3 + (py + 2 * di)) * 3 + (px + 2 * dj)] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = 4 * q;
+    float sc[NSET][4], sh[NSET][4], lo[NSET][4];
+#pragma unroll
+    for (int s = 0; s < NSET; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * s + c4 + r;
+            sc[s][r] = c < Cup ? A.tr[c] : 0.f;
+            sh[s][r] = c < Cup ? A.tr[Cup + c] : 0.f;
+            lo[s][r] = c < Cup ? A.tr[2 * Cup + c] : 0.f;
+        }
+    // the lane's output slot in every M tile: parity and channel quad
+    int parq[MT], oq[MT];
+    f32x4 bq[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = 16 * mt + c4;
+        parq[mt] = m0 / Cout;
+        oq[mt] = m0 - parq[mt] * Cout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bq[mt][r] = parq[mt] < 4 ? A.bias[oq[mt] + r] : 0.f;
+    }
+    const unsigned npi = (unsigned)A.N * h * w, npo = (unsigned)A.N * H * W;
+    const rsrc_t rx = mk_rsrc(A.x, npi * Cup * 4), ro = mk_rsrc(A.out, npo * Cout * 4);
+    const unsigned pxb = Cup * 4, pob = Cout * 4;
+    const f32x4* af = reinterpret_cast<const f32x4*>(s_af) + lane;
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < h + 1) ? y0 + A.jb.rb : h + 1;
+        const int j = cg * 15 + n - 1;
+        const bool jin = (unsigned)j < (unsigned)w;          // a real input column
+        const bool useful = n >= 1 && j <= w;                 // owns output columns 2 j, 2 j + 1 (j = w: only 2 w, from its left neighbour)
+        auto load = [&](int i, f32x4 (&v)[NSET]) {
+            const bool ok = jin && (unsigned)i < (unsigned)h;
+            const unsigned pix = (unsigned)((img * h + i) * w + j);
+#pragma unroll
+            for (int s = 0; s < NSET; ++s) v[s] = bld16(rx, (ok && 16 * s + c4 < Cup) ? (int)(pix * pxb + (unsigned)(16 * s + c4) * 4u) : -1);
+        };
+        auto xform = [&](int i, const f32x4 (&v)[NSET], float (&X)[NSET][4]) {
+            const bool ok = jin && (unsigned)i < (unsigned)h;
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[s][r] = (ok && 16 * s + c4 < Cup) ? fmaxf(fmaf(v[s][r], sc[s][r], sh[s][r]), lo[s][r]) : 0.f;
+        };
+        float Xp[NSET][4], Xc[NSET][4];
+        f32x4 raw[NSET];
+        load(y0 - 1, raw);
+        xform(y0 - 1, raw, Xp);
+        load(y0, raw);
+        for (int i = y0; i < y1; ++i) {
+            xform(i, raw, Xc);
+            load(i + 1 < y1 ? i + 1 : i, raw);  // next row (the last tick re-reads its own row: harmless, keeps the loop body uniform)
+            int oz = 0;
+            asm volatile("" : "+v"(oz));  // (opaque zero: the weight fragments are loop-invariant LDS reads -- hoisted, they cost 32 .. 256 registers)
+            const f32x4* afl = af + oz;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 d = bq[mt];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int s = 0; s < NSET; ++s) {
+                        const f32x4 a4 = afl[((mt * 4 + nb) * NSET + s) * 64];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xv = (nb >> 1) ? Xp[s][r] : Xc[s][r];
+                            const float bv = (nb & 1) ? dpp_f<DPP_SHR1>(xv) : xv;  // dj = 1: the left neighbour's value
+                            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], bv, d, 0, 0, 0);
+                        }
+                    }
+                const int py = parq[mt] >> 1, px = parq[mt] & 1, oy = 2 * i + py, ox = 2 * j + px;
+                const bool st = useful && parq[mt] < 4 && oy < H && ox < W;
+                bst16(ro, st ? (int)((unsigned)((img * H + oy) * W + ox) * pob + (unsigned)oq[mt] * 4u) : -1, d);
+            }
+#pragma unroll
+            for (int s = 0; s < NSET; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xp[s][r] = Xc[s][r];
+        }
+    }
+}
+
 namespace {
 static inline int rs32_grid(int njobs, int wg_per_cu) {
     static const int bpc_env = env_int("OCRS_RS32_BPC", 0);
@@ -1106,6 +1221,40 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
     bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, Cin, dwdw, 9 * Cin, st);
     OCRS_LAUNCH_CHECK();
     return OCRS_OK;
+}
+
+// 1 if ocrs_rs32_convt_fwd runs this shape: fp32, (Cup, Cout) in {(16, 8), (32, 16)} ((32, 32) is built and tested but slower than k_convt_fwd: OCRS_RS32_CTF_3232=1)
+long ocrs_rs32_convt_fwd_supported(int Cup, int Cout, int dtype) {
+    static const int on = env_int("OCRS_RS32", 1), onf = env_int("OCRS_RS32_CTF", 1);
+    static const int on32 = env_int("OCRS_RS32_CTF_3232", 0);  // (32, 32) at level 2: 256 MFMAs per strip row -- measured 296 us vs 253 us on k_convt_fwd: off
+    return (on && onf && dtype == 0 && ((Cup == 16 && Cout == 8) || (Cup == 32 && (Cout == 16 || (Cout == 32 && on32))))) ? 1 : 0;
+}
+// ConvTranspose2d(Cup, Cout, kernel_size=3, stride=2) + bias, cropped to the skip tensor's H x W (models.py:76-78, 87), fp32, row-streaming form.
+//   x [N][h][w][Cup] with load transform tr [3][Cup]; wt: the fp32 master weight [Cup][Cout][3][3] (reference layout); out [N][H][W][Cout], H <= 2 h + 1.
+int ocrs_rs32_convt_fwd(const float* x, const float* tr, const float* wt, const float* bias, float* out, int Cup, int Cout, int N, int h, int w, int H, int W,
+                        hipStream_t st) {
+    OCRS_CHECK_ARG(((Cup == 16 && Cout == 8) || (Cup == 32 && (Cout == 16 || Cout == 32))) && x && tr && wt && bias && out && N > 0 && h > 0 && w > 0 && H <= 2 * h + 1 && W <= 2 * w + 1);
+    OCRS_CHECK_ARG((long)N * H * W * Cout * 4 < (1L << 32) && (long)N * h * w * Cup * 4 < (1L << 32));
+    static const int rb_env = env_int("OCRS_RS32_CTF_RB", 32);
+    Rs32CF a{x, tr, wt, bias, out, Cup, Cout, N, h, w, H, W, rs32_jobs(N, h + 1, w + 1, 15, rb_env > 0 ? rb_env : 32)};
+    const int nset = Cup / 16, mt = 4 * Cout / 16;
+    const int grid = rs32_grid(a.jb.njobs, 2);
+    const size_t smem = (size_t)mt * 4 * nset * 64 * 4 * sizeof(float);
+#define CTF32_CASE(NS_, MT_)                                                                                   \
+    if (nset == NS_ && mt == MT_) {                                                                           \
+        static DevOnce once;                                                                                  \
+        if (once.need()) {                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rs32_ctf<NS_, MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) \
+                return OCRS_ERR_HIP;                                                                          \
+            once.done();                                                                                      \
+        }                                                                                                     \
+        OCRS_LAUNCH_T((k_rs32_ctf<NS_, MT_>), dim3(grid), dim3(256), smem, st, a);                            \
+        OCRS_LAUNCH_CHECK();                                                                                  \
+        return OCRS_OK;                                                                                       \
+    }
+    CTF32_CASE(1, 2) CTF32_CASE(2, 4) CTF32_CASE(2, 8)
+#undef CTF32_CASE
+    return OCRS_ERR_ARG;
 }
 
 }  // extern "C"

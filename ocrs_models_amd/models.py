@@ -400,7 +400,10 @@ class _DetRun:
             wpk = self.pack(P[f"up.{i}.up.weight"], 1, 4 * Cup, 4 * Cout, Cup, 0, 0, 0)
             t = self.empty(N, skip.H, skip.W, Cout)
             up.other_use = True
-            L.convt_fwd(ptr(up.t), ptr(up.tr), ptr(wpk), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W, self.dt)
+            if self.use_rs32 and L.rs32_convt_fwd_supported(Cup, Cout, self.dt):  # fp32, wide levels: row-streaming over the input grid (csrc/det_rs32.hip)
+                L.rs32_convt_fwd(ptr(up.t), ptr(up.tr), ptr(P[f"up.{i}.up.weight"]), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W)
+            else:
+                L.convt_fwd(ptr(up.t), ptr(up.tr), ptr(wpk), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W, self.dt)
             ta = _Act(t, _identity_tr(Cout, self.dev), Cout, skip.H, skip.W)
             self.convt[i] = (up, ta)
             up = self.double(f"up.{i}.contract", ta, skip, Cout)

@@ -579,6 +579,12 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
     ref = F.conv_transpose2d(xt, Wr, br, stride=2)[:, :, :H, :W]
     tol = TOL[dtype]
     assert rel(nchw(out), ref) < tol
+    if dtype == torch.float32 and (Cup, Cout) in ((16, 8), (32, 16), (32, 32)):
+        # fp32, wide levels: the row-streaming forward (csrc/det_rs32.hip: what the model runs) from the MASTER weight, incl. the odd last row / column
+        out2 = torch.full_like(out, float("nan"))
+        run.L.rs32_convt_fwd(ptr(xs), ptr(tr), ptr(Wt), ptr(bias), ptr(out2), Cup, Cout, N, h, w, H, W)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out2).all()) and rel(nchw(out2), ref) < 2e-6, rel(nchw(out2), ref)
     gy = nhwc(torch.randn(N, Cout, H, W, generator=g).to(dev), dtype)
     ref.backward(cpu(nchw(gy)))
     wpk_d = run.pack(Wt, 0, 9 * Cout, Cup, Cout, 1, 9, 9 * Cout)
