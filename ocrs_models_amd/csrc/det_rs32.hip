@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, (NSET * MT == 1) ? 3 : 2) void k_rs32_fwd(cons
                     f32x4 v = ring[k][s];
                     if constexpr (SPLIT) v = or4(v, ringb[k][s]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) X[s][r] = (ok && chok[s]) ? fmaxf(fmaf(v[r], sc[s][r], sh[s][r]), lo[s][r]) : 0.f;
+                    for (int r = 0; r < 4; ++r) X[s][r] = ((ok && chok[s]) ? 1.f : 0.f) * fmaxf(fmaf(v[r], sc[s][r], sh[s][r]), lo[s][r]);  // (0 / 1 factor: branch-free)
                 }
                 issue(k, yy + P);
                 // ---- depthwise: row yy completes output row yy - 1 (kernel row 2), continues row yy (row 1), opens row yy + 1 (row 0)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, (NSET * MT == 1) ? 3 : 2) void k_rs32_fwd(cons
                         bst16(rz, st ? (int)((unsigned)opix * (unsigned)pz + (unsigned)(16 * mt + 4 * q) * 4u) : -1, d);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float v = st ? d[r] : 0.f;
+                            const float v = (st ? 1.f : 0.f) * d[r];
                             s1[mt][r] += v;
                             s2[mt][r] = fmaf(v, v, s2[mt][r]);
                         }
@@ -287,7 +287,7 @@ constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of 
 // 2 s + 1): every per-channel instruction serves 28 columns, and ONE set of four MFMAs still yields du of both strips in place because the weight
 // fragment is block-diagonal over (strip, channel): A_r[(m, k)] = [m >> 3 == k >> 1] Wpw[4 (k & 1) + r][m & 7]  ->  D rows 0-7 = strip 0, 8-15 = strip 1.
 template <bool SPLIT, bool G2, bool STATS, int P, bool DUAL = false>
-__global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
+__global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs32B A) {  // (branch-free form: 134 .. 174 registers -> three workgroups per CU)
     static_assert(!(DUAL && SPLIT), "two strips per wave: single-source 8-channel blocks only");
     constexpr int TP2 = DUAL ? 36 : RS32_TP;  // pitch of a transpose row: 16 (or 2 x 16) pixels + pad
     __shared__ float s_cf[3 * 16];
@@ -409,11 +409,14 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
                     const f32x4 cA = *reinterpret_cast<const f32x4*>(kk), cB = *reinterpret_cast<const f32x4*>(kk + 16), cC = *reinterpret_cast<const f32x4*>(kk + 32);
                     const f32x4 msc = *reinterpret_cast<const f32x4*>(kk + 48), msh = *reinterpret_cast<const f32x4*>(kk + 64);
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(kk + 80), sh = *reinterpret_cast<const f32x4*>(kk + 96), lo = *reinterpret_cast<const f32x4*>(kk + 112);
+                    // (masks as 0 / 1 factors: hipcc turned per-lane ternaries around these expressions into exec-masked regions -- 17 s_and_saveexec per
+                    // row, each a scheduling barrier; out-of-range loads returned 0, so every masked value is finite)
+                    const float mO = (ok && okO) ? 1.f : 0.f, mI = (ok && okI) ? 1.f : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float gh = fmaf(zv[r], msc[r], msh[r]) > 0.f ? gv[r] : 0.f;
-                        dzc[r] = (ok && okO) ? fmaf(cA[r], gh, fmaf(cB[r], zv[r], cC[r])) : 0.f;
-                        X[2][r] = (ok && okI) ? fmaxf(fmaf(xv[r], sc[r], sh[r]), lo[r]) : 0.f;
+                        dzc[r] = mO * fmaf(cA[r], gh, fmaf(cB[r], zv[r], cC[r]));
+                        X[2][r] = mI * fmaxf(fmaf(xv[r], sc[r], sh[r]), lo[r]);
                     }
                 }
                 issue(k, yy + P);
@@ -432,10 +435,11 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
                 const int c = yy - 1;
                 const bool rowo = c >= y0 && c < y1;
                 const bool act = rowo && useful;
+                const float actf = act ? 1.f : 0.f;
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
                 float u[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dm[r] = act ? DU[1][r] : 0.f;
+                for (int r = 0; r < 4; ++r) dm[r] = actf * DU[1][r];
                 // dx~(c) = sum_{ky,kx} w[ky][kx] du(c + 1 - ky, col + 1 - kx):  ky = 0 -> row c + 1 (ring 2), kx = 0 -> column + 1 (row_shl)
                 // u(c)   = sum_{ky,kx} w[ky][kx] x~(c + ky - 1, col + kx - 1);  dWdw[ky][kx] += du(c) x~(c + ky - 1, col + kx - 1)
 #pragma unroll
@@ -455,9 +459,9 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwd(const Rs32B A) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (!act) u[r] = 0.f;
+                    u[r] *= actf;
                     if constexpr (STATS) {
-                        const float gh = (act && X[1][r] > 0.f) ? dx[r] : 0.f;
+                        const float gh = X[1][r] > 0.f ? actf * dx[r] : 0.f;
                         st1[r] += gh;
                         st2[r] = fmaf(gh, X[1][r], st2[r]);
                     }
@@ -544,10 +548,11 @@ struct Rs32Acc {
 template <bool STATS>
 __device__ __forceinline__ void rs32_centre(const float (&Xm)[4], const float (&X0)[4], const float (&Xp)[4], const float (&Dm)[4], const float (&D0)[4],
                                             const float (&Dp)[4], const float* kw, bool act, f32x4& dx, float (&u)[4], Rs32Acc& acc) {
+    const float actf = act ? 1.f : 0.f;  // (0 / 1 factor instead of per-lane ternaries: branch-free)
     float dm[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        dm[r] = act ? D0[r] : 0.f;
+        dm[r] = actf * D0[r];
         dx[r] = 0.f;
         u[r] = 0.f;
     }
@@ -569,9 +574,9 @@ __device__ __forceinline__ void rs32_centre(const float (&Xm)[4], const float (&
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (!act) u[r] = 0.f;
+        u[r] *= actf;
         if constexpr (STATS) {
-            const float gh = (act && X0[r] > 0.f) ? dx[r] : 0.f;
+            const float gh = X0[r] > 0.f ? actf * dx[r] : 0.f;
             acc.st1[r] += gh;
             acc.st2[r] = fmaf(gh, X0[r], acc.st2[r]);
         }
@@ -671,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwdp(const Rs32B A) {
             const float* kk = s_k + c4 + oz;
             const float* kw = s_w + c4 + oz;
             float dz0[4], dz1[4];
+            const float mOa = (oka && okO) ? 1.f : 0.f, mOb = (okb && okO) ? 1.f : 0.f, mIa = (oka && okI) ? 1.f : 0.f, mIb = (okb && okI) ? 1.f : 0.f;
             {
                 const f32x4 z0 = pz0, z1 = pz1, x0 = px0, x1 = px1;
                 f32x4 gv = pg;
@@ -691,10 +697,10 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwdp(const Rs32B A) {
                     if (R1 > best) { best = R1; k = 3; }
                     const float gp = best > 0.f ? gv[r] : 0.f;
                     const float gh0 = (k == e) ? gp : 0.f, gh1 = (k == 2 + e) ? gp : 0.f;
-                    dz0[r] = (oka && okO) ? fmaf(cA[r], gh0, fmaf(cB[r], z0[r], cC[r])) : 0.f;
-                    dz1[r] = (okb && okO) ? fmaf(cA[r], gh1, fmaf(cB[r], z1[r], cC[r])) : 0.f;
-                    X[2][r] = (oka && okI) ? fmaxf(fmaf(x0[r], sc[r], sh[r]), lo[r]) : 0.f;
-                    X[3][r] = (okb && okI) ? fmaxf(fmaf(x1[r], sc[r], sh[r]), lo[r]) : 0.f;
+                    dz0[r] = mOa * fmaf(cA[r], gh0, fmaf(cB[r], z0[r], cC[r]));
+                    dz1[r] = mOb * fmaf(cA[r], gh1, fmaf(cB[r], z1[r], cC[r]));
+                    X[2][r] = mIa * fmaxf(fmaf(x0[r], sc[r], sh[r]), lo[r]);
+                    X[3][r] = mIb * fmaxf(fmaf(x1[r], sc[r], sh[r]), lo[r]);
                 }
             }
             issue(i + 1);
@@ -1158,7 +1164,7 @@ static int rs32_bwd_rb() {
 }
 long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = Ca + Cb;
-    const int ga = rs32_grid(rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()).njobs, 2), gp = rs32_grid(rs32_jobs(N, H, W, RS32P_COLS, rs32_bwd_rb()).njobs, 2);
+    const int ga = rs32_grid(rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()).njobs, 3), gp = rs32_grid(rs32_jobs(N, H, W, RS32P_COLS, rs32_bwd_rb()).njobs, 2);
     return (long)(ga > gp ? ga : gp) * (Cout * Cin + 9 * Cin);  // (direct form: 14-column strips; pooled form: 12)
 }
 
@@ -1189,7 +1195,7 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
     const bool dual = dual_on && !pooled && Cb == 0 && Cin == 8 && Cout == 8;  // two 14-column strips per wave (8-channel tensors fill half the lanes)
     Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W,
             rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl};
-    const int grid = rs32_grid(a.jb.njobs, 2);
+    const int grid = rs32_grid(a.jb.njobs, (pooled || (dual && g2)) ? 2 : 3);
     if (pooled) {
         OCRS_CHECK_ARG(H >= 2 && W >= 2);
 #define RS32P_CASE(G2_, ST_)                                                                    \
