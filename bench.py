@@ -832,10 +832,13 @@ def main():
     if distributed and ddp_info:
         out["ddp"] = dict(ddp_info)
     if rank == 0 and world == 1 and not args.no_fp32 and args.dtype == "bf16":
-        k = max(3, args.steps // 3)
+        k = max(5, args.steps // 2)
         dt32, _, _, _ = run_det("fp32", 2, k, False)
+        alg32 = 3 * 4 * det_alg_elems_per_image(S, S) * B  # SURVEY 8(d)'s whole-step byte model at 4 bytes per element
         out["fp32_exact"] = {"value": round(B * k / dt32, 2), "unit": "images/s", "ms_per_step": round(dt32 / k * 1e3, 3), "steps": k,
-                             "note": "parity mode: fp32 storage, exact-fp32 MFMA"}
+                             "alg_GB_per_step": round(alg32 / 1e9, 2), "whole_step_frac": round(alg32 / (dt32 / k) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "parity mode = the reference's own arithmetic (train_detection.py:92-97, no autocast): fp32 storage, exact-fp32 MFMA; "
+                                     "levels 0-1 on the row-streaming kernels of csrc/det_rs32.hip (round 6)"}
     if rank == 0 and world == 1 and not args.no_ref_style:
         # the step exactly as the reference's loop runs it (train_detection.py:87-98): uint8 H2D copy + device transform_image + loss.item()
         k = max(5, args.steps // 2)

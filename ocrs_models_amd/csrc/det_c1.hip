@@ -104,11 +104,7 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
                     fs[11 + k] += nb[q + k / 3][k % 3];
                 }
             }
-#ifdef OCRS_INJECT_BATCH_BUG
-            if (uplane) uplane[((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);
-#else
             if (uplane) uplane[((long)it.n * H + it.h0 + q) * W + it.w0 + lane].v = f2bf(u);  // (exact: u is a bf16 value when uplane is given)
-#endif
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -117,11 +113,7 @@ __global__ __launch_bounds__(256) void k_c1_fwd2(const float* __restrict__ img, 
                 s1[i] += r;
                 s2[i] = fmaf(r, r, s2[i]);
             }
-#ifdef OCRS_INJECT_BATCH_BUG  // (test-of-the-tests build, tools/experiments/r5_inject_batch_bug.sh: neighbouring images swap their outputs)
-            if (z) store8(z + (((long)((it.n ^ 1) < N ? (it.n ^ 1) : it.n) * H + it.h0 + q) * W + it.w0 + lane) * 8, o);
-#else
             if (z) store8(z + (((long)it.n * H + it.h0 + q) * W + it.w0 + lane) * 8, o);  // (z == null: only the u plane is kept)
-#endif
         }
     };
     C1Img imA, imB;

@@ -10,6 +10,9 @@ rm -rf gpurun_out/ks; timeout 900 rocprofv3 --kernel-trace --stats --output-form
 cp $(find gpurun_out/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 # 3. per-launch trace of one detection step
 bash tools/run_trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step.txt $OUT/${TAG}_step_trace.txt
+# 3b. per-launch trace of one detection step in the fp32 parity mode (round 6: the row-streaming fp32 kernels of csrc/det_rs32.hip)
+rm -rf gpurun_out/trace32; timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace32 -- python bench.py --dtype fp32 --steps 3 --warmup 2 --no-crnn --no-cpu-baseline --no-roofline --no-fp32 --no-ref-style --no-ddp-probe --no-config1 --no-pmc > gpurun_out/trace32.log 2>&1
+python tools/trace_step.py gpurun_out/trace32 > $OUT/${TAG}_fp32_step_trace.txt 2>&1; rm -rf gpurun_out/trace32
 # 4. HBM traffic (two separate PMC passes, kernel-trace only)
 bash tools/run_pmc_hbm.sh ${TAG}_pmc_hbm.csv > $OUT/pmc_hbm.log 2>&1; cp gpurun_out/${TAG}_pmc_hbm.csv $OUT/
 # 5. SQ counters of the matrix-core / row-streaming block kernels (every instantiation of the step)
