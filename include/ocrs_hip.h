@@ -65,7 +65,8 @@ int ocrs_rs32_fwd(const float* xa, const float* xb, int Ca, int Cb, const float*
                   hipStream_t st);
 /* Backward of the same block in fp32 as ONE row-streaming pass (csrc/det_rs32.hip; the autograd of models.py:11-23 as train_detection.py:96 runs it):
  * replaces ocrs_bn_bwd_finalize + ocrs_pw_bwd + ocrs_dw_bwd -- per pixel g (+ g2), z and x are read once and dL/dx~ is written once, the depthwise-input
- * gradient `du` never goes to memory.  Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}.
+ * gradient `du` never goes to memory.  Cin = Ca + Cb in {8, 16} (concat 8 | 8), Cout in {8, 16}; of level 1 also 16 | 16 -> 16 (two single-source passes)
+ * and 16 -> 32.
  * pooled = 1 (single source only): g1 / g2 are at half resolution and routed through MaxPool2d(2) (models.py:54) to each window's first maximum.
  * gsum [2][Cout] fp64: the block's COMPLETE BatchNorm-backward sums (the dz coefficients are derived in the prologue; dgamma / dbeta are written);
  * bn: the block's load transform [3][Cout]; dwpw / dwdw ACCUMULATED through ws (ocrs_rs32_bwd_ws_floats() floats; alive until ocrs_bwd_defer_flush

@@ -277,6 +277,7 @@ struct Rs32B {
     Rs32Jobs jb;
     BnFin fin;
     BwdLast bl;
+    int ldw;  // row pitch of wpw (= Cin, or the concat's total when the launch handles ONE 16-channel source of a 16 | 16 block: see ocrs_rs32_bwd)
 };
 constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of the transpose buffers: 16-byte aligned rows, conflict-light
 
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // A_r[(m = input channel, k)] = Wpw[4 k + r][m]  (DUAL: block-diagonal over the two strips)
         const int mc = DUAL ? (n & 7) : n;
-        afd[r] = (c4 + r < Cout && mc < Cin && (!DUAL || (n >> 3) == sB)) ? A.wpw[(c4 + r) * Cin + mc] : 0.f;
+        afd[r] = (c4 + r < Cout && mc < Cin && (!DUAL || (n >> 3) == sB)) ? A.wpw[(c4 + r) * A.ldw + mc] : 0.f;
     }
     const unsigned npix = (unsigned)A.N * H * W;
     const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
@@ -531,6 +532,273 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
+// The one-pass backward for the 32-channel shapes of level 1 (NSET register sets of 16 input channels, MT tiles of 16 output channels; (2, 2) does not fit
+// the register file): 16 | 16 -> 16 (up.1.contract.seq.0) and 16 -> 32 (down.1.seq.0).  Same structure as k_rs32_bwd, every per-set / per-tile piece
+// indexed; a concat source is one whole register set (no per-lane source select).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+template <int NSET, int MT, bool SPLIT, bool G2, bool STATS>
+__global__ __launch_bounds__(256, 2) void k_rs32_bwdx(const Rs32B A) {
+    constexpr int CI = 16 * NSET, CO = 16 * MT;
+    static_assert(NSET * MT <= 2 && (!SPLIT || NSET == 2), "shapes of level 1");
+    __shared__ float s_cf[3 * CO];
+    __shared__ __attribute__((aligned(16))) float s_tz[4][2][CO * RS32_TP];  // per wave: dz^T of rows yy (slot yy & 1) and yy - 1
+    __shared__ __attribute__((aligned(16))) float s_tu[4][CI * RS32_TP];     // per wave: u^T
+    __shared__ float s_red[4][CO * CI + 9 * CI + 2 * CI];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * CI];               // [tap][input channel]
+    __shared__ __attribute__((aligned(16))) float s_ko[5 * CO];              // [A | B | C | mask scale | mask shift][output channel]
+    __shared__ __attribute__((aligned(16))) float s_ki[3 * CI];              // [scale | shift | lo][input channel]
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
+    bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    __syncthreads();
+    if (tid < 32) {
+        const int c = tid;
+        if (c < CO) {
+            const bool o = c < Cout;
+            s_ko[0 * CO + c] = o ? s_cf[c] : 0.f;
+            s_ko[1 * CO + c] = o ? s_cf[Cout + c] : 0.f;
+            s_ko[2 * CO + c] = o ? s_cf[2 * Cout + c] : 0.f;
+            s_ko[3 * CO + c] = o ? A.bn[c] : 0.f;
+            s_ko[4 * CO + c] = o ? A.bn[Cout + c] : 0.f;
+        }
+        if (c < CI) {
+            const bool i = c < Cin, ia = c < Ca;
+            const float* tr = ia ? A.tra : A.trb;
+            const int Cs = ia ? Ca : Cb, cc = ia ? c : c - Ca;
+            s_ki[0 * CI + c] = i ? tr[cc] : 0.f;
+            s_ki[1 * CI + c] = i ? tr[Cs + cc] : 0.f;
+            s_ki[2 * CI + c] = i ? tr[2 * Cs + cc] : 0.f;
+            for (int t = 0; t < 9; ++t) s_w[t * CI + c] = i ? A.wdw[c * 9 + t] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int c4 = 4 * q;
+    bool okO[MT], okI[NSET];
+    float afd[MT][NSET][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) okO[mt] = 16 * mt + c4 < Cout;
+#pragma unroll
+    for (int st = 0; st < NSET; ++st) okI[st] = 16 * st + c4 < Cin;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int st = 0; st < NSET; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)  // A_r[(m = input channel of set st, k)] = Wpw[16 mt + 4 k + r][16 st + m]
+                afd[mt][st][r] = (16 * mt + c4 + r < Cout && 16 * st + n < Cin) ? A.wpw[(16 * mt + c4 + r) * A.ldw + 16 * st + n] : 0.f;
+    const unsigned npix = (unsigned)A.N * H * W;
+    const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
+    const rsrc_t rg1 = mk_rsrc(A.g1, npix * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, npix * Cout * 4), rz = mk_rsrc(A.z, npix * Cout * 4);
+    const rsrc_t wa = mk_rsrc(A.gxa, npix * Ca * 4), wb = mk_rsrc(SPLIT ? A.gxb : A.gxa, npix * (SPLIT ? Cb : Ca) * 4);
+    const unsigned pa = Ca * 4, pb = Cb * 4, po = Cout * 4;
+
+    float aw[NSET][4][9], st1[NSET][4], st2[NSET][4];
+    f32x4 dwpw[MT][NSET];
+#pragma unroll
+    for (int st = 0; st < NSET; ++st) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dwpw[mt][st] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            st1[st][r] = st2[st][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) aw[st][r][t] = 0.f;
+        }
+    }
+    float* tu = s_tu[wave];
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < H) ? y0 + A.jb.rb : H;
+        const int col = cg * RS32_COLS + n - 1;
+        const bool colok = (unsigned)col < (unsigned)W;
+        const bool useful = n >= 1 && n <= RS32_COLS && col < W;
+        const int rowpix0 = img * H * W + col;
+
+        f32x4 rg[MT], rg2v[G2 ? MT : 1], rzv[MT], rx[NSET];
+        auto issue = [&](int yy) {
+            const bool ok = colok && (unsigned)yy < (unsigned)H && yy <= y1;
+            const unsigned pix = (unsigned)(rowpix0 + yy * W);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int oo = (ok && okO[mt]) ? (int)(pix * po + (unsigned)(16 * mt + c4) * 4u) : -1;
+                rg[mt] = bld16(rg1, oo);
+                if constexpr (G2) rg2v[mt] = bld16(rg2, oo);
+                rzv[mt] = bld16(rz, oo);
+            }
+#pragma unroll
+            for (int st = 0; st < NSET; ++st) {
+                const bool fromb = SPLIT && st == 1;  // (a concat source is one whole set: 16 | 16)
+                const unsigned off = fromb ? pix * pb + (unsigned)c4 * 4u : pix * pa + (unsigned)(16 * st + c4) * 4u;
+                rx[st] = bld16(fromb ? rbs : ra, (ok && okI[st]) ? (int)off : -1);
+            }
+        };
+        issue(y0 - 1);
+
+        float X[3][NSET][4], DU[3][NSET][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int st = 0; st < NSET; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[i][st][r] = DU[i][st][r] = 0.f;
+
+        for (int yy = y0 - 1; yy <= y1; ++yy) {
+            const bool ok = colok && (unsigned)yy < (unsigned)H;
+#pragma unroll
+            for (int st = 0; st < NSET; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    X[0][st][r] = X[1][st][r]; X[1][st][r] = X[2][st][r];
+                    DU[0][st][r] = DU[1][st][r]; DU[1][st][r] = DU[2][st][r];
+                }
+            int oz = 0;
+            asm volatile("" : "+v"(oz));  // (opaque zero: the constant vectors stay LDS reads inside the loop)
+            const float* ko = s_ko + c4 + oz;
+            const float* ki = s_ki + c4 + oz;
+            const float* kw = s_w + c4 + oz;
+            float dzc[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 gv = rg[mt];
+                if constexpr (G2) gv = gv + rg2v[mt];
+                const f32x4 zv = rzv[mt];
+                const f32x4 cA = *reinterpret_cast<const f32x4*>(ko + 16 * mt), cB = *reinterpret_cast<const f32x4*>(ko + CO + 16 * mt),
+                            cC = *reinterpret_cast<const f32x4*>(ko + 2 * CO + 16 * mt), msc = *reinterpret_cast<const f32x4*>(ko + 3 * CO + 16 * mt),
+                            msh = *reinterpret_cast<const f32x4*>(ko + 4 * CO + 16 * mt);
+                const float mO = (ok && okO[mt]) ? 1.f : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gh = fmaf(zv[r], msc[r], msh[r]) > 0.f ? gv[r] : 0.f;
+                    dzc[mt][r] = mO * fmaf(cA[r], gh, fmaf(cB[r], zv[r], cC[r]));
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < NSET; ++st) {
+                const f32x4 xv = rx[st];
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(ki + 16 * st), sh = *reinterpret_cast<const f32x4*>(ki + CI + 16 * st),
+                            lo = *reinterpret_cast<const f32x4*>(ki + 2 * CI + 16 * st);
+                const float mI = (ok && okI[st]) ? 1.f : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[2][st][r] = mI * fmaxf(fmaf(xv[r], sc[r], sh[r]), lo[r]);
+            }
+            issue(yy + 1);
+            {
+                float* tzw = s_tz[wave][yy & 1];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tzw[(16 * mt + c4 + r) * RS32_TP + n] = dzc[mt][r];
+#pragma unroll
+                for (int st = 0; st < NSET; ++st) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(afd[mt][st][r], dzc[mt][r], d, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) DU[2][st][r] = d[r];
+                }
+            }
+            const int c = yy - 1;
+            const bool act = useful && c >= y0 && c < y1;
+            const float actf = act ? 1.f : 0.f;
+            const unsigned opix = (unsigned)(img * H * W + c * W + col);
+#pragma unroll
+            for (int st = 0; st < NSET; ++st) {
+                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+                float u[4] = {0.f, 0.f, 0.f, 0.f}, dm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dm[r] = actf * DU[1][st][r];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 0) * CI + 16 * st), w1 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 1) * CI + 16 * st),
+                                w2 = *reinterpret_cast<const f32x4*>(kw + (ky * 3 + 2) * CI + 16 * st);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dv = DU[2 - ky][st][r];
+                        dx[r] = fmaf(w2[r], dpp_f<DPP_SHR1>(dv), fmaf(w1[r], dv, fmaf(w0[r], dpp_f<DPP_SHL1>(dv), dx[r])));
+                        const float xv = X[ky][st][r], xl = dpp_f<DPP_SHR1>(xv), xr = dpp_f<DPP_SHL1>(xv);
+                        u[r] = fmaf(w2[r], xr, fmaf(w1[r], xv, fmaf(w0[r], xl, u[r])));
+                        aw[st][r][ky * 3 + 0] = fmaf(dm[r], xl, aw[st][r][ky * 3 + 0]);
+                        aw[st][r][ky * 3 + 1] = fmaf(dm[r], xv, aw[st][r][ky * 3 + 1]);
+                        aw[st][r][ky * 3 + 2] = fmaf(dm[r], xr, aw[st][r][ky * 3 + 2]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u[r] *= actf;
+                    if constexpr (STATS) {
+                        const float gh = X[1][st][r] > 0.f ? actf * dx[r] : 0.f;
+                        st1[st][r] += gh;
+                        st2[st][r] = fmaf(gh, X[1][st][r], st2[st][r]);
+                    }
+                    tu[(16 * st + c4 + r) * RS32_TP + n] = u[r];
+                }
+                const bool fromb = SPLIT && st == 1;
+                const unsigned off = fromb ? opix * pb + (unsigned)c4 * 4u : opix * pa + (unsigned)(16 * st + c4) * 4u;
+                bst16(fromb ? wb : wa, (act && okI[st]) ? (int)off : -1, dx);
+            }
+            {
+                f32x4 a4[MT], b4[NSET];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a4[mt] = *reinterpret_cast<const f32x4*>(s_tz[wave][c & 1] + (16 * mt + n) * RS32_TP + c4);
+#pragma unroll
+                for (int st = 0; st < NSET; ++st) b4[st] = *reinterpret_cast<const f32x4*>(tu + (16 * st + n) * RS32_TP + c4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int st = 0; st < NSET; ++st)
+#pragma unroll
+                        for (int tt = 0; tt < 4; ++tt) dwpw[mt][st] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][tt], b4[st][tt], dwpw[mt][st], 0, 0, 0);
+            }
+        }
+    }
+    float* red = s_red[wave];
+#pragma unroll
+    for (int st = 0; st < NSET; ++st)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) red[(16 * mt + c4 + r) * CI + 16 * st + n] = dwpw[mt][st][r];  // dWpw[o = 16 mt + 4 k + r][ch = 16 st + n]
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float v = quad16_sum(aw[st][r][t]);
+                if (n == 0) red[CO * CI + (16 * st + c4 + r) * 9 + t] = v;
+            }
+            if constexpr (STATS) {
+                const float v1 = quad16_sum(st1[st][r]), v2 = quad16_sum(st2[st][r]);
+                if (n == 0) {
+                    red[CO * CI + 9 * CI + 16 * st + c4 + r] = v1;
+                    red[CO * CI + 9 * CI + CI + 16 * st + c4 + r] = v2;
+                }
+            }
+        }
+    __syncthreads();
+    const int ne = Cout * Cin + 9 * Cin;
+    for (int e = tid; e < ne + (STATS ? 2 * Cin : 0); e += 256) {
+        int idx;
+        if (e < Cout * Cin)
+            idx = (e / Cin) * CI + e % Cin;
+        else if (e < ne)
+            idx = CO * CI + (e - Cout * Cin);
+        else
+            idx = CO * CI + 9 * CI + ((e - ne) / Cin) * CI + (e - ne) % Cin;
+        const float v = (s_red[0][idx] + s_red[1][idx]) + (s_red[2][idx] + s_red[3][idx]);
+        if (e < ne)
+            A.ws[(long)blockIdx.x * ne + e] = v;
+        else if (A.bl.raw)
+            bwd_last_add(A.bl, Cin, (e - ne) % Cin, (e - ne) / Cin, v);
+    }
+    if constexpr (STATS) {
+        if (A.bl.raw) bwd_last_finish(A.bl, Cin, A.tra, A.trb, tid, 256, &s_flag);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
 // The same one-pass backward for a block whose output feeds ONLY MaxPool2d(2) (models.py:54): the gradient g (+ g2) arrives at half resolution and is
 // routed to each 2 x 2 window's first maximum in post-ReLU space (row-major order, strict >: ocrs_bn_bwd_reduce's / ocrs_pw_bwd's rule).  A tick is a
 // ROW PAIR (2 i, 2 i + 1) = one row of windows; a window's two columns are adjacent lanes (quad_perm [1,0,3,2]), so a strip needs TWO halo columns
@@ -614,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwdp(const Rs32B A) {
     const bool okO = c4 < Cout, okI = c4 < Cin;
     float afd[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) afd[r] = (c4 + r < Cout && n < Cin) ? A.wpw[(c4 + r) * Cin + n] : 0.f;
+    for (int r = 0; r < 4; ++r) afd[r] = (c4 + r < Cout && n < Cin) ? A.wpw[(c4 + r) * A.ldw + n] : 0.f;
     const unsigned npix = (unsigned)A.N * H * W, nppx = (unsigned)A.N * Hp * Wp;
     const rsrc_t ra = mk_rsrc(A.xa, npix * Cin * 4), rz = mk_rsrc(A.z, npix * Cout * 4), wa = mk_rsrc(A.gxa, npix * Cin * 4);
     const rsrc_t rg1 = mk_rsrc(A.g1, nppx * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, nppx * Cout * 4);
@@ -1041,7 +1309,7 @@ static double* rs32_last_scratch(int ndoubles, hipStream_t st) {
     static double* g_own[16] = {};
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
-    constexpr int CAP = BWD_LAST_SLOTS * 2 * 16 + 2;
+    constexpr int CAP = BWD_LAST_SLOTS * 2 * 32 + 2;
     if (ndoubles > CAP) return nullptr;
     if (!g_own[d]) {
         double* p = nullptr;
@@ -1154,6 +1422,8 @@ long ocrs_rs32_bwd_supported(int Ca, int Cb, int Cout, int pooled, int dtype) {
     static const int on = env_int("OCRS_RS32", 1), onb = env_int("OCRS_RS32_BWD", 1), onp = env_int("OCRS_RS32_BWDP", 1);
     if (!on || !onb || dtype != 0 || (pooled && (!onp || Cb))) return 0;
     const int Cin = Ca + Cb;
+    static const int onx = env_int("OCRS_RS32_BWDX", 1);
+    if (onx && !pooled && ((Ca == 16 && Cb == 16 && Cout == 16) || (Ca == 16 && Cb == 0 && Cout == 32))) return 1;  // level 1: two single-source passes / k_rs32_bwdx
     if (!(Cin == 8 || Cin == 16) || !(Cout == 8 || Cout == 16)) return 0;
     if (Cb && !(Ca == 8 && Cb == 8)) return 0;
     return 1;
@@ -1165,7 +1435,35 @@ static int rs32_bwd_rb() {
 long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = Ca + Cb;
     const int ga = rs32_grid(rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()).njobs, 3), gp = rs32_grid(rs32_jobs(N, H, W, RS32P_COLS, rs32_bwd_rb()).njobs, 2);
-    return (long)(ga > gp ? ga : gp) * (Cout * Cin + 9 * Cin);  // (direct form: 14-column strips; pooled form: 12)
+    return (long)(ga > gp ? ga : gp) * (Cout * Cin + 9 * Cin) * (Cb == 16 ? 2 : 1);  // (direct form: 14-column strips; pooled form: 12; 16 | 16: two passes)
+}
+
+// one single-source 16-channel pass of a 16 | 16 block (see ocrs_rs32_bwd): x / tr / gx = that source, wdw / wpw / dwpw / dwdw pre-offset to its channels
+static int rs32_bwd_one(const float* x, const float* tr, const float* wdw, const float* wpw, int ldw, const float* g1, const float* g2, const float* z,
+                        const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, float* gx, float* dwpw,
+                        float* dwdw, float* ws, const float* saved_p, double* gsum_p, int Cout, int N, int H, int W, hipStream_t st) {
+    const int Cin = 16;
+    const bool stats = gsum_p != nullptr;
+    BwdLast bl{nullptr, nullptr, gsum_p, nullptr, saved_p, nullptr, Cin, 0};
+    if (stats) {
+        double* p = rs32_last_scratch(BWD_LAST_SLOTS * 2 * Cin + 2, st);
+        if (!p) return OCRS_ERR_HIP;
+        bl.raw = p;
+        bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
+    }
+    Rs32B a{x, nullptr, tr, nullptr, wdw, wpw, g1, g2, z, bn, gx, nullptr, ws, Cin, 0, Cout, N, H, W, rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()),
+            BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, ldw};
+    const int grid = rs32_grid(a.jb.njobs, 3);
+#define RS32O_CASE(G2_, ST_)                                                                          \
+    if ((g2 != nullptr) == G2_ && stats == ST_) {                                                    \
+        OCRS_LAUNCH_T((k_rs32_bwd<false, G2_, ST_, 1, false>), dim3(grid), dim3(256), 0, st, a);     \
+        OCRS_LAUNCH_CHECK();                                                                         \
+    }
+    RS32O_CASE(false, false) RS32O_CASE(false, true) RS32O_CASE(true, false) RS32O_CASE(true, true)
+#undef RS32O_CASE
+    bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, ldw, dwdw, 9 * Cin, st);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
 }
 
 // Backward of one DepthwiseConv block in fp32 as ONE row-streaming pass (replaces ocrs_bn_bwd_finalize + ocrs_pw_bwd + ocrs_dw_bwd; the reference's
@@ -1183,6 +1481,16 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
     OCRS_CHECK_ARG((!gsum_a || saved_a) && (!gsum_b || (saved_b && Cb > 0)));
     const int Cin = Ca + Cb, Cmax = Cin > Cout ? Cin : Cout;
     OCRS_CHECK_ARG((long)N * H * W * Cmax * 4 < (1L << 32));
+    if (Ca == 16 && Cb == 16) {
+        // 16 | 16 -> Cout (up.1.contract.seq.0): every input-side quantity (dx~, dWdw, the column block of dWpw, the producer's sums) is per input channel,
+        // so the block runs as TWO single-source passes of the 16-channel kernel that share only the reads of g and z (a fused two-set form needs 330
+        // registers): pass s sees source s, the weight columns [16 s, 16 s + 16) at the concat's row pitch, and its own half of ws
+        const long half = ocrs_rs32_bwd_ws_floats(16, 0, Cout, N, H, W);
+        int rc = rs32_bwd_one(xa, tra, wdw, wpw, 32, g1, g2, z, bn, gsum, gamma, saved, dgamma, dbeta, gxa, dwpw, dwdw, ws, saved_a, gsum_a, Cout, N, H, W, st);
+        if (rc != OCRS_OK) return rc;
+        return rs32_bwd_one(xb, trb, wdw + 16 * 9, wpw + 16, 32, g1, g2, z, bn, gsum, gamma, saved, dgamma, dbeta, gxb, dwpw + 16, dwdw + 16 * 9, ws + half, saved_b,
+                            gsum_b, Cout, N, H, W, st);
+    }
     const bool stats = gsum_a || gsum_b;
     BwdLast bl{nullptr, nullptr, gsum_a, gsum_b, saved_a, saved_b, Ca, 0};
     if (stats) {
@@ -1194,8 +1502,21 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
     static const int dual_on = env_int("OCRS_RS32_DUAL", 1);
     const bool dual = dual_on && !pooled && Cb == 0 && Cin == 8 && Cout == 8;  // two 14-column strips per wave (8-channel tensors fill half the lanes)
     Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W,
-            rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl};
-    const int grid = rs32_grid(a.jb.njobs, (pooled || (dual && g2)) ? 2 : 3);
+            rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, Cin};
+    const bool wide = Cin > 16 || Cout > 16;
+    const int grid = rs32_grid(a.jb.njobs, (pooled || wide || (dual && g2)) ? 2 : 3);
+    if (wide) {
+#define RS32X_CASE(NS_, MT_, SP_, G2_, ST_)                                                                                  \
+    if (Cin == 16 * NS_ && Cout == 16 * MT_ && (Cb != 0) == SP_ && (g2 != nullptr) == G2_ && stats == ST_) {               \
+        OCRS_LAUNCH_T((k_rs32_bwdx<NS_, MT_, SP_, G2_, ST_>), dim3(grid), dim3(256), 0, st, a);                             \
+        OCRS_LAUNCH_CHECK();                                                                                                \
+    }
+        RS32X_CASE(1, 2, false, false, false) RS32X_CASE(1, 2, false, false, true) RS32X_CASE(1, 2, false, true, false) RS32X_CASE(1, 2, false, true, true)
+#undef RS32X_CASE
+        bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, Cin, dwdw, 9 * Cin, st);
+        OCRS_LAUNCH_CHECK();
+        return OCRS_OK;
+    }
     if (pooled) {
         OCRS_CHECK_ARG(H >= 2 && W >= 2);
 #define RS32P_CASE(G2_, ST_)                                                                    \

@@ -812,7 +812,8 @@ def test_rs32_block_forward(dev, Ca, Cb, Cout, pool, shape):
 
 @pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 28), (1, 67, 15)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("two_grads", [False, True])
-@pytest.mark.parametrize("C0,Ca,Cb,Cc", [(8, 8, 0, 8), (8, 8, 0, 16), (8, 16, 0, 16), (16, 16, 0, 8), (8, 8, 8, 8), (16, 8, 8, 16)])
+@pytest.mark.parametrize("C0,Ca,Cb,Cc", [(8, 8, 0, 8), (8, 8, 0, 16), (8, 16, 0, 16), (16, 16, 0, 8), (8, 8, 8, 8), (16, 8, 8, 16),
+                                         (16, 16, 16, 16), (8, 16, 0, 32)])  # level 1: 16 | 16 -> 16 as two single-source passes, 16 -> 32 on k_rs32_bwdx
 def test_rs32_block_backward(dev, C0, Ca, Cb, Cc, two_grads, shape):
     """ocrs_rs32_bwd (csrc/det_rs32.hip: the fp32 block backward as ONE row-streaming pass, round 6) on a two-level chain  x0 -> A (-> B) -> C:
     block C's backward (direct gradient, one or two gradient tensors, single input or the 8 | 8 concat) produces dL/dx~ of both halves, dWdw, dWpw,
