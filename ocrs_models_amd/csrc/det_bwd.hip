@@ -1846,7 +1846,8 @@ int ocrs_convt_bwd_parts(const void* x, const float* tr, const void* g, const vo
     OCRS_LAUNCH_CHECK();
     }
     if (!(parts & 2)) return OCRS_OK;
-    if (ws && det_rs32_ctw_supported(Cup, Cout, dtype))  // fp32, wide levels: weight AND bias gradient (into dbias; dbias64 stays as the caller zeroed it)
+    if (ws && det_rs32_ctw_supported(Cup, Cout, dtype) && (long)N * H * W * Cout * 4 < (1L << 32) && (long)N * h * w * Cup * 4 < (1L << 32))
+        // fp32, wide levels: weight AND bias gradient (into dbias; dbias64 stays as the caller zeroed it)
         return det_rs32_ctw_launch((const float*)x, tr, (const float*)g, dW, dbias, ws, Cup, Cout, N, h, w, H, W, st);
     {
         const int rc = ocrs_wgrad_gather(x, Cup, Cup, tr, g, Cout, Cout, dW, ws, N, h, w, H, W, 2, 0, 0, 3, 3, dtype, st);

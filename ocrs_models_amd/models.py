@@ -288,7 +288,7 @@ class _DetRun:
             r.prefix, r.a, r.b, r.z, r.tr, r.saved, r.Cin, r.Cout, r.H, r.W = prefix, a, b, z, tr, saved, Cin, Cout, H, W
             self.recs[prefix] = r
             return _Act(z, tr, Cout, H, W, src=prefix)
-        if self.use_rs32 and L.rs32_fwd_supported(a.C, Cb, Cout, self.dt):
+        if self.use_rs32 and L.rs32_fwd_supported(a.C, Cb, Cout, self.dt) and N * H * W * max(Cin, Cout) * 4 < 2 ** 32:  # (32-bit buffer offsets)
             # fp32 (parity mode), wide levels: register-resident row-streaming waves (csrc/det_rs32.hip) -- no LDS tile, exact-fp32 matrix cores
             pooled = gamma = None
             if pool and self.fuse_pool:
@@ -400,7 +400,8 @@ class _DetRun:
             wpk = self.pack(P[f"up.{i}.up.weight"], 1, 4 * Cup, 4 * Cout, Cup, 0, 0, 0)
             t = self.empty(N, skip.H, skip.W, Cout)
             up.other_use = True
-            if self.use_rs32 and L.rs32_convt_fwd_supported(Cup, Cout, self.dt):  # fp32, wide levels: row-streaming over the input grid (csrc/det_rs32.hip)
+            if (self.use_rs32 and L.rs32_convt_fwd_supported(Cup, Cout, self.dt)  # fp32, wide levels: row-streaming over the input grid (csrc/det_rs32.hip)
+                    and N * skip.H * skip.W * Cout * 4 < 2 ** 32):
                 L.rs32_convt_fwd(ptr(up.t), ptr(up.tr), ptr(P[f"up.{i}.up.weight"]), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W)
             else:
                 L.convt_fwd(ptr(up.t), ptr(up.tr), ptr(wpk), ptr(P[f"up.{i}.up.bias"]), ptr(t), Cup, Cout, N, up.H, up.W, skip.H, skip.W, self.dt)
@@ -505,7 +506,8 @@ class _DetRun:
                          ptr(g1), ptr(g2), pooled, ptr(r.z), ptr(r.tr), ptr(coef), ptr(gxa), ptr(gxb), ptr(self.G[f"{prefix}.seq.1.weight"]),
                          ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb), C, N, H, W, self.dt)
             return gxa, gxb
-        if self.use_rs32 and need_gx and L.rs32_bwd_supported(Ca, Cb, C, 1 if pooled else 0, self.dt):
+        if (self.use_rs32 and need_gx and L.rs32_bwd_supported(Ca, Cb, C, 1 if pooled else 0, self.dt) and N * H * W * max(r.Cin, C) * 4 < 2 ** 32
+                and (not pooled or (H >= 2 and W >= 2))):
             # fp32 (parity mode), wide levels: the whole block backward as ONE row-streaming pass (csrc/det_rs32.hip) -- dz coefficients derived in the
             # prologue, `du` never stored, both weight gradients and the producers' BatchNorm-backward sums from the same registers
             gxa = self.empty(N, H, W, Ca)
