@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
     bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
-    for (int i = tid; i < 4 * 3 * 16 * TP2; i += 256) (&s_t[0][0][0])[i] = 0.f;  // (DUAL: the transpose rows 8 .. 15 are never written and must read 0)
+    // zeroed: the first tick of a wave reads the dz^T slot of a row it never wrote (times u = 0: but uninitialised LDS may hold NaN / Inf bit patterns of an
+    // earlier kernel, and NaN x 0 = NaN in the MFMA -- caught by the full GPU suite in round 6); DUAL: rows 8 .. 15 are never written at all
+    for (int i = tid; i < 4 * 3 * 16 * TP2; i += 256) (&s_t[0][0][0])[i] = 0.f;
     __syncthreads();
     if (tid < 16) {
         const int c = tid;
@@ -552,6 +554,8 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwdx(const Rs32B A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ca = A.Ca, Cb = A.Cb, Cin = Ca + Cb, Cout = A.Cout, H = A.H, W = A.W;
     bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    for (int i = tid; i < 4 * 2 * CO * RS32_TP; i += 256) (&s_tz[0][0][0])[i] = 0.f;  // (see k_rs32_bwd: the first tick reads a slot it never wrote)
+    for (int i = tid; i < 4 * CI * RS32_TP; i += 256) (&s_tu[0][0])[i] = 0.f;
     __syncthreads();
     if (tid < 32) {
         const int c = tid;
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(256, 2) void k_rs32_bwdp(const Rs32B A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = A.Ca, Cout = A.Cout, H = A.H, W = A.W, Hp = H >> 1, Wp = W >> 1;
     bn_fin_coef(A.fin, Cout, s_cf, tid, 256, blockIdx.x == 0);
+    for (int i = tid; i < 4 * 5 * 16 * RS32_TP; i += 256) (&s_t[0][0][0])[i] = 0.f;  // (see k_rs32_bwd: the first tick reads a slot it never wrote)
     __syncthreads();
     if (tid < 16) {
         const int c = tid;
