@@ -40,9 +40,14 @@ constexpr int RS32_COLS = 14;  // output columns of a strip (16 lanes - 2 halo l
 struct Rs32Jobs {
     int ncg, nrb, rb, njobs;  // column groups per row, row blocks per image, rows per block, jobs = N * nrb * ncg (column group fastest)
 };
+// rb = the rows per job wanted (64 at full size: 3 % halo rows).  A wave walks its job row by row (~1 us per row), so a SMALL tensor cut into 64-row jobs
+// leaves most wave slots empty and every kernel takes >= 66 row times (the config-1-sized fp32 step, 2 x 512^2, went 3.9 -> 5.3 ms on the first form):
+// halve the rows per job (even values down to 8) until there are two jobs per resident wave slot
 static inline Rs32Jobs rs32_jobs(int N, int H, int W, int cols, int rb) {
     Rs32Jobs j;
     j.ncg = (W + cols - 1) / cols;
+    const long want = 2L * kNumCU * 3 * 4;
+    while (rb > 8 && (long)N * ((H + rb - 1) / rb) * j.ncg < want) rb = (rb / 2 + 1) & ~1;
     j.rb = rb;
     j.nrb = (H + rb - 1) / rb;
     j.njobs = N * j.nrb * j.ncg;
@@ -1344,8 +1349,7 @@ extern "C" {
 long det_rs32_ctw_ws_floats(int Cup, int Cout, int N, int h, int w, int dtype) {
     if (!det_rs32_ctw_supported(Cup, Cout, dtype)) return 0;
     const int CE = Cout >= 16 ? 16 : 8, nl = Cout / CE;
-    const Rs32Jobs jb = rs32_jobs(N, h, w, 16, rs32_ctw_rb());
-    return (long)rs32_grid(jb.njobs, 2) * 4 * (Cup * 9 * CE + CE) * nl;
+    return (long)rs32_grid(1 << 30, 2) * 4 * (Cup * 9 * CE + CE) * nl;  // (the grid cap: independent of how the rows are cut into jobs)
 }
 int det_rs32_ctw_launch(const float* x, const float* tr, const float* g, float* dW, float* dbias, float* ws, int Cup, int Cout, int N, int h, int w, int H,
                         int W, hipStream_t st) {
@@ -1439,8 +1443,8 @@ static int rs32_bwd_rb() {
 }
 long ocrs_rs32_bwd_ws_floats(int Ca, int Cb, int Cout, int N, int H, int W) {
     const int Cin = Ca + Cb;
-    const int ga = rs32_grid(rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()).njobs, 3), gp = rs32_grid(rs32_jobs(N, H, W, RS32P_COLS, rs32_bwd_rb()).njobs, 2);
-    return (long)(ga > gp ? ga : gp) * (Cout * Cin + 9 * Cin) * (Cb == 16 ? 2 : 1);  // (direct form: 14-column strips; pooled form: 12; 16 | 16: two passes)
+    (void)N; (void)H; (void)W;
+    return (long)rs32_grid(1 << 30, 3) * (Cout * Cin + 9 * Cin) * (Cb == 16 ? 2 : 1);  // (the grid cap; 16 | 16: two passes, each with its own half)
 }
 
 // one single-source 16-channel pass of a 16 | 16 block (see ocrs_rs32_bwd): x / tr / gx = that source, wdw / wpw / dwpw / dwdw pre-offset to its channels
