@@ -122,6 +122,12 @@ int ocrs_convt_fwd(const void* x, const float* tr, const void* wpk, const float*
 long ocrs_rs32_convt_fwd_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
 int ocrs_rs32_convt_fwd(const float* x, const float* tr, const float* wt, const float* bias, float* out, int Cup, int Cout, int N, int h, int w, int H, int W,
                         hipStream_t st);
+/* ... and its input gradient (the dx half of ocrs_convt_bwd_parts; autograd of models.py:76-78) in fp32 as row-streaming waves over the input grid, (Cup, Cout)
+   in {(16, 8), (32, 16)}, from the MASTER weight; x / tr / saved / gsum (nullable together): also the BatchNorm-backward sums of the block that produced x when
+   this ConvTranspose is its only consumer (as ocrs_convt_bwd's saved / gsum: [2][Cup] fp64, ACCUMULATED). */
+long ocrs_rs32_convt_dgrad_supported(int Cup, int Cout, int dtype); /* 1 / 0 */
+int ocrs_rs32_convt_dgrad(const float* g, const float* wt, float* dx, const float* x, const float* tr, const float* saved, double* gsum, int Cup, int Cout, int N,
+                          int h, int w, int H, int W, hipStream_t st);
 /* out_conv: nn.Conv2d(8, 1, 1) + nn.Sigmoid (models.py:125-129). */
 int ocrs_head_fwd(const void* z, const float* tr, const float* w, const float* b, float* pred, long P, int dtype, hipStream_t st);
 

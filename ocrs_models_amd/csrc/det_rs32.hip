@@ -1113,20 +1113,29 @@ __global__ __launch_bounds__(256, 2) void k_rs32_ctw(const Rs32CW A) {
         const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < h) ? y0 + A.jb.rb : h;
         const int j = cg * 16 + n;
         const bool jok = j < w;
-        for (int i = y0; i < y1; ++i) {
-            // ---- loads: x (MT quads) and the window positions of this lane's slots
-            f32x4 xv[MT], gv[NT];
+        // rows are loaded one tick ahead (the first form loaded and consumed in the same tick: every row paid a full memory latency, 1068 us at level 0)
+        f32x4 xv[MT], gv[NT], xn[MT], gn[NT];
+        auto issue = [&](int i) {
+            const bool live = i < y1;
             const unsigned ipix = (unsigned)((img * h + i) * w + j);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xv[mt] = bld16(rx, jok ? (int)(ipix * px_ + (unsigned)(16 * mt + c4) * 4u) : -1);
+            for (int mt = 0; mt < MT; ++mt) xn[mt] = bld16(rx, (live && jok) ? (int)(ipix * px_ + (unsigned)(16 * mt + c4) * 4u) : -1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pos = nt * PPS + ppos;  // 0 .. 8 (9: the empty half of the last set when CE = 8)
                 const int kh = pos / 3, kw = pos - 3 * kh;
                 const int oy = 2 * i + kh, ox = 2 * j + kw;
-                const bool ok = jok && pos < 9 && oy < H && ox < W;
-                gv[nt] = bld16(rg, ok ? (int)((unsigned)((img * H + oy) * W + ox) * pg + (unsigned)(A.o0 + oq) * 4u) : -1);
+                const bool ok = live && jok && pos < 9 && oy < H && ox < W;
+                gn[nt] = bld16(rg, ok ? (int)((unsigned)((img * H + oy) * W + ox) * pg + (unsigned)(A.o0 + oq) * 4u) : -1);
             }
+        };
+        issue(y0);
+        for (int i = y0; i < y1; ++i) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xv[mt] = xn[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gv[nt] = gn[nt];
+            issue(i + 1);
             // ---- x~ and g transposed into the wave's LDS rows (same wave writes and reads: in order, no barrier)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -1297,6 +1306,139 @@ __global__ __launch_bounds__(256, 2) void k_rs32_ctf(const Rs32CF A) {
             for (int s = 0; s < NSET; ++s)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Xp[s][r] = Xc[s][r];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// ConvTranspose2d input gradient in fp32 (+ the BatchNorm-backward sums of the block that produced x when the ConvTranspose is its only consumer):
+//   dx~[i][j][c] = sum_{kh,kw,o} W[c][o][kh][kw] g[2 i + kh][2 j + kw][o]      -- a stride-2 3 x 3 convolution of the output gradient
+// Same walk as k_rs32_ctw (16 input pixels per strip, every lane loads its own 3 x 3 window one row ahead); the window registers ARE the B operands
+// (K = (position, o)), the per-(tile, set) weight fragments come from an LDS table built once per workgroup from the master weight.  Replaces
+// k_convt_dgrad<float> (635 / 436 us at levels 0 / 1) and, with STATS, the k_bn_bwd_reduce<float> pass behind it (287 / 157 us).
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+struct Rs32CD {
+    const float *g, *wt, *x, *tr;
+    float* dx;
+    int Cup, Cout, N, h, w, H, W;
+    Rs32Jobs jb;
+    BwdLast bl;
+};
+
+template <int MT, int CE, bool STATS>
+__global__ __launch_bounds__(256, 2) void k_rs32_ctd(const Rs32CD A) {
+    constexpr int NT = (9 * CE + 15) / 16, PPS = 16 / CE;
+    __shared__ __attribute__((aligned(16))) float s_af[MT * NT * 64 * 4];  // [tile][set][lane][K step]
+    __shared__ float s_red[4][2][16 * MT];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cup = A.Cup, Cout = A.Cout, h = A.h, w = A.w, H = A.H, W = A.W;
+    for (int e = tid; e < MT * NT * 64 * 4; e += 256) {
+        const int r = e & 3, ln = (e >> 2) & 63, rest = e >> 8, nt = rest % NT, mt = rest / NT;
+        const int c = 16 * mt + (ln & 15), col = 16 * nt + 4 * (ln >> 4) + r, pos = col / CE, o = col - pos * CE;  // A_r[(m = c, k)] = W[c][o][pos], column = 16 nt + 4 k + r
+        s_af[e] = (c < Cup && pos < 9 && o < Cout) ? A.wt[(c * Cout + o) * 9 + pos] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = 4 * q;
+    const int ppos = PPS == 2 ? (q >> 1) : 0, oq = PPS == 2 ? 4 * (q & 1) : c4;
+    float sc[MT][4], sh[MT][4], lo[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[mt][r] = STATS ? A.tr[16 * mt + c4 + r] : 0.f;
+            sh[mt][r] = STATS ? A.tr[Cup + 16 * mt + c4 + r] : 0.f;
+            lo[mt][r] = STATS ? A.tr[2 * Cup + 16 * mt + c4 + r] : 0.f;
+        }
+    const unsigned npi = (unsigned)A.N * h * w, npo = (unsigned)A.N * H * W;
+    const rsrc_t rx = mk_rsrc(STATS ? A.x : A.g, STATS ? npi * Cup * 4 : 16), rg = mk_rsrc(A.g, npo * Cout * 4), wd = mk_rsrc(A.dx, npi * Cup * 4);
+    const unsigned px_ = Cup * 4, pg = Cout * 4;
+    const f32x4* af = reinterpret_cast<const f32x4*>(s_af) + lane;
+    float st1[MT][4], st2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1[mt][r] = st2[mt][r] = 0.f;
+
+    const Rs32Sched sched(A.jb.njobs, wave);
+    for (int job = sched.first; job < sched.end; job += sched.step) {
+        const int cg = job % A.jb.ncg, t = job / A.jb.ncg, rbk = t % A.jb.nrb, img = t / A.jb.nrb;
+        const int y0 = rbk * A.jb.rb, y1 = (y0 + A.jb.rb < h) ? y0 + A.jb.rb : h;
+        const int j = cg * 16 + n;
+        const bool jok = j < w;
+        f32x4 xv[STATS ? MT : 1], gv[NT], xn[STATS ? MT : 1], gn[NT];
+        auto issue = [&](int i) {
+            const bool live = i < y1;
+            const unsigned ipix = (unsigned)((img * h + i) * w + j);
+            if constexpr (STATS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xn[mt] = bld16(rx, (live && jok) ? (int)(ipix * px_ + (unsigned)(16 * mt + c4) * 4u) : -1);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pos = nt * PPS + ppos;
+                const int kh = pos / 3, kw = pos - 3 * kh;
+                const int oy = 2 * i + kh, ox = 2 * j + kw;
+                const bool ok = live && jok && pos < 9 && oy < H && ox < W && oq < Cout;
+                gn[nt] = bld16(rg, ok ? (int)((unsigned)((img * H + oy) * W + ox) * pg + (unsigned)oq * 4u) : -1);
+            }
+        };
+        issue(y0);
+        for (int i = y0; i < y1; ++i) {
+            if constexpr (STATS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xv[mt] = xn[mt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gv[nt] = gn[nt];
+            issue(i + 1);
+            int oz = 0;
+            asm volatile("" : "+v"(oz));  // (opaque zero: the weight fragments stay LDS reads inside the loop)
+            const f32x4* afl = af + oz;
+            const unsigned ipix = (unsigned)((img * h + i) * w + j);
+            const float actf = jok ? 1.f : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 a4 = afl[(mt * NT + nt) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[r], gv[nt][r], d, 0, 0, 0);
+                }
+                bst16(wd, (jok && 16 * mt + c4 < Cup) ? (int)(ipix * px_ + (unsigned)(16 * mt + c4) * 4u) : -1, d);
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xt = fmaxf(fmaf(xv[mt][r], sc[mt][r], sh[mt][r]), lo[mt][r]);
+                        const float gh = xt > 0.f ? actf * d[r] : 0.f;
+                        st1[mt][r] += gh;
+                        st2[mt][r] = fmaf(gh, xt, st2[mt][r]);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = quad16_sum(st1[mt][r]), v2 = quad16_sum(st2[mt][r]);
+                if (n == 0) {
+                    s_red[wave][0][16 * mt + c4 + r] = v1;
+                    s_red[wave][1][16 * mt + c4 + r] = v2;
+                }
+            }
+        __syncthreads();
+        if (A.bl.raw) {
+            for (int e = tid; e < 2 * Cup; e += 256) {
+                const int which = e / Cup, c = e - which * Cup;
+                bwd_last_add(A.bl, Cup, c, which, (s_red[0][which][c] + s_red[1][which][c]) + (s_red[2][which][c] + s_red[3][which][c]));
+            }
+            bwd_last_finish(A.bl, Cup, A.tr, nullptr, tid, 256, &s_flag);
         }
     }
 }
@@ -1590,6 +1732,41 @@ int ocrs_rs32_convt_fwd(const float* x, const float* tr, const float* wt, const 
     }
     CTF32_CASE(1, 2) CTF32_CASE(2, 4) CTF32_CASE(2, 8)
 #undef CTF32_CASE
+    return OCRS_ERR_ARG;
+}
+
+// 1 if ocrs_rs32_convt_dgrad runs this shape: fp32, (Cup, Cout) in {(16, 8), (32, 16)}
+long ocrs_rs32_convt_dgrad_supported(int Cup, int Cout, int dtype) {
+    static const int on = env_int("OCRS_RS32", 1), ond = env_int("OCRS_RS32_CTD", 1);
+    return (on && ond && dtype == 0 && ((Cup == 16 && Cout == 8) || (Cup == 32 && Cout == 16))) ? 1 : 0;
+}
+// ConvTranspose2d input gradient in fp32, row-streaming form (the dx half of ocrs_convt_bwd_parts; autograd of models.py:76-78 as train_detection.py:96
+// runs it): g [N][H][W][Cout] the gradient w.r.t. the (cropped) output, wt the fp32 MASTER weight [Cup][Cout][3][3], dx [N][h][w][Cup] = dL/dx~.
+// x / tr / saved / gsum (all nullable together): x is the raw output of a block consumed ONLY by this ConvTranspose -- its BatchNorm-backward sums
+// [sum ghat | sum ghat zhat] ([2][Cup] fp64, ACCUMULATED) come from this pass instead of ocrs_bn_bwd_reduce.
+int ocrs_rs32_convt_dgrad(const float* g, const float* wt, float* dx, const float* x, const float* tr, const float* saved, double* gsum, int Cup, int Cout, int N,
+                          int h, int w, int H, int W, hipStream_t st) {
+    OCRS_CHECK_ARG(ocrs_rs32_convt_dgrad_supported(Cup, Cout, 0) && g && wt && dx && N > 0 && h > 0 && w > 0 && H <= 2 * h + 1 && W <= 2 * w + 1);
+    OCRS_CHECK_ARG((!gsum || (x && tr && saved)) && (long)N * H * W * Cout * 4 < (1L << 32) && (long)N * h * w * Cup * 4 < (1L << 32));
+    const bool stats = gsum != nullptr;
+    BwdLast bl{nullptr, nullptr, gsum, nullptr, saved, nullptr, Cup, 0};
+    if (stats) {
+        double* p = rs32_last_scratch(BWD_LAST_SLOTS * 2 * Cup + 2, st);
+        if (!p) return OCRS_ERR_HIP;
+        bl.raw = p;
+        bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cup);
+    }
+    static const int rb_env = env_int("OCRS_RS32_CTD_RB", 32);
+    Rs32CD a{g, wt, x, tr, dx, Cup, Cout, N, h, w, H, W, rs32_jobs(N, h, w, 16, rb_env > 0 ? rb_env : 32), bl};
+    const int grid = rs32_grid(a.jb.njobs, 2);
+#define CTD32_CASE(MT_, CE_, ST_)                                                               \
+    if (Cup == 16 * MT_ && Cout == CE_ && stats == ST_) {                                       \
+        OCRS_LAUNCH_T((k_rs32_ctd<MT_, CE_, ST_>), dim3(grid), dim3(256), 0, st, a);            \
+        OCRS_LAUNCH_CHECK();                                                                    \
+        return OCRS_OK;                                                                         \
+    }
+    CTD32_CASE(1, 8, false) CTD32_CASE(1, 8, true) CTD32_CASE(2, 16, false) CTD32_CASE(2, 16, true)
+#undef CTD32_CASE
     return OCRS_ERR_ARG;
 }
 

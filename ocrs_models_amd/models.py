@@ -653,13 +653,24 @@ class _DetRun:
             ws = self.empty(L.convt_bwd_ws_floats(Cup, Cout, N, up_in.H, up_in.W, self.dt), dtype=torch.float32)
             self._hold(ws)  # (the fp32 row-streaming weight-gradient kernel queues its second stage until the end of the backward)
             sv = gs_up = None
-            if self.fuse_bn_bwd and up_in.src is not None and L.convt_bwd_stats_supported(Cup, Cout, self.dt):
+            # fp32, wide levels (round 6): the input gradient on the row-streaming kernel (csrc/det_rs32.hip) -- from the MASTER weight, and it also produces
+            # the producer block's BatchNorm-backward sums (no ocrs_bn_bwd_reduce pass); the weight / bias half stays ocrs_convt_bwd_parts(.., 2)
+            rs_ctd = (self.use_rs32 and L.rs32_convt_dgrad_supported(Cup, Cout, self.dt) and N * ta.H * ta.W * Cout * 4 < 2 ** 32
+                      and L.convt_bwd_splittable(Cup, Cout, self.dt))
+            if self.fuse_bn_bwd and up_in.src is not None and (rs_ctd or L.convt_bwd_stats_supported(Cup, Cout, self.dt)):
                 # the ConvTranspose is this block's only consumer and stages its z anyway: it also produces the block's BatchNorm-backward sums
                 sv, gs_up = self.recs[up_in.src].saved, self.zeros64(2 * Cup)
                 self.fused[up_in.src] = gs_up
             db64 = self.zeros64(Cout)
             args = (ptr(up_in.t), ptr(up_in.tr), ptr(gxa), ptr(wpk_d), ptr(dx), ptr(self.G[f"up.{i}.up.weight"]), ptr(self.G[f"up.{i}.up.bias"]), ptr(db64),
-                    ptr(ws), ptr(sv), ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W)
+                    ptr(ws), None if rs_ctd else ptr(sv), None if rs_ctd else ptr(gs_up), Cup, Cout, N, up_in.H, up_in.W, ta.H, ta.W)
+
+            def dgrad():
+                if rs_ctd:
+                    L.rs32_convt_dgrad(ptr(gxa), ptr(P[f"up.{i}.up.weight"]), ptr(dx), ptr(up_in.t), ptr(up_in.tr), ptr(sv), ptr(gs_up), Cup, Cout, N,
+                                       up_in.H, up_in.W, ta.H, ta.W)
+                else:
+                    L.convt_bwd_parts(*args, 1, self.dt)
             if side is not None and L.convt_bwd_splittable(Cup, Cout, self.dt):
                 flush_pending()
                 side.wait_stream(main)  # its operands (x, the output gradient, the zeroed accumulators) are ready in main-stream order
@@ -670,11 +681,15 @@ class _DetRun:
                 if self._defer_folds:
                     self.fold64(self.G[f"up.{i}.up.bias"], db64)  # (runs at the end of the backward, behind the join with the side stream)
                 keep.extend((gxa, ws, db64, wpk_d, up_in.t))
-                L.convt_bwd_parts(*args, 1, self.dt)
+                dgrad()
                 stage_done(f"up.{i}", side_work=True)
             else:
                 flush_pending()
-                L.convt_bwd(*args, self.dt)
+                if rs_ctd:
+                    L.convt_bwd_parts(*args, 2, self.dt)
+                    dgrad()
+                else:
+                    L.convt_bwd(*args, self.dt)
                 self.fold64(self.G[f"up.{i}.up.bias"], db64)  # generic (deep-level / fp32) path: bias gradient accumulated in fp64 (zeros on the tiled path)
                 stage_done(f"up.{i}")
             if self.capture is not None:

@@ -598,6 +598,23 @@ def test_conv_transpose(dev, dtype, Cup, Cout, h, w, H, W):
     assert rel(nchw(dx), xt.grad) < 10 * tol, "dgrad"
     assert rel(dW, Wr.grad) < 10 * tol, "wgrad"
     assert rel(db, br.grad) < 10 * tol, "dbias"
+    if run.L.rs32_convt_dgrad_supported(Cup, Cout, run.dt):
+        # fp32, wide levels: the row-streaming input-gradient kernel (csrc/det_rs32.hip: what the model runs) from the MASTER weight, without and with the
+        # producer block's BatchNorm-backward sums (reference sums from the kernel's own stored gradient, as below)
+        saved = torch.stack([0.1 * torch.randn(Cup, generator=g), 1 + 0.2 * torch.rand(Cup, generator=g)]).to(dev)  # [mean | rstd]
+        for with_stats in (False, True):
+            dx3 = torch.full_like(dx, float("nan"))
+            gsum3 = torch.zeros(2 * Cup, dtype=torch.float64, device=dev)
+            run.L.rs32_convt_dgrad(ptr(gy), ptr(Wt), ptr(dx3), ptr(xs) if with_stats else None, ptr(tr) if with_stats else None, ptr(saved) if with_stats else None,
+                                   ptr(gsum3) if with_stats else None, Cup, Cout, N, h, w, H, W)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(dx3).all()) and rel(nchw(dx3), xt.grad) < 2e-6, rel(nchw(dx3), xt.grad)
+            if with_stats:
+                dxf, xf = nchw(dx3).double(), nchw(xs).double()
+                pre = xf * tr[0].double().view(1, -1, 1, 1) + tr[1].double().view(1, -1, 1, 1)
+                gh = torch.where(pre > 0, dxf, torch.zeros_like(dxf))
+                zh = (xf - saved[0].double().view(1, -1, 1, 1)) * saved[1].double().view(1, -1, 1, 1)
+                assert rel(gsum3, torch.cat([gh.sum((0, 2, 3)), (gh * zh).sum((0, 2, 3))])) < 1e-5, "BatchNorm-backward sums (row-streaming dgrad)"
     if run.L.convt_bwd_stats_supported(Cup, Cout, run.dt):
         # the same pass can produce the BatchNorm-backward sums of the block that produced x (the ConvTranspose is its only consumer):
         # reference from the STORED gradient, ghat = dx * [x*scale+shift > 0], zhat = (x - mean) * rstd; everything else unchanged
@@ -747,7 +764,7 @@ def test_last_block_backward_from_head_gl_is_bit_identical(dev, shape):
 RS32_CASES = [(8, 0, 8), (8, 0, 16), (16, 0, 16), (8, 8, 8), (16, 0, 8), (16, 0, 32), (32, 0, 32), (16, 16, 16), (32, 0, 16)]
 
 
-@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 28), (1, 67, 15)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 28), (1, 67, 15), (2, 2, 3), (1, 9, 5)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("Ca,Cb,Cout", RS32_CASES)
 def test_rs32_block_forward(dev, Ca, Cb, Cout, pool, shape):
@@ -810,7 +827,7 @@ def test_rs32_block_forward(dev, Ca, Cb, Cout, pool, shape):
     assert torch.equal(out2.t, outs[True][0].t) and torch.equal(out2.tr, outs[True][0].tr)
 
 
-@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 28), (1, 67, 15)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 28), (1, 67, 15), (2, 3, 5), (1, 2, 30)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("two_grads", [False, True])
 @pytest.mark.parametrize("C0,Ca,Cb,Cc", [(8, 8, 0, 8), (8, 8, 0, 16), (8, 16, 0, 16), (16, 16, 0, 8), (8, 8, 8, 8), (16, 8, 8, 16),
                                          (16, 16, 16, 16), (8, 16, 0, 32)])  # level 1: 16 | 16 -> 16 as two single-source passes, 16 -> 32 on k_rs32_bwdx
@@ -900,7 +917,7 @@ def test_rs32_block_backward(dev, C0, Ca, Cb, Cc, two_grads, shape):
         assert v < 5e-4 and (k not in errs_old or v < 3 * errs_old[k] + 2e-5), (k, v, errs_old.get(k))
 
 
-@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 24), (1, 67, 13)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(2, 21, 37), (1, 150, 100), (3, 64, 24), (1, 67, 13), (2, 2, 3), (1, 5, 2)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("two_grads", [False, True])
 @pytest.mark.parametrize("C0,Ca,Cc", [(8, 8, 8), (8, 8, 16), (8, 16, 16), (16, 16, 8)])
 def test_rs32_block_backward_through_maxpool(dev, C0, Ca, Cc, two_grads, shape):
