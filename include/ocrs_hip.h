@@ -77,6 +77,13 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
                   const float* g2, const float* z, const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta,
                   float* gxa, float* gxb, float* dwpw, float* dwdw, float* ws, const float* saved_a, double* gsum_a, const float* saved_b, double* gsum_b,
                   int pooled, int Cout, int N, int H, int W, hipStream_t st);
+/* ocrs_rs32_bwd for the block in front of out_conv (models.py:125-129; 8 -> 8, single source): its output gradient is formed on the fly,
+   g[p][c] = gl[p] * whead[c], from out_conv's dL/dlogit gl [P] fp32 (what ocrs_head_bwd_gl / ocrs_head_bwd_loss write: 4 instead of 32 bytes per pixel) -- the same
+   fp32 product ocrs_head_bwd stores, so every output is bit-identical to ocrs_head_bwd + ocrs_rs32_bwd. */
+long ocrs_rs32_bwd_head_supported(int Ca, int Cb, int Cout, int dtype); /* 1 / 0 */
+int ocrs_rs32_bwd_head(const float* xa, int Ca, const float* tra, const float* wdw, const float* wpw, const float* gl, const float* whead, const float* z,
+                       const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, float* gxa, float* dwpw,
+                       float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, hipStream_t st);
 /* The same block forward on the matrix cores (csrc/det_mm.hip; bf16, Cin and Cout in {8, 16, 32} and the 32 | 32 concat): depthwise and
  * pointwise conv composed into one 3x3 implicit GEMM (effective weight Wpw[o][c] * Wdw[c][tap] built from the fp32 masters wdw [Cin][9],
  * wpw [Cout][Cin]).  The batch statistics go to ws as ocrs_mm_fwd_nparts() per-block partials [Cout][sum z | sum z^2] (fp32) that

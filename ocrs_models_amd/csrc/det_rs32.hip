@@ -30,6 +30,7 @@ constexpr int DPP_SHL1 = 0x101;  // row_shl:1  result[i] = src[i + 1]           
 
 __device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
 __device__ __forceinline__ f32x4 bld16(rsrc_t r, int off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+__device__ __forceinline__ float bld4(rsrc_t r, int off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
 __device__ __forceinline__ void bst16(rsrc_t r, int off, const f32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0); }
 __device__ __forceinline__ f32x4 or4(const f32x4& a, const f32x4& b) {  // lanes get their value from exactly one of two range-checked loads (the other returned 0)
     return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, a) | __builtin_bit_cast(u32x4, b));
@@ -283,6 +284,7 @@ struct Rs32B {
     BnFin fin;
     BwdLast bl;
     int ldw;  // row pitch of wpw (= Cin, or the concat's total when the launch handles ONE 16-channel source of a 16 | 16 block: see ocrs_rs32_bwd)
+    const float *gl, *whead;  // HEAD: the block in front of out_conv forms its output gradient g[c] = gl * whead[c] from out_conv's dL/dlogit (4 B per pixel)
 };
 constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of the transpose buffers: 16-byte aligned rows, conflict-light
 
@@ -292,8 +294,9 @@ constexpr int RS32_TP = 20;  // pitch (floats) of a [channel][16 pixels] row of 
 // (the kernel is VALU-issue bound: ~450 instructions per strip row).  The wave then runs TWO strips side by side, strip q >> 1 in lane groups (2 s,
 // 2 s + 1): every per-channel instruction serves 28 columns, and ONE set of four MFMAs still yields du of both strips in place because the weight
 // fragment is block-diagonal over (strip, channel): A_r[(m, k)] = [m >> 3 == k >> 1] Wpw[4 (k & 1) + r][m & 7]  ->  D rows 0-7 = strip 0, 8-15 = strip 1.
-template <bool SPLIT, bool G2, bool STATS, int P, bool DUAL = false>
-__global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs32B A) {  // (branch-free form: 134 .. 174 registers -> three workgroups per CU)
+template <bool SPLIT, bool G2, bool STATS, int P, bool DUAL = false, bool HEAD = false>
+__global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs32B A) {
+    static_assert(!(HEAD && (SPLIT || G2)), "HEAD: the single-source block in front of out_conv");  // (branch-free form: 134 .. 174 registers -> three workgroups per CU)
     static_assert(!(DUAL && SPLIT), "two strips per wave: single-source 8-channel blocks only");
     constexpr int TP2 = DUAL ? 36 : RS32_TP;  // pitch of a transpose row: 16 (or 2 x 16) pixels + pad
     __shared__ float s_cf[3 * 16];
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
         s_k[5 * 16 + c] = i ? tr[cc] : 0.f;
         s_k[6 * 16 + c] = i ? tr[Cs + cc] : 0.f;
         s_k[7 * 16 + c] = i ? tr[2 * Cs + cc] : 0.f;
-        s_k[8 * 16 + c] = (i && want) ? sv[cc] : 0.f;
+        s_k[8 * 16 + c] = HEAD ? (o ? A.whead[c] : 0.f) : ((i && want) ? sv[cc] : 0.f);  // (row 8: out_conv's weight in the HEAD form)
         for (int t = 0; t < 9; ++t) s_w[t * 16 + c] = i ? A.wdw[c * 9 + t] : 0.f;
     }
     __syncthreads();
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
     }
     const unsigned npix = (unsigned)A.N * H * W;
     const rsrc_t ra = mk_rsrc(A.xa, npix * Ca * 4), rbs = mk_rsrc(SPLIT ? A.xb : A.xa, npix * (SPLIT ? Cb : Ca) * 4);
-    const rsrc_t rg1 = mk_rsrc(A.g1, npix * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : A.g1, npix * Cout * 4), rz = mk_rsrc(A.z, npix * Cout * 4);
+    const rsrc_t rg1 = HEAD ? mk_rsrc(A.gl, npix * 4) : mk_rsrc(A.g1, npix * Cout * 4), rg2 = mk_rsrc(G2 ? A.g2 : (HEAD ? A.z : A.g1), npix * Cout * 4), rz = mk_rsrc(A.z, npix * Cout * 4);
     const rsrc_t wa = mk_rsrc(A.gxa, npix * Ca * 4), wb = mk_rsrc(SPLIT ? A.gxb : A.gxa, npix * (SPLIT ? Cb : Ca) * 4);
     const unsigned pa = Ca * 4, pb = Cb * 4, po = Cout * 4;
     const int qa = (okI && in_a) ? c4 * 4 : -1, qb = (okI && !in_a) ? (c4 - Ca) * 4 : -1;
@@ -370,12 +373,16 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
         const bool useful = n >= 1 && n <= RS32_COLS && col < W;
         const int rowpix0 = img * H * W + col;
 
-        f32x4 rg[P], rg2v[G2 ? P : 1], rzv[P], rx[P], rxb[SPLIT ? P : 1];
+        f32x4 rg[HEAD ? 1 : P], rg2v[G2 ? P : 1], rzv[P], rx[P], rxb[SPLIT ? P : 1];
+        float rgl[HEAD ? P : 1];
         auto issue = [&](int k, int yy) {
             const bool ok = colok && (unsigned)yy < (unsigned)H && yy <= y1;
             const unsigned pix = (unsigned)(rowpix0 + yy * W);
             const int oo = (ok && okO) ? (int)(pix * po + (unsigned)c4 * 4u) : -1;
-            rg[k] = bld16(rg1, oo);
+            if constexpr (HEAD)
+                rgl[k] = bld4(rg1, (ok && okO) ? (int)(pix * 4u) : -1);
+            else
+                rg[k] = bld16(rg1, oo);
             if constexpr (G2) rg2v[k] = bld16(rg2, oo);
             rzv[k] = bld16(rz, oo);
             rx[k] = bld16(ra, (ok && qa >= 0) ? (int)(pix * pa + (unsigned)qa) : -1);
@@ -409,7 +416,13 @@ __global__ __launch_bounds__(256, (DUAL && G2) ? 2 : 3) void k_rs32_bwd(const Rs
                 const float* kk = s_k + c4 + oz;
                 const float* kw = s_w + c4 + oz;
                 {
-                    f32x4 gv = rg[k];
+                    f32x4 gv;
+                    if constexpr (HEAD) {
+                        const f32x4 wh = *reinterpret_cast<const f32x4*>(kk + 128);  // g[c] = gl * whead[c]: the product k_head_bwd would have stored
+                        gv = wh * rgl[k];
+                    } else {
+                        gv = rg[k];
+                    }
                     if constexpr (G2) gv = gv + rg2v[k];
                     const f32x4 zv = rzv[k];
                     f32x4 xv = rx[k];
@@ -1603,7 +1616,7 @@ static int rs32_bwd_one(const float* x, const float* tr, const float* wdw, const
         bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
     }
     Rs32B a{x, nullptr, tr, nullptr, wdw, wpw, g1, g2, z, bn, gx, nullptr, ws, Cin, 0, Cout, N, H, W, rs32_jobs(N, H, W, RS32_COLS, rs32_bwd_rb()),
-            BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, ldw};
+            BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, ldw, nullptr, nullptr};
     const int grid = rs32_grid(a.jb.njobs, 3);
 #define RS32O_CASE(G2_, ST_)                                                                          \
     if ((g2 != nullptr) == G2_ && stats == ST_) {                                                    \
@@ -1653,7 +1666,7 @@ int ocrs_rs32_bwd(const float* xa, const float* xb, int Ca, int Cb, const float*
     static const int dual_on = env_int("OCRS_RS32_DUAL", 1);
     const bool dual = dual_on && !pooled && Cb == 0 && Cin == 8 && Cout == 8;  // two 14-column strips per wave (8-channel tensors fill half the lanes)
     Rs32B a{xa, xb, tra, trb, wdw, wpw, g1, g2, z, bn, gxa, gxb, ws, Ca, Cb, Cout, N, H, W,
-            rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, Cin};
+            rs32_jobs(N, H, W, pooled ? RS32P_COLS : (dual ? 2 * RS32_COLS : RS32_COLS), rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, Cin, nullptr, nullptr};
     const bool wide = Cin > 16 || Cout > 16;
     const int grid = rs32_grid(a.jb.njobs, (pooled || wide || (dual && g2)) ? 2 : 3);
     if (wide) {
@@ -1768,6 +1781,46 @@ int ocrs_rs32_convt_dgrad(const float* g, const float* wt, float* dx, const floa
     CTD32_CASE(1, 8, false) CTD32_CASE(1, 8, true) CTD32_CASE(2, 16, false) CTD32_CASE(2, 16, true)
 #undef CTD32_CASE
     return OCRS_ERR_ARG;
+}
+
+// 1 if ocrs_rs32_bwd_head runs the block in front of out_conv: fp32, 8 -> 8, single source
+long ocrs_rs32_bwd_head_supported(int Ca, int Cb, int Cout, int dtype) {
+    static const int onh = env_int("OCRS_RS32_HEAD", 1);
+    return (onh && Cb == 0 && Ca == 8 && Cout == 8 && ocrs_rs32_bwd_supported(Ca, Cb, Cout, 0, dtype)) ? 1 : 0;
+}
+// ocrs_rs32_bwd for the block in front of out_conv (models.py:125-129): its output gradient is formed on the fly, g[p][c] = gl[p] * whead[c], from out_conv's
+// dL/dlogit gl [P] fp32 (ocrs_head_bwd_gl / ocrs_head_bwd_loss write 4 instead of 32 bytes per pixel) -- the same fp32 product ocrs_head_bwd stores, so every
+// output is bit-identical to ocrs_head_bwd + ocrs_rs32_bwd.  Other arguments as ocrs_rs32_bwd (single source, one gradient).
+int ocrs_rs32_bwd_head(const float* xa, int Ca, const float* tra, const float* wdw, const float* wpw, const float* gl, const float* whead, const float* z,
+                       const float* bn, const double* gsum, const float* gamma, const float* saved, float* dgamma, float* dbeta, float* gxa, float* dwpw,
+                       float* dwdw, float* ws, const float* saved_a, double* gsum_a, int Cout, int N, int H, int W, hipStream_t st) {
+    OCRS_CHECK_ARG(ocrs_rs32_bwd_head_supported(Ca, 0, Cout, 0) && xa && tra && wdw && wpw && gl && whead && z && bn && gsum && gamma && saved && dgamma && dbeta);
+    OCRS_CHECK_ARG(gxa && dwpw && dwdw && ws && N > 0 && H > 0 && W > 0 && (!gsum_a || saved_a) && (long)N * H * W * 8 * 4 < (1L << 32));
+    const int Cin = Ca;
+    const bool stats = gsum_a != nullptr;
+    BwdLast bl{nullptr, nullptr, gsum_a, nullptr, saved_a, nullptr, Ca, 0};
+    if (stats) {
+        double* p = rs32_last_scratch(BWD_LAST_SLOTS * 2 * Cin + 2, st);
+        if (!p) return OCRS_ERR_HIP;
+        bl.raw = p;
+        bl.counter = reinterpret_cast<unsigned*>(p + BWD_LAST_SLOTS * 2 * Cin);
+    }
+    static const int dual_on = env_int("OCRS_RS32_DUAL", 1);
+    const bool dual = dual_on != 0;
+    Rs32B a{xa, nullptr, tra, nullptr, wdw, wpw, nullptr, nullptr, z, bn, gxa, nullptr, ws, Ca, 0, Cout, N, H, W,
+            rs32_jobs(N, H, W, dual ? 2 * RS32_COLS : RS32_COLS, rs32_bwd_rb()), BnFin{gsum, gamma, saved, dgamma, dbeta, (long)N * H * W}, bl, Cin, gl, whead};
+    const int grid = rs32_grid(a.jb.njobs, 3);
+    if (dual) {
+        if (stats) OCRS_LAUNCH_T((k_rs32_bwd<false, false, true, 1, true, true>), dim3(grid), dim3(256), 0, st, a);
+        else OCRS_LAUNCH_T((k_rs32_bwd<false, false, false, 1, true, true>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (stats) OCRS_LAUNCH_T((k_rs32_bwd<false, false, true, 1, false, true>), dim3(grid), dim3(256), 0, st, a);
+        else OCRS_LAUNCH_T((k_rs32_bwd<false, false, false, 1, false, true>), dim3(grid), dim3(256), 0, st, a);
+    }
+    OCRS_LAUNCH_CHECK();
+    bwd_reduce_or_defer(ws, grid, Cout * Cin + 9 * Cin, dwpw, Cout * Cin, Cin, Cin, dwdw, 9 * Cin, st);
+    OCRS_LAUNCH_CHECK();
+    return OCRS_OK;
 }
 
 }  // extern "C"

@@ -516,11 +516,20 @@ class _DetRun:
             svb, gsb = stat_target(b)
             ws = self.empty(L.rs32_bwd_ws_floats(Ca, Cb, C, N, H, W), dtype=torch.float32)
             self._hold(ws)  # (its reduction may be queued until the end of the backward)
+            gl = getattr(self, "_head_gl", None)
+            if gl is not None and g1 is gl:  # the block in front of out_conv: its output gradient is formed from gl (4 B / pixel) inside the launch
+                self._head_gl = None
+                L.rs32_bwd_head(ptr(a.t), Ca, ptr(a.tr), ptr(wdw), ptr(wpw), ptr(gl), ptr(P["out_conv.0.weight"]), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam),
+                                ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws),
+                                ptr(sva), ptr(gsa), C, N, H, W)
+                return gxa, gxb
             L.rs32_bwd(ptr(a.t), ptr(b.t) if b is not None else None, Ca, Cb, ptr(a.tr), ptr(b.tr) if b is not None else None, ptr(wdw), ptr(wpw), ptr(g1),
                        ptr(g2), ptr(r.z), ptr(r.tr), ptr(gsum), ptr(gam), ptr(r.saved), ptr(dgam), ptr(dbet), ptr(gxa), ptr(gxb),
                        ptr(self.G[f"{prefix}.seq.1.weight"]), ptr(self.G[f"{prefix}.seq.0.weight"]), ptr(ws), ptr(sva), ptr(gsa), ptr(svb), ptr(gsb),
                        1 if pooled else 0, C, N, H, W)
             return gxa, gxb
+        if getattr(self, "_head_gl", None) is not None and g1 is self._head_gl:
+            raise RuntimeError("internal: out_conv handed this block gl instead of its gradient, but the block did not route to a kernel that takes it")
         du = self.empty(N, H, W, r.Cin)
         ws = self.empty(L.pw_bwd_ws_floats(r.Cin, C, N, H, W), dtype=torch.float32)
         self._hold(ws)  # (its reduction may be queued until the end of the backward)
@@ -617,6 +626,9 @@ class _DetRun:
         r_up = self.recs.get(up.src) if up.src is not None else None
         head_gl = (self.head_gl and self.capture is None and gs_head is not None and r_up is not None and r_up.b is None and self.use_mm and self.fold_fin
                    and L.mm_bwd_head_supported(r_up.a.C, 0, r_up.Cout, N, H, W, self.dt))
+        if not head_gl and self.dt == 0:  # fp32 (round 6): the same hand-over on the row-streaming backward (ocrs_rs32_bwd_head; exactly _block_bwd's routing test)
+            head_gl = bool(self.head_gl and self.capture is None and gs_head is not None and r_up is not None and r_up.b is None and self.use_rs32
+                           and L.rs32_bwd_head_supported(r_up.a.C, 0, r_up.Cout, self.dt) and N * H * W * 8 * 4 < 2 ** 32)
         if deferred is not None and not (head_gl and (N * H * W) % 4 == 0 and deferred[0].data_ptr() == self.pred.data_ptr()):
             gpred, deferred = _losses.materialize_deferred(deferred), None
         if deferred is not None:

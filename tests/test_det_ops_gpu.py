@@ -982,3 +982,54 @@ def test_rs32_block_backward_through_maxpool(dev, C0, Ca, Cc, two_grads, shape):
     print("row-streaming (pooled) vs float64 autograd:", {k: f"{v:.1e}" for k, v in errs.items()})
     for k, v in errs.items():
         assert v < 5e-4 and (k not in errs_old or v < 3 * errs_old[k] + 2e-5), (k, v, errs_old.get(k))
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 37), (3, 64, 96), (1, 70, 30)], ids=lambda s: "x".join(map(str, s)))
+def test_rs32_last_block_backward_from_head_gl_is_bit_identical(dev, shape):
+    """fp32 counterpart of test_last_block_backward_from_head_gl_is_bit_identical: ocrs_head_bwd_gl + ocrs_rs32_bwd_head (out_conv's backward writes only
+    gl = dL/dlogit, the row-streaming backward of the block in front of it forms g[c] = gl * w[c] on the fly) against ocrs_head_bwd + ocrs_rs32_bwd on the
+    stored 8-channel gradient: dL/dx, dWdw, dWpw, dgamma, dbeta and both sets of fused BatchNorm-backward sums must be identical bit for bit."""
+    from ocrs_models_amd._lib import lib, ptr
+
+    L = lib()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(23 + H)
+    P_ = N * H * W
+    x = nhwc(torch.randn(N, 8, H, W, generator=g).to(dev), torch.float32)
+    tra = rand_tr(8, dev, g)
+    z = nhwc(torch.randn(N, 8, H, W, generator=g).to(dev), torch.float32)
+    tr = rand_tr(8, dev, g)
+    wdw = (torch.randn(8, 9, generator=g) / 3).to(dev)
+    wpw = (torch.randn(8, 8, generator=g) / 3).to(dev)
+    gamma = (1 + 0.1 * torch.randn(8, generator=g)).to(dev)
+    saved = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)
+    saved_a = torch.stack([0.1 * torch.randn(8, generator=g), 1 + 0.2 * torch.rand(8, generator=g)]).to(dev)
+    whead = torch.randn(8, generator=g).to(dev)
+    pred = torch.rand(P_, generator=g).to(dev)
+    gpred = torch.randn(P_, generator=g).to(dev)
+    assert bool(L.rs32_bwd_head_supported(8, 0, 8, 0))
+    outs = []
+    for head in (False, True):
+        acc = torch.zeros(9, dtype=torch.float64, device=dev)
+        gs_blk = torch.zeros(16, dtype=torch.float64, device=dev)
+        gs_a = torch.zeros(16, dtype=torch.float64, device=dev)
+        gx = torch.zeros(N, H, W, 8, device=dev)
+        dwpw, dwdw = torch.zeros(8, 8, device=dev), torch.zeros(8, 9, device=dev)
+        dgam, dbet = torch.zeros(8, device=dev), torch.zeros(8, device=dev)
+        ws = torch.empty(L.rs32_bwd_ws_floats(8, 0, 8, N, H, W), device=dev)
+        if head:
+            gl = torch.empty(P_, device=dev)
+            L.head_bwd_gl(ptr(z), ptr(tr), ptr(whead), ptr(pred), ptr(gpred), ptr(gl), ptr(acc), ptr(saved), ptr(gs_blk), P_, 0)
+            L.rs32_bwd_head(ptr(x), 8, ptr(tra), ptr(wdw), ptr(wpw), ptr(gl), ptr(whead), ptr(z), ptr(tr), ptr(gs_blk), ptr(gamma), ptr(saved), ptr(dgam), ptr(dbet),
+                            ptr(gx), ptr(dwpw), ptr(dwdw), ptr(ws), ptr(saved_a), ptr(gs_a), 8, N, H, W)
+        else:
+            gy = torch.empty(N, H, W, 8, device=dev)
+            L.head_bwd(ptr(z), ptr(tr), ptr(whead), ptr(pred), ptr(gpred), ptr(gy), ptr(acc), ptr(saved), ptr(gs_blk), P_, 0)
+            L.rs32_bwd(ptr(x), None, 8, 0, ptr(tra), None, ptr(wdw), ptr(wpw), ptr(gy), None, ptr(z), ptr(tr), ptr(gs_blk), ptr(gamma), ptr(saved), ptr(dgam), ptr(dbet),
+                       ptr(gx), None, ptr(dwpw), ptr(dwdw), ptr(ws), ptr(saved_a), ptr(gs_a), None, None, 0, 8, N, H, W)
+        torch.cuda.synchronize()
+        outs.append({"gx": gx.clone(), "dwpw": dwpw.clone(), "dwdw": dwdw.clone(), "dgam": dgam.clone(), "dbet": dbet.clone(), "gs_a": gs_a.clone(),
+                     "acc": acc.clone(), "gs_blk": gs_blk.clone()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["gx"].abs().sum() > 0
